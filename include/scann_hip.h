@@ -1,0 +1,140 @@
+/*
+ * scann_hip.h -- C ABI of libscann_hip.so: the MI355X (gfx950) implementation of the SCANN / SCANN+
+ * forward hot path.
+ *
+ * The reference (sinhvt3421/scann--material) has no FFI: its hot path is the Keras graph built by
+ * scann/models/scann_model.py:329-453 (create_model) and executed by `model.predict(inputs)`
+ * (scann_model.py:266,316).  This header is the boundary that replaces that graph execution; the
+ * Python facade (`scann--material_amd/scann`, class SCANN, `.model.predict`) binds it with ctypes.
+ * Each entry point names the reference interface it stands in for.
+ *
+ * Conventions: every function returns 0 on success or a negative scann_status code and never
+ * throws; all host buffers are caller-owned plain pointers; the library owns device memory.
+ * One handle per GPU; a handle is not thread-safe, distinct handles are.
+ */
+#ifndef SCANN_HIP_H
+#define SCANN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCANN_ABI_VERSION 1
+
+typedef enum scann_status {
+  SCANN_OK = 0,
+  SCANN_ERR_INVALID = -1,     /* bad argument / malformed batch (index out of range, ...) */
+  SCANN_ERR_UNSUPPORTED = -2, /* configuration outside what the kernels implement */
+  SCANN_ERR_NO_DEVICE = -3,   /* no HIP device / device_id out of range */
+  SCANN_ERR_HIP = -4,         /* a HIP runtime call failed (see scann_last_error) */
+  SCANN_ERR_WEIGHTS = -5,     /* weights missing / wrong shape / not loaded */
+  SCANN_ERR_OOM = -6
+} scann_status;
+
+/* Model hyper-parameters: the `model:` section of configs/ *.yaml as read by create_model
+ * (scann_model.py:330-447).  Keys not listed there (e.g. `scale`) are never read by the reference. */
+typedef struct scann_config {
+  int32_t n_atoms;        /* Embedding vocabulary, scann_model.py:362 */
+  int32_t embedding_dim;  /* :362 */
+  int32_t local_dim;      /* :373  (kernels require 128) */
+  int32_t num_head;       /* :399  (kernels require 8) */
+  int32_t n_attention;    /* :413 */
+  int32_t global_dim;     /* :425  (128) */
+  int32_t dense_out;      /* :438  (128) */
+  int32_t n_gauss;        /* 20, scann_model.py:378 */
+  float gaussian_d;       /* :378 */
+  int32_t g_update;       /* :380  SCANN+ geometry update */
+  int32_t use_attn_norm;  /* :404  ResidualNorm after each LocalAttention */
+  int32_t use_ga_norm;    /* :433  GlobalAttention(norm=...) */
+  int32_t use_ring;       /* :356  extra ring/aromatic input */
+  int32_t feature_cgcnn;  /* :334  92-d CGCNN features instead of the Embedding */
+  int32_t relu_out;       /* :446  mrelu on the output iff hyper.target == "e_b" */
+} scann_config_t;
+
+/* One named fp32 tensor inside a flat weight blob (the library's weight container; replaces the
+ * Keras HDF5 checkpoint read by load_model, scann_model.py:79,87,323).  Names are listed by
+ * scann_weight_name(); kernels are stored [in, out] like Keras Dense kernels. */
+typedef struct scann_tensor_desc {
+  const char* name;
+  int64_t offset; /* element offset into the blob */
+  int64_t numel;
+} scann_tensor_desc_t;
+
+/* A batch in packed (CSR) form.  The padded Keras input dict (scann_model.py:338-357; produced by
+ * DataIterator.__getitem__, datagenerator.py:123-133) maps to it as: real atoms (atom_mask) of all
+ * structures concatenated; per atom its unmasked neighbour slots in slot order; neighbour ids made
+ * global (structure offset + neighbors[b, a, n], the job of gather_shape, custom_layers.py:18-28). */
+typedef struct scann_batch {
+  int32_t n_struct;           /* B */
+  int32_t n_atom;             /* sum of real atoms */
+  int32_t n_edge;             /* sum of unmasked neighbour slots */
+  const int32_t* atomic;      /* [n_atom]  atomic number / embedding row ("atomic") */
+  const int32_t* mol_offset;  /* [n_struct + 1] first atom of each structure */
+  const int32_t* edge_offset; /* [n_atom + 1]  CSR row pointers */
+  const int32_t* edge_col;    /* [n_edge] global atom row of the neighbour */
+  const float* edge_dist;     /* [n_edge] "neighbor_distance" */
+  const float* edge_weight;   /* [n_edge] "neighbor_weight" */
+  const float* ring;          /* [n_atom, 2] "ring_aromatic" or NULL */
+  const float* cgcnn;         /* [n_atom, 92] CGCNN features or NULL */
+} scann_batch_t;
+
+typedef struct scann_handle scann_handle_t;
+typedef struct scann_dbatch scann_dbatch_t; /* a batch resident in HBM with its own workspace */
+
+/* Per-kernel device timing of one forward (HIP events on the handle's stream). */
+#define SCANN_PROF_SLOTS 8
+typedef struct scann_profile {
+  float ms_basis;     /* embed + edge basis MLP            (scann_model.py:362-389) */
+  float ms_atom;      /* sum over layers: atom-tile kernel (attention.py:37-40,160 + split filter_geo) */
+  float ms_edge;      /* sum over layers: edge-tile kernel (attention.py:136-216) */
+  float ms_readout;   /* after_Lc + GlobalAttention + head (scann_model.py:424-447) */
+  float ms_total;
+  int32_t n_edge_launch; /* number of edge-kernel launches timed (= n_attention) */
+  int32_t n_atom_launch;
+  int32_t reserved;
+} scann_profile_t;
+
+int scann_abi_version(void);
+int scann_device_count(void);
+
+/* Replaces create_model(config) (scann_model.py:329). */
+int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out);
+void scann_destroy(scann_handle_t* h);
+const char* scann_last_error(const scann_handle_t* h); /* h may be NULL: last create error */
+
+/* Canonical tensor list for this configuration (index 0..n-1); shape as up to 2 dims. */
+int scann_weight_count(const scann_handle_t* h);
+int scann_weight_name(const scann_handle_t* h, int index, const char** name, int64_t* rows, int64_t* cols);
+
+/* Replaces load_model / model.set_weights (scann_model.py:79,323). */
+int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_desc_t* manifest, int n);
+
+/* Replaces model.predict(inputs) (scann_model.py:266,316) on host buffers:
+ * y_out[n_struct]; ga_attn_out[n_atom] (packed GlobalAttention scores, attention.py:302) or NULL. */
+int scann_forward(scann_handle_t* h, const scann_batch_t* batch, float* y_out, float* ga_attn_out);
+
+/* Resident-batch path (inputs already in HBM; used for pipelined inference and by bench.py). */
+int scann_batch_upload(scann_handle_t* h, const scann_batch_t* batch, scann_dbatch_t** out);
+void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);
+int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot); /* async */
+int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out); /* syncs that batch */
+int scann_sync(scann_handle_t* h); /* all streams of the handle */
+int scann_num_streams(const scann_handle_t* h);
+
+/* Timed forward of a resident batch: HIP events around every kernel on its stream. */
+int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t* prof);
+
+/* Test hook: copy an intermediate of the last forward of `db` to host.
+ * what: 0 = centers after layer `layer` (0 = after dense_embed) [n_atom,128];
+ *       1 = geometry features after layer `layer` [n_edge,128];
+ *       2 = context (LocalAttention output incl. layer_norm) of layer `layer`>=1 [n_atom,128].
+ * Only valid when the forward was run with scann_set_debug(h, 1) (keeps per-layer copies). */
+int scann_set_debug(scann_handle_t* h, int on);
+int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANN_HIP_H */

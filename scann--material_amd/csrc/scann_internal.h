@@ -1,0 +1,114 @@
+// Internal declarations shared by the HIP kernels (scann_kernels.hip) and the C-ABI runtime
+// (scann_runtime.cpp).  Not part of the public boundary (include/scann_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scann {
+
+constexpr int D = 128;           // local_dim = global_dim = dense_out (all shipped configs)
+constexpr int NHEAD = 8;         // num_head
+constexpr int HDIM = D / NHEAD;  // 16
+constexpr int NG = 20;           // Gaussian basis size (scann_model.py:378)
+constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict-free b128 A-fragment reads)
+constexpr int TE = 64;           // edge rows per edge tile (two 32-row MFMA row tiles)
+constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row tile)
+constexpr int TB = 64;           // edges per basis-kernel workgroup
+constexpr int WPACK = D * D;     // floats in one packed 128x128 weight
+
+// One tile of the edge kernel: a run of whole atoms whose CSR rows are contiguous, <= TE edges.
+struct EdgeTile {
+  int32_t atom_begin, atom_end;
+  int32_t edge_begin, edge_end;
+};
+
+// Device pointers of one LocalAttention(+ResidualNorm) iteration.  128x128 kernels are stored in
+// the MFMA fragment order produced by pack_weight() (see scann_kernels.hip: gemm128).
+struct LayerParams {
+  // atom-tile kernel
+  const float *W1p, *W3p, *bg;  // filter_geo rows [0,128) (centre) and [256,384) (neighbour) + bias
+  const float *Wqp, *bq;        // query
+  // edge-tile kernel
+  const float *W2p;             // filter_geo rows [128,256) (geometry)
+  const float *Wkp, *bk;        // key
+  const float *lng_g, *lng_b;   // layer_norm_g
+  const float *ln_g, *ln_b;     // layer_norm
+  const float *Wfg, *bfg;       // base branch (g_update False): filter_geo [20,128] raw + bias
+  // ResidualNorm that follows this LocalAttention (applied at the head of the next atom kernel)
+  const float *Wf1p, *bf1, *Wf2p, *bf2, *lnr_g, *lnr_b;
+};
+
+struct HeadParams {
+  const float *Wap, *ba;                // after_Lc
+  const float *Wgqp, *bgq, *Wgkp, *bgk; // global_attention query / key
+  const float *Wb, *bb;                 // bf_property (row-major [128,128])
+  const float *wo, *bo;                 // predict_property [128], [1]
+};
+
+struct BasisParams {
+  const float *Wd, *bd, *Ww, *bw;  // neighbor_d / neighbor_w [20,128]
+  const float *cd, *cw;            // Gaussian centres (20 each)
+};
+
+// ---- launch wrappers (defined in scann_kernels.hip) -------------------------------------------
+
+// swish(E . W + b) per species -> lut[n_species,128]   (Embedding + dense_embed folded at load time)
+void launch_embed_lut(const float* emb, const float* W, const float* b, int n_species, int emb_dim,
+                      float* lut, hipStream_t s);
+
+// geom0[e,:] = swish(G(dist) Wd + bd) * swish(G(weight) Ww + bw)         (g_update)
+// or gd[e, 0:20] = G(dist) (base branch: the per-layer filter consumes the raw basis)
+void launch_basis(const BasisParams& p, const float* dist, const float* weight, int n_edge,
+                  float* geom, hipStream_t s);
+void launch_basis_raw(const float* cd, const float* dist, int n_edge, float* gd, hipStream_t s);
+
+struct AtomArgs {
+  const float* x;          // [n_atom,128] input rows (context of previous layer, or the LUT)
+  const int32_t* x_index;  // optional row indirection (layer 0: atomic number -> LUT row) or null
+  int32_t n_atom;
+  // ResidualNorm (ffn != 0): c = LN(x + W2 swish(W1 x + b1) + b2)
+  int32_t ffn;
+  const float *Wf1p, *bf1, *Wf2p, *bf2, *lnr_g, *lnr_b;
+  float* c;                // [n_atom,128] centres out (always written)
+  // projections
+  int32_t mode;            // 0: P1,P3,q (g_update)  1: q only (base)  2: readout (after_Lc -> gq, gk)
+  const float *WAp, *bA;   // mode 0: W1p,bg   | mode 2: after_Lc
+  const float *WBp;        // mode 0: W3p
+  const float *WCp, *bC;   // mode 0/1: Wq,bq  | mode 2: ga query
+  const float *WDp, *bD;   // mode 2: ga key
+  float *oA, *oB, *oC;     // mode 0: P1,P3,q | mode 1: -, -, q | mode 2: -, gk, gq
+};
+void launch_atom(const AtomArgs& a, hipStream_t s);
+
+struct EdgeArgs {
+  const EdgeTile* tiles;
+  int32_t n_tile;
+  int32_t g_update;
+  const int32_t* edge_offset;  // [n_atom+1]
+  const int32_t* edge_col;     // [n_edge]
+  const int32_t* edge_row;     // [n_edge] centre atom of each edge
+  float* geom;                 // [n_edge,128] in/out (g_update)
+  const float* gd;             // [n_edge,20] raw distance basis (base)
+  const float* edge_weight;    // [n_edge] (base)
+  const float *c, *P1, *P3, *q;  // [n_atom,128]
+  float* ctx;                  // [n_atom,128] out: LayerNorm(context)
+  LayerParams p;
+};
+void launch_edge(const EdgeArgs& a, hipStream_t s);
+
+struct ReadoutArgs {
+  const int32_t* mol_offset;  // [n_struct+1]
+  int32_t n_struct;
+  int32_t max_atoms;          // largest structure (sizes the dynamic LDS score buffer)
+  const float *gq, *gk;       // [n_atom,128]
+  int32_t use_ga_norm, relu_out;
+  HeadParams p;
+  float* ga_attn;             // [n_atom]
+  float* y;                   // [n_struct]
+};
+void launch_readout(const ReadoutArgs& a, hipStream_t s);
+
+// Host-side permutation of a row-major [128,128] (in,out) kernel into MFMA fragment order.
+void pack_weight(const float* W, int ld, float* Wp);
+
+}  // namespace scann

@@ -1,0 +1,608 @@
+// Hand-written CDNA4 (gfx950) kernels for the SCANN / SCANN+ forward hot path.
+//
+// Layout: structures are packed -- atoms [n_atom,128] and CSR edges [n_edge,128] -- so
+// the reference's padded [B,M,N,d] tensors (attention.py:136-212) are never materialised.  Every
+// dense projection is an fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, one k-ordered fma chain)
+// of a row tile staged in LDS against a 128x128 weight that each wave streams straight from
+// L2/HBM into registers in fragment order (no LDS staging of weights: a wave owns 32 output columns,
+// so every weight element is read by exactly one wave of the workgroup).
+//
+// Kernels (one launch each per LocalAttention iteration, see scann_runtime.cpp: run_forward):
+//   atom_kernel   : [ResidualNorm of previous layer] -> centres c; P1 = c W1 + bg, P3 = c W3, q = c Wq + bq
+//                   (attention.py:37-40, :160, and the centre/neighbour thirds of filter_geo :142-151)
+//   edge_kernel   : per tile of <=64 edges (whole atoms): U = G W2 (MFMA); geom' = LN_g(swish(U+P1[i]+P3[j])+G)
+//                   (:141-153); ang = c[j]*geom' (:136,:157); K = ang Wk + bk (MFMA, :163);
+//                   per (atom, head) softmax over its edges and ctx = LN(sum attn K + q) (:180-214)
+//   readout_kernel: GlobalAttention + bf_property + predict_property (attention.py:267-318,
+//                   scann_model.py:437-447), one workgroup per structure
+//   basis_kernel  : Gaussian expansion + neighbor_d/neighbor_w MLP (custom_layers.py:63-65,
+//                   scann_model.py:378-389)
+#include "scann_internal.h"
+
+namespace scann {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float swishf(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4swish(float4 a) { return make_float4(swishf(a.x), swishf(a.y), swishf(a.z), swishf(a.w)); }
+__device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+// ---- MFMA GEMM of a staged row tile against one packed 128x128 weight ---------------------------
+//
+// acc[rt] (32 rows x 32 cols per wave) += X[32*rt .. 32*rt+31][0..127] . W[0..127][32*wave .. +31]
+//
+// v_mfma_f32_32x32x2_f32 operand map: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+// The k order is ours to choose as long as A and B agree: k-step (t, i), lane half h <-> k = 8t + 4h + i,
+// so a lane's A operands for four consecutive steps are one 16-byte LDS read and its B operands one
+// 16-byte global read.  Packed weight element ((w*16 + t)*64 + lane)*4 + i = W[8t + 4(lane>>5) + i][32w + (lane&31)].
+template <int RT>
+__device__ __forceinline__ void gemm128(const float* __restrict__ sX, const float* __restrict__ Wp, int wave,
+                                        int lane, f32x16 (&acc)[RT]) {
+  const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + wave * (16 * 64) + lane;
+  float4 w[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) w[t] = wsrc[t * 64];
+  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[rt], 0, 0, 0);
+    }
+  }
+}
+
+template <int RT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT]) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[rt][i] = 0.0f;
+}
+
+// C/D map of the 32x32 MFMA: register i of lane l holds row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31.
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// ---- atom-tile kernel ------------------------------------------------------------------------------
+
+template <bool FFN, int MODE>
+__global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
+  __shared__ __attribute__((aligned(16))) float sX[TA * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sH[TA * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * TA;
+  const int nrows = min(TA, a.n_atom - row0);
+  const int col = 32 * wave + (lane & 31);
+
+  // stage x rows (zero-fill the ragged tail so the MFMAs see defined data)
+  for (int i = tid; i < TA * 32; i += 256) {
+    const int r = i >> 5, c4 = i & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows) {
+      const int src = a.x_index ? a.x_index[row0 + r] : (row0 + r);
+      v = reinterpret_cast<const float4*>(a.x)[(size_t)src * 32 + c4];
+    }
+    *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
+  }
+  __syncthreads();
+
+  f32x16 acc[1];
+  if (FFN) {
+    // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
+    zero_acc(acc);
+    gemm128<1>(sX, a.Wf1p, wave, lane, acc);
+    {
+      const float b = a.bf1[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b);
+    }
+    __syncthreads();
+    // y = h W2 + b2 ; t = x + y
+    zero_acc(acc);
+    gemm128<1>(sH, a.Wf2p, wave, lane, acc);
+    __syncthreads();  // every wave is done reading sH
+    {
+      const float b = a.bf2[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = acc_row(i, lane);
+        sH[r * LDS_STRIDE + col] = sX[r * LDS_STRIDE + col] + (acc[0][i] + b);
+      }
+    }
+    __syncthreads();
+    // c = LayerNorm(t): 8 threads per row, 4 float4 each
+    {
+      const int r = tid >> 3, sub = tid & 7;
+      float4 t[4];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        t[i] = *reinterpret_cast<const float4*>(&sH[r * LDS_STRIDE + 4 * (sub + 8 * i)]);
+        s += f4sum(t[i]);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * (1.0f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = sub + 8 * i;
+        const float4 g = reinterpret_cast<const float4*>(a.lnr_g)[c4];
+        const float4 be = reinterpret_cast<const float4*>(a.lnr_b)[c4];
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
+        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
+        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
+        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
+        *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = y;
+        if (r < nrows) reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] = y;
+      }
+    }
+    __syncthreads();
+  } else {
+    // centres are the staged rows themselves (layer 0, or use_attn_norm False)
+    for (int i = tid; i < TA * 32; i += 256) {
+      const int r = i >> 5, c4 = i & 31;
+      if (r < nrows)
+        reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] =
+            *reinterpret_cast<const float4*>(&sX[r * LDS_STRIDE + 4 * c4]);
+    }
+  }
+
+  if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3
+    zero_acc(acc);
+    gemm128<1>(sX, a.WAp, wave, lane, acc);
+    const float b = a.bA[col];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = acc_row(i, lane);
+      if (r < nrows) a.oA[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+    }
+    zero_acc(acc);
+    gemm128<1>(sX, a.WBp, wave, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = acc_row(i, lane);
+      if (r < nrows) a.oB[(size_t)(row0 + r) * D + col] = acc[0][i];
+    }
+  }
+  if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
+    zero_acc(acc);
+    gemm128<1>(sX, a.WCp, wave, lane, acc);
+    const float b = a.bC[col];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = acc_row(i, lane);
+      if (r < nrows) a.oC[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+    }
+  }
+  if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
+    zero_acc(acc);
+    gemm128<1>(sX, a.WAp, wave, lane, acc);
+    {
+      const float b = a.bA[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b);
+    }
+    __syncthreads();
+    zero_acc(acc);
+    gemm128<1>(sH, a.WCp, wave, lane, acc);
+    {
+      const float b = a.bC[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = acc_row(i, lane);
+        if (r < nrows) a.oC[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+      }
+    }
+    zero_acc(acc);
+    gemm128<1>(sH, a.WDp, wave, lane, acc);
+    {
+      const float b = a.bD[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = acc_row(i, lane);
+        if (r < nrows) a.oB[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+      }
+    }
+  }
+}
+
+void launch_atom(const AtomArgs& a, hipStream_t s) {
+  if (a.n_atom <= 0) return;
+  const dim3 grid((a.n_atom + TA - 1) / TA), block(256);
+#define SCANN_ATOM_CASE(F, M) hipLaunchKernelGGL((atom_kernel<F, M>), grid, block, 0, s, a)
+  if (a.ffn) {
+    if (a.mode == 0) SCANN_ATOM_CASE(true, 0);
+    else if (a.mode == 1) SCANN_ATOM_CASE(true, 1);
+    else SCANN_ATOM_CASE(true, 2);
+  } else {
+    if (a.mode == 0) SCANN_ATOM_CASE(false, 0);
+    else if (a.mode == 1) SCANN_ATOM_CASE(false, 1);
+    else SCANN_ATOM_CASE(false, 2);
+  }
+#undef SCANN_ATOM_CASE
+}
+
+// ---- edge-tile kernel ------------------------------------------------------------------------------
+
+template <bool GUPD>
+__global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
+  __shared__ __attribute__((aligned(16))) float sA[TE * LDS_STRIDE];  // G, then ang = c[j]*geom'
+  __shared__ __attribute__((aligned(16))) float sB[TE * LDS_STRIDE];  // U = G W2, then K
+  __shared__ int sCol[TE], sCtr[TE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const EdgeTile tile = a.tiles[blockIdx.x];
+  const int eb = tile.edge_begin;
+  const int ne = tile.edge_end - eb;
+  const int col = 32 * wave + (lane & 31);
+
+  if (tid < TE) {
+    sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
+    sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
+  }
+  f32x16 acc[2];
+  if (GUPD) {
+    for (int i = tid; i < TE * 32; i += 256) {
+      const int r = i >> 5, c4 = i & 31;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < ne) v = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
+      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = v;
+    }
+    __syncthreads();
+    // U = G . W2  (geometry third of the concat GEMM, attention.py:142-151)
+    zero_acc(acc);
+    gemm128<2>(sA, a.p.W2p, wave, lane, acc);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i];
+  }
+  __syncthreads();
+
+  // Row pass, 4 threads per edge row: geometry update + LayerNorm_g, gate with the gathered neighbour row.
+  {
+    const int r = tid >> 2, sub = tid & 3;
+    if (r < ne) {
+      const int ctr = sCtr[r], nb = sCol[r];
+      const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
+      if (GUPD) {
+        const float4* p1 = reinterpret_cast<const float4*>(a.P1) + (size_t)ctr * 32;
+        const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
+        float4 t[8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c4 = sub + 4 * i;
+          const float4 u = *reinterpret_cast<const float4*>(&sB[r * LDS_STRIDE + 4 * c4]);
+          const float4 g = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
+          // concat order [centre, geometry, neighbour] (attention.py:143-149): (c_i W1 + b) + g W2 + c_j W3
+          const float4 v = f4add(f4add(p1[c4], u), p3[c4]);
+          t[i] = f4add(f4swish(v), g);  // geometry_update + neighbor_geometry (:153)
+          s += f4sum(t[i]);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+          v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c4 = sub + 4 * i;
+          const float4 g = reinterpret_cast<const float4*>(a.p.lng_g)[c4];
+          const float4 be = reinterpret_cast<const float4*>(a.p.lng_b)[c4];
+          float4 y;
+          float inv;
+          inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
+          inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
+          inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
+          inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
+          reinterpret_cast<float4*>(a.geom)[(size_t)(eb + r) * 32 + c4] = y;  // threaded to the next layer (scann_model.py:415)
+          *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(crow[c4], y);  // attention.py:157
+        }
+      } else {
+        // base SCANN: geomL = swish(gd Wf + bf) * weight (attention.py:155), gd = raw Gaussian basis
+        float gd[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) gd[k] = a.gd[(size_t)(eb + r) * NG + k];
+        const float wgt = a.edge_weight[eb + r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c4 = sub + 4 * i;
+          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int k = 0; k < NG; ++k) {
+            const float4 wv = reinterpret_cast<const float4*>(a.p.Wfg)[k * 32 + c4];
+            acc4.x += gd[k] * wv.x; acc4.y += gd[k] * wv.y; acc4.z += gd[k] * wv.z; acc4.w += gd[k] * wv.w;
+          }
+          const float4 bv = reinterpret_cast<const float4*>(a.p.bfg)[c4];
+          float4 y = f4swish(f4add(acc4, bv));
+          y.x *= wgt; y.y *= wgt; y.z *= wgt; y.w *= wgt;
+          *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(crow[c4], y);
+        }
+      }
+    } else if (!GUPD) {
+      // ragged tail rows must be defined for the MFMA (GUPD staged zeros already)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+
+  // K = ang . Wk + bk  (attention.py:163)
+  zero_acc(acc);
+  gemm128<2>(sA, a.p.Wkp, wave, lane, acc);
+  {
+    const float b = a.p.bk[col];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + b;
+  }
+  __syncthreads();
+
+  // Attention, one wave per atom; lane l owns features 2l, 2l+1 (head l>>3).  Packed edges are all
+  // unmasked, so the additive -1e9 mask and the multiplicative mask (attention.py:186,206) are the
+  // identity here; an atom without edges reduces to ctx = LN(q), as the fully-masked row does.
+  const float2 lg = reinterpret_cast<const float2*>(a.p.ln_g)[lane];
+  const float2 lb = reinterpret_cast<const float2*>(a.p.ln_b)[lane];
+  for (int at = tile.atom_begin + wave; at < tile.atom_end; at += 4) {
+    const int e0 = a.edge_offset[at] - eb, e1 = a.edge_offset[at + 1] - eb;
+    const float2 q2 = reinterpret_cast<const float2*>(a.q)[(size_t)at * 64 + lane];
+    const float qx = q2.x * 0.25f, qy = q2.y * 0.25f;  // dk = hdim^-0.5 (attention.py:180-181)
+    float m = -INFINITY;
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = *reinterpret_cast<const float2*>(&sB[n * LDS_STRIDE + 2 * lane]);
+      float e = qx * k2.x + qy * k2.y;
+      e += __shfl_xor(e, 1);
+      e += __shfl_xor(e, 2);
+      e += __shfl_xor(e, 4);
+      m = fmaxf(m, e);
+    }
+    float ssum = 0.f;
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = *reinterpret_cast<const float2*>(&sB[n * LDS_STRIDE + 2 * lane]);
+      float e = qx * k2.x + qy * k2.y;
+      e += __shfl_xor(e, 1);
+      e += __shfl_xor(e, 2);
+      e += __shfl_xor(e, 4);
+      ssum += expf(e - m);
+    }
+    float cx = 0.f, cy = 0.f;
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = *reinterpret_cast<const float2*>(&sB[n * LDS_STRIDE + 2 * lane]);
+      float e = qx * k2.x + qy * k2.y;
+      e += __shfl_xor(e, 1);
+      e += __shfl_xor(e, 2);
+      e += __shfl_xor(e, 4);
+      const float attn = expf(e - m) / ssum;  // tf.nn.softmax (:189)
+      cx += attn * k2.x;                      // v = key (:198-206)
+      cy += attn * k2.y;
+    }
+    cx += q2.x;  // residual is the unscaled query (:212)
+    cy += q2.y;
+    float s = cx + cy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    const float dx = cx - mean, dy = cy - mean;
+    float v = dx * dx + dy * dy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+    float2 y;
+    float inv;
+    inv = rstd * lg.x; y.x = cx * inv + (lb.x - mean * inv);
+    inv = rstd * lg.y; y.y = cy * inv + (lb.y - mean * inv);
+    reinterpret_cast<float2*>(a.ctx)[(size_t)at * 64 + lane] = y;  // layer_norm (:214)
+  }
+}
+
+void launch_edge(const EdgeArgs& a, hipStream_t s) {
+  if (a.n_tile <= 0) return;
+  const dim3 grid(a.n_tile), block(256);
+  if (a.g_update) hipLaunchKernelGGL((edge_kernel<true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((edge_kernel<false>), grid, block, 0, s, a);
+}
+
+// ---- basis kernel ----------------------------------------------------------------------------------
+
+// exp(-(x - c)^2 / 0.25)  (custom_layers.py:63-65, width 0.5 squared at :51)
+__device__ __forceinline__ float gauss(float x, float c) {
+  const float d = x - c;
+  return expf(-(d * d) / 0.25f);
+}
+
+__global__ __launch_bounds__(256) void basis_kernel(BasisParams p, const float* __restrict__ dist,
+                                                    const float* __restrict__ weight, int n_edge,
+                                                    float* __restrict__ geom) {
+  __shared__ float sG[TB][2 * NG];
+  const int tid = threadIdx.x;
+  const int e0 = blockIdx.x * TB;
+  const int ne = min(TB, n_edge - e0);
+  for (int i = tid; i < TB * 2 * NG; i += 256) {
+    const int e = i / (2 * NG), k = i % (2 * NG);
+    float v = 0.f;
+    if (e < ne) v = k < NG ? gauss(dist[e0 + e], p.cd[k]) : gauss(weight[e0 + e], p.cw[k - NG]);
+    sG[e][k] = v;
+  }
+  __syncthreads();
+  const int col = tid & (D - 1), half = tid >> 7;
+  float wd[NG], ww[NG];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    wd[k] = p.Wd[k * D + col];
+    ww[k] = p.Ww[k * D + col];
+  }
+  const float bd = p.bd[col], bw = p.bw[col];
+  for (int e = half * (TB / 2); e < (half + 1) * (TB / 2); ++e) {
+    if (e >= ne) break;
+    float ad = 0.f, aw = 0.f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      ad += sG[e][k] * wd[k];
+      aw += sG[e][NG + k] * ww[k];
+    }
+    // neighbor_d * neighbor_w (scann_model.py:381-389)
+    geom[(size_t)(e0 + e) * D + col] = swishf(ad + bd) * swishf(aw + bw);
+  }
+}
+
+__global__ void basis_raw_kernel(const float* __restrict__ cd, const float* __restrict__ dist, int n_edge,
+                                 float* __restrict__ gd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_edge * NG) gd[i] = gauss(dist[i / NG], cd[i % NG]);
+}
+
+void launch_basis(const BasisParams& p, const float* dist, const float* weight, int n_edge, float* geom,
+                  hipStream_t s) {
+  if (n_edge <= 0) return;
+  hipLaunchKernelGGL(basis_kernel, dim3((n_edge + TB - 1) / TB), dim3(256), 0, s, p, dist, weight, n_edge, geom);
+}
+
+void launch_basis_raw(const float* cd, const float* dist, int n_edge, float* gd, hipStream_t s) {
+  if (n_edge <= 0) return;
+  const int n = n_edge * NG;
+  hipLaunchKernelGGL(basis_raw_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cd, dist, n_edge, gd);
+}
+
+// ---- embedding LUT (weight-load time) ----------------------------------------------------------------
+
+// lut[s,:] = swish(E[s,:] . W + b): Embedding (scann_model.py:362) followed by dense_embed (:373) has only
+// n_atoms distinct results, so it is folded into a table when weights are loaded.
+__global__ void embed_lut_kernel(const float* __restrict__ emb, const float* __restrict__ W,
+                                 const float* __restrict__ b, int emb_dim, float* __restrict__ lut) {
+  const int sp = blockIdx.x, col = threadIdx.x;
+  float acc = 0.f;
+  for (int k = 0; k < emb_dim; ++k) acc += emb[sp * emb_dim + k] * W[k * D + col];
+  lut[sp * D + col] = swishf(acc + b[col]);
+}
+
+void launch_embed_lut(const float* emb, const float* W, const float* b, int n_species, int emb_dim, float* lut,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(embed_lut_kernel, dim3(n_species), dim3(D), 0, s, emb, W, b, emb_dim, lut);
+}
+
+// ---- readout kernel ----------------------------------------------------------------------------------
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// One workgroup per structure.  GlobalAttention.call (attention.py:267-318) on the real atoms only
+// (the multiplicative atom mask zeroes every padded term), literal sum over j != i.
+__global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
+  extern __shared__ float sAgg[];  // [n] scores, reused for attention
+  __shared__ float sRep[D];
+  __shared__ float sRed[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a0 = a.mol_offset[blockIdx.x];
+  const int n = a.mol_offset[blockIdx.x + 1] - a0;
+  const float2* gq = reinterpret_cast<const float2*>(a.gq) + (size_t)a0 * 64;
+  const float2* gk = reinterpret_cast<const float2*>(a.gk) + (size_t)a0 * 64;
+
+  // agg_i = sum_{j != i} k_i . q_j   (:279-292)
+  for (int i = wave; i < n; i += 4) {
+    const float2 k2 = gk[(size_t)i * 64 + lane];
+    float agg = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const float2 q2 = gq[(size_t)j * 64 + lane];
+      const float e = wave_sum(k2.x * q2.x + k2.y * q2.y);
+      if (j != i) agg += e;
+    }
+    if (lane == 0) sAgg[i] = agg;
+  }
+  __syncthreads();
+  // normalise + softmax over atoms by wave 0 (:295-302)
+  if (wave == 0) {
+    float nrm = 1.0f;
+    if (a.use_ga_norm) {
+      float ss = 0.f;
+      for (int i = lane; i < n; i += 64) ss += sAgg[i] * sAgg[i];
+      nrm = sqrtf(wave_sum(ss));  // tf.linalg.normalize: no epsilon (n == 1 -> 0/0 = NaN as in the reference)
+    }
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+      const float v = a.use_ga_norm ? sAgg[i] / nrm : sAgg[i];
+      sAgg[i] = v;
+      m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    float ss = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float e = expf(sAgg[i] - m);
+      sAgg[i] = e;
+      ss += e;
+    }
+    ss = wave_sum(ss);
+    for (int i = lane; i < n; i += 64) {
+      const float at = sAgg[i] / ss;
+      sAgg[i] = at;
+      a.ga_attn[a0 + i] = at;
+    }
+  }
+  __syncthreads();
+  // rep = sum_i attn_i k_i  (:314-316)
+  if (tid < D) {
+    float r = 0.f;
+    for (int i = 0; i < n; ++i) r += sAgg[i] * a.gk[(size_t)(a0 + i) * D + tid];
+    sRep[tid] = r;
+  }
+  __syncthreads();
+  // bf_property + predict_property (scann_model.py:437-447)
+  float part = 0.f;
+  if (tid < D) {
+    float h = 0.f;
+    for (int k = 0; k < D; ++k) h += sRep[k] * a.p.Wb[k * D + tid];
+    part = swishf(h + a.p.bb[tid]) * a.p.wo[tid];
+  }
+  part = wave_sum(part);
+  if (lane == 0) sRed[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    float y = (sRed[0] + sRed[1]) + a.p.bo[0];
+    if (a.relu_out) y = fmaxf(y, 0.f);  // mrelu forward (custom_layers.py:15)
+    a.y[blockIdx.x] = y;
+  }
+}
+
+void launch_readout(const ReadoutArgs& a, hipStream_t s) {
+  if (a.n_struct <= 0) return;
+  const size_t lds = (size_t)(a.max_atoms > 0 ? a.max_atoms : 1) * sizeof(float);
+  hipLaunchKernelGGL(readout_kernel, dim3(a.n_struct), dim3(256), lds, s, a);
+}
+
+}  // namespace scann

@@ -1,0 +1,648 @@
+// C-ABI runtime of libscann_hip.so (include/scann_hip.h): handle / weight container / packed-batch
+// residency / launch schedule of the forward graph built by the reference's create_model
+// (scann_model.py:329-453).  Host side only -- all arithmetic is in scann_kernels.hip.
+#include "../../include/scann_hip.h"
+#include "scann_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace scann;
+
+namespace {
+
+constexpr int NSTREAM = 4;
+thread_local std::string g_create_error;
+
+struct WeightSpec {
+  std::string name;
+  int64_t rows, cols;  // cols == 0: vector of length rows
+  int64_t numel() const { return cols ? rows * cols : rows; }
+};
+
+}  // namespace
+
+struct scann_handle {
+  scann_config_t cfg{};
+  int device = 0;
+  std::string err;
+  hipStream_t streams[NSTREAM]{};
+  std::vector<WeightSpec> specs;
+  bool loaded = false;
+  bool debug = false;
+  float* d_weights = nullptr;  // one arena with every device-side weight image
+  std::vector<LayerParams> layers;
+  HeadParams head{};
+  BasisParams basis{};
+  const float* lut = nullptr;  // [n_atoms,128] swish(Embedding . dense_embed)
+  const float* cd = nullptr;   // distance Gaussian centres
+};
+
+struct scann_dbatch {
+  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0;
+  char* arena = nullptr;  // inputs + workspace, one allocation
+  // inputs
+  int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
+  float *dist = nullptr, *weight = nullptr;
+  EdgeTile* tiles = nullptr;
+  // workspace
+  float *geom = nullptr, *gd = nullptr, *c = nullptr, *ctx = nullptr, *P1 = nullptr, *P3 = nullptr, *q = nullptr;
+  float *gq = nullptr, *gk = nullptr, *ga = nullptr, *y = nullptr;
+  // debug copies (allocated on demand)
+  float *dbg_c = nullptr, *dbg_g = nullptr, *dbg_ctx = nullptr;
+  int dbg_layers = -1;
+  int last_slot = 0;
+};
+
+namespace {
+
+int fail(scann_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                               \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(h, e_ == hipErrorOutOfMemory ? SCANN_ERR_OOM : SCANN_ERR_HIP,                       \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                 \
+  } while (0)
+
+// Canonical tensor list; mirrors create_model (scann_model.py:329-453) and the layer constructors
+// (attention.py:25-35, 95-113, 260-262).  Must stay in step with oracle/scann_oracle.py:weight_shapes.
+std::vector<WeightSpec> build_specs(const scann_config_t& c) {
+  std::vector<WeightSpec> s;
+  const int64_t d = c.local_dim, dg = c.global_dim, dout = c.dense_out, emb = c.embedding_dim;
+  if (c.feature_cgcnn) {
+    s.push_back({"embed_atom/kernel", 92, emb});
+    s.push_back({"embed_atom/bias", emb, 0});
+  } else {
+    s.push_back({"embed_atom/embeddings", c.n_atoms, emb});
+  }
+  int64_t cin = emb;
+  if (c.use_ring) {
+    s.push_back({"extra_embed/kernel", 2, 10});
+    s.push_back({"extra_embed/bias", 10, 0});
+    cin += 10;
+  }
+  s.push_back({"dense_embed/kernel", cin, d});
+  s.push_back({"dense_embed/bias", d, 0});
+  if (c.g_update) {
+    s.push_back({"neighbor_d/kernel", c.n_gauss, d});
+    s.push_back({"neighbor_d/bias", d, 0});
+    s.push_back({"neighbor_w/kernel", c.n_gauss, d});
+    s.push_back({"neighbor_w/bias", d, 0});
+  }
+  for (int i = 0; i < c.n_attention; ++i) {
+    const std::string p = "local_attention_" + std::to_string(i) + "/";
+    s.push_back({p + "query/kernel", d, d});
+    s.push_back({p + "query/bias", d, 0});
+    s.push_back({p + "key/kernel", d, d});
+    s.push_back({p + "key/bias", d, 0});
+    s.push_back({p + "filter_geo/kernel", c.g_update ? 3 * d : (int64_t)c.n_gauss, d});
+    s.push_back({p + "filter_geo/bias", d, 0});
+    s.push_back({p + "layer_norm/gamma", d, 0});
+    s.push_back({p + "layer_norm/beta", d, 0});
+    if (c.g_update) {
+      s.push_back({p + "layer_norm_g/gamma", d, 0});
+      s.push_back({p + "layer_norm_g/beta", d, 0});
+    }
+    if (c.use_attn_norm) {
+      const std::string r = "residual_norm_" + std::to_string(i) + "/";
+      s.push_back({r + "dense_1/kernel", d, d});
+      s.push_back({r + "dense_1/bias", d, 0});
+      s.push_back({r + "dense_2/kernel", d, d});
+      s.push_back({r + "dense_2/bias", d, 0});
+      s.push_back({r + "layer_norm/gamma", d, 0});
+      s.push_back({r + "layer_norm/beta", d, 0});
+    }
+  }
+  s.push_back({"after_Lc/kernel", d, dg});
+  s.push_back({"after_Lc/bias", dg, 0});
+  s.push_back({"global_attention/query/kernel", dg, dg});
+  s.push_back({"global_attention/query/bias", dg, 0});
+  s.push_back({"global_attention/key/kernel", dg, dg});
+  s.push_back({"global_attention/key/bias", dg, 0});
+  s.push_back({"bf_property/kernel", dg, dout});
+  s.push_back({"bf_property/bias", dout, 0});
+  s.push_back({"predict_property/kernel", dout, 1});
+  s.push_back({"predict_property/bias", 1, 0});
+  return s;
+}
+
+// np.linspace(0, stop, 20, dtype="float32") (scann_model.py:378,384): computed in double, cast once.
+void linspace20(double stop, float* out) {
+  const double step = stop / (NG - 1);
+  for (int i = 0; i < NG; ++i) out[i] = (float)(i * step);
+  out[NG - 1] = (float)stop;
+}
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+namespace scann {
+// Fragment order consumed by gemm128 (scann_kernels.hip): element ((w*16 + t)*64 + lane)*4 + i holds
+// W[8t + 4(lane>>5) + i][32w + (lane&31)].
+void pack_weight(const float* W, int ld, float* Wp) {
+  for (int w = 0; w < 4; ++w)
+    for (int t = 0; t < 16; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 4; ++i)
+          Wp[((size_t)(w * 16 + t) * 64 + lane) * 4 + i] = W[(size_t)(8 * t + 4 * (lane >> 5) + i) * ld + 32 * w + (lane & 31)];
+}
+}  // namespace scann
+
+extern "C" {
+
+int scann_abi_version(void) { return SCANN_ABI_VERSION; }
+
+int scann_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* scann_last_error(const scann_handle_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out) {
+  if (!cfg || !out) return fail(nullptr, SCANN_ERR_INVALID, "scann_create: null argument");
+  *out = nullptr;
+  if (cfg->local_dim != D || cfg->global_dim != D || cfg->dense_out != D || cfg->num_head != NHEAD || cfg->n_gauss != NG)
+    return fail(nullptr, SCANN_ERR_UNSUPPORTED,
+                "scann_create: kernels implement local_dim = global_dim = dense_out = 128, num_head = 8, 20 Gaussians "
+                "(every shipped reference config)");
+  if (cfg->use_ring || cfg->feature_cgcnn)
+    return fail(nullptr, SCANN_ERR_UNSUPPORTED, "scann_create: use_ring / feature=cgcnn inputs are not implemented yet");
+  if (cfg->n_atoms <= 0 || cfg->embedding_dim <= 0 || cfg->n_attention < 0 || !(cfg->gaussian_d > 0))
+    return fail(nullptr, SCANN_ERR_INVALID, "scann_create: bad hyper-parameter");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, SCANN_ERR_NO_DEVICE, "scann_create: no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, SCANN_ERR_NO_DEVICE, "scann_create: device_id out of range");
+  scann_handle* h = new scann_handle();
+  h->cfg = *cfg;
+  h->device = device_id;
+  h->specs = build_specs(*cfg);
+  if (hipSetDevice(device_id) != hipSuccess) {
+    delete h;
+    return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipSetDevice failed");
+  }
+  for (int i = 0; i < NSTREAM; ++i) {
+    if (hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking) != hipSuccess) {
+      delete h;
+      return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipStreamCreate failed");
+    }
+  }
+  *out = h;
+  return SCANN_OK;
+}
+
+void scann_destroy(scann_handle_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < NSTREAM; ++i)
+    if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
+  if (h->d_weights) (void)hipFree(h->d_weights);
+  delete h;
+}
+
+int scann_num_streams(const scann_handle_t*) { return NSTREAM; }
+
+int scann_weight_count(const scann_handle_t* h) { return h ? (int)h->specs.size() : SCANN_ERR_INVALID; }
+
+int scann_weight_name(const scann_handle_t* h, int index, const char** name, int64_t* rows, int64_t* cols) {
+  if (!h || index < 0 || index >= (int)h->specs.size()) return SCANN_ERR_INVALID;
+  if (name) *name = h->specs[index].name.c_str();
+  if (rows) *rows = h->specs[index].rows;
+  if (cols) *cols = h->specs[index].cols;
+  return SCANN_OK;
+}
+
+int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_desc_t* manifest, int n) {
+  if (!h || !blob || !manifest || n <= 0) return fail(h, SCANN_ERR_INVALID, "scann_load_weights: null argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::map<std::string, const scann_tensor_desc_t*> by_name;
+  for (int i = 0; i < n; ++i)
+    if (manifest[i].name) by_name[manifest[i].name] = &manifest[i];
+  std::map<std::string, const float*> src;
+  for (const WeightSpec& s : h->specs) {
+    auto it = by_name.find(s.name);
+    if (it == by_name.end()) return fail(h, SCANN_ERR_WEIGHTS, "scann_load_weights: missing tensor " + s.name);
+    if (it->second->numel != s.numel() || it->second->offset < 0)
+      return fail(h, SCANN_ERR_WEIGHTS, "scann_load_weights: wrong size for tensor " + s.name);
+    src[s.name] = blob + it->second->offset;
+  }
+  const scann_config_t& c = h->cfg;
+  const int L = c.n_attention;
+  // host image of the device arena
+  std::vector<float> img;
+  img.reserve((size_t)(L * 8 + 8) * WPACK);
+  auto put_raw = [&](const float* p, size_t numel) {
+    const size_t off = img.size();
+    img.insert(img.end(), p, p + numel);
+    while (img.size() % 64) img.push_back(0.f);  // keep every tensor 256-byte aligned
+    return off;
+  };
+  auto put_packed = [&](const float* W) {  // W: row-major [128,128] slice, leading dim 128
+    const size_t off = img.size();
+    img.resize(off + WPACK);
+    pack_weight(W, D, img.data() + off);
+    return off;
+  };
+  struct LOff {
+    size_t W1p, W3p, bg, Wqp, bq, W2p, Wkp, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, Wf1p, bf1, Wf2p, bf2, lnr_g, lnr_b;
+  };
+  std::vector<LOff> lo(L);
+  const size_t NONE = (size_t)-1;
+  for (int i = 0; i < L; ++i) {
+    const std::string p = "local_attention_" + std::to_string(i) + "/";
+    LOff& o = lo[i];
+    o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
+    const float* fg = src[p + "filter_geo/kernel"];
+    if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
+      o.W1p = put_packed(fg);
+      o.W2p = put_packed(fg + (size_t)D * D);
+      o.W3p = put_packed(fg + (size_t)2 * D * D);
+      o.bg = put_raw(src[p + "filter_geo/bias"], D);
+      o.lng_g = put_raw(src[p + "layer_norm_g/gamma"], D);
+      o.lng_b = put_raw(src[p + "layer_norm_g/beta"], D);
+    } else {
+      o.Wfg = put_raw(fg, (size_t)NG * D);
+      o.bfg = put_raw(src[p + "filter_geo/bias"], D);
+    }
+    o.Wqp = put_packed(src[p + "query/kernel"]);
+    o.bq = put_raw(src[p + "query/bias"], D);
+    o.Wkp = put_packed(src[p + "key/kernel"]);
+    o.bk = put_raw(src[p + "key/bias"], D);
+    o.ln_g = put_raw(src[p + "layer_norm/gamma"], D);
+    o.ln_b = put_raw(src[p + "layer_norm/beta"], D);
+    if (c.use_attn_norm) {
+      const std::string r = "residual_norm_" + std::to_string(i) + "/";
+      o.Wf1p = put_packed(src[r + "dense_1/kernel"]);
+      o.bf1 = put_raw(src[r + "dense_1/bias"], D);
+      o.Wf2p = put_packed(src[r + "dense_2/kernel"]);
+      o.bf2 = put_raw(src[r + "dense_2/bias"], D);
+      o.lnr_g = put_raw(src[r + "layer_norm/gamma"], D);
+      o.lnr_b = put_raw(src[r + "layer_norm/beta"], D);
+    }
+  }
+  const size_t oWa = put_packed(src["after_Lc/kernel"]), oba = put_raw(src["after_Lc/bias"], D);
+  const size_t oWgq = put_packed(src["global_attention/query/kernel"]), obgq = put_raw(src["global_attention/query/bias"], D);
+  const size_t oWgk = put_packed(src["global_attention/key/kernel"]), obgk = put_raw(src["global_attention/key/bias"], D);
+  const size_t oWb = put_raw(src["bf_property/kernel"], (size_t)D * D), obb = put_raw(src["bf_property/bias"], D);
+  const size_t owo = put_raw(src["predict_property/kernel"], D), obo = put_raw(src["predict_property/bias"], 1);
+  size_t oWd = NONE, obd = NONE, oWw = NONE, obw = NONE;
+  if (c.g_update) {
+    oWd = put_raw(src["neighbor_d/kernel"], (size_t)NG * D);
+    obd = put_raw(src["neighbor_d/bias"], D);
+    oWw = put_raw(src["neighbor_w/kernel"], (size_t)NG * D);
+    obw = put_raw(src["neighbor_w/bias"], D);
+  }
+  float cen[2 * NG];
+  linspace20((double)c.gaussian_d, cen);
+  linspace20(M_PI * 2.0, cen + NG);
+  const size_t ocd = put_raw(cen, NG), ocw = put_raw(cen + NG, NG);
+  const size_t oemb = put_raw(src["embed_atom/embeddings"], (size_t)c.n_atoms * c.embedding_dim);
+  const size_t oWe = put_raw(src["dense_embed/kernel"], (size_t)c.embedding_dim * D);
+  const size_t obe = put_raw(src["dense_embed/bias"], D);
+  const size_t olut = img.size();
+  img.resize(olut + (size_t)c.n_atoms * D, 0.f);
+
+  if (h->d_weights) {
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipFree(h->d_weights));
+    h->d_weights = nullptr;
+    h->loaded = false;
+  }
+  HIPCHK(h, hipMalloc((void**)&h->d_weights, img.size() * sizeof(float)));
+  HIPCHK(h, hipMemcpy(h->d_weights, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  const float* base = h->d_weights;
+  auto P = [&](size_t off) -> const float* { return off == NONE ? nullptr : base + off; };
+  h->layers.assign(L, LayerParams{});
+  for (int i = 0; i < L; ++i) {
+    const LOff& o = lo[i];
+    LayerParams& lp = h->layers[i];
+    lp.W1p = P(o.W1p); lp.W3p = P(o.W3p); lp.bg = P(o.bg);
+    lp.Wqp = P(o.Wqp); lp.bq = P(o.bq);
+    lp.W2p = P(o.W2p); lp.Wkp = P(o.Wkp); lp.bk = P(o.bk);
+    lp.lng_g = P(o.lng_g); lp.lng_b = P(o.lng_b); lp.ln_g = P(o.ln_g); lp.ln_b = P(o.ln_b);
+    lp.Wfg = P(o.Wfg); lp.bfg = P(o.bfg);
+    lp.Wf1p = P(o.Wf1p); lp.bf1 = P(o.bf1); lp.Wf2p = P(o.Wf2p); lp.bf2 = P(o.bf2);
+    lp.lnr_g = P(o.lnr_g); lp.lnr_b = P(o.lnr_b);
+  }
+  h->head = HeadParams{P(oWa), P(oba), P(oWgq), P(obgq), P(oWgk), P(obgk), P(oWb), P(obb), P(owo), P(obo)};
+  h->basis = BasisParams{P(oWd), P(obd), P(oWw), P(obw), P(ocd), P(ocw)};
+  h->cd = P(ocd);
+  h->lut = P(olut);
+  // Embedding + dense_embed folded into a per-species table, computed on the device.
+  launch_embed_lut(P(oemb), P(oWe), P(obe), c.n_atoms, c.embedding_dim, h->d_weights + olut, h->streams[0]);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  h->loaded = true;
+  return SCANN_OK;
+}
+
+int scann_set_debug(scann_handle_t* h, int on) {
+  if (!h) return SCANN_ERR_INVALID;
+  h->debug = on != 0;
+  return SCANN_OK;
+}
+
+void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
+  if (!db) return;
+  if (h) (void)hipSetDevice(h->device);
+  if (h) (void)hipDeviceSynchronize();
+  if (db->arena) (void)hipFree(db->arena);
+  if (db->dbg_c) (void)hipFree(db->dbg_c);
+  if (db->dbg_g) (void)hipFree(db->dbg_g);
+  if (db->dbg_ctx) (void)hipFree(db->dbg_ctx);
+  delete db;
+}
+
+int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t** out) {
+  if (!h || !b || !out) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: null argument");
+  *out = nullptr;
+  const int32_t B = b->n_struct, A = b->n_atom, E = b->n_edge;
+  if (B <= 0 || A <= 0 || E < 0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: empty batch");
+  if (!b->atomic || !b->mol_offset || !b->edge_offset || (E > 0 && (!b->edge_col || !b->edge_dist || !b->edge_weight)))
+    return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: null array");
+  if (b->mol_offset[0] != 0 || b->mol_offset[B] != A || b->edge_offset[0] != 0 || b->edge_offset[A] != E)
+    return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: offsets do not cover the batch");
+  int32_t max_atoms = 0;
+  for (int s = 0; s < B; ++s) {
+    const int32_t n = b->mol_offset[s + 1] - b->mol_offset[s];
+    if (n <= 0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: structure without atoms");
+    max_atoms = std::max(max_atoms, n);
+  }
+  if ((size_t)max_atoms * sizeof(float) > 60000) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: structure too large");
+  for (int a = 0; a < A; ++a)
+    if (b->atomic[a] < 0 || b->atomic[a] >= h->cfg.n_atoms)
+      return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: atomic number outside the embedding table (n_atoms)");
+  std::vector<int32_t> edge_row((size_t)E);
+  std::vector<EdgeTile> tiles;
+  {
+    int s = 0;
+    EdgeTile cur{0, 0, 0, 0};
+    for (int a = 0; a < A; ++a) {
+      while (a >= b->mol_offset[s + 1]) ++s;
+      const int32_t e0 = b->edge_offset[a], e1 = b->edge_offset[a + 1];
+      if (e1 < e0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: edge_offset not monotone");
+      if (e1 - e0 > TE)
+        return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: an atom has more than 64 neighbours (edge-tile limit)");
+      for (int e = e0; e < e1; ++e) {
+        if (b->edge_col[e] < b->mol_offset[s] || b->edge_col[e] >= b->mol_offset[s + 1])
+          return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: neighbour index outside its structure");
+        edge_row[e] = a;
+      }
+      // greedy tiling: whole atoms, <= TE edges and <= TA atoms per tile
+      if ((e1 - cur.edge_begin) > TE || (a - cur.atom_begin) >= TA) {
+        cur.atom_end = a;
+        cur.edge_end = e0;
+        tiles.push_back(cur);
+        cur = EdgeTile{a, a, e0, e0};
+      }
+    }
+    cur.atom_end = A;
+    cur.edge_end = E;
+    tiles.push_back(cur);
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  scann_dbatch* db = new scann_dbatch();
+  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms;
+  // arena layout: inputs first (one H2D copy), then workspace
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
+  const size_t o_atomic = take((size_t)A * 4), o_mol = take((size_t)(B + 1) * 4), o_eoff = take((size_t)(A + 1) * 4);
+  const size_t o_col = take((size_t)E * 4), o_row = take((size_t)E * 4), o_dist = take((size_t)E * 4), o_wgt = take((size_t)E * 4);
+  const size_t o_tiles = take(tiles.size() * sizeof(EdgeTile));
+  const size_t in_bytes = off;
+  const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
+  const size_t o_geom = take(h->cfg.g_update ? rowE : 0), o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
+  const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
+  const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
+  hipError_t e = hipMalloc((void**)&db->arena, off);
+  if (e != hipSuccess) {
+    delete db;
+    return fail(h, e == hipErrorOutOfMemory ? SCANN_ERR_OOM : SCANN_ERR_HIP, std::string("hipMalloc(batch arena): ") + hipGetErrorString(e));
+  }
+  std::vector<char> img(in_bytes, 0);
+  memcpy(img.data() + o_atomic, b->atomic, (size_t)A * 4);
+  memcpy(img.data() + o_mol, b->mol_offset, (size_t)(B + 1) * 4);
+  memcpy(img.data() + o_eoff, b->edge_offset, (size_t)(A + 1) * 4);
+  if (E > 0) {
+    memcpy(img.data() + o_col, b->edge_col, (size_t)E * 4);
+    memcpy(img.data() + o_row, edge_row.data(), (size_t)E * 4);
+    memcpy(img.data() + o_dist, b->edge_dist, (size_t)E * 4);
+    memcpy(img.data() + o_wgt, b->edge_weight, (size_t)E * 4);
+  }
+  memcpy(img.data() + o_tiles, tiles.data(), tiles.size() * sizeof(EdgeTile));
+  e = hipMemcpy(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(db->arena);
+    delete db;
+    return fail(h, SCANN_ERR_HIP, std::string("hipMemcpy(batch inputs): ") + hipGetErrorString(e));
+  }
+  char* a0 = db->arena;
+  db->atomic = (int32_t*)(a0 + o_atomic); db->mol_offset = (int32_t*)(a0 + o_mol); db->edge_offset = (int32_t*)(a0 + o_eoff);
+  db->edge_col = (int32_t*)(a0 + o_col); db->edge_row = (int32_t*)(a0 + o_row);
+  db->dist = (float*)(a0 + o_dist); db->weight = (float*)(a0 + o_wgt); db->tiles = (EdgeTile*)(a0 + o_tiles);
+  db->geom = (float*)(a0 + o_geom); db->gd = (float*)(a0 + o_gd);
+  db->c = (float*)(a0 + o_c); db->ctx = (float*)(a0 + o_ctx); db->P1 = (float*)(a0 + o_P1); db->P3 = (float*)(a0 + o_P3);
+  db->q = (float*)(a0 + o_q); db->gq = (float*)(a0 + o_gq); db->gk = (float*)(a0 + o_gk);
+  db->ga = (float*)(a0 + o_ga); db->y = (float*)(a0 + o_y);
+  *out = db;
+  return SCANN_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Timer {
+  hipStream_t s;
+  bool on;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> kind;
+  void mark(int k) {
+    if (!on) return;
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    (void)hipEventRecord(e, s);
+    ev.push_back(e);
+    kind.push_back(k);
+  }
+};
+
+int ensure_debug(scann_handle* h, scann_dbatch* db) {
+  const int L = h->cfg.n_attention;
+  if (db->dbg_layers == L) return SCANN_OK;
+  HIPCHK(h, hipMalloc((void**)&db->dbg_c, (size_t)(L + 1) * db->n_atom * D * 4));
+  HIPCHK(h, hipMalloc((void**)&db->dbg_ctx, (size_t)std::max(L, 1) * db->n_atom * D * 4));
+  if (h->cfg.g_update) HIPCHK(h, hipMalloc((void**)&db->dbg_g, (size_t)(L + 1) * std::max(db->n_edge, 1) * D * 4));
+  db->dbg_layers = L;
+  return SCANN_OK;
+}
+
+// The forward graph of create_model (scann_model.py:362-447) as a launch schedule on one stream.
+// kind codes for the timer: 0 basis, 1 atom, 2 edge, 3 readout.
+int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
+  if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
+  const scann_config_t& c = h->cfg;
+  const int L = c.n_attention;
+  const size_t rowA = (size_t)db->n_atom * D * 4, rowE = (size_t)db->n_edge * D * 4;
+  if (h->debug) {
+    const int r = ensure_debug(h, db);
+    if (r) return r;
+  }
+  if (tm) tm->mark(-1);
+  if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, db->geom, s);
+  else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
+  if (tm) tm->mark(0);
+  if (h->debug && c.g_update && db->n_edge) HIPCHK(h, hipMemcpyAsync(db->dbg_g, db->geom, rowE, hipMemcpyDeviceToDevice, s));
+
+  for (int l = 0; l <= L; ++l) {
+    // atom kernel at the head of layer l: ResidualNorm of layer l-1, centres, projections of layer l
+    AtomArgs a{};
+    a.n_atom = db->n_atom;
+    if (l == 0) {
+      a.x = h->lut;
+      a.x_index = db->atomic;
+      a.ffn = 0;
+    } else {
+      a.x = db->ctx;
+      a.x_index = nullptr;
+      a.ffn = c.use_attn_norm ? 1 : 0;
+      const LayerParams& pp = h->layers[l - 1];
+      a.Wf1p = pp.Wf1p; a.bf1 = pp.bf1; a.Wf2p = pp.Wf2p; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
+    }
+    a.c = db->c;
+    if (l < L) {
+      const LayerParams& p = h->layers[l];
+      a.mode = c.g_update ? 0 : 1;
+      a.WAp = p.W1p; a.bA = p.bg; a.WBp = p.W3p; a.WCp = p.Wqp; a.bC = p.bq;
+      a.oA = db->P1; a.oB = db->P3; a.oC = db->q;
+    } else {
+      a.mode = 2;
+      a.WAp = h->head.Wap; a.bA = h->head.ba; a.WCp = h->head.Wgqp; a.bC = h->head.bgq; a.WDp = h->head.Wgkp; a.bD = h->head.bgk;
+      a.oB = db->gk; a.oC = db->gq;
+    }
+    launch_atom(a, s);
+    if (tm) tm->mark(l < L ? 1 : 3);
+    if (h->debug) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
+    if (l == L) break;
+    EdgeArgs ea{};
+    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update;
+    ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
+    ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
+    ea.c = db->c; ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = db->ctx;
+    ea.p = h->layers[l];
+    launch_edge(ea, s);
+    if (tm) tm->mark(2);
+    if (h->debug) {
+      HIPCHK(h, hipMemcpyAsync(db->dbg_ctx + (size_t)l * db->n_atom * D, db->ctx, rowA, hipMemcpyDeviceToDevice, s));
+      if (c.g_update && db->n_edge)
+        HIPCHK(h, hipMemcpyAsync(db->dbg_g + (size_t)(l + 1) * db->n_edge * D, db->geom, rowE, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  ReadoutArgs r{};
+  r.mol_offset = db->mol_offset; r.n_struct = db->n_struct; r.max_atoms = db->max_atoms;
+  r.gq = db->gq; r.gk = db->gk; r.use_ga_norm = c.use_ga_norm; r.relu_out = c.relu_out;
+  r.p = h->head; r.ga_attn = db->ga; r.y = db->y;
+  launch_readout(r, s);
+  if (tm) tm->mark(3);
+  HIPCHK(h, hipGetLastError());
+  return SCANN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot) {
+  if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_forward_resident: null argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int slot = ((stream_slot % NSTREAM) + NSTREAM) % NSTREAM;
+  db->last_slot = slot;
+  return run_forward(h, db, h->streams[slot], nullptr);
+}
+
+int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out) {
+  if (!h || !db || !y_out) return fail(h, SCANN_ERR_INVALID, "scann_batch_download: null argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->streams[db->last_slot];
+  HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
+  if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return SCANN_OK;
+}
+
+int scann_sync(scann_handle_t* h) {
+  if (!h) return SCANN_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  for (int i = 0; i < NSTREAM; ++i) HIPCHK(h, hipStreamSynchronize(h->streams[i]));
+  return SCANN_OK;
+}
+
+int scann_forward(scann_handle_t* h, const scann_batch_t* batch, float* y_out, float* ga_attn_out) {
+  scann_dbatch_t* db = nullptr;
+  int r = scann_batch_upload(h, batch, &db);
+  if (r) return r;
+  r = scann_forward_resident(h, db, 0);
+  if (!r) r = scann_batch_download(h, db, y_out, ga_attn_out);
+  const std::string keep = h->err;
+  scann_batch_free(h, db);
+  if (r) h->err = keep;
+  return r;
+}
+
+int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t* prof) {
+  if (!h || !db || !prof) return fail(h, SCANN_ERR_INVALID, "scann_forward_profile: null argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  memset(prof, 0, sizeof(*prof));
+  Timer tm{h->streams[0], true, {}, {}};
+  db->last_slot = 0;
+  const int r = run_forward(h, db, h->streams[0], &tm);
+  if (r) return r;
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  for (size_t i = 1; i < tm.ev.size(); ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]);
+    switch (tm.kind[i]) {
+      case 0: prof->ms_basis += ms; break;
+      case 1: prof->ms_atom += ms; prof->n_atom_launch++; break;
+      case 2: prof->ms_edge += ms; prof->n_edge_launch++; break;
+      default: prof->ms_readout += ms; break;
+    }
+  }
+  if (tm.ev.size() >= 2) (void)hipEventElapsedTime(&prof->ms_total, tm.ev.front(), tm.ev.back());
+  for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
+  return SCANN_OK;
+}
+
+int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer, float* out) {
+  if (!h || !db || !out) return fail(h, SCANN_ERR_INVALID, "scann_debug_read: null argument");
+  const int L = h->cfg.n_attention;
+  if (db->dbg_layers != L) return fail(h, SCANN_ERR_INVALID, "scann_debug_read: forward was not run with debug on");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->streams[db->last_slot]));
+  const size_t rowA = (size_t)db->n_atom * D, rowE = (size_t)db->n_edge * D;
+  const float* src = nullptr;
+  size_t n = 0;
+  if (what == 0 && layer >= 0 && layer <= L) { src = db->dbg_c + layer * rowA; n = rowA; }
+  else if (what == 1 && h->cfg.g_update && layer >= 0 && layer <= L) { src = db->dbg_g + layer * rowE; n = rowE; }
+  else if (what == 2 && layer >= 1 && layer <= L) { src = db->dbg_ctx + (layer - 1) * rowA; n = rowA; }
+  else return fail(h, SCANN_ERR_INVALID, "scann_debug_read: bad selector");
+  if (n) HIPCHK(h, hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+  return SCANN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+"""ctypes binding of libscann_hip.so (include/scann_hip.h) and the padded-dict <-> packed-CSR shim.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libscann_hip.so")
+
+SCANN_OK = 0
+STATUS = {0: "OK", -1: "INVALID", -2: "UNSUPPORTED", -3: "NO_DEVICE", -4: "HIP", -5: "WEIGHTS", -6: "OOM"}
+
+
+class ScannHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libscann_hip: %s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_atoms", C.c_int32), ("embedding_dim", C.c_int32), ("local_dim", C.c_int32), ("num_head", C.c_int32),
+        ("n_attention", C.c_int32), ("global_dim", C.c_int32), ("dense_out", C.c_int32), ("n_gauss", C.c_int32),
+        ("gaussian_d", C.c_float), ("g_update", C.c_int32), ("use_attn_norm", C.c_int32), ("use_ga_norm", C.c_int32),
+        ("use_ring", C.c_int32), ("feature_cgcnn", C.c_int32), ("relu_out", C.c_int32),
+    ]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_int64), ("numel", C.c_int64)]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("n_struct", C.c_int32), ("n_atom", C.c_int32), ("n_edge", C.c_int32),
+        ("atomic", C.c_void_p), ("mol_offset", C.c_void_p), ("edge_offset", C.c_void_p), ("edge_col", C.c_void_p),
+        ("edge_dist", C.c_void_p), ("edge_weight", C.c_void_p), ("ring", C.c_void_p), ("cgcnn", C.c_void_p),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("ms_basis", C.c_float), ("ms_atom", C.c_float), ("ms_edge", C.c_float), ("ms_readout", C.c_float),
+        ("ms_total", C.c_float), ("n_edge_launch", C.c_int32), ("n_atom_launch", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/scann_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("scann_abi_version", C.c_int, []),
+    ("scann_device_count", C.c_int, []),
+    ("scann_create", C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(_P)]),
+    ("scann_destroy", None, [_P]),
+    ("scann_last_error", C.c_char_p, [_P]),
+    ("scann_weight_count", C.c_int, [_P]),
+    ("scann_weight_name", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("scann_load_weights", C.c_int, [_P, _P, C.POINTER(TensorDesc), C.c_int]),
+    ("scann_forward", C.c_int, [_P, C.POINTER(Batch), _P, _P]),
+    ("scann_batch_upload", C.c_int, [_P, C.POINTER(Batch), C.POINTER(_P)]),
+    ("scann_batch_free", None, [_P, _P]),
+    ("scann_forward_resident", C.c_int, [_P, _P, C.c_int]),
+    ("scann_batch_download", C.c_int, [_P, _P, _P, _P]),
+    ("scann_sync", C.c_int, [_P]),
+    ("scann_num_streams", C.c_int, [_P]),
+    ("scann_forward_profile", C.c_int, [_P, _P, C.POINTER(Profile)]),
+    ("scann_set_debug", C.c_int, [_P, C.c_int]),
+    ("scann_debug_read", C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the in-tree library and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(
+            "libscann_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C scann--material_amd/csrc`; this package has no CPU fallback" % p)
+    lib = C.CDLL(p)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.scann_abi_version() != 1:
+        raise OSError("libscann_hip.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class PackedBatch:
+    """Host-side packed (CSR) batch: the arrays scann_batch_t points at."""
+
+    def __init__(self, atomic, mol_offset, edge_offset, edge_col, edge_dist, edge_weight, pad_shape=None, gidx=None):
+        self.atomic = np.ascontiguousarray(atomic, dtype=np.int32)
+        self.mol_offset = np.ascontiguousarray(mol_offset, dtype=np.int32)
+        self.edge_offset = np.ascontiguousarray(edge_offset, dtype=np.int32)
+        self.edge_col = np.ascontiguousarray(edge_col, dtype=np.int32)
+        self.edge_dist = np.ascontiguousarray(edge_dist, dtype=np.float32)
+        self.edge_weight = np.ascontiguousarray(edge_weight, dtype=np.float32)
+        self.pad_shape = pad_shape  # (B, M) of the padded dict it came from
+        self.atom_mask = gidx       # bool [B, M] or None
+
+    @property
+    def n_struct(self):
+        return int(self.mol_offset.shape[0] - 1)
+
+    @property
+    def n_atom(self):
+        return int(self.atomic.shape[0])
+
+    @property
+    def n_edge(self):
+        return int(self.edge_col.shape[0])
+
+    def as_struct(self):
+        return Batch(self.n_struct, self.n_atom, self.n_edge, _ptr(self.atomic), _ptr(self.mol_offset),
+                     _ptr(self.edge_offset), _ptr(self.edge_col), _ptr(self.edge_dist), _ptr(self.edge_weight),
+                     None, None)
+
+    def repad_ga(self, ga_packed):
+        """Packed GlobalAttention scores -> the reference's [B, M, 1] (padded atoms score exactly 0:
+        softmax of -1e9, attention.py:299-302)."""
+        if self.pad_shape is None:
+            return ga_packed
+        out = np.zeros(self.pad_shape + (1,), dtype=np.float32)
+        out[self.atom_mask, 0] = ga_packed
+        return out
+
+
+def pack_inputs(inputs):
+    """Keras input dict (scann_model.py:338-357; DataIterator.__getitem__, datagenerator.py:123-133)
+    -> PackedBatch.  Real atoms are those with atom_mask set; real edges the unmasked neighbour
+    slots of real atoms, kept in slot order; neighbour ids become global atom rows (what
+    gather_shape + tf.gather_nd do in the reference, custom_layers.py:18-28, attention.py:136)."""
+    atomic = np.asarray(inputs["atomic"])
+    if atomic.ndim != 2:
+        raise NotImplementedError("feature='cgcnn' inputs are not supported by the HIP path yet")
+    amask = np.asarray(inputs["atom_mask"]).astype(bool)
+    if amask.ndim == 3:
+        amask = amask[..., 0]
+    nbr = np.asarray(inputs["neighbors"]).astype(np.int64)
+    nmask = np.asarray(inputs["neighbor_mask"]).astype(bool)
+    B, M = atomic.shape
+    if nbr.shape[:2] != (B, M) or nmask.shape != nbr.shape or amask.shape != (B, M):
+        raise ValueError("inconsistent input shapes")
+    counts = amask.sum(1)
+    if (counts == 0).any():
+        raise ValueError("a structure in the batch has no atoms")
+    mol_offset = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(counts, out=mol_offset[1:])
+    gidx = (np.cumsum(amask, 1) - 1) + mol_offset[:-1, None]  # global row of every real atom
+    emask = nmask & amask[:, :, None]
+    bsel = np.broadcast_to(np.arange(B)[:, None, None], nbr.shape)[emask]
+    tgt = nbr[emask]
+    if tgt.size and ((tgt < 0).any() or (tgt >= M).any() or not amask[bsel, tgt].all()):
+        raise ValueError("an unmasked neighbour slot points at a padded atom")
+    edge_col = gidx[bsel, tgt]
+    deg = emask.sum(2)[amask]
+    edge_offset = np.zeros(deg.shape[0] + 1, dtype=np.int64)
+    np.cumsum(deg, out=edge_offset[1:])
+    dist = np.asarray(inputs["neighbor_distance"], dtype=np.float32)[emask]
+    wgt = np.asarray(inputs["neighbor_weight"], dtype=np.float32)[emask]
+    return PackedBatch(atomic[amask], mol_offset, edge_offset, edge_col, dist, wgt, pad_shape=(B, M), gidx=amask)
+
+
+class ResidentBatch:
+    """A batch uploaded to HBM (scann_dbatch_t) together with its workspace."""
+
+    def __init__(self, engine, packed, handle):
+        self.engine, self.packed, self._h = engine, packed, handle
+
+    def free(self):
+        if self._h is not None and self.engine._h is not None:
+            self.engine.lib.scann_batch_free(self.engine._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One scann_handle_t: the forward graph of create_model on one GPU."""
+
+    def __init__(self, cfg_struct, device=0):
+        self.lib = load_library()
+        self._h = None
+        h = _P()
+        rc = self.lib.scann_create(C.byref(cfg_struct), int(device), C.byref(h))
+        if rc != SCANN_OK:
+            raise ScannHipError(rc, (self.lib.scann_last_error(None) or b"").decode())
+        self._h = h
+        self.cfg = cfg_struct
+        self.device = device
+
+    def _check(self, rc):
+        if rc != SCANN_OK:
+            raise ScannHipError(rc, (self.lib.scann_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h is not None:
+            self.lib.scann_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def weight_specs(self):
+        out = []
+        for i in range(self.lib.scann_weight_count(self._h)):
+            name, r, c = C.c_char_p(), C.c_int64(), C.c_int64()
+            self._check(self.lib.scann_weight_name(self._h, i, C.byref(name), C.byref(r), C.byref(c)))
+            out.append((name.value.decode(), (r.value, c.value) if c.value else (r.value,)))
+        return out
+
+    def load_weights(self, weights):
+        specs = self.weight_specs()
+        chunks, descs, off = [], [], 0
+        names = []
+        for name, shape in specs:
+            if name not in weights:
+                raise ScannHipError(-5, "missing tensor " + name)
+            t = np.ascontiguousarray(weights[name], dtype=np.float32)
+            if tuple(t.shape) != tuple(shape):
+                raise ScannHipError(-5, "tensor %s has shape %s, expected %s" % (name, t.shape, shape))
+            chunks.append(t.ravel())
+            names.append(name.encode())
+            descs.append((names[-1], off, t.size))
+            off += t.size
+        blob = np.concatenate(chunks).astype(np.float32)
+        arr = (TensorDesc * len(descs))(*[TensorDesc(n, o, s) for n, o, s in descs])
+        self._check(self.lib.scann_load_weights(self._h, _ptr(blob), arr, len(descs)))
+
+    def forward(self, packed, want_ga=True):
+        y = np.empty(packed.n_struct, dtype=np.float32)
+        ga = np.empty(packed.n_atom, dtype=np.float32) if want_ga else None
+        st = packed.as_struct()
+        self._check(self.lib.scann_forward(self._h, C.byref(st), _ptr(y), _ptr(ga)))
+        return y, ga
+
+    def upload(self, packed):
+        st = packed.as_struct()
+        db = _P()
+        self._check(self.lib.scann_batch_upload(self._h, C.byref(st), C.byref(db)))
+        return ResidentBatch(self, packed, db)
+
+    def forward_resident(self, rb, slot=0):
+        self._check(self.lib.scann_forward_resident(self._h, rb._h, int(slot)))
+
+    def download(self, rb, want_ga=True):
+        y = np.empty(rb.packed.n_struct, dtype=np.float32)
+        ga = np.empty(rb.packed.n_atom, dtype=np.float32) if want_ga else None
+        self._check(self.lib.scann_batch_download(self._h, rb._h, _ptr(y), _ptr(ga)))
+        return y, ga
+
+    def sync(self):
+        self._check(self.lib.scann_sync(self._h))
+
+    def num_streams(self):
+        return self.lib.scann_num_streams(self._h)
+
+    def profile(self, rb):
+        p = Profile()
+        self._check(self.lib.scann_forward_profile(self._h, rb._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_ if k != "reserved"}
+
+    def set_debug(self, on):
+        self._check(self.lib.scann_set_debug(self._h, int(bool(on))))
+
+    def debug_read(self, rb, what, layer):
+        n = rb.packed.n_edge if what == 1 else rb.packed.n_atom
+        out = np.empty((n, 128), dtype=np.float32)
+        self._check(self.lib.scann_debug_read(self._h, rb._h, int(what), int(layer), _ptr(out)))
+        return out

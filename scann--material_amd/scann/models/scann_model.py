@@ -1,0 +1,258 @@
+"""SCANN facade on the MI355X HIP path.
+
+Mirrors the public surface of the reference's ``scann/models/scann_model.py`` -- ``SCANN(config,
+pretrained, mode)``, ``.model.predict(inputs)``, ``.prepare_dataset``, ``.evaluate``,
+``.predict_data``, ``create_model`` -- with the Keras graph execution replaced by
+``libscann_hip.so`` (include/scann_hip.h) through ctypes.  No TensorFlow, no PyTorch.
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+
+import numpy as np
+
+from .. import _hip
+
+INPUT_NAMES = ["atomic", "atom_mask", "neighbors", "neighbor_mask", "neighbor_weight", "neighbor_distance"]
+
+# keys some shipped yaml files omit (model_qm9_std.yaml / model_ptgp.yaml; train.py:37-43 injects the CLI ones)
+_MODEL_DEFAULTS = dict(feature="atomic", use_ring=False, use_drop=False, g_update=False, gaussian_d=4.0,
+                       use_attn_norm=True, use_ga_norm=True)
+_HYPER_DEFAULTS = dict(scaler=False, scheduler="cosine", use_ref=False, target="", pretrained="")
+
+
+def normalize_config(config):
+    """Fill the keys the reference reads but some of its yaml files lack (deliberate deviation: the
+    reference raises KeyError there)."""
+    config.setdefault("model", {})
+    config.setdefault("hyper", {})
+    for k, v in _MODEL_DEFAULTS.items():
+        config["model"].setdefault(k, v)
+    for k, v in _HYPER_DEFAULTS.items():
+        config["hyper"].setdefault(k, v)
+    return config
+
+
+def config_struct(config):
+    m = config["model"]
+    if m["feature"] not in ("atomic", "cgcnn"):
+        raise ValueError("model.feature must be 'atomic' or 'cgcnn'")
+    return _hip.Config(
+        n_atoms=int(m["n_atoms"]), embedding_dim=int(m["embedding_dim"]), local_dim=int(m["local_dim"]),
+        num_head=int(m["num_head"]), n_attention=int(m["n_attention"]), global_dim=int(m["global_dim"]),
+        dense_out=int(m["dense_out"]), n_gauss=20, gaussian_d=float(m["gaussian_d"]),
+        g_update=int(bool(m["g_update"])), use_attn_norm=int(bool(m["use_attn_norm"])),
+        use_ga_norm=int(bool(m["use_ga_norm"])), use_ring=int(bool(m["use_ring"])),
+        feature_cgcnn=int(m["feature"] == "cgcnn"),
+        relu_out=int(config["hyper"].get("target") == "e_b"),  # scann_model.py:446
+    )
+
+
+def keras_default_init(specs, seed=None):
+    """Keras default initialisers for a fresh model (what create_model yields before training):
+    Dense kernels Glorot-uniform, biases 0, Embedding U(-0.05, 0.05), LayerNorm gamma 1 / beta 0."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in specs:
+        leaf = name.rsplit("/", 1)[1]
+        if leaf == "kernel":
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            t = rng.uniform(-lim, lim, size=shape)
+        elif leaf == "embeddings":
+            t = rng.uniform(-0.05, 0.05, size=shape)
+        elif leaf == "gamma":
+            t = np.ones(shape)
+        else:
+            t = np.zeros(shape)
+        w[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return w
+
+
+class HipModel:
+    """Stand-in for the ``tf.keras.Model`` that ``create_model`` returns (scann_model.py:449):
+    ``predict`` runs the whole forward graph on the GPU."""
+
+    def __init__(self, config, weights=None, device=None, infer=False, seed=None):
+        self.config = normalize_config(config)
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("SCANN_DEVICE") is None \
+                else int(os.environ["SCANN_DEVICE"])
+        self.engine = _hip.Engine(config_struct(self.config), device)
+        self.infer = infer  # True: outputs [y, global_attention scores] (scann_model.py:81-83)
+        self.input_names = list(INPUT_NAMES) + (["ring_aromatic"] if self.config["model"]["use_ring"] else [])
+        self.output_names = ["predict_property"] + (["global_attention"] if infer else [])
+        self._weights = None
+        self.set_weights(weights if weights is not None else keras_default_init(self.engine.weight_specs(), seed))
+
+    # -- weights ---------------------------------------------------------------------------------
+    def set_weights(self, weights):
+        self.engine.load_weights(weights)
+        self._weights = {n: np.array(weights[n], dtype=np.float32) for n, _ in self.engine.weight_specs()}
+
+    def get_weights(self):
+        return dict(self._weights)
+
+    def count_params(self):
+        return int(sum(v.size for v in self._weights.values()))
+
+    def save(self, path):
+        """Weight container: a zip (npz) of the named fp32 tensors plus the yaml config as JSON.
+        Takes the place of the Keras full-model HDF5 (scann_model.py:166-177)."""
+        buf = io.BytesIO()
+        np.savez(buf, __config__=np.array(json.dumps(self.config)), **self._weights)
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "wb") as f:
+            f.write(buf.getvalue())
+
+    # -- inference ---------------------------------------------------------------------------------
+    def predict(self, inputs, batch_size=None, verbose=0, **_):
+        """``model.predict(inputs)`` (scann_model.py:266,316): ``[B,1]`` or, in infer mode,
+        ``[[B,1], [B,M,1]]``."""
+        packed = inputs if isinstance(inputs, _hip.PackedBatch) else _hip.pack_inputs(inputs)
+        y, ga = self.engine.forward(packed, want_ga=self.infer)
+        y = y.reshape(-1, 1)
+        if self.infer:
+            return [y, packed.repad_ga(ga)]
+        return y
+
+    __call__ = predict
+
+    def summary(self):
+        print("SCANN HIP model: %d parameters, %d local-attention layers, g_update=%s" % (
+            self.count_params(), self.config["model"]["n_attention"], self.config["model"]["g_update"]))
+
+
+def _read_container(path):
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic.startswith(b"\x89HDF"):
+        raise NotImplementedError(
+            "%s is a Keras HDF5 checkpoint; importing the reference's .h5 files needs h5py and is not "
+            "implemented yet (SURVEY.md section 8f-3).  Use a container written by HipModel.save()." % path)
+    z = np.load(path, allow_pickle=False)
+    cfg = json.loads(str(z["__config__"]))
+    return cfg, {k: z[k] for k in z.files if k != "__config__"}
+
+
+def load_model(path, custom_objects=None, infer=False, config=None):
+    """``tf.keras.models.load_model`` counterpart (scann_model.py:79,87,323)."""
+    cfg, weights = _read_container(path)
+    if config is not None:  # the caller's yaml wins for everything but the architecture
+        cfg["hyper"].update({k: v for k, v in config.get("hyper", {}).items()})
+    return HipModel(cfg, weights, infer=infer)
+
+
+def create_model_pretrained(pretrained):
+    model = load_model(pretrained)
+    model.summary()
+    return model
+
+
+def create_model(config, seed=None):
+    """The graph builder (scann_model.py:329-453): returns a model with fresh Keras-default weights."""
+    model = HipModel(config, seed=seed)
+    model.summary()
+    return model
+
+
+class SCANN:
+    """API facade, same constructor and methods as the reference class (scann_model.py:42-319)."""
+
+    def __init__(self, config=None, pretrained="", mode="train"):
+        self.config = normalize_config(config)
+        self.model = None
+        self.mean, self.std = 0, 1
+        if "target_mean" in self.config["hyper"]:
+            self.mean = float(self.config["hyper"]["target_mean"])
+            self.std = float(self.config["hyper"]["target_std"])
+        if mode == "train" or mode == "eval":
+            if pretrained:
+                print("load pretrained model from ", pretrained, "\n")
+                self.model = create_model_pretrained(pretrained)
+                self.config["hyper"]["pretrained"] = pretrained
+            else:
+                self.model = create_model(self.config)
+        else:
+            self.model = load_model(pretrained, infer=True)
+
+    @classmethod
+    def load_model_infer(cls, path):
+        return load_model(path, infer=True)
+
+    @classmethod
+    def load_model(cls, path):
+        return create_model_pretrained(path)
+
+    def prepare_dataset(self, split=True):
+        from ..utils.datagenerator import DataIterator
+        from ..utils.general import load_dataset, split_data
+
+        hy, mo = self.config["hyper"], self.config["model"]
+        data_energy, data_neighbor = load_dataset(
+            use_ref=hy["use_ref"], use_ring=mo["use_ring"], dataset=hy["data_energy_path"],
+            dataset_neighbor=hy["data_nei_path"], target_prop=hy["target"])
+        if hy["scaler"]:
+            target = [d[1] for d in data_energy]
+            self.mean, self.std = np.mean(target, dtype="float32"), np.std(target, dtype="float32")
+            print("Normalize dataset property with mean: ", self.mean, " , std: ", self.std, "\n")
+            data_energy[:, 1] = (data_energy[:, 1] - self.mean) / self.std
+        hy["target_mean"] = str(self.mean)
+        hy["target_std"] = str(self.std)
+        hy["data_size"] = len(data_energy)
+        kw = dict(batch_size=hy["batch_size"], use_ring=mo["use_ring"], feature=mo["feature"], g_update=mo["g_update"])
+        if split:
+            train, valid, test, extra = split_data(len_data=len(data_energy), test_percent=hy["test_percent"],
+                                                   train_size=hy["train_size"], test_size=hy["test_size"])
+            assert len(extra) == 0, "Split was inexact {} {} {} {}".format(len(train), len(valid), len(test), len(extra))
+            print("Number of train data : ", len(train), " , Number of valid data: ", len(valid),
+                  " , Number of test data: ", len(test), "\n")
+            self.trainIter, self.validIter, self.testIter = [
+                DataIterator(data_neighbor=data_neighbor[idx], data_energy=data_energy[idx],
+                             shuffle=(len(idx) == len(train)), **kw)
+                for idx in (train, valid, test)]
+            return train, valid, test
+        self.dataIter = DataIterator(data_neighbor=data_neighbor, data_energy=data_energy, **kw)
+
+    def _out_dir(self):
+        return "{}_{}".format(self.config["hyper"]["save_path"], self.config["hyper"]["target"])
+
+    def train(self, epochs=1000):
+        raise NotImplementedError(
+            "training (backward kernels, Adam, RCCL gradient all-reduce) is the next row of the scope table "
+            "(SURVEY.md section 8a17 / 8e); this round ships the forward path")
+
+    def evaluate(self):
+        """Test-set loop of the reference (scann_model.py:247-313): predict every batch, report
+        R2 and MAE * std, write report.txt."""
+        from sklearn.metrics import mean_absolute_error, r2_score
+
+        if getattr(self, "model", None) is None:
+            print("Load best validation weight for predicting testset", "\n")
+            t = self.config["hyper"]["target"]
+            self.model = load_model("{}/models/model_{}.h5".format(self._out_dir(), t))
+        data = self.dataIter if hasattr(self, "dataIter") else self.testIter
+        y_predict, y = [], []
+        for i in range(len(data)):
+            inputs, target = data.__getitem__(i)
+            output = self.model.predict(inputs)
+            if isinstance(output, list):
+                output = output[0]
+            y.extend(list(target))
+            y_predict.extend(list(np.squeeze(output, -1)))
+            if i % 10 == 0:
+                print(f"{i}/{len(data)}")
+        mae = mean_absolute_error(y, y_predict) * self.std
+        r2 = r2_score(y, y_predict)
+        print("Result for testset ", self.config["hyper"]["target"], " : R2 score: ", r2, " and MAE: ", mae)
+        os.makedirs(self._out_dir(), exist_ok=True)
+        with open("{}/report.txt".format(self._out_dir()), "w") as f:
+            f.write("Test MAE: " + str(mae) + ", Test R2: " + str(r2))
+        return mae, r2
+
+    def predict_data(self, ip):
+        out = self.model.predict(ip)
+        if isinstance(out, list):  # infer mode (the reference tests len(out) == 2, scann_model.py:317)
+            return out[0] * self.std + self.mean, out[1]
+        return out * self.std + self.mean

@@ -1,0 +1,69 @@
+"""Host batch helpers with the reference's names and semantics (scann/utils/general.py:14-144).
+Only the parts that feed the forward path; the pymatgen / openbabel file loaders are out of scope."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def pad_sequence(sequences, maxlen=None, dtype="int32", value=0, padding="post"):
+    """Post-pad a list of variable-length sequences to ``[len(sequences), maxlen, ...]``; sequences
+    longer than ``maxlen`` keep their last ``maxlen`` items (general.py:14-32)."""
+    if maxlen is None:
+        maxlen = max(len(s) for s in sequences)
+    trailing = np.asarray(sequences[0]).shape[1:]
+    out = np.full((len(sequences), maxlen) + trailing, value, dtype=dtype)
+    for i, s in enumerate(sequences):
+        s = np.asarray(s[-maxlen:] if maxlen else s[:0], dtype=dtype)
+        if len(s):
+            out[i, : len(s)] = s
+    return out
+
+
+def pad_nested_sequences(sequences, max_len_1, max_len_2, dtype="int32", value=0):
+    """Pad a ragged 3-D list to ``[B, max_len_2, max_len_1]`` (general.py:35-50)."""
+    out = np.full((len(sequences), max_len_2, max_len_1), value, dtype=dtype)
+    for b, outer in enumerate(sequences):
+        outer = outer[-max_len_2:]
+        for a, inner in enumerate(outer):
+            inner = inner[-max_len_1:]
+            if len(inner):
+                out[b, a, : len(inner)] = np.asarray(inner, dtype=dtype)
+    return out
+
+
+def split_data(len_data, test_percent=0.1, train_size=None, test_size=None):
+    """Random train/valid/test split with the reference's sizing rule (general.py:79-101)."""
+    if train_size:
+        n_train, n_test = train_size, test_size
+    else:
+        n_train = int(len_data * (1 - test_percent * 2))
+        n_test = int(len_data * test_percent)
+    n_val = len_data - n_train - n_test
+    perm = np.random.permutation(len_data)
+    train, valid, test, extra = np.split(perm, [n_train, n_train + n_val, n_train + n_val + n_test])
+    return train, valid, test, extra
+
+
+def load_dataset(dataset, dataset_neighbor, target_prop, use_ref=False, use_ring=True):
+    """Load the ``*_data_energy.npy`` / ``*_data_neighbor*.npy`` object arrays written by the
+    reference's preprocessing (general.py:104-144)."""
+    data_full = np.load(dataset, allow_pickle=True)
+    if use_ref:
+        print("Using reference energy optimization", "\n")
+    if use_ring:
+        print("Using ring aromatic information", "\n")
+    rows = []
+    for d in data_full:
+        if use_ring:
+            rows.append([d["Atomic"], float(d["Properties"][target_prop]),
+                         np.stack([d["Features"][x] for x in d["Features"]], -1)])
+        elif use_ref:
+            rows.append([d["Atomic"], float(d["Properties"][target_prop]) - float(d["Properties"]["Ref_energy"])])
+        else:
+            rows.append([d["Atomic"], float(d["Properties"][target_prop])])
+    data_energy = np.empty(len(rows), dtype=object)
+    for i, r in enumerate(rows):
+        data_energy[i] = r
+    data_energy = np.array(rows, dtype="object") if len(rows) else data_energy
+    data_neighbor = np.array(np.load(dataset_neighbor, allow_pickle=True), dtype="object")
+    return data_energy, data_neighbor
