@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""QM9-shaped forward throughput of the SCANN+ HIP path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward of the whole graph (scann_model.py:329-453) over one batch of 128 synthetic QM9-shaped
+molecules (configs/model_qm9.yaml: 7 local-attention layers, d=128, 8 heads, g_update) whose packed inputs are
+already resident in HBM.  Steps are issued round-robin on the handle's HIP streams (batches are independent);
+the timed region is bracketed by barrier + device sync; value = molecules of all ranks / max-over-ranks time.
+Inference shards by structure with no data-path collective ("weak" scaling: per-GPU work fixed).
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel = edge_kernel, fp32 MFMA bound; achieved =
+algorithmic FLOPs per launch / HIP-event launch duration) and `cpu_baseline` (the NumPy/C oracle timed on the
+host cores -- a reported baseline, not the product path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+
+from scann import _hip  # noqa: E402  (loads libscann_hip.so; no torch / no oracle on the product path)
+from scann.models.scann_model import HipModel, normalize_config  # noqa: E402
+
+D = 128
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+QM9_MODEL = dict(n_atoms=10, embedding_dim=48, n_attention=7, local_dim=128, num_head=8, global_dim=128,
+                 dense_out=128, scale=0.5, use_attn_norm=True, use_ga_norm=True, use_ring=False, g_update=True,
+                 gaussian_d=4.0)  # configs/model_qm9.yaml:1-14
+
+
+def synth_packed_batch(rng, n_mol, worst=False):
+    """Synthetic QM9-shaped molecules straight into packed form: atoms ~ clip(round(N(18,2.9)),3,29),
+    species {H .51, C .35, N .06, O .08, F .002}, neighbours per atom ~ U[3, min(12, A-1)] without replacement,
+    distance ~ U(0.9, 4.0), solid angle ~ U(0.4, 3.5)."""
+    zs = np.array([1, 6, 7, 8, 9])
+    ps = np.array([0.51, 0.35, 0.06, 0.08, 0.002])
+    ps = ps / ps.sum()
+    atomic, mol_off, e_off, cols = [], [0], [0], []
+    for _ in range(n_mol):
+        A = 29 if worst else int(np.clip(np.rint(rng.normal(18.0, 2.9)), 3, 29))
+        base = mol_off[-1]
+        atomic.append(rng.choice(zs, size=A, p=ps))
+        hi = min(12, A - 1)
+        deg = np.full(A, 12) if worst else rng.integers(3, hi + 1, size=A)
+        keys = rng.random((A, A))
+        keys[np.arange(A), np.arange(A)] = 2.0  # never pick self
+        order = np.argsort(keys, axis=1)
+        for a in range(A):
+            cols.append(base + order[a, : deg[a]])
+            e_off.append(e_off[-1] + int(deg[a]))
+        mol_off.append(base + A)
+    cols = np.concatenate(cols)
+    E = cols.shape[0]
+    return _hip.PackedBatch(np.concatenate(atomic), mol_off, e_off, cols,
+                            rng.uniform(0.9, 4.0, size=E), rng.uniform(0.4, 3.5, size=E))
+
+
+def edge_flops(E):
+    """Algorithmic FLOPs of one edge_kernel launch: per edge the geometry third of filter_geo (2 d^2), the key
+    projection (2 d^2) and the q.k / attn.k contractions (4 d) -- SURVEY.md 8(d) minimal form, edge part."""
+    return E * (4 * D * D + 4 * D)
+
+
+def total_flops_min(A, E, L=7, emb=48):
+    f = A * 2 * emb * D + 2 * E * 2 * 20 * D + L * (E * (4 * D * D + 4 * D) + A * 10 * D * D)
+    return f + A * 6 * D * D + 2 * D * D + 2 * D  # + readout (GA pair term is per-structure A^2, omitted: <1 %)
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The oracle (checker) timed on this host's cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import scann_oracle as so
+
+    cfg = so.default_config("qm9")
+    w = so.init_weights(cfg, 1234)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        import scann_oracle_c as soc  # C/OpenMP port of the same padded-dense algorithm
+
+        de, dn = so.synth_dataset(128, 0)
+        inputs, _ = so.pad_batch(de, dn, True)
+        soc.forward(cfg, w, inputs)  # warm
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds_budget:
+            soc.forward(cfg, w, inputs)
+            n += 128
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
+                "sample": "%d molecules (batches of 128, QM9-shaped seed 0), C/OpenMP fp32 restatement of the "
+                          "reference's padded-dense graph, %d threads" % (n, cores)}
+    except ImportError:
+        pass
+    de, dn = so.synth_dataset(128, 0)
+    inputs, _ = so.pad_batch(de, dn, True)
+    n, t0 = 0, time.perf_counter()
+    while n == 0 or time.perf_counter() - t0 < seconds_budget:
+        so.forward(cfg, w, inputs, np.float32)
+        n += 128
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": "%d molecules (batches of 128, QM9-shaped seed 0), NumPy fp32 restatement of the reference's "
+                      "padded-dense graph (BLAS threads = host cores)" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--pool", type=int, default=32, help="distinct resident batches cycled through")
+    ap.add_argument("--worst", action="store_true", help="Swc: every molecule 29 atoms x 12 neighbours")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    cfg = normalize_config({"model": dict(QM9_MODEL), "hyper": {"target": "homo", "batch_size": args.batch}})
+    ndev = _hip.load_library().scann_device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs a GPU: libscann_hip has no CPU fallback")
+    model = HipModel(cfg, device=local % ndev, seed=1234)  # random-init weights of the QM9 architecture
+    eng = model.engine
+    nstream = eng.num_streams()
+    pool_n = max(nstream, (args.pool // nstream) * nstream)
+    rng = np.random.default_rng(1000 + rank)
+    pool = [eng.upload(synth_packed_batch(rng, args.batch, args.worst)) for _ in range(pool_n)]
+    mols_per_step = args.batch
+
+    dist = None
+    if world > 1:  # coordination only (barrier + max of the timings); never touches the GPU through torch
+        import torch
+        import torch.distributed as dist_mod
+
+        dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        dist = dist_mod
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def run(nsteps):
+        for i in range(nsteps):
+            eng.forward_resident(pool[i % pool_n], i % nstream)
+
+    run(args.warmup)
+    eng.sync()
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    eng.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel launch durations (HIP events on the launch stream), rank 0, sequential launches
+    roof = None
+    if rank == 0:
+        ms_edge = n_edge = fl = 0.0
+        prof_tot = []
+        for i in range(args.profile_reps):
+            rb = pool[i % pool_n]
+            p = eng.profile(rb)
+            if i >= 2:  # first reps warm the caches
+                ms_edge += p["ms_edge"]
+                n_edge += p["n_edge_launch"]
+                fl += edge_flops(rb.packed.n_edge) * p["n_edge_launch"]
+                prof_tot.append(p)
+        avg_ms = ms_edge / max(n_edge, 1)
+        achieved = fl / max(n_edge, 1) / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "edge_kernel_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        roof = {"bound": "mfma", "kernel": "edge_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                "avg_launch_us": avg_ms * 1e3,
+                "per_forward_ms": {k: float(np.mean([p[k] for p in prof_tot])) for k in
+                                   ("ms_basis", "ms_atom", "ms_edge", "ms_readout", "ms_total")}}
+
+    if rank == 0:
+        A = float(np.mean([rb.packed.n_atom for rb in pool]))
+        E = float(np.mean([rb.packed.n_edge for rb in pool]))
+        value = world * args.steps * mols_per_step / elapsed
+        out = {
+            "metric": "QM9 molecules/s forward", "value": value, "unit": "molecules/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: QM9-shaped%s, configs/model_qm9.yaml (SCANN+, L=7, d=128, H=8), "
+                                   "batch=128 per step, forward" % (" worst-case 29x12" if args.worst else ""),
+                       "batch": args.batch, "atoms_per_batch": A, "edges_per_batch": E,
+                       "streams": nstream, "parallelism": "dp%d (independent shards, no collective)" % world},
+            "whole_path_tflops_min": world * args.steps * total_flops_min(A, E) / elapsed / 1e12,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    for rb in pool:
+        rb.free()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

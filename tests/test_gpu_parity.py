@@ -69,3 +69,151 @@ def test_every_layer_intermediate(hip_lib):
     rb.free()
     bad = {k: v for k, v in worst.items() if not v <= RTOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("over", [
+    dict(model=dict(g_update=False)),                      # base SCANN branch (attention.py:155)
+    dict(model=dict(use_attn_norm=False)),                 # no ResidualNorm (scann_model.py:404-408)
+    dict(model=dict(use_ga_norm=False)),                   # GlobalAttention(norm=False)
+    dict(hyper=dict(target="e_b")),                        # mrelu head (scann_model.py:446)
+    dict(model=dict(g_update=False, use_attn_norm=False, use_ga_norm=False)),
+    dict(model=dict(n_attention=1)),
+    dict(model=dict(n_attention=0)),
+], ids=["base", "no_attn_norm", "no_ga_norm", "e_b", "base_plain", "L1", "L0"])
+def test_branches(hip_lib, over):
+    cfg, w, inputs, model = make(n=10, seed=3, **{k: dict(v) for k, v in over.items()})
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL
+    assert rel_err(ga, ga_ref) <= RTOL
+
+
+def test_keras_default_init_and_configs(hip_lib):
+    """Keras-default weights (zero biases, unit gamma) and the other shipped architectures."""
+    for name, kind, n in (("qm9", "qm9", 16), ("qm9_std", "qm9", 8), ("mp2018", "mp2018", 6)):
+        cfg, w, inputs, model = make(name, n=n, seed=5, kind=kind, perturb=False)
+        y, ga = model.predict(inputs)
+        y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+        assert rel_err(y, y_ref) <= RTOL, name
+        assert rel_err(ga, ga_ref) <= RTOL, name
+
+
+def test_worst_case_and_ragged(hip_lib):
+    """Swc (29 atoms x 12 neighbours everywhere) and a batch holding a 3-atom next to a 29-atom molecule."""
+    cfg, w, inputs, model = make(n=6, kind="worst")
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+    de, dn = so.synth_dataset(64, 11)
+    sizes = np.array([len(e[0]) for e in de])
+    pick = [int(sizes.argmin()), int(sizes.argmax()), 0, 1]
+    inputs, _ = so.pad_batch(de[pick], dn[pick], True)
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+
+
+def test_isolated_atom_and_masked_garbage(hip_lib):
+    """An atom whose neighbour slots are all masked gives ctx = LN(q) (attention.py:186-212); garbage in masked
+    slots changes nothing; extra padding rows/columns leave real outputs unchanged."""
+    cfg, w, inputs, model = make(n=5, seed=7)
+    inputs = {k: np.array(v) for k, v in inputs.items()}
+    inputs["neighbor_mask"][0, 1, :] = False  # isolate atom 1 of molecule 0
+    y0, ga0 = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y0, y_ref) <= RTOL and rel_err(ga0, ga_ref) <= RTOL
+    rng = np.random.default_rng(0)
+    g = {k: np.array(v) for k, v in inputs.items()}
+    dead = ~g["neighbor_mask"]
+    g["neighbor_distance"][dead] = rng.uniform(0, 9, dead.sum()).astype("float32")
+    g["neighbor_weight"][dead] = rng.uniform(0, 9, dead.sum()).astype("float32")
+    y1, ga1 = model.predict(g)
+    assert np.array_equal(y0, y1) and np.array_equal(ga0, ga1)
+    B, M, N = g["neighbors"].shape
+    pad = {
+        "atomic": np.pad(inputs["atomic"], ((0, 0), (0, 3))),
+        "atom_mask": np.pad(inputs["atom_mask"], ((0, 0), (0, 3), (0, 0))),
+        "neighbors": np.pad(inputs["neighbors"], ((0, 0), (0, 3), (0, 2))),
+        "neighbor_mask": np.pad(inputs["neighbor_mask"], ((0, 0), (0, 3), (0, 2))),
+        "neighbor_weight": np.pad(inputs["neighbor_weight"], ((0, 0), (0, 3), (0, 2))),
+        "neighbor_distance": np.pad(inputs["neighbor_distance"], ((0, 0), (0, 3), (0, 2))),
+    }
+    y2, ga2 = model.predict(pad)
+    assert np.array_equal(y0, y2) and np.array_equal(ga0, ga2[:, :M]) and not ga2[:, M:].any()
+
+
+def test_batch_composition_and_permutation(hip_lib):
+    """Molecule order permutes outputs; a molecule's result does not depend on its batch mates; relabelling the
+    atoms of a molecule leaves y unchanged (to rounding) and permutes the GA scores."""
+    cfg, w, inputs, model = make(n=9, seed=2)
+    de, dn = so.synth_dataset(9, 2)
+    y, ga = model.predict(inputs)
+    perm = np.random.default_rng(1).permutation(9)
+    ip, _ = so.pad_batch(de[perm], dn[perm], True)
+    yp, gap = model.predict(ip)
+    assert np.array_equal(yp, y[perm])
+    single, _ = so.pad_batch(de[2:3], dn[2:3], True)
+    ys, gas = model.predict(single)
+    assert np.array_equal(ys[0], y[2])
+    # atom relabelling of molecule 0
+    A = len(de[0][0])
+    p = np.random.default_rng(3).permutation(A)          # new position i holds old atom p[i]
+    inv = np.argsort(p)
+    e0 = [[de[0][0][j] for j in p], de[0][1]]
+    n0 = [[[n[0], int(inv[n[1]]), n[2], n[3], n[4]] for n in dn[0][j]] for j in p]
+    de2, dn2 = np.empty(1, dtype=object), np.empty(1, dtype=object)
+    de2[0], dn2[0] = e0, n0
+    i2, _ = so.pad_batch(de2, dn2, True)
+    y2, ga2 = model.predict(i2)
+    assert rel_err(y2, ys) <= 1e-5
+    assert rel_err(ga2[0, :A, 0], gas[0, :A, 0][p]) <= 1e-5
+
+
+def test_single_atom_structure_is_nan_like_reference(hip_lib):
+    """tf.linalg.normalize has no epsilon: a 1-atom structure gives 0/0 = NaN with use_ga_norm (attention.py:297)."""
+    from scann import _hip
+
+    cfg, w, inputs, model = make(n=2)
+    pk = _hip.PackedBatch([6, 1, 1, 8], [0, 1, 4], [0, 0, 1, 2, 4], [2, 1, 1, 2], [1.0, 1.1, 1.2, 1.3],
+                          [1.0, 2.0, 1.5, 0.7])
+    y, ga = model.engine.forward(pk)
+    assert np.isnan(y[0]) and np.isfinite(y[1])
+
+
+def test_resident_pipeline_matches_sync(hip_lib):
+    """Batches run asynchronously on different streams give the same bytes as the synchronous call."""
+    from scann import _hip
+
+    cfg, w, inputs, model = make(n=8)
+    eng = model.engine
+    pks = []
+    for s in range(6):
+        de, dn = so.synth_dataset(8 + s, 20 + s)
+        pks.append(_hip.pack_inputs(so.pad_batch(de, dn, True)[0]))
+    sync = [eng.forward(pk) for pk in pks]
+    rbs = [eng.upload(pk) for pk in pks]
+    for rep in range(3):
+        for i, rb in enumerate(rbs):
+            eng.forward_resident(rb, i)
+    eng.sync()
+    for rb, (y, ga) in zip(rbs, sync):
+        y2, ga2 = eng.download(rb)
+        assert np.array_equal(y, y2) and np.array_equal(ga, ga2)
+        rb.free()
+
+
+def test_errors_are_reported(hip_lib):
+    from scann import _hip
+
+    cfg, w, inputs, model = make(n=2)
+    bad = _hip.PackedBatch([6, 1], [0, 2], [0, 1, 2], [1, 5], [1.0, 1.0], [1.0, 1.0])  # neighbour outside structure
+    with pytest.raises(_hip.ScannHipError) as e:
+        model.engine.forward(bad)
+    assert e.value.code == -1
+    bad = _hip.PackedBatch([6, 11], [0, 2], [0, 1, 2], [1, 0], [1.0, 1.0], [1.0, 1.0])  # Z >= n_atoms
+    with pytest.raises(_hip.ScannHipError):
+        model.engine.forward(bad)
+    w2 = dict(w)
+    w2.pop("after_Lc/bias")
+    with pytest.raises(_hip.ScannHipError):
+        model.engine.load_weights(w2)
