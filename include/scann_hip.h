@@ -134,6 +134,10 @@ int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t
 int scann_set_debug(scann_handle_t* h, int on);
 int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer, float* out);
 
+/* Diagnostic builds (-DSCANN_STAMPS) only: per-tile phase clocks [n_tile, 16] of the last edge-kernel launch of
+ * `db`; returns the number of tiles copied.  The shipped library returns SCANN_ERR_UNSUPPORTED. */
+int scann_debug_stamps(scann_handle_t* h, scann_dbatch_t* db, uint64_t* out, int max_tiles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,7 @@ struct EdgeArgs {
   const float* edge_weight;    // [n_edge] (base)
   const float *c, *P1, *P3, *q;  // [n_atom,128]
   float* ctx;                  // [n_atom,128] out: LayerNorm(context)
+  unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS) only: [n_tile,16] phase clocks, else null
   LayerParams p;
 };
 void launch_edge(const EdgeArgs& a, hipStream_t s);

@@ -23,7 +23,28 @@ namespace scann {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float swishf(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+// Diagnostic build only (-DSCANN_STAMPS): per-workgroup phase timestamps, written to a buffer nothing else reads.
+#ifdef SCANN_STAMPS
+#define STAMP(buf, slot)                                                                      \
+  do {                                                                                        \
+    if ((buf) && threadIdx.x == 0) {                                                          \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
+    }                                                                                         \
+  } while (0)
+#else
+#define STAMP(buf, slot) do {} while (0)
+#endif
+
+// swish(x) = x * sigmoid(x) on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each.
+// Measured effect on the end-to-end parity error: DESIGN.md "numerics".
+__device__ __forceinline__ float swishf(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
+// e^x through v_exp_f32 (2^x, 1 ulp); used where the argument is <= 0 (softmax numerators).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
@@ -38,13 +59,17 @@ __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a
 // The k order is ours to choose as long as A and B agree: k-step (t, i), lane half h <-> k = 8t + 4h + i,
 // so a lane's A operands for four consecutive steps are one 16-byte LDS read and its B operands one
 // 16-byte global read.  Packed weight element ((w*16 + t)*64 + lane)*4 + i = W[8t + 4(lane>>5) + i][32w + (lane&31)].
-template <int RT>
-__device__ __forceinline__ void gemm128(const float* __restrict__ sX, const float* __restrict__ Wp, int wave,
-                                        int lane, f32x16 (&acc)[RT]) {
+// load_w: one wave's 128x32 slab of a packed weight, 16 coalesced 1-KiB reads, issued early so the
+// L2/HBM latency hides under whatever precedes the MFMAs.
+__device__ __forceinline__ void load_w(const float* __restrict__ Wp, int wave, int lane, float4 (&w)[16]) {
   const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + wave * (16 * 64) + lane;
-  float4 w[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) w[t] = wsrc[t * 64];
+}
+
+template <int RT>
+__device__ __forceinline__ void mma128(const float* __restrict__ sX, const float4 (&w)[16], int lane,
+                                       f32x16 (&acc)[RT]) {
   const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
@@ -57,6 +82,14 @@ __device__ __forceinline__ void gemm128(const float* __restrict__ sX, const floa
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[rt], 0, 0, 0);
     }
   }
+}
+
+template <int RT>
+__device__ __forceinline__ void gemm128(const float* __restrict__ sX, const float* __restrict__ Wp, int wave,
+                                        int lane, f32x16 (&acc)[RT]) {
+  float4 w[16];
+  load_w(Wp, wave, lane, w);
+  mma128<RT>(sX, w, lane, acc);
 }
 
 template <int RT>
@@ -246,18 +279,27 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 
 template <bool GUPD>
 __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
-  __shared__ __attribute__((aligned(16))) float sA[TE * LDS_STRIDE];  // G, then ang = c[j]*geom'
+  __shared__ __attribute__((aligned(16))) float sA[TE * LDS_STRIDE];  // G, then ang = c[j]*geom', then q rows + logits
   __shared__ __attribute__((aligned(16))) float sB[TE * LDS_STRIDE];  // U = G W2, then K
-  __shared__ int sCol[TE], sCtr[TE];
+  __shared__ int sCol[TE], sCtr[TE], sOff[TA + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const EdgeTile tile = a.tiles[blockIdx.x];
   const int eb = tile.edge_begin;
   const int ne = tile.edge_end - eb;
+  const int natom = tile.atom_end - tile.atom_begin;
   const int col = 32 * wave + (lane & 31);
+  float* const sQ = sA;                    // [<=TA][LDS_STRIDE] query rows of the tile's atoms (attention phase)
+  float* const sE = sA + TA * LDS_STRIDE;  // [TE][8] logits, then attention weights
 
+  STAMP(a.stamps, 0);
+  float4 w[16];
+  if (GUPD) load_w(a.p.W2p, wave, lane, w);  // in flight while the geometry tile is staged
+  else load_w(a.p.Wkp, wave, lane, w);
   if (tid < TE) {
     sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
     sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
+  } else if (tid - TE <= natom) {
+    sOff[tid - TE] = a.edge_offset[tile.atom_begin + (tid - TE)] - eb;  // tile-local CSR row pointers
   }
   f32x16 acc[2];
   if (GUPD) {
@@ -268,15 +310,19 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
       *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = v;
     }
     __syncthreads();
+    STAMP(a.stamps, 1);
     // U = G . W2  (geometry third of the concat GEMM, attention.py:142-151)
     zero_acc(acc);
-    gemm128<2>(sA, a.p.W2p, wave, lane, acc);
+    mma128<2>(sA, w, lane, acc);
+    STAMP(a.stamps, 2);
+    load_w(a.p.Wkp, wave, lane, w);  // key weights arrive during the row pass
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i];
   }
   __syncthreads();
+  STAMP(a.stamps, 3);
 
   // Row pass, 4 threads per edge row: geometry update + LayerNorm_g, gate with the gathered neighbour row.
   {
@@ -353,11 +399,21 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
         *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  // query rows of this tile's atoms: fetched now, parked in registers across the key GEMM
+  float4 qreg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
+    qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (la < natom) qreg[i] = reinterpret_cast<const float4*>(a.q)[(size_t)(tile.atom_begin + la) * 32 + c4];
+  }
   __syncthreads();
+  STAMP(a.stamps, 4);
 
   // K = ang . Wk + bk  (attention.py:163)
   zero_acc(acc);
-  gemm128<2>(sA, a.p.Wkp, wave, lane, acc);
+  mma128<2>(sA, w, lane, acc);
+  STAMP(a.stamps, 5);
   {
     const float b = a.p.bk[col];
 #pragma unroll
@@ -365,63 +421,106 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + b;
   }
-  __syncthreads();
-
-  // Attention, one wave per atom; lane l owns features 2l, 2l+1 (head l>>3).  Packed edges are all
-  // unmasked, so the additive -1e9 mask and the multiplicative mask (attention.py:186,206) are the
-  // identity here; an atom without edges reduces to ctx = LN(q), as the fully-masked row does.
-  const float2 lg = reinterpret_cast<const float2*>(a.p.ln_g)[lane];
-  const float2 lb = reinterpret_cast<const float2*>(a.p.ln_b)[lane];
-  for (int at = tile.atom_begin + wave; at < tile.atom_end; at += 4) {
-    const int e0 = a.edge_offset[at] - eb, e1 = a.edge_offset[at + 1] - eb;
-    const float2 q2 = reinterpret_cast<const float2*>(a.q)[(size_t)at * 64 + lane];
-    const float qx = q2.x * 0.25f, qy = q2.y * 0.25f;  // dk = hdim^-0.5 (attention.py:180-181)
-    float m = -INFINITY;
-    for (int n = e0; n < e1; ++n) {
-      const float2 k2 = *reinterpret_cast<const float2*>(&sB[n * LDS_STRIDE + 2 * lane]);
-      float e = qx * k2.x + qy * k2.y;
-      e += __shfl_xor(e, 1);
-      e += __shfl_xor(e, 2);
-      e += __shfl_xor(e, 4);
-      m = fmaxf(m, e);
-    }
-    float ssum = 0.f;
-    for (int n = e0; n < e1; ++n) {
-      const float2 k2 = *reinterpret_cast<const float2*>(&sB[n * LDS_STRIDE + 2 * lane]);
-      float e = qx * k2.x + qy * k2.y;
-      e += __shfl_xor(e, 1);
-      e += __shfl_xor(e, 2);
-      e += __shfl_xor(e, 4);
-      ssum += expf(e - m);
-    }
-    float cx = 0.f, cy = 0.f;
-    for (int n = e0; n < e1; ++n) {
-      const float2 k2 = *reinterpret_cast<const float2*>(&sB[n * LDS_STRIDE + 2 * lane]);
-      float e = qx * k2.x + qy * k2.y;
-      e += __shfl_xor(e, 1);
-      e += __shfl_xor(e, 2);
-      e += __shfl_xor(e, 4);
-      const float attn = expf(e - m) / ssum;  // tf.nn.softmax (:189)
-      cx += attn * k2.x;                      // v = key (:198-206)
-      cy += attn * k2.y;
-    }
-    cx += q2.x;  // residual is the unscaled query (:212)
-    cy += q2.y;
-    float s = cx + cy;
+  __syncthreads();  // K complete, sA no longer read by any MFMA
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / D);
-    const float dx = cx - mean, dy = cy - mean;
-    float v = dx * dx + dy * dy;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-    float2 y;
-    float inv;
-    inv = rstd * lg.x; y.x = cx * inv + (lb.x - mean * inv);
-    inv = rstd * lg.y; y.y = cy * inv + (lb.y - mean * inv);
-    reinterpret_cast<float2*>(a.ctx)[(size_t)at * 64 + lane] = y;  // layer_norm (:214)
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
+    *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
   }
+  __syncthreads();
+  STAMP(a.stamps, 6);
+
+  // Attention.  Packed edges are all unmasked, so the additive -1e9 mask and the multiplicative mask
+  // (attention.py:186,206) are the identity; an atom without edges reduces to ctx = LN(q), exactly what the
+  // reference's fully-masked row yields (uniform softmax zeroed by the mask).
+  // (1) logits: thread = (edge row, pair of heads); e[b,h,c,n] = sum_d (q*dk)[c,h,d] k[c,n,h,d]  (:180-183)
+  {
+    const int n = tid >> 2, hh = tid & 3;
+    if (n < ne) {
+      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + 32 * hh;
+      const float* krow = sB + n * LDS_STRIDE + 32 * hh;
+      float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
+        e0 += (q4.x * 0.25f) * k4.x; e0 += (q4.y * 0.25f) * k4.y; e0 += (q4.z * 0.25f) * k4.z; e0 += (q4.w * 0.25f) * k4.w;
+      }
+#pragma unroll
+      for (int j = 4; j < 8; ++j) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
+        e1 += (q4.x * 0.25f) * k4.x; e1 += (q4.y * 0.25f) * k4.y; e1 += (q4.z * 0.25f) * k4.z; e1 += (q4.w * 0.25f) * k4.w;
+      }
+      *reinterpret_cast<float2*>(&sE[n * 8 + 2 * hh]) = make_float2(e0, e1);
+    }
+  }
+  __syncthreads();
+  STAMP(a.stamps, 8);
+  // (2) softmax (tf.nn.softmax, :189) + context + residual: thread = (atom group, float4 chunk); the 4 lanes of
+  // a head recompute that head's softmax rather than exchanging it.  exp via v_exp_f32, 1/sum via v_rcp_f32.
+  {
+    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
+    for (int la = lgp; la < natom; la += 8) {
+      const int e0 = sOff[la], e1 = sOff[la + 1];
+      float m = -INFINITY;
+      for (int n = e0; n < e1; ++n) m = fmaxf(m, sE[n * 8 + h]);
+      float ssum = 0.f;
+      for (int n = e0; n < e1; ++n) ssum += fast_exp(sE[n * 8 + h] - m);
+      const float rs = __builtin_amdgcn_rcpf(ssum);
+      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int n = e0; n < e1; ++n) {
+        const float attn = fast_exp(sE[n * 8 + h] - m) * rs;
+        const float4 k4 = *reinterpret_cast<const float4*>(&sB[n * LDS_STRIDE + 4 * c4]);
+        cx.x += attn * k4.x; cx.y += attn * k4.y; cx.z += attn * k4.z; cx.w += attn * k4.w;  // v = key (:198-206)
+      }
+      float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
+      *qp = f4add(cx, *qp);  // residual is the unscaled query (:212)
+    }
+  }
+  __syncthreads();
+  STAMP(a.stamps, 9);
+  // (3) LayerNorm of the context rows (:214): 8 threads per atom row
+  {
+    const int r = tid >> 3, sub = tid & 7;
+    if (r < natom) {
+      float4 t[4];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        t[i] = *reinterpret_cast<const float4*>(&sQ[r * LDS_STRIDE + 4 * (sub + 8 * i)]);
+        s += f4sum(t[i]);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * (1.0f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = sub + 8 * i;
+        const float4 g = reinterpret_cast<const float4*>(a.p.ln_g)[c4];
+        const float4 be = reinterpret_cast<const float4*>(a.p.ln_b)[c4];
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
+        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
+        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
+        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
+        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + r) * 32 + c4] = y;
+      }
+    }
+  }
+  STAMP(a.stamps, 7);
 }
 
 void launch_edge(const EdgeArgs& a, hipStream_t s) {

@@ -55,6 +55,7 @@ struct scann_dbatch {
   float *gq = nullptr, *gk = nullptr, *ga = nullptr, *y = nullptr;
   // debug copies (allocated on demand)
   float *dbg_c = nullptr, *dbg_g = nullptr, *dbg_ctx = nullptr;
+  unsigned long long* stamps = nullptr;  // diagnostic build only
   int dbg_layers = -1;
   int last_slot = 0;
 };
@@ -365,6 +366,7 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   if (db->dbg_c) (void)hipFree(db->dbg_c);
   if (db->dbg_g) (void)hipFree(db->dbg_g);
   if (db->dbg_ctx) (void)hipFree(db->dbg_ctx);
+  if (db->stamps) (void)hipFree(db->stamps);
   delete db;
 }
 
@@ -545,6 +547,10 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
     ea.c = db->c; ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = db->ctx;
     ea.p = h->layers[l];
+#ifdef SCANN_STAMPS
+    if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
+    ea.stamps = db->stamps;
+#endif
     launch_edge(ea, s);
     if (tm) tm->mark(2);
     if (h->debug) {
@@ -626,6 +632,21 @@ int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t
   if (tm.ev.size() >= 2) (void)hipEventElapsedTime(&prof->ms_total, tm.ev.front(), tm.ev.back());
   for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
   return SCANN_OK;
+}
+
+int scann_debug_stamps(scann_handle_t* h, scann_dbatch_t* db, uint64_t* out, int max_tiles) {
+  if (!h || !db || !out) return fail(h, SCANN_ERR_INVALID, "scann_debug_stamps: null argument");
+#ifdef SCANN_STAMPS
+  if (!db->stamps) return fail(h, SCANN_ERR_INVALID, "scann_debug_stamps: no forward has run");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  const int n = std::min(max_tiles, db->n_tile);
+  HIPCHK(h, hipMemcpy(out, db->stamps, (size_t)n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return n;
+#else
+  (void)max_tiles;
+  return fail(h, SCANN_ERR_UNSUPPORTED, "scann_debug_stamps: library was not built with -DSCANN_STAMPS");
+#endif
 }
 
 int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer, float* out) {

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libscann_hip.so")
+LIB_PATH = os.environ.get("SCANN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libscann_hip.so")
 
 SCANN_OK = 0
 STATUS = {0: "OK", -1: "INVALID", -2: "UNSUPPORTED", -3: "NO_DEVICE", -4: "HIP", -5: "WEIGHTS", -6: "OOM"}
@@ -71,6 +71,7 @@ SYMBOLS = [
     ("scann_forward_profile", C.c_int, [_P, _P, C.POINTER(Profile)]),
     ("scann_set_debug", C.c_int, [_P, C.c_int]),
     ("scann_debug_read", C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    ("scann_debug_stamps", C.c_int, [_P, _P, _P, C.c_int]),
 ]
 
 _lib = None
@@ -286,6 +287,13 @@ class Engine:
 
     def set_debug(self, on):
         self._check(self.lib.scann_set_debug(self._h, int(bool(on))))
+
+    def debug_stamps(self, rb, max_tiles=4096):
+        out = np.zeros((max_tiles, 16), dtype=np.uint64)
+        n = self.lib.scann_debug_stamps(self._h, rb._h, _ptr(out), int(max_tiles))
+        if n < 0:
+            self._check(n)
+        return out[:n]
 
     def debug_read(self, rb, what, layer):
         n = rb.packed.n_edge if what == 1 else rb.packed.n_atom

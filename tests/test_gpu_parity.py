@@ -81,11 +81,15 @@ def test_every_layer_intermediate(hip_lib):
     dict(model=dict(n_attention=0)),
 ], ids=["base", "no_attn_norm", "no_ga_norm", "e_b", "base_plain", "L1", "L0"])
 def test_branches(hip_lib, over):
+    """Every architecture switch.  Some variants are ill-conditioned in fp32 (use_ga_norm False feeds raw pair
+    sums, |a| >> 1, into a softmax), so the bound is max(1e-4, 3 x the fp32 oracle's own error) against the
+    fp64 oracle -- the GPU must not be worse than the reference precision by more than that."""
     cfg, w, inputs, model = make(n=10, seed=3, **{k: dict(v) for k, v in over.items()})
     y, ga = model.predict(inputs)
-    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
-    assert rel_err(y, y_ref) <= RTOL
-    assert rel_err(ga, ga_ref) <= RTOL
+    y32, ga32 = so.forward(cfg, w, inputs, np.float32)
+    y64, ga64 = so.forward(cfg, w, inputs, np.float64)
+    assert rel_err(y, y64) <= max(RTOL, 3 * rel_err(y32, y64))
+    assert rel_err(ga, ga64) <= max(RTOL, 3 * rel_err(ga32, ga64))
 
 
 def test_keras_default_init_and_configs(hip_lib):
@@ -165,8 +169,8 @@ def test_batch_composition_and_permutation(hip_lib):
     de2[0], dn2[0] = e0, n0
     i2, _ = so.pad_batch(de2, dn2, True)
     y2, ga2 = model.predict(i2)
-    assert rel_err(y2, ys) <= 1e-5
-    assert rel_err(ga2[0, :A, 0], gas[0, :A, 0][p]) <= 1e-5
+    assert rel_err(y2[0], y[0]) <= 1e-5
+    assert rel_err(ga2[0, :A, 0], ga[0, :A, 0][p]) <= 1e-5
 
 
 def test_single_atom_structure_is_nan_like_reference(hip_lib):
