@@ -160,6 +160,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
+    t_issue = time.perf_counter() - t0  # host time to enqueue every launch (diagnostic: host- vs device-bound)
     eng.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -207,6 +208,7 @@ def main():
                                    "batch=128 per step, forward" % (" worst-case 29x12" if args.worst else ""),
                        "batch": args.batch, "atoms_per_batch": A, "edges_per_batch": E,
                        "streams": nstream, "parallelism": "dp%d (independent shards, no collective)" % world},
+            "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "whole_path_tflops_min": world * args.steps * total_flops_min(A, E) / elapsed / 1e12,
             "roofline": roof,
         }

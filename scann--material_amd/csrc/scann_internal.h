@@ -11,7 +11,7 @@ constexpr int NHEAD = 8;         // num_head
 constexpr int HDIM = D / NHEAD;  // 16
 constexpr int NG = 20;           // Gaussian basis size (scann_model.py:378)
 constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict-free b128 A-fragment reads)
-constexpr int TE = 64;           // edge rows per edge tile (two 32-row MFMA row tiles)
+constexpr int TE_MAX = 64;       // edge rows per edge tile: 32 or 64 (one or two 32-row MFMA row tiles)
 constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row tile)
 constexpr int TB = 64;           // edges per basis-kernel workgroup
 constexpr int WPACK = D * D;     // floats in one packed 128x128 weight
@@ -83,6 +83,7 @@ void launch_atom(const AtomArgs& a, hipStream_t s);
 struct EdgeArgs {
   const EdgeTile* tiles;
   int32_t n_tile;
+  int32_t tile_rows;           // 32 or 64: edge rows per tile the tile table was built for
   int32_t g_update;
   const int32_t* edge_offset;  // [n_atom+1]
   const int32_t* edge_col;     // [n_edge]

@@ -277,33 +277,51 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 
 // ---- edge-tile kernel ------------------------------------------------------------------------------
 
-template <bool GUPD>
-__global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
-  __shared__ __attribute__((aligned(16))) float sA[TE * LDS_STRIDE];  // G, then ang = c[j]*geom', then q rows + logits
-  __shared__ __attribute__((aligned(16))) float sB[TE * LDS_STRIDE];  // U = G W2, then K
-  __shared__ int sCol[TE], sCtr[TE], sOff[TA + 1];
+#ifndef EDGE_OCC32
+#define EDGE_OCC32 3  // waves per SIMD requested for the 32-row tile variant
+#endif
+// RT = 32-row MFMA row tiles per edge tile (tile holds <= 32*RT edges of whole atoms, <= TA atoms).
+template <bool GUPD, int RT>
+__global__ __launch_bounds__(256, RT == 1 ? EDGE_OCC32 : 2) void edge_kernel(EdgeArgs a) {
+  constexpr int TEK = 32 * RT;     // edge rows per tile
+  constexpr int TPR = 256 / TEK;   // threads per edge row in the row pass (4 or 8)
+  constexpr int NCH = 32 / TPR;    // float4 chunks per thread
+  constexpr int SA_ROWS = TEK > TA ? TEK : TA;
+  __shared__ __attribute__((aligned(16))) float sA[SA_ROWS * LDS_STRIDE];  // G, then ang = c[j]*geom', then query rows
+  __shared__ __attribute__((aligned(16))) float sB[TEK * LDS_STRIDE];      // U = G W2, then K
+  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];           // logits
+  __shared__ __attribute__((aligned(16))) float sPar[4 * D];               // layer_norm_g gamma/beta, layer_norm gamma/beta
+  __shared__ int sCol[TEK], sCtr[TEK], sOff[TA + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const EdgeTile tile = a.tiles[blockIdx.x];
   const int eb = tile.edge_begin;
   const int ne = tile.edge_end - eb;
   const int natom = tile.atom_end - tile.atom_begin;
   const int col = 32 * wave + (lane & 31);
-  float* const sQ = sA;                    // [<=TA][LDS_STRIDE] query rows of the tile's atoms (attention phase)
-  float* const sE = sA + TA * LDS_STRIDE;  // [TE][8] logits, then attention weights
+  float* const sQ = sA;  // [<=TA][LDS_STRIDE] query rows of the tile's atoms (attention phase)
 
   STAMP(a.stamps, 0);
   float4 w[16];
   if (GUPD) load_w(a.p.W2p, wave, lane, w);  // in flight while the geometry tile is staged
   else load_w(a.p.Wkp, wave, lane, w);
-  if (tid < TE) {
+  if (tid < TEK) {
     sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
     sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
-  } else if (tid - TE <= natom) {
-    sOff[tid - TE] = a.edge_offset[tile.atom_begin + (tid - TE)] - eb;  // tile-local CSR row pointers
+  } else if (tid - TEK <= natom) {
+    sOff[tid - TEK] = a.edge_offset[tile.atom_begin + (tid - TEK)] - eb;  // tile-local CSR row pointers
   }
-  f32x16 acc[2];
+  if (tid < D) {
+    if (GUPD) {
+      sPar[tid] = a.p.lng_g[tid];
+      sPar[D + tid] = a.p.lng_b[tid];
+    }
+  } else {
+    sPar[2 * D + (tid - D)] = a.p.ln_g[tid - D];
+    sPar[3 * D + (tid - D)] = a.p.ln_b[tid - D];
+  }
+  f32x16 acc[RT];
   if (GUPD) {
-    for (int i = tid; i < TE * 32; i += 256) {
+    for (int i = tid; i < TEK * 32; i += 256) {
       const int r = i >> 5, c4 = i & 31;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < ne) v = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
@@ -313,31 +331,33 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
     STAMP(a.stamps, 1);
     // U = G . W2  (geometry third of the concat GEMM, attention.py:142-151)
     zero_acc(acc);
-    mma128<2>(sA, w, lane, acc);
+    mma128<RT>(sA, w, lane, acc);
     STAMP(a.stamps, 2);
     load_w(a.p.Wkp, wave, lane, w);  // key weights arrive during the row pass
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i];
   }
   __syncthreads();
   STAMP(a.stamps, 3);
 
-  // Row pass, 4 threads per edge row: geometry update + LayerNorm_g, gate with the gathered neighbour row.
+  // Row pass, TPR threads per edge row: geometry update + LayerNorm_g, gate with the gathered neighbour row.
   {
-    const int r = tid >> 2, sub = tid & 3;
+    const int r = tid / TPR, sub = tid % TPR;
     if (r < ne) {
       const int ctr = sCtr[r], nb = sCol[r];
       const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
       if (GUPD) {
         const float4* p1 = reinterpret_cast<const float4*>(a.P1) + (size_t)ctr * 32;
         const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
-        float4 t[8];
+        float4 t[NCH], cn[NCH];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c4 = sub + 4 * i;
+        for (int i = 0; i < NCH; ++i) cn[i] = crow[sub + TPR * i];  // neighbour centre row (attention.py:136), used below
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c4 = sub + TPR * i;
           const float4 u = *reinterpret_cast<const float4*>(&sB[r * LDS_STRIDE + 4 * c4]);
           const float4 g = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
           // concat order [centre, geometry, neighbour] (attention.py:143-149): (c_i W1 + b) + g W2 + c_j W3
@@ -345,23 +365,23 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
           t[i] = f4add(f4swish(v), g);  // geometry_update + neighbor_geometry (:153)
           s += f4sum(t[i]);
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
         const float mean = s * (1.0f / D);
         float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NCH; ++i) {
           const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
           v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o);
         const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c4 = sub + 4 * i;
-          const float4 g = reinterpret_cast<const float4*>(a.p.lng_g)[c4];
-          const float4 be = reinterpret_cast<const float4*>(a.p.lng_b)[c4];
+        for (int i = 0; i < NCH; ++i) {
+          const int c4 = sub + TPR * i;
+          const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
+          const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
           float4 y;
           float inv;
           inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
@@ -369,7 +389,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
           inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
           inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
           reinterpret_cast<float4*>(a.geom)[(size_t)(eb + r) * 32 + c4] = y;  // threaded to the next layer (scann_model.py:415)
-          *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(crow[c4], y);  // attention.py:157
+          *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);  // attention.py:157
         }
       } else {
         // base SCANN: geomL = swish(gd Wf + bf) * weight (attention.py:155), gd = raw Gaussian basis
@@ -378,8 +398,8 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
         for (int k = 0; k < NG; ++k) gd[k] = a.gd[(size_t)(eb + r) * NG + k];
         const float wgt = a.edge_weight[eb + r];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c4 = sub + 4 * i;
+        for (int i = 0; i < NCH; ++i) {
+          const int c4 = sub + TPR * i;
           float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int k = 0; k < NG; ++k) {
@@ -392,11 +412,11 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
           *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(crow[c4], y);
         }
       }
-    } else if (!GUPD) {
+    } else if (!GUPD && r < TEK) {
       // ragged tail rows must be defined for the MFMA (GUPD staged zeros already)
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < NCH; ++i)
+        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + TPR * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   // query rows of this tile's atoms: fetched now, parked in registers across the key GEMM
@@ -412,12 +432,12 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
 
   // K = ang . Wk + bk  (attention.py:163)
   zero_acc(acc);
-  mma128<2>(sA, w, lane, acc);
+  mma128<RT>(sA, w, lane, acc);
   STAMP(a.stamps, 5);
   {
     const float b = a.p.bk[col];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + b;
   }
@@ -433,26 +453,24 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
   // Attention.  Packed edges are all unmasked, so the additive -1e9 mask and the multiplicative mask
   // (attention.py:186,206) are the identity; an atom without edges reduces to ctx = LN(q), exactly what the
   // reference's fully-masked row yields (uniform softmax zeroed by the mask).
-  // (1) logits: thread = (edge row, pair of heads); e[b,h,c,n] = sum_d (q*dk)[c,h,d] k[c,n,h,d]  (:180-183)
+  // (1) logits: thread = (edge row, 8/TPR heads); e[b,h,c,n] = sum_d (q*dk)[c,h,d] k[c,n,h,d]  (:180-183)
   {
-    const int n = tid >> 2, hh = tid & 3;
+    constexpr int HPT = NHEAD / TPR;  // heads per thread
+    const int n = tid / TPR, hh = tid % TPR;
     if (n < ne) {
-      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + 32 * hh;
-      const float* krow = sB + n * LDS_STRIDE + 32 * hh;
-      float e0 = 0.f, e1 = 0.f;
+      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + HDIM * HPT * hh;
+      const float* krow = sB + n * LDS_STRIDE + HDIM * HPT * hh;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
-        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
-        e0 += (q4.x * 0.25f) * k4.x; e0 += (q4.y * 0.25f) * k4.y; e0 += (q4.z * 0.25f) * k4.z; e0 += (q4.w * 0.25f) * k4.w;
-      }
+      for (int hp = 0; hp < HPT; ++hp) {
+        float e = 0.f;
 #pragma unroll
-      for (int j = 4; j < 8; ++j) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
-        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
-        e1 += (q4.x * 0.25f) * k4.x; e1 += (q4.y * 0.25f) * k4.y; e1 += (q4.z * 0.25f) * k4.z; e1 += (q4.w * 0.25f) * k4.w;
+        for (int j = 0; j < 4; ++j) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qrow + HDIM * hp + 4 * j);
+          const float4 k4 = *reinterpret_cast<const float4*>(krow + HDIM * hp + 4 * j);
+          e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
+        }
+        sE[n * NHEAD + HPT * hh + hp] = e;
       }
-      *reinterpret_cast<float2*>(&sE[n * 8 + 2 * hh]) = make_float2(e0, e1);
     }
   }
   __syncthreads();
@@ -464,13 +482,13 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
     for (int la = lgp; la < natom; la += 8) {
       const int e0 = sOff[la], e1 = sOff[la + 1];
       float m = -INFINITY;
-      for (int n = e0; n < e1; ++n) m = fmaxf(m, sE[n * 8 + h]);
+      for (int n = e0; n < e1; ++n) m = fmaxf(m, sE[n * NHEAD + h]);
       float ssum = 0.f;
-      for (int n = e0; n < e1; ++n) ssum += fast_exp(sE[n * 8 + h] - m);
+      for (int n = e0; n < e1; ++n) ssum += fast_exp(sE[n * NHEAD + h] - m);
       const float rs = __builtin_amdgcn_rcpf(ssum);
       float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int n = e0; n < e1; ++n) {
-        const float attn = fast_exp(sE[n * 8 + h] - m) * rs;
+        const float attn = fast_exp(sE[n * NHEAD + h] - m) * rs;
         const float4 k4 = *reinterpret_cast<const float4*>(&sB[n * LDS_STRIDE + 4 * c4]);
         cx.x += attn * k4.x; cx.y += attn * k4.y; cx.z += attn * k4.z; cx.w += attn * k4.w;  // v = key (:198-206)
       }
@@ -508,8 +526,8 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c4 = sub + 8 * i;
-        const float4 g = reinterpret_cast<const float4*>(a.p.ln_g)[c4];
-        const float4 be = reinterpret_cast<const float4*>(a.p.ln_b)[c4];
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
         float4 y;
         float inv;
         inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
@@ -526,8 +544,13 @@ __global__ __launch_bounds__(256) void edge_kernel(EdgeArgs a) {
 void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
   const dim3 grid(a.n_tile), block(256);
-  if (a.g_update) hipLaunchKernelGGL((edge_kernel<true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((edge_kernel<false>), grid, block, 0, s, a);
+  if (a.tile_rows == 32) {
+    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((edge_kernel<false, 1>), grid, block, 0, s, a);
+  } else {
+    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((edge_kernel<false, 2>), grid, block, 0, s, a);
+  }
 }
 
 // ---- basis kernel ----------------------------------------------------------------------------------

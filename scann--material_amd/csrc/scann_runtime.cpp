@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -16,7 +17,7 @@ using namespace scann;
 
 namespace {
 
-constexpr int NSTREAM = 4;
+constexpr int MAX_STREAM = 16;
 thread_local std::string g_create_error;
 
 struct WeightSpec {
@@ -31,10 +32,12 @@ struct scann_handle {
   scann_config_t cfg{};
   int device = 0;
   std::string err;
-  hipStream_t streams[NSTREAM]{};
+  hipStream_t streams[MAX_STREAM]{};
+  int nstream = 4;  // HIP streams batches are spread over (env SCANN_STREAMS, 1..16)
   std::vector<WeightSpec> specs;
   bool loaded = false;
   bool debug = false;
+  int edge_tile = 64;  // edge rows per tile (32 or 64); env SCANN_EDGE_TILE overrides
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -44,7 +47,7 @@ struct scann_handle {
 };
 
 struct scann_dbatch {
-  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0;
+  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0, tile_rows = 64;
   char* arena = nullptr;  // inputs + workspace, one allocation
   // inputs
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
@@ -192,11 +195,13 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->cfg = *cfg;
   h->device = device_id;
   h->specs = build_specs(*cfg);
+  if (const char* et = getenv("SCANN_EDGE_TILE")) h->edge_tile = atoi(et) == 32 ? 32 : 64;
+  if (const char* ns = getenv("SCANN_STREAMS")) h->nstream = std::min(MAX_STREAM, std::max(1, atoi(ns)));
   if (hipSetDevice(device_id) != hipSuccess) {
     delete h;
     return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipSetDevice failed");
   }
-  for (int i = 0; i < NSTREAM; ++i) {
+  for (int i = 0; i < h->nstream; ++i) {
     if (hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking) != hipSuccess) {
       delete h;
       return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipStreamCreate failed");
@@ -210,13 +215,13 @@ void scann_destroy(scann_handle_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  for (int i = 0; i < NSTREAM; ++i)
+  for (int i = 0; i < MAX_STREAM; ++i)
     if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
   if (h->d_weights) (void)hipFree(h->d_weights);
   delete h;
 }
 
-int scann_num_streams(const scann_handle_t*) { return NSTREAM; }
+int scann_num_streams(const scann_handle_t* h) { return h ? h->nstream : 0; }
 
 int scann_weight_count(const scann_handle_t* h) { return h ? (int)h->specs.size() : SCANN_ERR_INVALID; }
 
@@ -391,22 +396,26 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
       return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: atomic number outside the embedding table (n_atoms)");
   std::vector<int32_t> edge_row((size_t)E);
   std::vector<EdgeTile> tiles;
-  {
+  int tile_rows = h->edge_tile;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int want = tile_rows;
+    tiles.clear();
     int s = 0;
     EdgeTile cur{0, 0, 0, 0};
     for (int a = 0; a < A; ++a) {
       while (a >= b->mol_offset[s + 1]) ++s;
       const int32_t e0 = b->edge_offset[a], e1 = b->edge_offset[a + 1];
       if (e1 < e0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: edge_offset not monotone");
-      if (e1 - e0 > TE)
+      if (e1 - e0 > TE_MAX)
         return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: an atom has more than 64 neighbours (edge-tile limit)");
+      if (e1 - e0 > tile_rows) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom: fall back to 64-row tiles
       for (int e = e0; e < e1; ++e) {
         if (b->edge_col[e] < b->mol_offset[s] || b->edge_col[e] >= b->mol_offset[s + 1])
           return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: neighbour index outside its structure");
         edge_row[e] = a;
       }
       // greedy tiling: whole atoms, <= TE edges and <= TA atoms per tile
-      if ((e1 - cur.edge_begin) > TE || (a - cur.atom_begin) >= TA) {
+      if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= TA) {
         cur.atom_end = a;
         cur.edge_end = e0;
         tiles.push_back(cur);
@@ -416,10 +425,11 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     cur.atom_end = A;
     cur.edge_end = E;
     tiles.push_back(cur);
+    if (tile_rows == want) break;  // no atom overflowed the requested tile size
   }
   HIPCHK(h, hipSetDevice(h->device));
   scann_dbatch* db = new scann_dbatch();
-  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms;
+  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows;
   // arena layout: inputs first (one H2D copy), then workspace
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
@@ -542,7 +552,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (h->debug) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
     if (l == L) break;
     EdgeArgs ea{};
-    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update;
+    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.tile_rows = db->tile_rows; ea.g_update = c.g_update;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
     ea.c = db->c; ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = db->ctx;
@@ -576,7 +586,7 @@ extern "C" {
 int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot) {
   if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_forward_resident: null argument");
   HIPCHK(h, hipSetDevice(h->device));
-  const int slot = ((stream_slot % NSTREAM) + NSTREAM) % NSTREAM;
+  const int slot = ((stream_slot % h->nstream) + h->nstream) % h->nstream;
   db->last_slot = slot;
   return run_forward(h, db, h->streams[slot], nullptr);
 }
@@ -594,7 +604,7 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
 int scann_sync(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  for (int i = 0; i < NSTREAM; ++i) HIPCHK(h, hipStreamSynchronize(h->streams[i]));
+  for (int i = 0; i < h->nstream; ++i) HIPCHK(h, hipStreamSynchronize(h->streams[i]));
   return SCANN_OK;
 }
 
