@@ -73,6 +73,24 @@ def total_flops_min(A, E, L=7, emb=48):
     return f + A * 6 * D * D + 2 * D * D + 2 * D  # + readout (GA pair term is per-structure A^2, omitted: <1 %)
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(affinity mask, cgroup v2/v1 CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The oracle (checker) timed on this host's cores on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -80,7 +98,8 @@ def cpu_baseline(seconds_budget=12.0):
 
     cfg = so.default_config("qm9")
     w = so.init_weights(cfg, 1234)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # before the OpenMP runtime of the C port starts
     try:
         import scann_oracle_c as soc  # C/OpenMP port of the same padded-dense algorithm
 

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/*.npz from the NumPy oracle (oracle/scann_oracle.py).  The reference itself cannot run
+here (TensorFlow absent), so these vectors pin the oracle against drift and give the GPU tests
+committed inputs/outputs; each file holds the padded inputs, the weight seed + a digest of the weights, the fp64 and
+fp32 oracle outputs and per-layer checksums.   Run:  python tests/golden/make_golden.py"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import scann_oracle as so  # noqa: E402
+
+CASES = {
+    # name: (base config, model overrides, hyper overrides, dataset kind, n structures, data seed)
+    "qm9_plus": ("qm9", {}, {}, "qm9", 6, 101),
+    "qm9_base": ("qm9", {"g_update": False}, {}, "qm9", 5, 102),
+    "qm9_no_norms": ("qm9", {"use_attn_norm": False, "use_ga_norm": False, "n_attention": 3}, {}, "qm9", 4, 103),
+    "qm9_e_b": ("qm9", {"n_attention": 2}, {"target": "e_b"}, "qm9", 4, 104),
+    "mp2018": ("mp2018", {"n_attention": 3}, {}, "mp2018", 3, 105),
+}
+WEIGHT_SEED = 4321
+
+
+def weights_digest(w):
+    h = hashlib.sha256()
+    for k in sorted(w):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+def build(name):
+    base, mo, hy, kind, n, seed = CASES[name]
+    cfg = so.default_config(base)
+    cfg["model"].update(mo)
+    cfg["hyper"].update(hy)
+    w = so.init_weights(cfg, WEIGHT_SEED, perturb=True)
+    de, dn = so.synth_dataset(n, seed, kind)
+    inputs, _ = so.pad_batch(de, dn, g_update=cfg["model"]["g_update"])
+    return cfg, w, inputs
+
+
+def main():
+    for name in CASES:
+        cfg, w, inputs = build(name)
+        inter = {}
+        y64, ga64 = so.forward(cfg, w, inputs, np.float64, intermediates=inter)
+        y32, ga32 = so.forward(cfg, w, inputs, np.float32)
+        sums = {"sum_" + k: np.float64(np.sum(v[np.isfinite(v)])) for k, v in inter.items() if k.startswith(("centers", "context"))}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), weight_seed=WEIGHT_SEED, weights_sha256=weights_digest(w),
+                            y64=y64, ga64=ga64, y32=y32, ga32=ga32, **sums, **{"in_" + k: v for k, v in inputs.items()})
+        print(name, y64[:3, 0])
+
+
+if __name__ == "__main__":
+    main()

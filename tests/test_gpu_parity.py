@@ -221,3 +221,61 @@ def test_errors_are_reported(hip_lib):
     w2.pop("after_Lc/bias")
     with pytest.raises(_hip.ScannHipError):
         model.engine.load_weights(w2)
+
+
+@pytest.mark.parametrize("name", ["qm9_plus", "qm9_base", "qm9_no_norms", "qm9_e_b", "mp2018"])
+def test_golden_vectors(hip_lib, name):
+    """Committed fixtures (tests/golden/*.npz, written by make_golden.py from the oracle)."""
+    import importlib.util
+    import os
+
+    from scann.models.scann_model import HipModel
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    cfg, w, _ = mg.build(name)
+    z = np.load(os.path.join(here, "golden", name + ".npz"))
+    inputs = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    model = HipModel(cfg, w, device=0, infer=True)
+    y, ga = model.predict(inputs)
+    tol_y = max(RTOL, 3 * rel_err(z["y32"], z["y64"]))
+    tol_g = max(RTOL, 3 * rel_err(z["ga32"], z["ga64"]))
+    assert rel_err(y, z["y64"]) <= tol_y and rel_err(ga, z["ga64"]) <= tol_g
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE config 2 sizes (batch 128, QM9 shapes) through the resident multi-stream pipeline: size-independent
+    properties instead of the (slow) oracle -- GA scores of every molecule sum to 1, outputs are finite, a batch split
+    in two gives the same bytes (batch-composition independence), and a sampled batch matches the fp32 oracle."""
+    from scann import _hip
+
+    cfg, w, _, model = make(n=2)
+    eng = model.engine
+    de, dn = so.synth_dataset(128 * 12, 77)
+    rbs, pks = [], []
+    for b in range(12):
+        inputs, _ = so.pad_batch(de[128 * b:128 * (b + 1)], dn[128 * b:128 * (b + 1)], True)
+        pks.append(_hip.pack_inputs(inputs))
+        rbs.append(eng.upload(pks[-1]))
+    for rep in range(2):
+        for i, rb in enumerate(rbs):
+            eng.forward_resident(rb, i)
+    eng.sync()
+    outs = [eng.download(rb) for rb in rbs]
+    for pk, (y, ga) in zip(pks, outs):
+        assert np.isfinite(y).all() and np.isfinite(ga).all()
+        sums = np.add.reduceat(ga, pk.mol_offset[:-1])
+        assert np.allclose(sums, 1.0, atol=2e-6)
+    from scann.parallel import concat_outputs, split_packed
+
+    halves = split_packed(pks[3], 2)
+    y2, ga2 = concat_outputs([eng.forward(h) for h in halves])
+    assert np.array_equal(y2, outs[3][0]) and np.array_equal(ga2, outs[3][1])
+    inputs, _ = so.pad_batch(de[128 * 5:128 * 6], dn[128 * 5:128 * 6], True)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(outs[5][0], y_ref[:, 0]) <= RTOL
+    assert rel_err(outs[5][1], ga_ref[..., 0][inputs["atom_mask"][..., 0]]) <= RTOL
+    for rb in rbs:
+        rb.free()

@@ -1,0 +1,198 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, padded-dict <-> CSR
+packing, the reference-named helpers, config defaults, data-parallel sharding (world_size 2 over gloo)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scann_oracle as so
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from scann import _hip
+
+    header = open(os.path.join(ROOT, "include", "scann_hip.h")).read()
+    declared = set(re.findall(r"\b(scann_[a-z_]+)\s*\(", header))
+    bound = {n for n, _, _ in _hip.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for n in declared:
+        assert hasattr(hip_lib, n), n
+    assert hip_lib.scann_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(hip_lib):
+    from scann import _hip
+    from scann.models.scann_model import config_struct, normalize_config
+
+    if hip_lib.scann_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(_hip.ScannHipError) as e:
+        _hip.Engine(config_struct(normalize_config(so.default_config())))
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_unsupported_config_is_rejected(hip_lib):
+    from scann import _hip
+    from scann.models.scann_model import config_struct, normalize_config
+
+    cfg = normalize_config(so.default_config())
+    cfg["model"]["local_dim"] = 64
+    with pytest.raises(_hip.ScannHipError) as e:
+        _hip.Engine(config_struct(cfg))
+    assert e.value.code == -2
+
+
+def test_pack_inputs_matches_padded_semantics():
+    from scann import _hip
+
+    de, dn = so.synth_dataset(7, 4)
+    inputs, _ = so.pad_batch(de, dn, True)
+    pk = _hip.pack_inputs(inputs)
+    sizes = [len(e[0]) for e in de]
+    assert pk.n_struct == 7 and pk.n_atom == sum(sizes)
+    assert np.array_equal(np.diff(pk.mol_offset), sizes)
+    assert pk.n_edge == int(inputs["neighbor_mask"].sum())
+    # every edge: same structure, right neighbour, right scalars, slot order preserved
+    e = 0
+    for b in range(7):
+        for a in range(sizes[b]):
+            row = pk.mol_offset[b] + a
+            assert pk.edge_offset[row] == e
+            for k, n in enumerate(dn[b][a]):
+                assert pk.edge_col[e] == pk.mol_offset[b] + n[1]
+                assert pk.edge_weight[e] == np.float32(n[2]) and pk.edge_dist[e] == np.float32(n[-1])
+                e += 1
+    ga = np.arange(pk.n_atom, dtype=np.float32) + 1
+    padded = pk.repad_ga(ga)
+    assert padded.shape == inputs["atomic"].shape + (1,)
+    assert np.array_equal(padded[..., 0][inputs["atom_mask"][..., 0]], ga) and padded[~inputs["atom_mask"][..., 0]].sum() == 0
+
+
+def test_pack_inputs_rejects_edge_to_padding():
+    from scann import _hip
+
+    de, dn = so.synth_dataset(2, 4)
+    inputs, _ = so.pad_batch(de, dn, True)
+    small = int(np.argmin([len(e[0]) for e in de]))
+    if inputs["atom_mask"][small, -1, 0]:
+        pytest.skip("both molecules have the same size")
+    inputs["neighbors"][small, 0, 0] = inputs["atomic"].shape[1] - 1
+    with pytest.raises(ValueError):
+        _hip.pack_inputs(inputs)
+
+
+def test_data_iterator_and_pad_helpers_follow_reference_contract():
+    from scann.utils import DataIterator, pad_nested_sequences, pad_sequence, split_data
+
+    de, dn = so.synth_dataset(10, 6)
+    for g_update in (True, False):
+        it = DataIterator(de, dn, batch_size=4, g_update=g_update)
+        assert len(it) == 3
+        for i in range(len(it)):
+            inputs, y = it[i]
+            ref, yref = so.pad_batch(de[4 * i: 4 * i + 4], dn[4 * i: 4 * i + 4], g_update)
+            assert np.array_equal(y, yref)
+            for k in ref:
+                assert np.array_equal(inputs[k], ref[k]) and inputs[k].dtype == ref[k].dtype, k
+    assert pad_sequence([[1, 2, 3], [4]], maxlen=2).tolist() == [[2, 3], [4, 0]]  # keeps the LAST maxlen items
+    assert pad_nested_sequences([[[1], [2, 3]], [[4]]], 2, 2, value=9).tolist() == [[[1, 9], [2, 3]], [[4, 9], [9, 9]]]
+    np.random.seed(0)
+    tr, va, te, ex = split_data(100, test_percent=0.1)
+    assert (len(tr), len(va), len(te), len(ex)) == (80, 10, 10, 0)
+    assert sorted(np.concatenate([tr, va, te]).tolist()) == list(range(100))
+    tr, va, te, ex = split_data(100, train_size=70, test_size=20)
+    assert (len(tr), len(va), len(te)) == (70, 10, 20)
+
+
+def test_config_defaults_for_incomplete_reference_yaml():
+    import yaml
+    from scann.models import normalize_config
+
+    ptgp = yaml.safe_load("model:\n  n_atoms: 80\n  embedding_dim: 48\n  n_attention: 11\n  local_dim: 128\n"
+                          "  num_head: 8\n  global_dim: 128\n  dense_out: 128\n  scale: 0.5\n  use_attn_norm: True\n"
+                          "  use_ga_norm: True\n  use_ring: True\nhyper:\n  batch_size: 64\n")
+    cfg = normalize_config(ptgp)
+    assert cfg["model"]["g_update"] is False and cfg["model"]["gaussian_d"] == 4.0 and cfg["model"]["feature"] == "atomic"
+    assert cfg["hyper"]["scaler"] is False and cfg["hyper"]["scheduler"] == "cosine"
+
+
+def test_weight_names_agree_between_oracle_and_library(hip_lib):
+    """scann_weight_name needs no device: build the spec list through a config the library accepts."""
+    from scann.models.scann_model import keras_default_init
+
+    for name in ("qm9", "mp2018"):
+        cfg = so.default_config(name)
+        specs = so.weight_shapes(cfg)
+        w = keras_default_init(specs, seed=0)
+        assert set(w) == {n for n, _ in specs}
+        assert sum(v.size for v in w.values()) == so.count_params(cfg)
+        assert not w["dense_embed/bias"].any() and (w["local_attention_0/layer_norm/gamma"] == 1).all()
+
+
+def test_split_packed_balances_and_roundtrips():
+    from scann import _hip
+    from scann.parallel import concat_outputs, rank_slice, split_packed
+
+    de, dn = so.synth_dataset(40, 8)
+    inputs, _ = so.pad_batch(de, dn, True)
+    pk = _hip.pack_inputs(inputs)
+    for n in (1, 2, 3, 8):
+        shards = split_packed(pk, n)
+        assert len(shards) == n and sum(s.n_struct for s in shards) == 40
+        assert sum(s.n_edge for s in shards) == pk.n_edge and sum(s.n_atom for s in shards) == pk.n_atom
+        assert max(s.n_edge for s in shards) <= 1.35 * pk.n_edge / n + 400
+        for s in shards:
+            assert s.mol_offset[0] == 0 and s.edge_offset[0] == 0 and s.edge_col.min() >= 0 and s.edge_col.max() < s.n_atom
+        ys = concat_outputs([(np.arange(s.n_struct, dtype=np.float32), np.zeros(s.n_atom, np.float32)) for s in shards])
+        assert ys[0].shape == (40,) and ys[1].shape == (pk.n_atom,)
+    assert [rank_slice(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+_WORKER = r'''
+import os, sys, numpy as np
+sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import torch, torch.distributed as dist
+import scann_oracle as so
+from scann import _hip
+from scann.parallel import split_packed
+import torch_ref
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = so.default_config("qm9"); cfg["model"]["n_attention"] = 2
+w = so.init_weights(cfg, 5, perturb=True)
+de, dn = so.synth_dataset(9, 12)
+inputs, _ = so.pad_batch(de, dn, True)
+pk = _hip.pack_inputs(inputs)
+shard = split_packed(pk, world)[rank]               # each rank computes only its own structures
+y, ga = torch_ref.forward_packed(cfg, w, shard)     # CPU stand-in for the per-rank handle
+parts = [None] * world
+dist.all_gather_object(parts, (y[:, 0], ga))
+t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)   # bench.py's max-over-ranks timing
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0:
+    yf, gaf = so.forward(cfg, w, inputs, np.float64)
+    yy = np.concatenate([p[0] for p in parts]); gg = np.concatenate([p[1] for p in parts])
+    assert np.allclose(yy, yf[:, 0], rtol=1e-9), (yy, yf[:, 0])
+    assert np.allclose(gg, gaf[..., 0][inputs["atom_mask"][..., 0]], rtol=1e-9)
+    assert abs(t.item() - 0.1 * world) < 1e-12
+    print("SHARD_OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharded_inference_over_gloo(tmp_path):
+    """World size 2 on CPU: shard by structure, no data-path collective, concatenate -> identical to one rank."""
+    pytest.importorskip("torch")
+    script = tmp_path / "worker.py"
+    script.write_text("ROOT = %r\n" % ROOT + _WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SHARD_OK" in outs[0]

@@ -1,0 +1,81 @@
+"""Independent cross-check of the NumPy oracle's op semantics: the same graph written a second time with stock
+torch CPU ops (F.embedding, F.linear, F.silu, F.layer_norm, F.softmax) on the PACKED/CSR layout, so it shares
+neither the layout nor the hand-written LayerNorm/softmax/swish of oracle/scann_oracle.py.  Test-only."""
+import math
+
+import numpy as np
+
+
+def forward_packed(config, weights, pk, dtype="float64"):
+    import torch
+    import torch.nn.functional as F
+
+    dt = getattr(torch, dtype)
+    cfg = config["model"]
+    W = {k: torch.tensor(np.asarray(v), dtype=dt) for k, v in weights.items()}
+    d, H = cfg["local_dim"], cfg["num_head"]
+    hd = d // H
+
+    def lin(x, p):
+        return F.linear(x, W[p + "/kernel"].T, W[p + "/bias"])
+
+    def ln(x, p):
+        return F.layer_norm(x, (x.shape[-1],), W[p + "/gamma"], W[p + "/beta"], eps=1e-6)
+
+    def gauss(x, stop):
+        c = torch.tensor(np.linspace(0, stop, 20, dtype="float32"), dtype=dt)
+        return torch.exp(-((x[:, None] - c[None, :]) ** 2) / 0.25)
+
+    atomic = torch.tensor(pk.atomic, dtype=torch.long)
+    col = torch.tensor(pk.edge_col, dtype=torch.long)
+    deg = np.diff(pk.edge_offset)
+    row = torch.tensor(np.repeat(np.arange(pk.n_atom), deg), dtype=torch.long)
+    dist = torch.tensor(pk.edge_dist, dtype=dt)
+    wgt = torch.tensor(pk.edge_weight, dtype=dt)
+    A, E = pk.n_atom, pk.n_edge
+
+    c = F.silu(lin(F.embedding(atomic, W["embed_atom/embeddings"]), "dense_embed"))
+    gd = gauss(dist, cfg["gaussian_d"])
+    if cfg["g_update"]:
+        geom = F.silu(lin(gd, "neighbor_d")) * F.silu(lin(gauss(wgt, math.pi * 2), "neighbor_w"))
+    for i in range(cfg["n_attention"]):
+        p = "local_attention_%d" % i
+        cn = c[col]
+        if cfg["g_update"]:
+            upd = F.silu(lin(torch.cat([c[row], geom, cn], -1), p + "/filter_geo"))
+            geom = ln(upd + geom, p + "/layer_norm_g")
+            g = geom
+        else:
+            g = F.silu(lin(gd, p + "/filter_geo")) * wgt[:, None]
+        q = lin(c, p + "/query")
+        k = lin(cn * g, p + "/key")
+        e = ((q[row] * hd ** -0.5).view(E, H, hd) * k.view(E, H, hd)).sum(-1)  # [E,H]
+        attn = torch.zeros_like(e)
+        off = pk.edge_offset
+        for a in range(A):  # per-atom softmax over its own edges
+            if off[a + 1] > off[a]:
+                attn[off[a]:off[a + 1]] = F.softmax(e[off[a]:off[a + 1]], 0)
+        ctx = torch.zeros(A, d, dtype=dt).index_add_(0, row, (attn[:, :, None] * k.view(E, H, hd)).reshape(E, d)) + q
+        ctx = ln(ctx, p + "/layer_norm")
+        if cfg["use_attn_norm"]:
+            r = "residual_norm_%d" % i
+            c = ln(ctx + lin(F.silu(lin(ctx, r + "/dense_1")), r + "/dense_2"), r + "/layer_norm")
+        else:
+            c = ctx
+    z = F.silu(lin(c, "after_Lc"))
+    gq, gk = lin(z, "global_attention/query"), lin(z, "global_attention/key")
+    ys, gas = [], []
+    for s in range(pk.n_struct):
+        a0, a1 = pk.mol_offset[s], pk.mol_offset[s + 1]
+        en = gk[a0:a1] @ gq[a0:a1].T
+        agg = (en - torch.diag(torch.diag(en))).sum(-1)
+        if cfg["use_ga_norm"]:
+            agg = agg / torch.linalg.vector_norm(agg)
+        at = F.softmax(agg, 0)
+        rep = (at[:, None] * gk[a0:a1]).sum(0)
+        y = lin(F.silu(lin(rep, "bf_property")), "predict_property")
+        if config.get("hyper", {}).get("target") == "e_b":
+            y = torch.relu(y)
+        ys.append(y)
+        gas.append(at)
+    return torch.stack(ys).numpy().reshape(-1, 1), torch.cat(gas).numpy()
