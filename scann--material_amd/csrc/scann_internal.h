@@ -13,7 +13,7 @@ constexpr int NG = 20;           // Gaussian basis size (scann_model.py:378)
 constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict-free b128 A-fragment reads)
 constexpr int TE_MAX = 64;       // edge rows per edge tile: 32 or 64 (one or two 32-row MFMA row tiles)
 constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row tile)
-constexpr int TB = 64;           // edges per basis-kernel workgroup
+constexpr int TB = 16;           // edges per basis-kernel workgroup
 constexpr int WPACK = D * D;     // floats in one packed 128x128 weight
 
 // One tile of the edge kernel: a run of whole atoms whose CSR rows are contiguous, <= TE edges.

@@ -43,6 +43,8 @@ __device__ __forceinline__ float swishf(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
 }
 
+__device__ __forceinline__ float swish_exact(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+
 // e^x through v_exp_f32 (2^x, 1 ulp); used where the argument is <= 0 (softmax numerators).
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
@@ -105,6 +107,7 @@ __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (
 
 // ---- atom-tile kernel ------------------------------------------------------------------------------
 
+// Weights are double-buffered in registers: the slab for GEMM g+1 is requested before the MFMAs of GEMM g.
 template <bool FFN, int MODE>
 __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[TA * LDS_STRIDE];
@@ -113,6 +116,12 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
   const int row0 = blockIdx.x * TA;
   const int nrows = min(TA, a.n_atom - row0);
   const int col = 32 * wave + (lane & 31);
+  // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
+  const float* const firstW = MODE == 1 ? a.WCp : a.WAp;
+
+  float4 wA[16], wB[16];
+  if (FFN) load_w(a.Wf1p, wave, lane, wA);
+  else load_w(firstW, wave, lane, wA);
 
   // stage x rows (zero-fill the ragged tail so the MFMAs see defined data)
   for (int i = tid; i < TA * 32; i += 256) {
@@ -121,6 +130,7 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
     if (r < nrows) {
       const int src = a.x_index ? a.x_index[row0 + r] : (row0 + r);
       v = reinterpret_cast<const float4*>(a.x)[(size_t)src * 32 + c4];
+      if (!FFN) reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] = v;  // centres = staged rows (layer 0 / no ResidualNorm)
     }
     *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
   }
@@ -129,8 +139,9 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
   f32x16 acc[1];
   if (FFN) {
     // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
+    load_w(a.Wf2p, wave, lane, wB);
     zero_acc(acc);
-    gemm128<1>(sX, a.Wf1p, wave, lane, acc);
+    mma128<1>(sX, wA, lane, acc);
     {
       const float b = a.bf1[col];
 #pragma unroll
@@ -138,8 +149,9 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
     }
     __syncthreads();
     // y = h W2 + b2 ; t = x + y
+    load_w(firstW, wave, lane, wA);
     zero_acc(acc);
-    gemm128<1>(sH, a.Wf2p, wave, lane, acc);
+    mma128<1>(sH, wB, lane, acc);
     __syncthreads();  // every wave is done reading sH
     {
       const float b = a.bf2[col];
@@ -190,27 +202,23 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
       }
     }
     __syncthreads();
-  } else {
-    // centres are the staged rows themselves (layer 0, or use_attn_norm False)
-    for (int i = tid; i < TA * 32; i += 256) {
-      const int r = i >> 5, c4 = i & 31;
-      if (r < nrows)
-        reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] =
-            *reinterpret_cast<const float4*>(&sX[r * LDS_STRIDE + 4 * c4]);
-    }
   }
 
-  if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3
+  if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
+    load_w(a.WBp, wave, lane, wB);
     zero_acc(acc);
-    gemm128<1>(sX, a.WAp, wave, lane, acc);
-    const float b = a.bA[col];
+    mma128<1>(sX, wA, lane, acc);
+    {
+      const float b = a.bA[col];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = acc_row(i, lane);
-      if (r < nrows) a.oA[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+      for (int i = 0; i < 16; ++i) {
+        const int r = acc_row(i, lane);
+        if (r < nrows) a.oA[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+      }
     }
+    load_w(a.WCp, wave, lane, wA);
     zero_acc(acc);
-    gemm128<1>(sX, a.WBp, wave, lane, acc);
+    mma128<1>(sX, wB, lane, acc);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = acc_row(i, lane);
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
   }
   if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
     zero_acc(acc);
-    gemm128<1>(sX, a.WCp, wave, lane, acc);
+    mma128<1>(sX, wA, lane, acc);
     const float b = a.bC[col];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -228,16 +236,18 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
     }
   }
   if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
+    load_w(a.WCp, wave, lane, wB);
     zero_acc(acc);
-    gemm128<1>(sX, a.WAp, wave, lane, acc);
+    mma128<1>(sX, wA, lane, acc);
     {
       const float b = a.bA[col];
 #pragma unroll
       for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b);
     }
     __syncthreads();
+    load_w(a.WDp, wave, lane, wA);
     zero_acc(acc);
-    gemm128<1>(sH, a.WCp, wave, lane, acc);
+    mma128<1>(sH, wB, lane, acc);
     {
       const float b = a.bC[col];
 #pragma unroll
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
       }
     }
     zero_acc(acc);
-    gemm128<1>(sH, a.WDp, wave, lane, acc);
+    mma128<1>(sH, wA, lane, acc);
     {
       const float b = a.bD[col];
 #pragma unroll
@@ -568,6 +578,14 @@ __global__ __launch_bounds__(256) void basis_kernel(BasisParams p, const float* 
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * TB;
   const int ne = min(TB, n_edge - e0);
+  const int col = tid & (D - 1), half = tid >> 7;
+  float wd[NG], ww[NG];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {  // this thread's column of both [20,128] kernels, in flight during the basis phase
+    wd[k] = p.Wd[k * D + col];
+    ww[k] = p.Ww[k * D + col];
+  }
+  const float bd = p.bd[col], bw = p.bw[col];
   for (int i = tid; i < TB * 2 * NG; i += 256) {
     const int e = i / (2 * NG), k = i % (2 * NG);
     float v = 0.f;
@@ -575,16 +593,8 @@ __global__ __launch_bounds__(256) void basis_kernel(BasisParams p, const float* 
     sG[e][k] = v;
   }
   __syncthreads();
-  const int col = tid & (D - 1), half = tid >> 7;
-  float wd[NG], ww[NG];
-#pragma unroll
-  for (int k = 0; k < NG; ++k) {
-    wd[k] = p.Wd[k * D + col];
-    ww[k] = p.Ww[k * D + col];
-  }
-  const float bd = p.bd[col], bw = p.bw[col];
-  for (int e = half * (TB / 2); e < (half + 1) * (TB / 2); ++e) {
-    if (e >= ne) break;
+#pragma unroll 2
+  for (int e = half; e < ne; e += 2) {
     float ad = 0.f, aw = 0.f;
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(256) void basis_kernel(BasisParams p, const float* 
       aw += sG[e][NG + k] * ww[k];
     }
     // neighbor_d * neighbor_w (scann_model.py:381-389)
-    geom[(size_t)(e0 + e) * D + col] = swishf(ad + bd) * swishf(aw + bw);
+    geom[(size_t)(e0 + e) * D + col] = swish_exact(ad + bd) * swish_exact(aw + bw);
   }
 }
 
@@ -644,29 +654,67 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// One workgroup per structure.  GlobalAttention.call (attention.py:267-318) on the real atoms only
-// (the multiplicative atom mask zeroes every padded term), literal sum over j != i.
+// One workgroup per structure.  GlobalAttention.call (attention.py:267-318) on the real atoms only (the
+// multiplicative atom mask zeroes every padded term).  The pair energies E[i][j] = k_i . q_j (:279) are 32x32 MFMA
+// tiles; wave w contracts features [32w, 32w+32) of every tile, masks the diagonal (:282-285) and rows/columns past
+// the structure, keeps per-lane partial row sums over all column tiles, reduces them across the 32 columns once
+// per row tile, and the four waves' partial sums are added in fixed order (deterministic).
 __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
-  extern __shared__ float sAgg[];  // [n] scores, reused for attention
+  extern __shared__ float sDyn[];  // [4][npad] partial row sums, then [npad] scores / attention
   __shared__ float sRep[D];
   __shared__ float sRed[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a0 = a.mol_offset[blockIdx.x];
   const int n = a.mol_offset[blockIdx.x + 1] - a0;
-  const float2* gq = reinterpret_cast<const float2*>(a.gq) + (size_t)a0 * 64;
-  const float2* gk = reinterpret_cast<const float2*>(a.gk) + (size_t)a0 * 64;
+  const int T = (n + 31) >> 5, npad = T << 5;
+  float* sPart = sDyn;            // [4][npad]
+  float* sAgg = sDyn + 4 * npad;  // [npad]
+  const float4* gq4 = reinterpret_cast<const float4*>(a.gq) + (size_t)a0 * 32;
+  const float4* gk4 = reinterpret_cast<const float4*>(a.gk) + (size_t)a0 * 32;
+  const int r = lane & 31, h = lane >> 5;
 
-  // agg_i = sum_{j != i} k_i . q_j   (:279-292)
-  for (int i = wave; i < n; i += 4) {
-    const float2 k2 = gk[(size_t)i * 64 + lane];
-    float agg = 0.f;
-    for (int j = 0; j < n; ++j) {
-      const float2 q2 = gq[(size_t)j * 64 + lane];
-      const float e = wave_sum(k2.x * q2.x + k2.y * q2.y);
-      if (j != i) agg += e;
+  for (int it = 0; it < T; ++it) {
+    const int irow = it * 32 + r;
+    float4 ka[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)  // features 32*wave + 8t + 4h .. +3 of key row irow
+      ka[t] = irow < n ? gk4[(size_t)irow * 32 + 8 * wave + 2 * t + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float part[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = 0.f;
+    for (int jt = 0; jt < T; ++jt) {
+      const int jrow = jt * 32 + r;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 qb = jrow < n ? gq4[(size_t)jrow * 32 + 8 * wave + 2 * t + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t].x, qb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t].y, qb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t].z, qb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t].w, qb.w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int gi = it * 32 + acc_row(i, lane);  // key index (row), this lane's column is query index jrow
+        part[i] += (gi != jrow) ? acc[i] : 0.f;     // mask_center (:282-285); padded rows/cols contribute exact zeros
+      }
     }
-    if (lane == 0) sAgg[i] = agg;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = part[i];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      if (r == 0) sPart[wave * npad + it * 32 + acc_row(i, lane)] = v;
+    }
   }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256)  // agg_i (:289-292)
+    sAgg[i] = ((sPart[i] + sPart[npad + i]) + sPart[2 * npad + i]) + sPart[3 * npad + i];
   __syncthreads();
   // normalise + softmax over atoms by wave 0 (:295-302)
   if (wave == 0) {
@@ -697,19 +745,23 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
     }
   }
   __syncthreads();
-  // rep = sum_i attn_i k_i  (:314-316)
-  if (tid < D) {
-    float r = 0.f;
-    for (int i = 0; i < n; ++i) r += sAgg[i] * a.gk[(size_t)(a0 + i) * D + tid];
-    sRep[tid] = r;
+  // rep = sum_i attn_i k_i  (:314-316): two half-sums over interleaved atoms per feature, fixed order
+  {
+    const int f = tid & (D - 1), half = tid >> 7;
+    float rsum = 0.f;
+    for (int i = half; i < n; i += 2) rsum += sAgg[i] * a.gk[(size_t)(a0 + i) * D + f];
+    if (half == 1) sRep[f] = rsum;
+    __syncthreads();
+    if (half == 0) sRep[f] = rsum + sRep[f];
   }
   __syncthreads();
   // bf_property + predict_property (scann_model.py:437-447)
   float part = 0.f;
   if (tid < D) {
-    float h = 0.f;
-    for (int k = 0; k < D; ++k) h += sRep[k] * a.p.Wb[k * D + tid];
-    part = swishf(h + a.p.bb[tid]) * a.p.wo[tid];
+    float hsum = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < D; ++k) hsum += sRep[k] * a.p.Wb[k * D + tid];
+    part = swish_exact(hsum + a.p.bb[tid]) * a.p.wo[tid];
   }
   part = wave_sum(part);
   if (lane == 0) sRed[wave] = part;
@@ -723,7 +775,8 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
 
 void launch_readout(const ReadoutArgs& a, hipStream_t s) {
   if (a.n_struct <= 0) return;
-  const size_t lds = (size_t)(a.max_atoms > 0 ? a.max_atoms : 1) * sizeof(float);
+  const size_t npad = (size_t)((a.max_atoms + 31) / 32) * 32;
+  const size_t lds = 5 * npad * sizeof(float);  // 4 partial-sum rows + the score row
   hipLaunchKernelGGL(readout_kernel, dim3(a.n_struct), dim3(256), lds, s, a);
 }
 

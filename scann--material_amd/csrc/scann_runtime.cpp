@@ -390,7 +390,7 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (n <= 0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: structure without atoms");
     max_atoms = std::max(max_atoms, n);
   }
-  if ((size_t)max_atoms * sizeof(float) > 60000) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: structure too large");
+  if ((size_t)max_atoms * 5 * sizeof(float) > 60000) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: structure too large");
   for (int a = 0; a < A; ++a)
     if (b->atomic[a] < 0 || b->atomic[a] >= h->cfg.n_atoms)
       return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: atomic number outside the embedding table (n_atoms)");
