@@ -62,6 +62,20 @@ void launch_basis(const BasisParams& p, const float* dist, const float* weight, 
                   float* geom, hipStream_t s);
 void launch_basis_raw(const float* cd, const float* dist, int n_edge, float* gd, hipStream_t s);
 
+// General embedding (use_ring / feature="cgcnn"); the plain Embedding path uses the per-species LUT instead.
+struct EmbedArgs {
+  int32_t n_atom, emb_dim;
+  const int32_t* atomic;   // [n_atom] (feature="atomic")
+  const float* cgcnn;      // [n_atom,92] or null
+  const float* ring;       // [n_atom,2] or null
+  const float *emb;        // embed_atom/embeddings [n_atoms,emb]
+  const float *We, *be;    // embed_atom/kernel [92,emb], bias (cgcnn)
+  const float *Wr, *br;    // extra_embed [2,10], [10]
+  const float *Wde, *bde;  // dense_embed [emb(+10),128], [128]
+  float* c0;               // [n_atom,128]
+};
+void launch_embed(const EmbedArgs& a, hipStream_t s);
+
 struct AtomArgs {
   const float* x;          // [n_atom,128] input rows (context of previous layer, or the LUT)
   const int32_t* x_index;  // optional row indirection (layer 0: atomic number -> LUT row) or null

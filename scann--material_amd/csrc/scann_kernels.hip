@@ -641,6 +641,47 @@ void launch_embed_lut(const float* emb, const float* W, const float* b, int n_sp
   hipLaunchKernelGGL(embed_lut_kernel, dim3(n_species), dim3(D), 0, s, emb, W, b, emb_dim, lut);
 }
 
+// ---- general embedding kernel (use_ring / feature="cgcnn") -----------------------------------------------
+
+// c0 = swish(dense_embed(concat[embed, extra_embed(ring)]))  (scann_model.py:361-374): `embed` is the Embedding row
+// (feature="atomic", :362) or Dense(92 -> emb) of the CGCNN features without activation (:365); ring/aromatic flags go
+// through Dense(2 -> 10) (:368) and are concatenated (:371).  8 atoms per 128-thread workgroup.
+__global__ __launch_bounds__(128) void embed_kernel(EmbedArgs a) {
+  __shared__ float sV[8][160];
+  const int tid = threadIdx.x;
+  const int a0 = blockIdx.x * 8;
+  const int na = min(8, a.n_atom - a0);
+  const int cin = a.emb_dim + (a.ring ? 10 : 0);
+  for (int i = tid; i < na * cin; i += 128) {
+    const int la = i / cin, k = i % cin, at = a0 + la;
+    float v;
+    if (k < a.emb_dim) {
+      if (a.cgcnn) {
+        float acc = 0.f;
+        for (int j = 0; j < 92; ++j) acc += a.cgcnn[(size_t)at * 92 + j] * a.We[j * a.emb_dim + k];
+        v = acc + a.be[k];
+      } else {
+        v = a.emb[(size_t)a.atomic[at] * a.emb_dim + k];
+      }
+    } else {
+      const int r = k - a.emb_dim;
+      v = (a.ring[(size_t)at * 2] * a.Wr[r] + a.ring[(size_t)at * 2 + 1] * a.Wr[10 + r]) + a.br[r];
+    }
+    sV[la][k] = v;
+  }
+  __syncthreads();
+  for (int la = 0; la < na; ++la) {
+    float acc = 0.f;
+    for (int k = 0; k < cin; ++k) acc += sV[la][k] * a.Wde[k * D + tid];
+    a.c0[(size_t)(a0 + la) * D + tid] = swishf(acc + a.bde[tid]);
+  }
+}
+
+void launch_embed(const EmbedArgs& a, hipStream_t s) {
+  if (a.n_atom <= 0) return;
+  hipLaunchKernelGGL(embed_kernel, dim3((a.n_atom + 7) / 8), dim3(128), 0, s, a);
+}
+
 // ---- readout kernel ----------------------------------------------------------------------------------
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -44,6 +44,7 @@ struct scann_handle {
   BasisParams basis{};
   const float* lut = nullptr;  // [n_atoms,128] swish(Embedding . dense_embed)
   const float* cd = nullptr;   // distance Gaussian centres
+  EmbedArgs embed{};           // weight pointers of the general embedding path (use_ring / cgcnn)
 };
 
 struct scann_dbatch {
@@ -51,7 +52,7 @@ struct scann_dbatch {
   char* arena = nullptr;  // inputs + workspace, one allocation
   // inputs
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
-  float *dist = nullptr, *weight = nullptr;
+  float *dist = nullptr, *weight = nullptr, *ring = nullptr, *cgcnn = nullptr, *c0 = nullptr;
   EdgeTile* tiles = nullptr;
   // workspace
   float *geom = nullptr, *gd = nullptr, *c = nullptr, *ctx = nullptr, *P1 = nullptr, *P3 = nullptr, *q = nullptr;
@@ -183,8 +184,8 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
     return fail(nullptr, SCANN_ERR_UNSUPPORTED,
                 "scann_create: kernels implement local_dim = global_dim = dense_out = 128, num_head = 8, 20 Gaussians "
                 "(every shipped reference config)");
-  if (cfg->use_ring || cfg->feature_cgcnn)
-    return fail(nullptr, SCANN_ERR_UNSUPPORTED, "scann_create: use_ring / feature=cgcnn inputs are not implemented yet");
+  if (cfg->embedding_dim + (cfg->use_ring ? 10 : 0) > 160)
+    return fail(nullptr, SCANN_ERR_UNSUPPORTED, "scann_create: embedding_dim (+10 ring features) must be <= 160");
   if (cfg->n_atoms <= 0 || cfg->embedding_dim <= 0 || cfg->n_attention < 0 || !(cfg->gaussian_d > 0))
     return fail(nullptr, SCANN_ERR_INVALID, "scann_create: bad hyper-parameter");
   int ndev = 0;
@@ -317,8 +318,20 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   linspace20((double)c.gaussian_d, cen);
   linspace20(M_PI * 2.0, cen + NG);
   const size_t ocd = put_raw(cen, NG), ocw = put_raw(cen + NG, NG);
-  const size_t oemb = put_raw(src["embed_atom/embeddings"], (size_t)c.n_atoms * c.embedding_dim);
-  const size_t oWe = put_raw(src["dense_embed/kernel"], (size_t)c.embedding_dim * D);
+  const bool general_embed = c.use_ring || c.feature_cgcnn;
+  const int64_t cin = c.embedding_dim + (c.use_ring ? 10 : 0);
+  size_t oemb = NONE, oWc = NONE, obc = NONE, oWr = NONE, obr = NONE;
+  if (c.feature_cgcnn) {
+    oWc = put_raw(src["embed_atom/kernel"], (size_t)92 * c.embedding_dim);
+    obc = put_raw(src["embed_atom/bias"], c.embedding_dim);
+  } else {
+    oemb = put_raw(src["embed_atom/embeddings"], (size_t)c.n_atoms * c.embedding_dim);
+  }
+  if (c.use_ring) {
+    oWr = put_raw(src["extra_embed/kernel"], 20);
+    obr = put_raw(src["extra_embed/bias"], 10);
+  }
+  const size_t oWe = put_raw(src["dense_embed/kernel"], (size_t)cin * D);
   const size_t obe = put_raw(src["dense_embed/bias"], D);
   const size_t olut = img.size();
   img.resize(olut + (size_t)c.n_atoms * D, 0.f);
@@ -349,10 +362,16 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   h->basis = BasisParams{P(oWd), P(obd), P(oWw), P(obw), P(ocd), P(ocw)};
   h->cd = P(ocd);
   h->lut = P(olut);
-  // Embedding + dense_embed folded into a per-species table, computed on the device.
-  launch_embed_lut(P(oemb), P(oWe), P(obe), c.n_atoms, c.embedding_dim, h->d_weights + olut, h->streams[0]);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  h->embed = EmbedArgs{};
+  h->embed.emb_dim = c.embedding_dim;
+  h->embed.emb = P(oemb); h->embed.We = P(oWc); h->embed.be = P(obc); h->embed.Wr = P(oWr); h->embed.br = P(obr);
+  h->embed.Wde = P(oWe); h->embed.bde = P(obe);
+  if (!general_embed) {
+    // Embedding + dense_embed folded into a per-species table, computed on the device.
+    launch_embed_lut(P(oemb), P(oWe), P(obe), c.n_atoms, c.embedding_dim, h->d_weights + olut, h->streams[0]);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  }
   h->loaded = true;
   return SCANN_OK;
 }
@@ -380,7 +399,7 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   *out = nullptr;
   const int32_t B = b->n_struct, A = b->n_atom, E = b->n_edge;
   if (B <= 0 || A <= 0 || E < 0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: empty batch");
-  if (!b->atomic || !b->mol_offset || !b->edge_offset || (E > 0 && (!b->edge_col || !b->edge_dist || !b->edge_weight)))
+  if ((!b->atomic && !h->cfg.feature_cgcnn) || !b->mol_offset || !b->edge_offset || (E > 0 && (!b->edge_col || !b->edge_dist || !b->edge_weight)))
     return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: null array");
   if (b->mol_offset[0] != 0 || b->mol_offset[B] != A || b->edge_offset[0] != 0 || b->edge_offset[A] != E)
     return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: offsets do not cover the batch");
@@ -391,9 +410,14 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     max_atoms = std::max(max_atoms, n);
   }
   if ((size_t)max_atoms * 5 * sizeof(float) > 60000) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: structure too large");
-  for (int a = 0; a < A; ++a)
-    if (b->atomic[a] < 0 || b->atomic[a] >= h->cfg.n_atoms)
-      return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: atomic number outside the embedding table (n_atoms)");
+  if (!h->cfg.feature_cgcnn) {
+    for (int a = 0; a < A; ++a)
+      if (b->atomic[a] < 0 || b->atomic[a] >= h->cfg.n_atoms)
+        return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: atomic number outside the embedding table (n_atoms)");
+  } else if (!b->cgcnn) {
+    return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: feature=cgcnn needs batch.cgcnn [n_atom,92]");
+  }
+  if (h->cfg.use_ring && !b->ring) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: use_ring needs batch.ring [n_atom,2]");
   std::vector<int32_t> edge_row((size_t)E);
   std::vector<EdgeTile> tiles;
   int tile_rows = h->edge_tile;
@@ -436,9 +460,11 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_atomic = take((size_t)A * 4), o_mol = take((size_t)(B + 1) * 4), o_eoff = take((size_t)(A + 1) * 4);
   const size_t o_col = take((size_t)E * 4), o_row = take((size_t)E * 4), o_dist = take((size_t)E * 4), o_wgt = take((size_t)E * 4);
   const size_t o_tiles = take(tiles.size() * sizeof(EdgeTile));
+  const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
   const size_t o_geom = take(h->cfg.g_update ? rowE : 0), o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
+  const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
   hipError_t e = hipMalloc((void**)&db->arena, off);
@@ -447,7 +473,9 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     return fail(h, e == hipErrorOutOfMemory ? SCANN_ERR_OOM : SCANN_ERR_HIP, std::string("hipMalloc(batch arena): ") + hipGetErrorString(e));
   }
   std::vector<char> img(in_bytes, 0);
-  memcpy(img.data() + o_atomic, b->atomic, (size_t)A * 4);
+  if (b->atomic) memcpy(img.data() + o_atomic, b->atomic, (size_t)A * 4);
+  if (h->cfg.use_ring) memcpy(img.data() + o_ring, b->ring, (size_t)A * 2 * 4);
+  if (h->cfg.feature_cgcnn) memcpy(img.data() + o_cg, b->cgcnn, (size_t)A * 92 * 4);
   memcpy(img.data() + o_mol, b->mol_offset, (size_t)(B + 1) * 4);
   memcpy(img.data() + o_eoff, b->edge_offset, (size_t)(A + 1) * 4);
   if (E > 0) {
@@ -467,6 +495,7 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->atomic = (int32_t*)(a0 + o_atomic); db->mol_offset = (int32_t*)(a0 + o_mol); db->edge_offset = (int32_t*)(a0 + o_eoff);
   db->edge_col = (int32_t*)(a0 + o_col); db->edge_row = (int32_t*)(a0 + o_row);
   db->dist = (float*)(a0 + o_dist); db->weight = (float*)(a0 + o_wgt); db->tiles = (EdgeTile*)(a0 + o_tiles);
+  db->ring = (float*)(a0 + o_ring); db->cgcnn = (float*)(a0 + o_cg); db->c0 = (float*)(a0 + o_c0);
   db->geom = (float*)(a0 + o_geom); db->gd = (float*)(a0 + o_gd);
   db->c = (float*)(a0 + o_c); db->ctx = (float*)(a0 + o_ctx); db->P1 = (float*)(a0 + o_P1); db->P3 = (float*)(a0 + o_P3);
   db->q = (float*)(a0 + o_q); db->gq = (float*)(a0 + o_gq); db->gk = (float*)(a0 + o_gk);
@@ -521,13 +550,22 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   if (tm) tm->mark(0);
   if (h->debug && c.g_update && db->n_edge) HIPCHK(h, hipMemcpyAsync(db->dbg_g, db->geom, rowE, hipMemcpyDeviceToDevice, s));
 
+  const bool general_embed = c.use_ring || c.feature_cgcnn;
+  if (general_embed) {
+    EmbedArgs e = h->embed;
+    e.n_atom = db->n_atom; e.atomic = db->atomic; e.c0 = db->c0;
+    e.ring = c.use_ring ? db->ring : nullptr;
+    e.cgcnn = c.feature_cgcnn ? db->cgcnn : nullptr;
+    launch_embed(e, s);
+    if (tm) tm->mark(0);
+  }
   for (int l = 0; l <= L; ++l) {
     // atom kernel at the head of layer l: ResidualNorm of layer l-1, centres, projections of layer l
     AtomArgs a{};
     a.n_atom = db->n_atom;
     if (l == 0) {
-      a.x = h->lut;
-      a.x_index = db->atomic;
+      a.x = general_embed ? db->c0 : h->lut;
+      a.x_index = general_embed ? nullptr : db->atomic;
       a.ffn = 0;
     } else {
       a.x = db->ctx;

@@ -106,8 +106,11 @@ def _ptr(a):
 class PackedBatch:
     """Host-side packed (CSR) batch: the arrays scann_batch_t points at."""
 
-    def __init__(self, atomic, mol_offset, edge_offset, edge_col, edge_dist, edge_weight, pad_shape=None, gidx=None):
-        self.atomic = np.ascontiguousarray(atomic, dtype=np.int32)
+    def __init__(self, atomic, mol_offset, edge_offset, edge_col, edge_dist, edge_weight, pad_shape=None, gidx=None,
+                 ring=None, cgcnn=None):
+        self.atomic = np.ascontiguousarray(atomic, dtype=np.int32) if atomic is not None else None
+        self.ring = np.ascontiguousarray(ring, dtype=np.float32) if ring is not None else None      # [n_atom, 2]
+        self.cgcnn = np.ascontiguousarray(cgcnn, dtype=np.float32) if cgcnn is not None else None  # [n_atom, 92]
         self.mol_offset = np.ascontiguousarray(mol_offset, dtype=np.int32)
         self.edge_offset = np.ascontiguousarray(edge_offset, dtype=np.int32)
         self.edge_col = np.ascontiguousarray(edge_col, dtype=np.int32)
@@ -122,7 +125,7 @@ class PackedBatch:
 
     @property
     def n_atom(self):
-        return int(self.atomic.shape[0])
+        return int(self.edge_offset.shape[0] - 1)
 
     @property
     def n_edge(self):
@@ -131,7 +134,7 @@ class PackedBatch:
     def as_struct(self):
         return Batch(self.n_struct, self.n_atom, self.n_edge, _ptr(self.atomic), _ptr(self.mol_offset),
                      _ptr(self.edge_offset), _ptr(self.edge_col), _ptr(self.edge_dist), _ptr(self.edge_weight),
-                     None, None)
+                     _ptr(self.ring), _ptr(self.cgcnn))
 
     def repad_ga(self, ga_packed):
         """Packed GlobalAttention scores -> the reference's [B, M, 1] (padded atoms score exactly 0:
@@ -149,14 +152,15 @@ def pack_inputs(inputs):
     slots of real atoms, kept in slot order; neighbour ids become global atom rows (what
     gather_shape + tf.gather_nd do in the reference, custom_layers.py:18-28, attention.py:136)."""
     atomic = np.asarray(inputs["atomic"])
-    if atomic.ndim != 2:
-        raise NotImplementedError("feature='cgcnn' inputs are not supported by the HIP path yet")
+    cgcnn = None
+    if atomic.ndim == 3:  # feature="cgcnn": [B, M, 92] float features instead of atomic numbers (scann_model.py:334)
+        cgcnn, atomic = atomic, None
     amask = np.asarray(inputs["atom_mask"]).astype(bool)
     if amask.ndim == 3:
         amask = amask[..., 0]
     nbr = np.asarray(inputs["neighbors"]).astype(np.int64)
     nmask = np.asarray(inputs["neighbor_mask"]).astype(bool)
-    B, M = atomic.shape
+    B, M = amask.shape
     if nbr.shape[:2] != (B, M) or nmask.shape != nbr.shape or amask.shape != (B, M):
         raise ValueError("inconsistent input shapes")
     counts = amask.sum(1)
@@ -176,7 +180,9 @@ def pack_inputs(inputs):
     np.cumsum(deg, out=edge_offset[1:])
     dist = np.asarray(inputs["neighbor_distance"], dtype=np.float32)[emask]
     wgt = np.asarray(inputs["neighbor_weight"], dtype=np.float32)[emask]
-    return PackedBatch(atomic[amask], mol_offset, edge_offset, edge_col, dist, wgt, pad_shape=(B, M), gidx=amask)
+    ring = np.asarray(inputs["ring_aromatic"], dtype=np.float32)[amask] if "ring_aromatic" in inputs else None
+    return PackedBatch(atomic[amask] if atomic is not None else None, mol_offset, edge_offset, edge_col, dist, wgt,
+                       pad_shape=(B, M), gidx=amask, ring=ring, cgcnn=cgcnn[amask] if cgcnn is not None else None)
 
 
 class ResidentBatch:

@@ -33,8 +33,10 @@ def split_packed(packed, n_shards):
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         a0, a1 = int(mol[lo]), int(mol[hi])
         e0, e1 = int(eoff[a0]), int(eoff[a1])
-        shards.append(PackedBatch(packed.atomic[a0:a1], mol[lo:hi + 1] - a0, eoff[a0:a1 + 1] - e0,
-                                  packed.edge_col[e0:e1] - a0, packed.edge_dist[e0:e1], packed.edge_weight[e0:e1]))
+        cut = lambda x: x[a0:a1] if x is not None else None  # noqa: E731
+        shards.append(PackedBatch(cut(packed.atomic), mol[lo:hi + 1] - a0, eoff[a0:a1 + 1] - e0,
+                                  packed.edge_col[e0:e1] - a0, packed.edge_dist[e0:e1], packed.edge_weight[e0:e1],
+                                  ring=cut(packed.ring), cgcnn=cut(packed.cgcnn)))
     return shards
 
 

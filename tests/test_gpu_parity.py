@@ -92,6 +92,25 @@ def test_branches(hip_lib, over):
     assert rel_err(ga, ga64) <= max(RTOL, 3 * rel_err(ga32, ga64))
 
 
+@pytest.mark.parametrize("ring,cgcnn", [(True, False), (False, True), (True, True)], ids=["ring", "cgcnn", "ring+cgcnn"])
+def test_ring_and_cgcnn_embeddings(hip_lib, ring, cgcnn):
+    """scann_model.py:361-374: extra ring/aromatic embedding and the 92-d CGCNN feature variant."""
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    cfg["model"].update(n_attention=2, use_ring=ring, feature="cgcnn" if cgcnn else "atomic")
+    w = so.init_weights(cfg, 99, perturb=True)
+    de, dn = so.synth_dataset(7, 31, use_ring=ring)
+    inputs, _ = so.pad_batch(de, dn, True, use_ring=ring)
+    if cgcnn:
+        table = np.random.default_rng(5).integers(0, 2, size=(101, 92)).astype("float32")  # stand-in for atomic_features
+        inputs["atomic"] = table[inputs["atomic"]]
+    model = HipModel(cfg, w, device=0, infer=True)
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+
+
 def test_keras_default_init_and_configs(hip_lib):
     """Keras-default weights (zero biases, unit gamma) and the other shipped architectures."""
     for name, kind, n in (("qm9", "qm9", 16), ("qm9_std", "qm9", 8), ("mp2018", "mp2018", 6)):
