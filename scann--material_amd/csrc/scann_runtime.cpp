@@ -38,6 +38,8 @@ struct scann_handle {
   bool loaded = false;
   bool debug = false;
   int edge_tile = 64;  // edge rows per tile (32 or 64); env SCANN_EDGE_TILE overrides
+  int n_cu = 256;      // compute units of the device
+  int persist_min_tiles = 1 << 30;  // launches with at least this many edge tiles use edge_kernel_persistent (env SCANN_PERSIST_MIN)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -197,6 +199,11 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->device = device_id;
   h->specs = build_specs(*cfg);
   if (const char* et = getenv("SCANN_EDGE_TILE")) h->edge_tile = atoi(et) == 32 ? 32 : 64;
+  if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+  }
   if (const char* ns = getenv("SCANN_STREAMS")) h->nstream = std::min(MAX_STREAM, std::max(1, atoi(ns)));
   if (hipSetDevice(device_id) != hipSuccess) {
     delete h;
@@ -595,6 +602,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
     ea.c = db->c; ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = db->ctx;
     ea.p = h->layers[l];
+    ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles) ? h->n_cu : 0;
 #ifdef SCANN_STAMPS
     if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
     ea.stamps = db->stamps;

@@ -146,6 +146,23 @@ class PackedBatch:
         return out
 
 
+def concat_packed(parts):
+    """Several packed batches -> one (structures are independent and the packed layout carries no per-batch padding,
+    so a group of batches is just their concatenation with rebased offsets).  Used to fuse resident batches into one
+    launch sequence; outputs come back in the same order."""
+    parts = list(parts)
+    a_off = np.cumsum([0] + [p.n_atom for p in parts])
+    e_off = np.cumsum([0] + [p.n_edge for p in parts])
+    cat = lambda xs: np.concatenate(xs) if all(x is not None for x in xs) else None  # noqa: E731
+    return PackedBatch(
+        cat([p.atomic for p in parts]),
+        np.concatenate([[0]] + [p.mol_offset[1:].astype(np.int64) + a_off[i] for i, p in enumerate(parts)]),
+        np.concatenate([[0]] + [p.edge_offset[1:].astype(np.int64) + e_off[i] for i, p in enumerate(parts)]),
+        np.concatenate([p.edge_col.astype(np.int64) + a_off[i] for i, p in enumerate(parts)]),
+        np.concatenate([p.edge_dist for p in parts]), np.concatenate([p.edge_weight for p in parts]),
+        ring=cat([p.ring for p in parts]), cgcnn=cat([p.cgcnn for p in parts]))
+
+
 def pack_inputs(inputs):
     """Keras input dict (scann_model.py:338-357; DataIterator.__getitem__, datagenerator.py:123-133)
     -> PackedBatch.  Real atoms are those with atom_mask set; real edges the unmasked neighbour

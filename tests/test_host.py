@@ -196,3 +196,14 @@ def test_two_rank_sharded_inference_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "SHARD_OK" in outs[0]
+
+
+def test_concat_packed_equals_packing_the_union():
+    from scann import _hip
+
+    de, dn = so.synth_dataset(12, 5)
+    whole = _hip.pack_inputs(so.pad_batch(de, dn, True)[0])
+    parts = [_hip.pack_inputs(so.pad_batch(de[i:i + 4], dn[i:i + 4], True)[0]) for i in (0, 4, 8)]
+    cat = _hip.concat_packed(parts)
+    for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+        assert np.array_equal(getattr(cat, f), getattr(whole, f)), f
