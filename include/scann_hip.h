@@ -138,6 +138,29 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
  * `db`; returns the number of tiles copied.  The shipped library returns SCANN_ERR_UNSUPPORTED. */
 int scann_debug_stamps(scann_handle_t* h, scann_dbatch_t* db, uint64_t* out, int max_tiles);
 
+/* ---- training step: replaces model.compile(loss=rmse, Adam(lr, decay=1e-5)) + model.fit (scann_model.py:199-241) ----
+ * Gradients are hand-written derivatives of the forward graph; parameters, gradients and Adam moments are flat fp32
+ * vectors in scann_weight_name() order.  Supported: g_update=1, feature="atomic", use_ring=0 (every shipped config).
+ * Data-parallel use: every rank calls forward on its shard, the SSE / count are summed over ranks (host side or
+ * scann_allreduce_sse), then backward, scann_allreduce_grads (one flat RCCL all-reduce), scann_adam_step. */
+int64_t scann_param_count(const scann_handle_t* h);
+int scann_train_begin(scann_handle_t* h);
+/* training-mode forward on stream 0: keeps per-layer activations in `db`; `dropout` = rate of the two Dropout(0.1)
+ * layers (scann_model.py:374, attention.py:29), 0 disables; targets[n_struct]; *sse_out = sum (y - target)^2 of this batch */
+int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, double* sse_out);
+/* accumulates d(rmse)/d(params) into the gradient vector; rmse = sqrt(sse_global / count_global) (losses.py:5-6) */
+int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_global, int64_t count_global);
+int scann_zero_grads(scann_handle_t* h);
+int scann_allreduce_grads(scann_handle_t* h);                 /* RCCL sum over the communicator; no-op without one */
+int scann_allreduce_sse(scann_handle_t* h, double* sse, int64_t* count); /* in-place sum over ranks */
+/* g += 2*l2*w on the regularised kernels, then Adam (epsilon outside the sqrt, as tf.keras); lr_t already includes the
+ * schedule and the legacy decay 1/(1 + 1e-5*iterations); refreshes the packed device weights */
+int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2);
+int scann_get_grads(scann_handle_t* h, float* out);           /* [scann_param_count] */
+int scann_get_weights(scann_handle_t* h, float* out);         /* current master parameters, same order */
+int scann_comm_unique_id(char* out128);                       /* ncclGetUniqueId on rank 0; broadcast by the caller */
+int scann_comm_init(scann_handle_t* h, const char* id128, int rank, int world);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,18 @@ constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row
 constexpr int TB = 16;           // edges per basis-kernel workgroup
 constexpr int WPACK = D * D;     // floats in one packed 128x128 weight
 
+// Inverted dropout keyed by (seed, tag, element index): the backward pass regenerates the identical mask.
+// Returns 0 (dropped) or 1/(1-p).
+__host__ __device__ inline float drop_scale(unsigned long long seed, unsigned tag, size_t idx, float p) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((unsigned long long)tag << 48);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.0f / (1.0f - p);
+}
+constexpr unsigned DROP_TAG_EMBED = 1000;  // Dropout(0.1) after dense_embed (scann_model.py:374); ResidualNorm l uses tag l
+
 // One tile of the edge kernel: a run of whole atoms whose CSR rows are contiguous, <= TE edges.
 struct EdgeTile {
   int32_t atom_begin, atom_end;
@@ -84,6 +96,11 @@ struct AtomArgs {
   int32_t ffn;
   const float *Wf1p, *bf1, *Wf2p, *bf2, *lnr_g, *lnr_b;
   float* c;                // [n_atom,128] centres out (always written)
+  // training only: Dropout(0.1) on the staged rows (layer 0, scann_model.py:374) or on the ResidualNorm branch
+  // (attention.py:29); drop_p == 0 in inference
+  float drop_p;
+  uint32_t drop_tag;
+  unsigned long long drop_seed;
   // projections
   int32_t mode;            // 0: P1,P3,q (g_update)  1: q only (base)  2: readout (after_Lc -> gq, gk)
   const float *WAp, *bA;   // mode 0: W1p,bg   | mode 2: after_Lc

@@ -130,6 +130,13 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
     if (r < nrows) {
       const int src = a.x_index ? a.x_index[row0 + r] : (row0 + r);
       v = reinterpret_cast<const float4*>(a.x)[(size_t)src * 32 + c4];
+      if (!FFN && a.drop_p > 0.f) {  // training: Dropout after dense_embed (scann_model.py:374)
+        const size_t e = (size_t)(row0 + r) * D + 4 * c4;
+        v.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
+        v.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
+        v.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
+        v.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
+      }
       if (!FFN) reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] = v;  // centres = staged rows (layer 0 / no ResidualNorm)
     }
     *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
@@ -158,7 +165,9 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = acc_row(i, lane);
-        sH[r * LDS_STRIDE + col] = sX[r * LDS_STRIDE + col] + (acc[0][i] + b);
+        float y = acc[0][i] + b;
+        if (a.drop_p > 0.f) y *= drop_scale(a.drop_seed, a.drop_tag, (size_t)(row0 + r) * D + col, a.drop_p);  // attention.py:29 (training)
+        sH[r * LDS_STRIDE + col] = sX[r * LDS_STRIDE + col] + y;
       }
     }
     __syncthreads();

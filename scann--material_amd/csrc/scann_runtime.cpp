@@ -3,6 +3,9 @@
 // (scann_model.py:329-453).  Host side only -- all arithmetic is in scann_kernels.hip.
 #include "../../include/scann_hip.h"
 #include "scann_internal.h"
+#include "scann_train.h"
+
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -47,6 +50,22 @@ struct scann_handle {
   const float* lut = nullptr;  // [n_atoms,128] swish(Embedding . dense_embed)
   const float* cd = nullptr;   // distance Gaussian centres
   EmbedArgs embed{};           // weight pointers of the general embedding path (use_ring / cgcnn)
+  // canonical (spec-order) flat parameter vector and how the device arena is derived from it
+  std::vector<float> host_master;
+  std::vector<int64_t> spec_off;
+  std::vector<RepackDesc> descs;
+  size_t arena_floats = 0, o_lut = 0, o_emb = 0, o_Wde = 0, o_bde = 0;
+  struct LayerT { const float *W1T, *W2T, *W3T, *WqT, *WkT, *Wf1T, *Wf2T; };
+  std::vector<LayerT> layersT;  // packed transposes for the backward dX GEMMs
+  const float *WaT = nullptr, *WgqT = nullptr, *WgkT = nullptr;
+  // training state (scann_train_begin)
+  float *t_master = nullptr, *t_grad = nullptr, *t_m = nullptr, *t_v = nullptr, *t_l2 = nullptr;
+  RepackDesc* t_descs = nullptr;
+  int64_t t_step = 0;
+  float train_drop_p = 0.f;            // > 0 only inside scann_train_forward
+  unsigned long long train_seed = 0;
+  ncclComm_t comm = nullptr;
+  int comm_world = 1;
 };
 
 struct scann_dbatch {
@@ -226,6 +245,9 @@ void scann_destroy(scann_handle_t* h) {
   for (int i = 0; i < MAX_STREAM; ++i)
     if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
   if (h->d_weights) (void)hipFree(h->d_weights);
+  for (void* q : {(void*)h->t_master, (void*)h->t_grad, (void*)h->t_m, (void*)h->t_v, (void*)h->t_l2, (void*)h->t_descs})
+    if (q) (void)hipFree(q);
+  if (h->comm) ncclCommDestroy(h->comm);
   delete h;
 }
 
@@ -247,14 +269,30 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   std::map<std::string, const scann_tensor_desc_t*> by_name;
   for (int i = 0; i < n; ++i)
     if (manifest[i].name) by_name[manifest[i].name] = &manifest[i];
+  // canonical flat parameter vector: the tensors in spec order
   std::map<std::string, const float*> src;
-  for (const WeightSpec& s : h->specs) {
-    auto it = by_name.find(s.name);
-    if (it == by_name.end()) return fail(h, SCANN_ERR_WEIGHTS, "scann_load_weights: missing tensor " + s.name);
-    if (it->second->numel != s.numel() || it->second->offset < 0)
-      return fail(h, SCANN_ERR_WEIGHTS, "scann_load_weights: wrong size for tensor " + s.name);
-    src[s.name] = blob + it->second->offset;
+  {
+    size_t total = 0;
+    for (const WeightSpec& s : h->specs) {
+      auto it = by_name.find(s.name);
+      if (it == by_name.end()) return fail(h, SCANN_ERR_WEIGHTS, "scann_load_weights: missing tensor " + s.name);
+      if (it->second->numel != s.numel() || it->second->offset < 0)
+        return fail(h, SCANN_ERR_WEIGHTS, "scann_load_weights: wrong size for tensor " + s.name);
+      total += (size_t)s.numel();
+    }
+    h->host_master.resize(total);
+    h->spec_off.clear();
+    size_t off = 0;
+    for (const WeightSpec& s : h->specs) {
+      memcpy(h->host_master.data() + off, blob + by_name[s.name]->offset, (size_t)s.numel() * sizeof(float));
+      src[s.name] = h->host_master.data() + off;
+      h->spec_off.push_back((int64_t)off);
+      off += (size_t)s.numel();
+    }
   }
+  h->descs.clear();
+  const float* const mbase = h->host_master.data();
+  const float* const mend = mbase + h->host_master.size();
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention;
   // host image of the device arena
@@ -264,14 +302,30 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     const size_t off = img.size();
     img.insert(img.end(), p, p + numel);
     while (img.size() % 64) img.push_back(0.f);  // keep every tensor 256-byte aligned
+    if (p >= mbase && p < mend)                  // derived from a parameter: re-copied after every optimiser step
+      for (size_t done = 0; done < numel; done += 16384)
+        h->descs.push_back(RepackDesc{(int64_t)(p - mbase + done), (int64_t)(off + done), 0, (int32_t)std::min<size_t>(16384, numel - done)});
     return off;
   };
   auto put_packed = [&](const float* W) {  // W: row-major [128,128] slice, leading dim 128
     const size_t off = img.size();
     img.resize(off + WPACK);
     pack_weight(W, D, img.data() + off);
+    h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 0, 0});
     return off;
   };
+  auto put_packedT = [&](const float* W) {  // fragment-order image of W^T (backward: dX = dY . W^T)
+    const size_t off = img.size();
+    img.resize(off + WPACK);
+    std::vector<float> wt((size_t)D * D);
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) wt[(size_t)j * D + i] = W[(size_t)i * D + j];
+    pack_weight(wt.data(), D, img.data() + off);
+    h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 1, 0});
+    return off;
+  };
+  struct LTOff { size_t W1T, W2T, W3T, WqT, WkT, Wf1T, Wf2T; };
+  std::vector<LTOff> lto(L);
   struct LOff {
     size_t W1p, W3p, bg, Wqp, bq, W2p, Wkp, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, Wf1p, bf1, Wf2p, bf2, lnr_g, lnr_b;
   };
@@ -282,10 +336,14 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     LOff& o = lo[i];
     o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     const float* fg = src[p + "filter_geo/kernel"];
+    lto[i] = LTOff{(size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
     if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
       o.W1p = put_packed(fg);
       o.W2p = put_packed(fg + (size_t)D * D);
       o.W3p = put_packed(fg + (size_t)2 * D * D);
+      lto[i].W1T = put_packedT(fg);
+      lto[i].W2T = put_packedT(fg + (size_t)D * D);
+      lto[i].W3T = put_packedT(fg + (size_t)2 * D * D);
       o.bg = put_raw(src[p + "filter_geo/bias"], D);
       o.lng_g = put_raw(src[p + "layer_norm_g/gamma"], D);
       o.lng_b = put_raw(src[p + "layer_norm_g/beta"], D);
@@ -294,6 +352,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       o.bfg = put_raw(src[p + "filter_geo/bias"], D);
     }
     o.Wqp = put_packed(src[p + "query/kernel"]);
+    lto[i].WqT = put_packedT(src[p + "query/kernel"]);
+    lto[i].WkT = put_packedT(src[p + "key/kernel"]);
     o.bq = put_raw(src[p + "query/bias"], D);
     o.Wkp = put_packed(src[p + "key/kernel"]);
     o.bk = put_raw(src[p + "key/bias"], D);
@@ -301,6 +361,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     o.ln_b = put_raw(src[p + "layer_norm/beta"], D);
     if (c.use_attn_norm) {
       const std::string r = "residual_norm_" + std::to_string(i) + "/";
+      lto[i].Wf1T = put_packedT(src[r + "dense_1/kernel"]);
+      lto[i].Wf2T = put_packedT(src[r + "dense_2/kernel"]);
       o.Wf1p = put_packed(src[r + "dense_1/kernel"]);
       o.bf1 = put_raw(src[r + "dense_1/bias"], D);
       o.Wf2p = put_packed(src[r + "dense_2/kernel"]);
@@ -309,6 +371,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       o.lnr_b = put_raw(src[r + "layer_norm/beta"], D);
     }
   }
+  const size_t oWaT = put_packedT(src["after_Lc/kernel"]), oWgqT = put_packedT(src["global_attention/query/kernel"]),
+               oWgkT = put_packedT(src["global_attention/key/kernel"]);
   const size_t oWa = put_packed(src["after_Lc/kernel"]), oba = put_raw(src["after_Lc/bias"], D);
   const size_t oWgq = put_packed(src["global_attention/query/kernel"]), obgq = put_raw(src["global_attention/query/bias"], D);
   const size_t oWgk = put_packed(src["global_attention/key/kernel"]), obgk = put_raw(src["global_attention/key/bias"], D);
@@ -365,6 +429,11 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lp.Wf1p = P(o.Wf1p); lp.bf1 = P(o.bf1); lp.Wf2p = P(o.Wf2p); lp.bf2 = P(o.bf2);
     lp.lnr_g = P(o.lnr_g); lp.lnr_b = P(o.lnr_b);
   }
+  h->layersT.assign(L, scann_handle::LayerT{});
+  for (int i = 0; i < L; ++i)
+    h->layersT[i] = scann_handle::LayerT{P(lto[i].W1T), P(lto[i].W2T), P(lto[i].W3T), P(lto[i].WqT), P(lto[i].WkT), P(lto[i].Wf1T), P(lto[i].Wf2T)};
+  h->WaT = P(oWaT); h->WgqT = P(oWgqT); h->WgkT = P(oWgkT);
+  h->arena_floats = img.size(); h->o_lut = olut; h->o_emb = oemb; h->o_Wde = oWe; h->o_bde = obe;
   h->head = HeadParams{P(oWa), P(oba), P(oWgq), P(obgq), P(oWgk), P(obgk), P(oWb), P(obb), P(owo), P(obo)};
   h->basis = BasisParams{P(oWd), P(obd), P(oWw), P(obw), P(ocd), P(ocw)};
   h->cd = P(ocd);
@@ -389,6 +458,8 @@ int scann_set_debug(scann_handle_t* h, int on) {
   return SCANN_OK;
 }
 
+static void free_train_ws(scann_dbatch* db);
+
 void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   if (!db) return;
   if (h) (void)hipSetDevice(h->device);
@@ -398,6 +469,7 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   if (db->dbg_g) (void)hipFree(db->dbg_g);
   if (db->dbg_ctx) (void)hipFree(db->dbg_ctx);
   if (db->stamps) (void)hipFree(db->stamps);
+  free_train_ws(db);
   delete db;
 }
 
@@ -582,6 +654,11 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       a.Wf1p = pp.Wf1p; a.bf1 = pp.bf1; a.Wf2p = pp.Wf2p; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
     }
     a.c = db->c;
+    if (h->train_drop_p > 0.f) {  // training-mode Dropout(0.1) layers (scann_model.py:374, attention.py:29)
+      a.drop_p = (l == 0 || c.use_attn_norm) ? h->train_drop_p : 0.f;
+      a.drop_seed = h->train_seed;
+      a.drop_tag = l == 0 ? DROP_TAG_EMBED : (unsigned)(l - 1);
+    }
     if (l < L) {
       const LayerParams& p = h->layers[l];
       a.mode = c.g_update ? 0 : 1;
@@ -719,6 +796,346 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
   else if (what == 2 && layer >= 1 && layer <= L) { src = db->dbg_ctx + (layer - 1) * rowA; n = rowA; }
   else return fail(h, SCANN_ERR_INVALID, "scann_debug_read: bad selector");
   if (n) HIPCHK(h, hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+  return SCANN_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Training path: training-mode forward, hand-written backward, Adam, RCCL all-reduce.
+// =====================================================================================================================
+
+struct scann_train_ws {  // per resident batch, allocated on first use
+  char* arena = nullptr;
+  float *tA[10] = {};   // [n_atom,128] temporaries
+  float *tE[10] = {};   // [n_edge,128] temporaries
+  float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
+  double* sse = nullptr;
+  float drop_p = 0.f;
+  unsigned long long seed = 0;
+};
+
+namespace {
+
+std::map<scann_dbatch*, scann_train_ws> g_train_ws;  // keyed by batch; freed with the batch
+
+int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
+  scann_train_ws& w = g_train_ws[db];
+  *out = &w;
+  if (w.arena) return SCANN_OK;
+  const size_t rowA = align_up((size_t)db->n_atom * D * 4), rowE = align_up((size_t)std::max(db->n_edge, 1) * D * 4);
+  const size_t rowB = align_up((size_t)db->n_struct * D * 4);
+  const size_t total = 10 * rowA + 10 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
+                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256;
+  HIPCHK(h, hipMalloc((void**)&w.arena, total));
+  char* p = w.arena;
+  for (int i = 0; i < 10; ++i) { w.tA[i] = (float*)p; p += rowA; }
+  for (int i = 0; i < 10; ++i) { w.tE[i] = (float*)p; p += rowE; }
+  w.rep = (float*)p; p += rowB;
+  w.dpre = (float*)p; p += rowB;
+  w.dy = (float*)p; p += align_up((size_t)db->n_struct * 4);
+  w.targets = (float*)p; p += align_up((size_t)db->n_struct * 4);
+  w.dlut = (float*)p; p += align_up((size_t)h->cfg.n_atoms * D * 4);
+  w.sse = (double*)p;
+  return SCANN_OK;
+}
+
+}  // namespace
+
+static void free_train_ws(scann_dbatch* db) {
+  auto it = g_train_ws.find(db);
+  if (it == g_train_ws.end()) return;
+  if (it->second.arena) (void)hipFree(it->second.arena);
+  g_train_ws.erase(it);
+}
+
+namespace {
+
+int64_t spec_offset(const scann_handle* h, const std::string& name) {
+  for (size_t i = 0; i < h->specs.size(); ++i)
+    if (h->specs[i].name == name) return h->spec_off[i];
+  return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t scann_param_count(const scann_handle_t* h) {
+  if (!h) return SCANN_ERR_INVALID;
+  int64_t n = 0;
+  for (const WeightSpec& s : h->specs) n += s.numel();
+  return n;
+}
+
+int scann_train_begin(scann_handle_t* h) {
+  if (!h) return SCANN_ERR_INVALID;
+  if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "scann_train_begin: weights not loaded");
+  if (!h->cfg.g_update || h->cfg.use_ring || h->cfg.feature_cgcnn)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: the backward pass covers g_update=1, feature=atomic, use_ring=0");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = h->host_master.size();
+  if (!h->t_master) {
+    HIPCHK(h, hipMalloc((void**)&h->t_master, n * 4));
+    HIPCHK(h, hipMalloc((void**)&h->t_grad, n * 4));
+    HIPCHK(h, hipMalloc((void**)&h->t_m, n * 4));
+    HIPCHK(h, hipMalloc((void**)&h->t_v, n * 4));
+    HIPCHK(h, hipMalloc((void**)&h->t_l2, n * 4));
+    HIPCHK(h, hipMalloc((void**)&h->t_descs, h->descs.size() * sizeof(RepackDesc)));
+  }
+  HIPCHK(h, hipMemcpy(h->t_master, h->host_master.data(), n * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemset(h->t_grad, 0, n * 4));
+  HIPCHK(h, hipMemset(h->t_m, 0, n * 4));
+  HIPCHK(h, hipMemset(h->t_v, 0, n * 4));
+  HIPCHK(h, hipMemcpy(h->t_descs, h->descs.data(), h->descs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
+  // kernel_regularizer=l2(1e-4) mask: LocalAttention query/key/filter_geo, ResidualNorm dense_1/2, GlobalAttention
+  // query/key, after_Lc, bf_property (attention.py:27-28,95-109,260-265; scann_model.py:428,441)
+  std::vector<float> l2(n, 0.f);
+  for (size_t i = 0; i < h->specs.size(); ++i) {
+    const std::string& nm = h->specs[i].name;
+    const bool is_kernel = nm.size() > 7 && nm.compare(nm.size() - 7, 7, "/kernel") == 0;
+    const bool reg = is_kernel && (nm.find("local_attention_") == 0 || nm.find("residual_norm_") == 0 ||
+                                   nm.find("global_attention/") == 0 || nm.find("after_Lc/") == 0 || nm.find("bf_property/") == 0);
+    if (reg) std::fill(l2.begin() + h->spec_off[i], l2.begin() + h->spec_off[i] + h->specs[i].numel(), 1.0f);
+  }
+  HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
+  h->t_step = 0;
+  return SCANN_OK;
+}
+
+int scann_zero_grads(scann_handle_t* h) {
+  if (!h || !h->t_grad) return fail(h, SCANN_ERR_INVALID, "scann_zero_grads: call scann_train_begin first");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, h->streams[0]));
+  return SCANN_OK;
+}
+
+int scann_get_grads(scann_handle_t* h, float* out) {
+  if (!h || !h->t_grad || !out) return fail(h, SCANN_ERR_INVALID, "scann_get_grads: no training state");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  HIPCHK(h, hipMemcpy(out, h->t_grad, h->host_master.size() * 4, hipMemcpyDeviceToHost));
+  return SCANN_OK;
+}
+
+int scann_get_weights(scann_handle_t* h, float* out) {
+  if (!h || !out) return SCANN_ERR_INVALID;
+  if (!h->t_master) {
+    memcpy(out, h->host_master.data(), h->host_master.size() * 4);
+    return SCANN_OK;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  HIPCHK(h, hipMemcpy(out, h->t_master, h->host_master.size() * 4, hipMemcpyDeviceToHost));
+  memcpy(h->host_master.data(), out, h->host_master.size() * 4);
+  return SCANN_OK;
+}
+
+int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, double* sse_out) {
+  if (!h || !db || !targets || !sse_out) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: null argument");
+  if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: call scann_train_begin first");
+  HIPCHK(h, hipSetDevice(h->device));
+  scann_train_ws* w = nullptr;
+  int r = ensure_train_ws(h, db, &w);
+  if (r) return r;
+  hipStream_t s = h->streams[0];
+  db->last_slot = 0;
+  w->drop_p = dropout;
+  w->seed = seed;
+  const bool dbg = h->debug;
+  h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)
+  h->train_drop_p = dropout;
+  h->train_seed = seed;
+  r = run_forward(h, db, s, nullptr);
+  h->train_drop_p = 0.f;
+  h->debug = dbg;
+  if (r) return r;
+  HIPCHK(h, hipMemcpyAsync(w->targets, targets, (size_t)db->n_struct * 4, hipMemcpyHostToDevice, s));
+  launch_sse(db->y, w->targets, db->n_struct, w->sse, s);
+  HIPCHK(h, hipMemcpyAsync(sse_out, w->sse, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return SCANN_OK;
+}
+
+int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_global, int64_t count_global) {
+  if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_train_backward: null argument");
+  if (!h->t_grad || g_train_ws.find(db) == g_train_ws.end() || db->dbg_layers != h->cfg.n_attention)
+    return fail(h, SCANN_ERR_INVALID, "scann_train_backward: run scann_train_forward on this batch first");
+  HIPCHK(h, hipSetDevice(h->device));
+  scann_train_ws& w = g_train_ws[db];
+  hipStream_t s = h->streams[0];
+  const scann_config_t& c = h->cfg;
+  const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
+  const size_t nA = (size_t)A * D, nE = (size_t)E * D;
+  float* const G = h->t_grad;
+  auto g = [&](const std::string& name) { return G + spec_offset(h, name); };
+  const double rmse = std::sqrt(sse_global / (double)count_global);
+  const float scale = rmse > 0 ? (float)(1.0 / ((double)count_global * rmse)) : 0.f;
+  launch_dy(db->y, w.targets, B, scale, w.dy, s);
+
+  // named temporaries
+  float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4], *t3 = w.tA[5], *dQ = w.tA[6],
+        *dP1 = w.tA[7], *dP3 = w.tA[8], *t4 = w.tA[9];
+  float *eAng = w.tE[0], *eK = w.tE[1], *edK = w.tE[2], *edAng = w.tE[3], *eU = w.tE[4], *eV = w.tE[5], *eT = w.tE[6],
+        *edGt = w.tE[7], *edGa = w.tE[8], *edGb = w.tE[9];
+  const float* cL = db->dbg_c + (size_t)L * nA;  // centres entering after_Lc
+
+  // ---- readout (scann_model.py:424-447, attention.py:267-318) ----
+  // forward recompute: preA = cL.Wa + ba (t0), z = swish(preA) (t1); gq, gk, ga, y are still in the batch workspace
+  launch_linear(cL, h->head.Wap, h->head.ba, t1, t0, A, 2, s);
+  ReadoutBwdArgs ra{};
+  ra.mol_offset = db->mol_offset; ra.n_struct = B; ra.max_atoms = db->max_atoms; ra.use_ga_norm = c.use_ga_norm;
+  ra.gq = db->gq; ra.gk = db->gk; ra.ga = db->ga; ra.dy = w.dy;
+  ra.Wb = h->head.Wb; ra.bb = h->head.bb; ra.wo = h->head.wo;
+  ra.dgq = t2; ra.dgk = t3; ra.rep_out = w.rep; ra.dpre_out = w.dpre;
+  ra.dwo = g("predict_property/kernel"); ra.dbo = g("predict_property/bias");
+  launch_readout_bwd(ra, s);
+  launch_wgrad(w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B, s);
+  launch_wgrad(t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), A, s);
+  launch_wgrad(t1, t3, g("global_attention/key/kernel"), g("global_attention/key/bias"), A, s);
+  launch_linear(t2, h->WgqT, nullptr, t4, nullptr, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
+  launch_linear(t3, h->WgkT, nullptr, t4, nullptr, A, 1, s);
+  launch_swish_bwd(t0, t4, t2, nA, s);                        // dpreA
+  launch_wgrad(cL, t2, g("after_Lc/kernel"), g("after_Lc/bias"), A, s);
+  launch_linear(t2, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
+
+  const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerParams& p = h->layers[l];
+    const scann_handle::LayerT& pt = h->layersT[l];
+    const std::string la = "local_attention_" + std::to_string(l) + "/", rn = "residual_norm_" + std::to_string(l) + "/";
+    const float* c_in = db->dbg_c + (size_t)l * nA;        // centres entering LocalAttention l
+    const float* ctx = db->dbg_ctx + (size_t)l * nA;       // LocalAttention output (after layer_norm)
+    const float* Gin = db->dbg_g + (size_t)l * nE;         // geometry entering layer l
+    const float* Gout = db->dbg_g + (size_t)(l + 1) * nE;  // geometry leaving layer l (= layer_norm_g output)
+
+    // ---- ResidualNorm backward (attention.py:37-40): c_{l+1} = LN(x + drop(W2 swish(W1 x + b1) + b2)), x = ctx ----
+    if (c.use_attn_norm) {
+      launch_linear(ctx, p.Wf1p, p.bf1, t1, t0, A, 2, s);   // pre1 (t0), H1 (t1)
+      launch_linear(t1, p.Wf2p, p.bf2, t2, nullptr, A, 0, s);  // Y
+      launch_dropout(t2, nA, w.seed, (unsigned)l, w.drop_p, s);
+      launch_add(t2, ctx, nA, s);                            // T2 = x + drop(Y)
+      launch_ln_bwd(t2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
+      HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
+      launch_dropout(t3, nA, w.seed, (unsigned)l, w.drop_p, s);  // dY
+      launch_wgrad(t1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A, s);
+      launch_linear(t3, pt.Wf2T, nullptr, t4, nullptr, A, 0, s);  // dH1
+      launch_swish_bwd(t0, t4, t3, nA, s);                        // dpre1
+      launch_wgrad(ctx, t3, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A, s);
+      launch_linear(t3, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
+    } else {
+      HIPCHK(h, hipMemcpyAsync(dCtx, dC, nA * 4, hipMemcpyDeviceToDevice, s));
+    }
+
+    // ---- LocalAttention backward (attention.py:118-216) ----
+    // forward recompute of what the fused kernels do not keep
+    launch_linear(c_in, p.W1p, p.bg, db->P1, nullptr, A, 0, s);
+    launch_linear(c_in, p.W3p, nullptr, db->P3, nullptr, A, 0, s);
+    launch_linear(c_in, p.Wqp, p.bq, db->q, nullptr, A, 0, s);
+    launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
+    launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
+    HIPCHK(h, hipMemsetAsync(dC, 0, nA * 4, s));                 // dC now collects d loss / d centres_l
+    launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, s);
+    launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
+    launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
+    launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, dC, edGt, E, s);  // dC[j] += dang*G' ; dG'tot
+    // geometry update: G' = LN_g(swish(V) + G), V = G.W2 + P1[i] + P3[j]
+    launch_linear(Gin, p.W2p, nullptr, eU, nullptr, E, 0, s);
+    launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
+    float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
+    launch_ln_bwd(eT, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
+    HIPCHK(h, hipMemsetAsync(dP1, 0, nA * 4, s));
+    HIPCHK(h, hipMemsetAsync(dP3, 0, nA * 4, s));
+    launch_edge_dv(eV, dGnext, db->edge_row, db->edge_col, eU, dP1, dP3, E, s);  // dV (in eU), dP1[i] += dV, dP3[j] += dV
+    float* fgk = g(la + "filter_geo/kernel");
+    launch_wgrad(Gin, eU, fgk + (size_t)D * D, nullptr, E, s);                   // dW2
+    launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                // dG += dV.W2^T
+    // per-atom projections
+    launch_wgrad(c_in, dP1, fgk, g(la + "filter_geo/bias"), A, s);
+    launch_wgrad(c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A, s);
+    launch_wgrad(c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A, s);
+    launch_linear(dP1, pt.W1T, nullptr, dC, nullptr, A, 1, s);
+    launch_linear(dP3, pt.W3T, nullptr, dC, nullptr, A, 1, s);
+    launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
+    dG_in = dGnext;
+  }
+  // ---- basis MLP and embedding (scann_model.py:362-389) ----
+  if (dG_in)
+    launch_basis_bwd(h->basis, db->dist, db->weight, dG_in, E, g("neighbor_d/kernel"), g("neighbor_d/bias"),
+                     g("neighbor_w/kernel"), g("neighbor_w/bias"), s);
+  launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, s);
+  HIPCHK(h, hipMemsetAsync(w.dlut, 0, (size_t)c.n_atoms * D * 4, s));
+  launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
+                   c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), s);
+  HIPCHK(h, hipGetLastError());
+  return SCANN_OK;
+}
+
+int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2) {
+  if (!h || !h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_adam_step: call scann_train_begin first");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->streams[0];
+  h->t_step += 1;
+  const double t = (double)h->t_step;
+  const float lr_hat = (float)((double)lr_t * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+  const size_t n = h->host_master.size();
+  // t_l2 holds a 0/1 mask; fold the coefficient in by scaling through the kernel argument
+  launch_adam(h->t_master, h->t_grad, h->t_m, h->t_v, h->t_l2, n, lr_hat, beta1, beta2, eps, l2, s);
+  launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, s);
+  launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
+                   h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(s));
+  return SCANN_OK;
+}
+
+int scann_comm_unique_id(char* out128) {
+  if (!out128) return SCANN_ERR_INVALID;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return SCANN_ERR_HIP;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, 128);
+  return SCANN_OK;
+}
+
+int scann_comm_init(scann_handle_t* h, const char* id128, int rank, int world) {
+  if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(h, SCANN_ERR_INVALID, "scann_comm_init: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
+  const ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
+  if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  h->comm_world = world;
+  return SCANN_OK;
+}
+
+int scann_allreduce_grads(scann_handle_t* h) {
+  if (!h || !h->t_grad) return fail(h, SCANN_ERR_INVALID, "scann_allreduce_grads: no training state");
+  if (!h->comm || h->comm_world == 1) return SCANN_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  // one fused flat all-reduce (890,977 floats = 3.56 MB at the QM9 config): latency-bound on xGMI, so a single call
+  const ncclResult_t r = ncclAllReduce(h->t_grad, h->t_grad, h->host_master.size(), ncclFloat, ncclSum, h->comm, h->streams[0]);
+  if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  return SCANN_OK;
+}
+
+int scann_allreduce_sse(scann_handle_t* h, double* sse, int64_t* count) {
+  if (!h || !sse || !count) return SCANN_ERR_INVALID;
+  if (!h->comm || h->comm_world == 1) return SCANN_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  double* d = nullptr;
+  HIPCHK(h, hipMalloc((void**)&d, 2 * sizeof(double)));
+  const double v[2] = {*sse, (double)*count};
+  HIPCHK(h, hipMemcpy(d, v, sizeof(v), hipMemcpyHostToDevice));
+  const ncclResult_t r = ncclAllReduce(d, d, 2, ncclDouble, ncclSum, h->comm, h->streams[0]);
+  if (r != ncclSuccess) { (void)hipFree(d); return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+  double o[2];
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  HIPCHK(h, hipMemcpy(o, d, sizeof(o), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  *sse = o[0];
+  *count = (int64_t)(o[1] + 0.5);
   return SCANN_OK;
 }
 

@@ -1,0 +1,53 @@
+// Declarations of the training-path kernels (scann_train.hip).  Internal.
+#pragma once
+#include "scann_internal.h"
+
+namespace scann {
+
+struct ReadoutBwdArgs {
+  const int32_t* mol_offset;
+  int32_t n_struct, max_atoms, use_ga_norm;
+  const float *gq, *gk, *ga;   // forward tensors [n_atom,128], [n_atom]
+  const float* dy;             // [n_struct] d loss / d y
+  const float *Wb, *bb, *wo;   // bf_property (row-major), predict_property
+  float *dgq, *dgk;            // [n_atom,128] out
+  float *rep_out, *dpre_out;   // [n_struct,128] out (inputs of the bf_property weight gradient)
+  float *dwo, *dbo;            // gradients (atomic)
+};
+
+// One region of the device weight arena, regenerated from the flat master parameters after each optimiser step.
+struct RepackDesc {
+  int64_t src;        // element offset into the master (canonical) parameter vector
+  int64_t dst;        // element offset into the weight arena
+  int32_t transpose;  // packed image of W^T instead of W (backward dX GEMMs)
+  int32_t raw;        // > 0: plain copy of this many elements (<= 16384); 0: 128x128 fragment-order pack
+};
+
+void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags, hipStream_t s);
+void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s);
+void launch_swish_bwd(const float* pre, const float* dout, float* dpre, size_t n, hipStream_t s);
+void launch_add(float* dst, const float* src, size_t n, hipStream_t s);
+void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s);
+void launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
+                   int accumulate, hipStream_t s);
+void launch_edge_ang(const float* c, const int* nb, const float* g, float* ang, int n_edge, hipStream_t s);
+void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dc,
+                      float* dg_tot, int n_edge, hipStream_t s);
+void launch_edge_v(const float* U, const float* P1, const float* P3, const int* ctr, const int* nb, const float* G, float* V,
+                   float* T, int n_edge, hipStream_t s);
+void launch_edge_dv(const float* V, const float* dT, const int* ctr, const int* nb, float* dV, float* dP1, float* dP3,
+                    int n_edge, hipStream_t s);
+void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
+                     float* dK, float* dgamma, float* dbeta, int n_atom, hipStream_t s);
+void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);
+void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weight, const float* dgeom, int n_edge, float* dWd,
+                      float* dbd, float* dWw, float* dbw, hipStream_t s);
+void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const float* emb, const float* W, const float* b,
+                      float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, hipStream_t s);
+void launch_sse(const float* y, const float* t, int n, double* out, hipStream_t s);
+void launch_dy(const float* y, const float* t, int n, float scale, float* dy, hipStream_t s);
+void launch_adam(float* w, const float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,
+                 float eps, float l2, hipStream_t s);
+void launch_repack(const RepackDesc* descs, int n, const float* master, float* arena, hipStream_t s);
+
+}  // namespace scann

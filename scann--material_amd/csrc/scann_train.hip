@@ -1,0 +1,664 @@
+// Training-path kernels (backward pass, loss, Adam) for the SCANN+ graph -- SURVEY.md section 8 row a17.
+//
+// Reference semantics: model.compile(loss=root_mean_squared_error, optimizer=Adam(lr, decay=1e-5)) + model.fit
+// (scann_model.py:199-241); loss = sqrt(mean((y_pred - y_true)^2)) (losses.py:5-6) + sum of l2(1e-4) kernel
+// regularisers (attention.py:27-28,95-109,260-265; scann_model.py:428,441).  Keras differentiates the forward graph
+// of create_model; here the backward is written by hand as a sequence of small kernels over packed [rows,128]
+// tensors (first version: modular, activations recomputed from the per-layer tensors the training forward keeps).
+// Every formula is the exact derivative of the corresponding forward line cited next to it.
+#include "scann_internal.h"
+#include "scann_train.h"
+
+namespace scann {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swish_(float x) { return x * sigmoidf_(x); }
+// d/dx [x * sigmoid(x)] = s * (1 + x * (1 - s))
+__device__ __forceinline__ float dswish_(float x) {
+  const float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ int acc_row_(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// ---- linear: Y = act(X . W + b) on 64-row tiles (same MFMA fragment scheme as the forward kernels) -----------------
+// flags: bit0 accumulate into Y, bit1 swish.  P (optional) receives the pre-activation X.W + b.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                     const float* __restrict__ bias, float* __restrict__ Y,
+                                                     float* __restrict__ P, int rows, int flags) {
+  __shared__ __attribute__((aligned(16))) float sX[64 * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * 64;
+  const int nrows = min(64, rows - row0);
+  const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + wave * (16 * 64) + lane;
+  float4 w[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) w[t] = wsrc[t * 64];
+  for (int i = tid; i < 64 * 32; i += 256) {
+    const int r = i >> 5, c4 = i & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows) v = reinterpret_cast<const float4*>(X)[(size_t)(row0 + r) * 32 + c4];
+    *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
+  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[rt], 0, 0, 0);
+    }
+  const int col = 32 * wave + (lane & 31);
+  const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = 32 * rt + acc_row_(i, lane);
+      if (r < nrows) {
+        const size_t o = (size_t)(row0 + r) * D + col;
+        float v = acc[rt][i] + b;
+        if (P) P[o] = v;
+        if (flags & 2) v = swish_(v);
+        if (flags & 1) v += Y[o];
+        Y[o] = v;
+      }
+    }
+}
+
+void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags,
+                   hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(linear_kernel, dim3((rows + 63) / 64), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
+}
+
+// ---- weight gradient: dW[i][j] += sum_rows X[row][i] dY[row][j];  db[j] += sum_rows dY[row][j] ---------------------
+// A workgroup reduces a 256-row slab with MFMA (A = X^T read column-wise from LDS) and adds its 128x128 partial with
+// float atomics (order of the adds is not fixed: gradients are reproducible to rounding only).
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                    float* __restrict__ dW, float* __restrict__ db, int rows) {
+  __shared__ __attribute__((aligned(16))) float sX[64 * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sD[64 * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab0 = blockIdx.x * 256;
+  f32x16 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+  float bsum = 0.f;  // thread tid < 128 owns column tid of db
+  for (int chunk = 0; chunk < 4; ++chunk) {
+    const int row0 = slab0 + chunk * 64;
+    if (row0 >= rows) break;
+    const int nrows = min(64, rows - row0);
+    __syncthreads();
+    for (int i = tid; i < 64 * 32; i += 256) {
+      const int r = i >> 5, c4 = i & 31;
+      float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vd = vx;
+      if (r < nrows) {
+        vx = reinterpret_cast<const float4*>(X)[(size_t)(row0 + r) * 32 + c4];
+        vd = reinterpret_cast<const float4*>(dY)[(size_t)(row0 + r) * 32 + c4];
+      }
+      *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = vx;
+      *reinterpret_cast<float4*>(&sD[r * LDS_STRIDE + 4 * c4]) = vd;
+    }
+    __syncthreads();
+    if (db && tid < D)
+      for (int r = 0; r < 64; ++r) bsum += sD[r * LDS_STRIDE + tid];
+    // k runs over the 64 rows of the chunk: MFMA step s uses rows 2s + (lane>>5)
+    const int h = lane >> 5, f = lane & 31;
+#pragma unroll 4
+    for (int s2 = 0; s2 < 32; ++s2) {
+      const int k = 2 * s2 + h;
+      const float bv = sD[k * LDS_STRIDE + 32 * wave + f];  // B[k][j = 32*wave + f]
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float av = sX[k * LDS_STRIDE + 32 * m + f];   // A[i = 32*m + f][k]
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+      }
+    }
+  }
+  const int col = 32 * wave + (lane & 31);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) atomicAdd(&dW[(size_t)(32 * m + acc_row_(i, lane)) * D + col], acc[m][i]);
+  if (db && tid < D) atomicAdd(&db[tid], bsum);
+}
+
+void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, X, dY, dW, db, rows);
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------------------
+
+__global__ void swish_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dout,
+                                 float* __restrict__ dpre, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dpre[i] = dout[i] * dswish_(pre[i]);
+}
+void launch_swish_bwd(const float* pre, const float* dout, float* dpre, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(swish_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, dout, dpre, n);
+}
+
+__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+void launch_add(float* dst, const float* src, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
+}
+
+__global__ void dropout_kernel(float* __restrict__ x, size_t n, unsigned long long seed, unsigned tag, float p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= drop_scale(seed, tag, i, p);
+}
+void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s) {
+  if (n && p > 0.f) hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, seed, tag, p);
+}
+
+// ---- LayerNorm backward (rows of 128; one wave per row) ---------------------------------------------------------------
+// y = xhat*gamma + beta, xhat = (x - mean) * rstd  (attention.py:35,111,113; eps 1e-6)
+// dxhat = dy*gamma ; dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)) ; dgamma += dy*xhat ; dbeta += dy
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                     int rows_per_wave, int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+  const float2 g = reinterpret_cast<const float2*>(gamma)[lane];
+  float2 dg = make_float2(0.f, 0.f), dbt = dg;
+  for (int r = r0; r < min(rows, r0 + rows_per_wave); ++r) {
+    const float2 xv = reinterpret_cast<const float2*>(x)[(size_t)r * 64 + lane];
+    const float2 dyv = reinterpret_cast<const float2*>(dy)[(size_t)r * 64 + lane];
+    float s = xv.x + xv.y;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    const float cx = xv.x - mean, cy = xv.y - mean;
+    float v = cx * cx + cy * cy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+    const float hx = cx * rstd, hy = cy * rstd;
+    const float ax = dyv.x * g.x, ay = dyv.y * g.y;
+    float m1 = ax + ay, m2 = ax * hx + ay * hy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      m1 += __shfl_xor(m1, o);
+      m2 += __shfl_xor(m2, o);
+    }
+    m1 *= (1.0f / D);
+    m2 *= (1.0f / D);
+    float2 out = make_float2(rstd * (ax - m1 - hx * m2), rstd * (ay - m1 - hy * m2));
+    float2* dst = reinterpret_cast<float2*>(dx) + (size_t)r * 64 + lane;
+    if (accumulate) {
+      const float2 old = *dst;
+      out.x += old.x;
+      out.y += old.y;
+    }
+    *dst = out;
+    dg.x += dyv.x * hx; dg.y += dyv.y * hy;
+    dbt.x += dyv.x; dbt.y += dyv.y;
+  }
+  atomicAdd(&dgamma[2 * lane], dg.x);
+  atomicAdd(&dgamma[2 * lane + 1], dg.y);
+  atomicAdd(&dbeta[2 * lane], dbt.x);
+  atomicAdd(&dbeta[2 * lane + 1], dbt.y);
+}
+void launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
+                   int accumulate, hipStream_t s) {
+  if (rows <= 0) return;
+  const int rpw = 8;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 4 * rpw - 1) / (4 * rpw)), dim3(256), 0, s, x, gamma, dy, dx, dgamma,
+                     dbeta, rows, rpw, accumulate);
+}
+
+// ---- edge elementwise kernels (thread = float4 chunk of an edge row) -------------------------------------------------
+
+// ang = c[nb] * G'  (attention.py:136,157)
+__global__ void edge_ang_kernel(const float4* __restrict__ c, const int* __restrict__ nb, const float4* __restrict__ g,
+                                float4* __restrict__ ang, int n_edge) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_edge * 32) return;
+  const int e = (int)(i >> 5), c4 = (int)(i & 31);
+  const float4 a = c[(size_t)nb[e] * 32 + c4], b = g[i];
+  ang[i] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+// backward of ang = cn * G':  dc[nb] += dang * G' (atomic),  dG'(total) = dang * cn + dG'(from the next layer)
+__global__ void edge_dang_kernel(const float4* __restrict__ c, const int* __restrict__ nb, const float4* __restrict__ g,
+                                 const float4* __restrict__ dang, const float4* __restrict__ dg_in,
+                                 float* __restrict__ dc, float4* __restrict__ dg_tot, int n_edge) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_edge * 32) return;
+  const int e = (int)(i >> 5), c4 = (int)(i & 31);
+  const int j = nb[e];
+  const float4 cn = c[(size_t)j * 32 + c4], gg = g[i], da = dang[i];
+  float4 t = make_float4(da.x * cn.x, da.y * cn.y, da.z * cn.z, da.w * cn.w);
+  if (dg_in) {
+    const float4 o = dg_in[i];
+    t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+  }
+  dg_tot[i] = t;
+  float* d = dc + (size_t)j * D + 4 * c4;
+  atomicAdd(d + 0, da.x * gg.x);
+  atomicAdd(d + 1, da.y * gg.y);
+  atomicAdd(d + 2, da.z * gg.z);
+  atomicAdd(d + 3, da.w * gg.w);
+}
+// V = U + P1[ctr] + P3[nb] ; T = swish(V) + G   (attention.py:142-153)
+__global__ void edge_v_kernel(const float4* __restrict__ U, const float4* __restrict__ P1, const float4* __restrict__ P3,
+                              const int* __restrict__ ctr, const int* __restrict__ nb, const float4* __restrict__ G,
+                              float4* __restrict__ V, float4* __restrict__ T, int n_edge) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_edge * 32) return;
+  const int e = (int)(i >> 5), c4 = (int)(i & 31);
+  const float4 u = U[i], a = P1[(size_t)ctr[e] * 32 + c4], b = P3[(size_t)nb[e] * 32 + c4], g = G[i];
+  const float4 v = make_float4((a.x + u.x) + b.x, (a.y + u.y) + b.y, (a.z + u.z) + b.z, (a.w + u.w) + b.w);
+  V[i] = v;
+  T[i] = make_float4(swish_(v.x) + g.x, swish_(v.y) + g.y, swish_(v.z) + g.z, swish_(v.w) + g.w);
+}
+// dV = dT * swish'(V);  dP1[ctr] += dV ; dP3[nb] += dV (atomics)
+__global__ void edge_dv_kernel(const float4* __restrict__ V, const float4* __restrict__ dT, const int* __restrict__ ctr,
+                               const int* __restrict__ nb, float4* __restrict__ dV, float* __restrict__ dP1,
+                               float* __restrict__ dP3, int n_edge) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_edge * 32) return;
+  const int e = (int)(i >> 5), c4 = (int)(i & 31);
+  const float4 v = V[i], t = dT[i];
+  const float4 d = make_float4(t.x * dswish_(v.x), t.y * dswish_(v.y), t.z * dswish_(v.z), t.w * dswish_(v.w));
+  dV[i] = d;
+  float* p1 = dP1 + (size_t)ctr[e] * D + 4 * c4;
+  float* p3 = dP3 + (size_t)nb[e] * D + 4 * c4;
+  atomicAdd(p1 + 0, d.x); atomicAdd(p1 + 1, d.y); atomicAdd(p1 + 2, d.z); atomicAdd(p1 + 3, d.w);
+  atomicAdd(p3 + 0, d.x); atomicAdd(p3 + 1, d.y); atomicAdd(p3 + 2, d.z); atomicAdd(p3 + 3, d.w);
+}
+#define EDGE_GRID(n_edge) dim3((unsigned)(((size_t)(n_edge) * 32 + 255) / 256)), dim3(256)
+void launch_edge_ang(const float* c, const int* nb, const float* g, float* ang, int n_edge, hipStream_t s) {
+  if (n_edge > 0)
+    hipLaunchKernelGGL(edge_ang_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)c, nb, (const float4*)g, (float4*)ang, n_edge);
+}
+void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dc,
+                      float* dg_tot, int n_edge, hipStream_t s) {
+  if (n_edge > 0)
+    hipLaunchKernelGGL(edge_dang_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)c, nb, (const float4*)g,
+                       (const float4*)dang, (const float4*)dg_in, dc, (float4*)dg_tot, n_edge);
+}
+void launch_edge_v(const float* U, const float* P1, const float* P3, const int* ctr, const int* nb, const float* G, float* V,
+                   float* T, int n_edge, hipStream_t s) {
+  if (n_edge > 0)
+    hipLaunchKernelGGL(edge_v_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)U, (const float4*)P1, (const float4*)P3, ctr,
+                       nb, (const float4*)G, (float4*)V, (float4*)T, n_edge);
+}
+void launch_edge_dv(const float* V, const float* dT, const int* ctr, const int* nb, float* dV, float* dP1, float* dP3,
+                    int n_edge, hipStream_t s) {
+  if (n_edge > 0)
+    hipLaunchKernelGGL(edge_dv_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)V, (const float4*)dT, ctr, nb, (float4*)dV,
+                       dP1, dP3, n_edge);
+}
+
+// ---- attention backward: one wave per atom, lane l owns features 2l, 2l+1 (head l>>3) -----------------------------
+// forward (attention.py:180-214): e[n,h] = 0.25 sum_d q[h,d] K[n,h,d]; attn = softmax_n(e); pre = sum_n attn K[n] + q;
+// ctx = LN(pre).  Given dctx: dpre = LN'(dctx); dq += dpre; dattn[n,h] = sum_d dpre[h,d] K[n,h,d];
+// de = attn*(dattn - sum_m attn[m] dattn[m]); dK[n] = attn*dpre + 0.25*de*q ; dq[h,:] += 0.25 sum_n de[n,h] K[n,h,:].
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ K,
+                                                       const int* __restrict__ edge_offset,
+                                                       const float* __restrict__ dctx, const float* __restrict__ gamma,
+                                                       float* __restrict__ dq, float* __restrict__ dK,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int n_atom,
+                                                       int atoms_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int a0 = (blockIdx.x * 4 + wave) * atoms_per_wave;
+  const float2 g = reinterpret_cast<const float2*>(gamma)[lane];
+  float2 dg = make_float2(0.f, 0.f), dbt = dg;
+  for (int at = a0; at < min(n_atom, a0 + atoms_per_wave); ++at) {
+    const int e0 = edge_offset[at], e1 = edge_offset[at + 1];
+    const float2 q2 = reinterpret_cast<const float2*>(q)[(size_t)at * 64 + lane];
+    const float qx = q2.x * 0.25f, qy = q2.y * 0.25f;
+    float m = -INFINITY;
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = reinterpret_cast<const float2*>(K)[(size_t)n * 64 + lane];
+      float e = qx * k2.x + qy * k2.y;
+      e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
+      m = fmaxf(m, e);
+    }
+    float ssum = 0.f;
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = reinterpret_cast<const float2*>(K)[(size_t)n * 64 + lane];
+      float e = qx * k2.x + qy * k2.y;
+      e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
+      ssum += expf(e - m);
+    }
+    float px = 0.f, py = 0.f;  // pre = sum attn K + q
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = reinterpret_cast<const float2*>(K)[(size_t)n * 64 + lane];
+      float e = qx * k2.x + qy * k2.y;
+      e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
+      const float attn = expf(e - m) / ssum;
+      px += attn * k2.x; py += attn * k2.y;
+    }
+    px += q2.x; py += q2.y;
+    // LayerNorm backward
+    float s = px + py;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    const float cx = px - mean, cy = py - mean;
+    float v = cx * cx + cy * cy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+    const float hx = cx * rstd, hy = cy * rstd;
+    const float2 dyv = reinterpret_cast<const float2*>(dctx)[(size_t)at * 64 + lane];
+    const float ax = dyv.x * g.x, ay = dyv.y * g.y;
+    float m1 = ax + ay, m2 = ax * hx + ay * hy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      m1 += __shfl_xor(m1, o);
+      m2 += __shfl_xor(m2, o);
+    }
+    m1 *= (1.0f / D); m2 *= (1.0f / D);
+    const float dpx = rstd * (ax - m1 - hx * m2), dpy = rstd * (ay - m1 - hy * m2);
+    dg.x += dyv.x * hx; dg.y += dyv.y * hy; dbt.x += dyv.x; dbt.y += dyv.y;
+    // softmax backward: dot = sum_m attn[m] dattn[m] per head
+    float dot = 0.f;
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = reinterpret_cast<const float2*>(K)[(size_t)n * 64 + lane];
+      float e = qx * k2.x + qy * k2.y, da = dpx * k2.x + dpy * k2.y;
+      e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
+      da += __shfl_xor(da, 1); da += __shfl_xor(da, 2); da += __shfl_xor(da, 4);
+      dot += (expf(e - m) / ssum) * da;
+    }
+    float dqx = dpx, dqy = dpy;  // residual path (attention.py:212)
+    for (int n = e0; n < e1; ++n) {
+      const float2 k2 = reinterpret_cast<const float2*>(K)[(size_t)n * 64 + lane];
+      float e = qx * k2.x + qy * k2.y, da = dpx * k2.x + dpy * k2.y;
+      e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
+      da += __shfl_xor(da, 1); da += __shfl_xor(da, 2); da += __shfl_xor(da, 4);
+      const float attn = expf(e - m) / ssum;
+      const float de = attn * (da - dot);
+      reinterpret_cast<float2*>(dK)[(size_t)n * 64 + lane] =
+          make_float2(attn * dpx + 0.25f * de * q2.x, attn * dpy + 0.25f * de * q2.y);
+      dqx += 0.25f * de * k2.x; dqy += 0.25f * de * k2.y;
+    }
+    reinterpret_cast<float2*>(dq)[(size_t)at * 64 + lane] = make_float2(dqx, dqy);
+  }
+  atomicAdd(&dgamma[2 * lane], dg.x);
+  atomicAdd(&dgamma[2 * lane + 1], dg.y);
+  atomicAdd(&dbeta[2 * lane], dbt.x);
+  atomicAdd(&dbeta[2 * lane + 1], dbt.y);
+}
+void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
+                     float* dK, float* dgamma, float* dbeta, int n_atom, hipStream_t s) {
+  if (n_atom <= 0) return;
+  const int apw = 2;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((n_atom + 4 * apw - 1) / (4 * apw)), dim3(256), 0, s, q, K, edge_offset, dctx,
+                     gamma, dq, dK, dgamma, dbeta, n_atom, apw);
+}
+
+// ---- readout backward: one workgroup per structure ------------------------------------------------------------------
+// forward (attention.py:279-316, scann_model.py:437-447): a_i = sum_{j!=i} gk_i.gq_j ; an = a/|a| ; at = softmax(an);
+// rep = sum_i at_i gk_i ; pre = rep.Wb + bb ; h = swish(pre) ; y = h.wo + bo (mrelu has an identity gradient).
+__global__ __launch_bounds__(128) void readout_bwd_kernel(ReadoutBwdArgs a) {
+  extern __shared__ float sd[];  // [n] attn, [n] agg, [n] da
+  __shared__ float sRep[D], sV[D], sS[D], sW[D], sRed[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mol = blockIdx.x;
+  const int a0 = a.mol_offset[mol];
+  const int n = a.mol_offset[mol + 1] - a0;
+  float* sAt = sd;
+  float* sAgg = sd + n;
+  float* sDa = sd + 2 * n;
+  const float dy = a.dy[mol];
+  // rep, S = sum_j gq_j
+  float rep = 0.f, S = 0.f;
+  for (int i = 0; i < n; ++i) {
+    rep += a.ga[a0 + i] * a.gk[(size_t)(a0 + i) * D + tid];
+    S += a.gq[(size_t)(a0 + i) * D + tid];
+  }
+  sRep[tid] = rep;
+  sS[tid] = S;
+  for (int i = tid; i < n; i += 128) sAt[i] = a.ga[a0 + i];
+  __syncthreads();
+  // head: pre_j, h_j
+  float pre = a.bb[tid];
+  for (int k = 0; k < D; ++k) pre += sRep[k] * a.Wb[k * D + tid];
+  const float hj = swish_(pre);
+  const float dh = dy * a.wo[tid];
+  const float dpre = dh * dswish_(pre);
+  atomicAdd(&a.dwo[tid], dy * hj);
+  if (tid == 0) atomicAdd(a.dbo, dy);
+  a.rep_out[(size_t)mol * D + tid] = rep;
+  a.dpre_out[(size_t)mol * D + tid] = dpre;
+  sV[tid] = dpre;
+  __syncthreads();
+  // drep_k = sum_j dpre_j Wb[k][j]
+  float drep = 0.f;
+  for (int j = 0; j < D; ++j) drep += sV[j] * a.Wb[tid * D + j];
+  __syncthreads();
+  sV[tid] = drep;  // now drep
+  __syncthreads();
+  // per atom: dat_i = drep.gk_i ; a_i = gk_i.(S - gq_i)
+  for (int i = wave; i < n; i += 2) {
+    const float2 k2 = reinterpret_cast<const float2*>(a.gk)[(size_t)(a0 + i) * 64 + lane];
+    const float2 q2 = reinterpret_cast<const float2*>(a.gq)[(size_t)(a0 + i) * 64 + lane];
+    float d1 = sV[2 * lane] * k2.x + sV[2 * lane + 1] * k2.y;
+    float d2 = k2.x * (sS[2 * lane] - q2.x) + k2.y * (sS[2 * lane + 1] - q2.y);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      d1 += __shfl_xor(d1, o);
+      d2 += __shfl_xor(d2, o);
+    }
+    if (lane == 0) {
+      sDa[i] = d1;   // dat_i
+      sAgg[i] = d2;  // a_i
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // softmax and normalisation backward (n is small)
+    float dot = 0.f, nrm2 = 0.f;
+    for (int i = 0; i < n; ++i) {
+      dot += sAt[i] * sDa[i];
+      nrm2 += sAgg[i] * sAgg[i];
+    }
+    const float nrm = sqrtf(nrm2);
+    float proj = 0.f;
+    for (int i = 0; i < n; ++i) {
+      sDa[i] = sAt[i] * (sDa[i] - dot);  // dan_i
+      if (a.use_ga_norm) proj += (sAgg[i] / nrm) * sDa[i];
+    }
+    if (a.use_ga_norm)
+      for (int i = 0; i < n; ++i) sDa[i] = (sDa[i] - (sAgg[i] / nrm) * proj) / nrm;  // da_i
+    sRed[0] = 0.f;
+  }
+  __syncthreads();
+  // W = sum_i da_i gk_i ; dgk_i = at_i*drep + da_i (S - gq_i) ; dgq_j = W - da_j gk_j
+  float Wacc = 0.f;
+  for (int i = 0; i < n; ++i) Wacc += sDa[i] * a.gk[(size_t)(a0 + i) * D + tid];
+  sW[tid] = Wacc;
+  for (int i = 0; i < n; ++i) {
+    const size_t o = (size_t)(a0 + i) * D + tid;
+    const float gk = a.gk[o], gq = a.gq[o];
+    a.dgk[o] = sAt[i] * sV[tid] + sDa[i] * (sS[tid] - gq);
+    a.dgq[o] = Wacc - sDa[i] * gk;
+  }
+}
+void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s) {
+  if (a.n_struct <= 0) return;
+  hipLaunchKernelGGL(readout_bwd_kernel, dim3(a.n_struct), dim3(128), (size_t)3 * a.max_atoms * sizeof(float), s, a);
+}
+
+// ---- basis backward: geom0 = swish(gd.Wd + bd) * swish(gw.Ww + bw)  (scann_model.py:378-389) ---------------------------
+__device__ __forceinline__ float gauss_(float x, float c) {
+  const float d = x - c;
+  return expf(-(d * d) / 0.25f);
+}
+__global__ __launch_bounds__(128) void basis_bwd_kernel(BasisParams p, const float* __restrict__ dist,
+                                                        const float* __restrict__ weight, const float* __restrict__ dgeom,
+                                                        int n_edge, float* dWd, float* dbd, float* dWw, float* dbw) {
+  __shared__ float sG[32][2 * NG];
+  const int tid = threadIdx.x;
+  const int e0 = blockIdx.x * 32;
+  const int ne = min(32, n_edge - e0);
+  for (int i = tid; i < 32 * 2 * NG; i += 128) {
+    const int e = i / (2 * NG), k = i % (2 * NG);
+    float v = 0.f;
+    if (e < ne) v = k < NG ? gauss_(dist[e0 + e], p.cd[k]) : gauss_(weight[e0 + e], p.cw[k - NG]);
+    sG[e][k] = v;
+  }
+  __syncthreads();
+  float wd[NG], ww[NG], gdw[NG], gww[NG];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    wd[k] = p.Wd[k * D + tid];
+    ww[k] = p.Ww[k * D + tid];
+    gdw[k] = 0.f;
+    gww[k] = 0.f;
+  }
+  const float bd = p.bd[tid], bw = p.bw[tid];
+  float gbd = 0.f, gbw = 0.f;
+  for (int e = 0; e < ne; ++e) {
+    float ad = 0.f, aw = 0.f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      ad += sG[e][k] * wd[k];
+      aw += sG[e][NG + k] * ww[k];
+    }
+    ad += bd; aw += bw;
+    const float dg = dgeom[(size_t)(e0 + e) * D + tid];
+    const float dpd = dg * swish_(aw) * dswish_(ad), dpw = dg * swish_(ad) * dswish_(aw);
+    gbd += dpd; gbw += dpw;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      gdw[k] += sG[e][k] * dpd;
+      gww[k] += sG[e][NG + k] * dpw;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    atomicAdd(&dWd[k * D + tid], gdw[k]);
+    atomicAdd(&dWw[k * D + tid], gww[k]);
+  }
+  atomicAdd(&dbd[tid], gbd);
+  atomicAdd(&dbw[tid], gbw);
+}
+void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weight, const float* dgeom, int n_edge, float* dWd,
+                      float* dbd, float* dWw, float* dbw, hipStream_t s) {
+  if (n_edge > 0)
+    hipLaunchKernelGGL(basis_bwd_kernel, dim3((n_edge + 31) / 32), dim3(128), 0, s, p, dist, weight, dgeom, n_edge, dWd, dbd,
+                       dWw, dbw);
+}
+
+// ---- embedding backward (Embedding + dense_embed, scann_model.py:362,373) -------------------------------------------------
+// c0[a] = drop(swish(pre[Z_a])), pre[s] = E[s].W + b.   dlut[s] = sum_{a: Z_a = s} dc0[a] (dropout already applied to dc0).
+__global__ void embed_scatter_kernel(const float* __restrict__ dc0, const int* __restrict__ atomic, float* __restrict__ dlut,
+                                     int n_atom) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)n_atom * D) atomicAdd(&dlut[(size_t)atomic[i / D] * D + (i % D)], dc0[i]);
+}
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ W,
+                                                        const float* __restrict__ b, const float* __restrict__ dlut,
+                                                        int n_species, int emb_dim, float* dEmb, float* dW, float* db) {
+  // one workgroup per species; thread = output column
+  extern __shared__ float sdp[];  // [128] dpre
+  const int sp = blockIdx.x, col = threadIdx.x;
+  float pre = b[col];
+  for (int k = 0; k < emb_dim; ++k) pre += emb[sp * emb_dim + k] * W[k * D + col];
+  const float dpre = dlut[sp * D + col] * dswish_(pre);
+  sdp[col] = dpre;
+  atomicAdd(&db[col], dpre);
+  for (int k = 0; k < emb_dim; ++k) atomicAdd(&dW[k * D + col], emb[sp * emb_dim + k] * dpre);
+  __syncthreads();
+  for (int k = col; k < emb_dim; k += 128) {
+    float acc = 0.f;
+    for (int j = 0; j < D; ++j) acc += sdp[j] * W[k * D + j];
+    dEmb[sp * emb_dim + k] += acc;  // accumulate; each species row is touched by exactly one workgroup
+  }
+}
+void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const float* emb, const float* W, const float* b,
+                      float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, hipStream_t s) {
+  if (n_atom <= 0) return;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)(((size_t)n_atom * D + 255) / 256)), dim3(256), 0, s, dc0, atomic,
+                     dlut, n_atom);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_species), dim3(128), D * sizeof(float), s, emb, W, b, dlut, n_species, emb_dim,
+                     dEmb, dW, db);
+}
+
+// ---- loss ------------------------------------------------------------------------------------------------------------------
+__global__ void sse_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, double* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double d = (double)y[i] - (double)t[i];
+    s += d * d;
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+void launch_sse(const float* y, const float* t, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(sse_kernel, dim3(1), dim3(256), 0, s, y, t, n, out);
+}
+// d rmse / d y_i = (y_i - t_i) / (count * rmse)   (losses.py:5-6 over the GLOBAL batch)
+__global__ void dy_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, float scale, float* __restrict__ dy) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dy[i] = (y[i] - t[i]) * scale;
+}
+void launch_dy(const float* y, const float* t, int n, float scale, float* dy, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(dy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, t, n, scale, dy);
+}
+
+// ---- Adam (tf.keras.optimizers.Adam, epsilon 1e-7) + l2 regulariser gradient ------------------------------------------------
+// g += 2*l2*w on regularised kernels; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_hat * m / (sqrt(v) + eps)
+// with lr_hat = lr_t * sqrt(1 - b2^t) / (1 - b1^t) computed by the caller.
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ l2mask, size_t n, float lr_hat, float b1, float b2, float eps,
+                            float l2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] + 2.0f * l2 * l2mask[i] * w[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  w[i] -= lr_hat * mi / (sqrtf(vi) + eps);
+}
+void launch_adam(float* w, const float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,
+                 float eps, float l2, hipStream_t s) {
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, g, m, v, l2mask, n, lr_hat, b1, b2, eps, l2);
+}
+
+// ---- master weights -> MFMA fragment order (after every optimiser step) --------------------------------------------------------
+// dst[((w*16 + t)*64 + lane)*4 + i] = M[8t + 4(lane>>5) + i][32w + (lane&31)], M = W (ld 128) or W^T.
+__global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float* __restrict__ master, float* __restrict__ arena) {
+  const RepackDesc d = descs[blockIdx.y];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 16383
+  if (idx >= D * D) return;
+  if (d.raw) {
+    if (idx < d.raw) arena[d.dst + idx] = master[d.src + idx];
+    return;
+  }
+  const int i = idx & 3, lane = (idx >> 2) & 63, t = (idx >> 8) & 15, w = idx >> 12;
+  const int k = 8 * t + 4 * (lane >> 5) + i, j = 32 * w + (lane & 31);
+  arena[d.dst + idx] = d.transpose ? master[d.src + (size_t)j * D + k] : master[d.src + (size_t)k * D + j];
+}
+void launch_repack(const RepackDesc* descs, int n, const float* master, float* arena, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(repack_kernel, dim3(D * D / 256, n), dim3(256), 0, s, descs, master, arena);
+}
+
+}  // namespace scann

@@ -72,6 +72,18 @@ SYMBOLS = [
     ("scann_set_debug", C.c_int, [_P, C.c_int]),
     ("scann_debug_read", C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     ("scann_debug_stamps", C.c_int, [_P, _P, _P, C.c_int]),
+    ("scann_param_count", C.c_int64, [_P]),
+    ("scann_train_begin", C.c_int, [_P]),
+    ("scann_train_forward", C.c_int, [_P, _P, _P, C.c_float, C.c_uint64, C.POINTER(C.c_double)]),
+    ("scann_train_backward", C.c_int, [_P, _P, C.c_double, C.c_int64]),
+    ("scann_zero_grads", C.c_int, [_P]),
+    ("scann_allreduce_grads", C.c_int, [_P]),
+    ("scann_allreduce_sse", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("scann_adam_step", C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    ("scann_get_grads", C.c_int, [_P, _P]),
+    ("scann_get_weights", C.c_int, [_P, _P]),
+    ("scann_comm_unique_id", C.c_int, [C.c_char_p]),
+    ("scann_comm_init", C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
 ]
 
 _lib = None
@@ -97,6 +109,15 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def comm_unique_id():
+    """ncclGetUniqueId (rank 0); the 128 bytes are handed to the other ranks by the caller (e.g. over gloo)."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().scann_comm_unique_id(buf)
+    if rc != SCANN_OK:
+        raise ScannHipError(rc, "scann_comm_unique_id failed")
+    return buf.raw
 
 
 def _ptr(a):
@@ -307,6 +328,57 @@ class Engine:
         p = Profile()
         self._check(self.lib.scann_forward_profile(self._h, rb._h, C.byref(p)))
         return {k: getattr(p, k) for k, _ in Profile._fields_ if k != "reserved"}
+
+    # -- training (scann_model.py:199-241) --------------------------------------------------------------------
+    def _unflatten(self, flat):
+        out, off = {}, 0
+        for name, shape in self.weight_specs():
+            n = int(np.prod(shape))
+            out[name] = flat[off:off + n].reshape(shape).copy()
+            off += n
+        return out
+
+    def param_count(self):
+        return int(self.lib.scann_param_count(self._h))
+
+    def train_begin(self):
+        self._check(self.lib.scann_train_begin(self._h))
+
+    def train_forward(self, rb, targets, dropout=0.0, seed=0):
+        t = np.ascontiguousarray(targets, dtype=np.float32)
+        sse = C.c_double()
+        self._check(self.lib.scann_train_forward(self._h, rb._h, _ptr(t), float(dropout), int(seed), C.byref(sse)))
+        return sse.value
+
+    def train_backward(self, rb, sse_global, count_global):
+        self._check(self.lib.scann_train_backward(self._h, rb._h, float(sse_global), int(count_global)))
+
+    def zero_grads(self):
+        self._check(self.lib.scann_zero_grads(self._h))
+
+    def allreduce_grads(self):
+        self._check(self.lib.scann_allreduce_grads(self._h))
+
+    def allreduce_sse(self, sse, count):
+        a, b = C.c_double(sse), C.c_int64(count)
+        self._check(self.lib.scann_allreduce_sse(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def adam_step(self, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, l2=1e-4):
+        self._check(self.lib.scann_adam_step(self._h, float(lr_t), float(beta1), float(beta2), float(eps), float(l2)))
+
+    def get_grads(self):
+        flat = np.empty(self.param_count(), dtype=np.float32)
+        self._check(self.lib.scann_get_grads(self._h, _ptr(flat)))
+        return self._unflatten(flat)
+
+    def get_weights(self):
+        flat = np.empty(self.param_count(), dtype=np.float32)
+        self._check(self.lib.scann_get_weights(self._h, _ptr(flat)))
+        return self._unflatten(flat)
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self.lib.scann_comm_init(self._h, unique_id, int(rank), int(world)))
 
     def set_debug(self, on):
         self._check(self.lib.scann_set_debug(self._h, int(bool(on))))

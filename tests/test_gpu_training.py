@@ -1,0 +1,139 @@
+"""GPU tests of the training step: hand-written backward vs torch autograd (fp64, CPU) of the independent torch
+graph (tests/torch_ref.py), Adam + l2 regulariser vs a NumPy restatement of tf.keras Adam, dropout statistics."""
+import numpy as np
+import pytest
+
+import scann_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(n=6, L=2, seed=1, **model_over):
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    cfg["model"]["n_attention"] = L
+    cfg["model"].update(model_over)
+    w = so.init_weights(cfg, 3, perturb=True)
+    de, dn = so.synth_dataset(n, seed)
+    inputs, targets = so.pad_batch(de, dn, True)
+    pk = _hip.pack_inputs(inputs)
+    model = HipModel(cfg, w, device=0)
+    return cfg, w, pk, targets, model
+
+
+def grad_errors(got, ref):
+    out = {}
+    for k, r in ref.items():
+        scale = max(float(np.sqrt(np.mean(r * r))), 1e-12)
+        out[k] = float(np.max(np.abs(got[k].astype(np.float64) - r)) / max(float(np.abs(r).max()), scale))
+    return out
+
+
+@pytest.mark.parametrize("over", [dict(), dict(use_attn_norm=False), dict(use_ga_norm=False)], ids=["qm9", "no_attn_norm", "no_ga_norm"])
+def test_gradients_match_autograd(hip_lib, over):
+    import torch_ref
+
+    cfg, w, pk, targets, model = setup(**over)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    loss, rmse, ref, y_ref = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 1e-5 * max(rmse, 1e-6)
+    # the autograd loss includes the l2 term; the library adds 2*l2*W inside the optimiser step -> remove it here
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+    errs = grad_errors(got, ref)
+    bad = {k: v for k, v in errs.items() if not v <= 2e-3}
+    assert not bad, bad
+    rb.free()
+
+
+def test_seven_layer_gradients_and_accumulation(hip_lib):
+    """Full QM9 depth; two backward calls accumulate (gradient of the sum)."""
+    import torch_ref
+
+    cfg, w, pk, targets, model = setup(n=5, L=7, seed=4)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    g1 = eng.get_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    g2 = eng.get_grads()
+    _, _, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+    errs = grad_errors(g1, ref)
+    assert max(errs.values()) <= 5e-3, {k: v for k, v in errs.items() if v > 5e-3}
+    for k in g1:
+        assert np.allclose(g2[k], 2 * g1[k], rtol=2e-3, atol=1e-7 + 2e-3 * np.abs(g1[k]).max())
+    rb.free()
+
+
+def test_adam_step_matches_keras_formula(hip_lib):
+    """tf.keras Adam (epsilon outside the sqrt) with the l2(1e-4) regulariser gradient; forward afterwards uses the
+    updated (re-packed) weights."""
+    import torch_ref
+
+    cfg, w, pk, targets, model = setup()
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    m = {k: np.zeros_like(v, dtype=np.float64) for k, v in w.items()}
+    v = {k: np.zeros_like(x, dtype=np.float64) for k, x in w.items()}
+    wref = {k: x.astype(np.float64) for k, x in w.items()}
+    lr, b1, b2, eps = 5e-4, 0.9, 0.999, 1e-7
+    for step in range(1, 4):
+        sse = eng.train_forward(rb, targets)
+        eng.zero_grads()
+        eng.train_backward(rb, sse, pk.n_struct)
+        g = eng.get_grads()
+        lr_t = lr / (1 + 1e-5 * (step - 1))  # legacy `decay`
+        eng.adam_step(lr_t)
+        for k in wref:
+            gi = g[k].astype(np.float64) + (2e-4 * wref[k] if k.endswith(torch_ref.REGULARIZED) else 0.0)
+            m[k] = b1 * m[k] + (1 - b1) * gi
+            v[k] = b2 * v[k] + (1 - b2) * gi * gi
+            wref[k] -= lr_t * np.sqrt(1 - b2 ** step) / (1 - b1 ** step) * m[k] / (np.sqrt(v[k]) + eps)
+    got = eng.get_weights()
+    for k in wref:
+        assert np.allclose(got[k], wref[k], rtol=1e-4, atol=2e-6), k
+    # the inference path sees the new weights
+    y_new, _ = eng.forward(pk)
+    y_fresh = type(model)(cfg, got, device=0).predict(pk)  # a fresh model loaded with the updated parameters
+    assert np.allclose(y_new, y_fresh[:, 0], rtol=1e-5, atol=1e-6)
+    rb.free()
+
+
+def test_loss_decreases_and_dropout_is_active(hip_lib):
+    cfg, w, pk, targets, model = setup(n=16, L=2, seed=9)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    s0 = eng.train_forward(rb, targets)
+    s_drop_a = eng.train_forward(rb, targets, dropout=0.1, seed=1)
+    s_drop_b = eng.train_forward(rb, targets, dropout=0.1, seed=2)
+    s_drop_a2 = eng.train_forward(rb, targets, dropout=0.1, seed=1)
+    assert s_drop_a != s0 and s_drop_a != s_drop_b and s_drop_a == s_drop_a2  # masks depend on the seed only
+    # a learnable target: standardised carbon count of each molecule
+    nC = np.array([np.sum(pk.atomic[pk.mol_offset[i]:pk.mol_offset[i + 1]] == 6) for i in range(pk.n_struct)], dtype=np.float64)
+    t2 = ((nC - nC.mean()) / (nC.std() + 1e-9)).astype(np.float32)
+    s_start = eng.train_forward(rb, t2)
+    for step in range(80):
+        sse = eng.train_forward(rb, t2, dropout=0.1, seed=100 + step)
+        eng.zero_grads()
+        eng.train_backward(rb, sse, pk.n_struct)
+        eng.adam_step(2e-3 / (1 + 1e-5 * step))
+    final = eng.train_forward(rb, t2)
+    assert final < 0.25 * s_start, (s_start, final)
+    rb.free()

@@ -6,13 +6,32 @@ import math
 import numpy as np
 
 
-def forward_packed(config, weights, pk, dtype="float64"):
+REGULARIZED = ("query/kernel", "key/kernel", "filter_geo/kernel", "dense_1/kernel", "dense_2/kernel",
+               "after_Lc/kernel", "bf_property/kernel")  # kernel_regularizer=l2(1e-4): attention.py:27-28,95-109,260-265; scann_model.py:428,441
+
+
+def loss_and_grads(config, weights, pk, targets):
+    """Training loss of the reference (scann_model.py:210-214: RMSE + sum of l2(1e-4) kernel regularisers) and its
+    gradient w.r.t. every tensor, by torch autograd in fp64.  Dropout layers are inactive (rate 0)."""
+    import torch
+
+    W = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in weights.items()}
+    y, _ = forward_packed(config, W, pk, "float64", as_tensor=True)
+    t = torch.tensor(np.asarray(targets), dtype=torch.float64).reshape(-1, 1)
+    rmse = torch.sqrt(torch.mean((y - t) ** 2))  # losses.py:5-6
+    reg = sum((W[k] ** 2).sum() for k in W if k.endswith(REGULARIZED)) * 1e-4
+    loss = rmse + reg
+    loss.backward()
+    return float(loss), float(rmse), {k: v.grad.numpy() for k, v in W.items()}, y.detach().numpy()
+
+
+def forward_packed(config, weights, pk, dtype="float64", as_tensor=False):
     import torch
     import torch.nn.functional as F
 
     dt = getattr(torch, dtype)
     cfg = config["model"]
-    W = {k: torch.tensor(np.asarray(v), dtype=dt) for k, v in weights.items()}
+    W = {k: (v if torch.is_tensor(v) else torch.tensor(np.asarray(v), dtype=dt)) for k, v in weights.items()}
     d, H = cfg["local_dim"], cfg["num_head"]
     hd = d // H
 
@@ -78,4 +97,6 @@ def forward_packed(config, weights, pk, dtype="float64"):
             y = torch.relu(y)
         ys.append(y)
         gas.append(at)
+    if as_tensor:
+        return torch.stack(ys).reshape(-1, 1), torch.cat(gas)
     return torch.stack(ys).numpy().reshape(-1, 1), torch.cat(gas).numpy()
