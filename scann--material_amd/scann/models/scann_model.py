@@ -219,16 +219,30 @@ class SCANN:
         return "{}_{}".format(self.config["hyper"]["save_path"], self.config["hyper"]["target"])
 
     def train(self, epochs=1000):
-        raise NotImplementedError(
-            "training (backward kernels, Adam, RCCL gradient all-reduce) is the next row of the scope table "
-            "(SURVEY.md section 8a17 / 8e); this round ships the forward path")
+        """``compile`` + ``fit`` of the reference (scann_model.py:199-245): RMSE loss + l2 regularisers, Adam with the
+        legacy decay, CosineDecay or SGDR schedule, best-val_mae checkpoint, early stopping; afterwards the model is
+        dropped so that ``evaluate`` reloads the best checkpoint, exactly like the reference."""
+        import yaml
+
+        from .trainer import fit
+
+        os.makedirs("{}/models/".format(self._out_dir()), exist_ok=True)
+        if int(os.environ.get("RANK", "0")) == 0:
+            yaml.safe_dump(self.config, open("{}/config.yaml".format(self._out_dir()), "w"), default_flow_style=False)
+
+        class _Hist:
+            pass
+
+        self.hist = _Hist()
+        self.hist.history = fit(self, epochs)
+        del self.model
 
     def evaluate(self):
         """Test-set loop of the reference (scann_model.py:247-313): predict every batch, report
         R2 and MAE * std, write report.txt."""
         from sklearn.metrics import mean_absolute_error, r2_score
 
-        if getattr(self, "model", None) is None:
+        if not hasattr(self, "model") or self.model is None:
             print("Load best validation weight for predicting testset", "\n")
             t = self.config["hyper"]["target"]
             self.model = load_model("{}/models/model_{}.h5".format(self._out_dir(), t))
@@ -248,7 +262,13 @@ class SCANN:
         print("Result for testset ", self.config["hyper"]["target"], " : R2 score: ", r2, " and MAE: ", mae)
         os.makedirs(self._out_dir(), exist_ok=True)
         with open("{}/report.txt".format(self._out_dir()), "w") as f:
+            if hasattr(self, "hist"):  # scann_model.py:292-311
+                f.write("Training MAE: " + str(min(self.hist.history["mae"]) * self.std) + "\n")
+                f.write("Val MAE: " + str(min(self.hist.history["val_mae"]) * self.std) + "\n")
             f.write("Test MAE: " + str(mae) + ", Test R2: " + str(r2))
+        if hasattr(self, "hist"):
+            np.save("{}/hist_data.npy".format(self._out_dir()), np.array([y_predict, y, self.hist.history], dtype=object))
+            print("Saved model record for dataset")
         return mae, r2
 
     def predict_data(self, ip):

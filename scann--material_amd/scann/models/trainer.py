@@ -1,0 +1,193 @@
+"""Training loop behind ``SCANN.train`` -- the counterpart of ``model.compile(...)`` + ``model.fit(...)`` +
+callbacks in the reference (scann_model.py:163-241, custom_layers.py:78-179), driving the HIP training step
+(``scann_train_forward`` / ``scann_train_backward`` / ``scann_allreduce_grads`` / ``scann_adam_step``).
+
+Data parallelism: every rank sees the same global batch (same shuffle seed), keeps its contiguous
+slice of structures, and the ranks exchange exactly two things per step over RCCL: the scalar SSE/count (the loss is
+``sqrt(mean_batch((y_hat - y)^2))`` over the GLOBAL batch, losses.py:5-6) and one flat fp32 gradient all-reduce.
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+
+import numpy as np
+
+from .. import _hip
+from ..parallel import rank_slice
+
+
+def cosine_decay(step, initial_lr, decay_steps, alpha):
+    """tf.keras.optimizers.schedules.CosineDecay as configured at scann_model.py:203-208."""
+    s = min(float(step), float(decay_steps))
+    cos = 0.5 * (1.0 + math.cos(math.pi * s / float(decay_steps)))
+    return initial_lr * ((1.0 - alpha) * cos + alpha)
+
+
+class SGDRC:
+    """Warm-restart schedule with validation-triggered decay, behaviour of the reference callback
+    (custom_layers.py:78-179): the rate stays at ``lr_max`` until ``val_mae <= trigger_val_mae``; from then on every
+    epoch advances a cosine cycle of ``ti`` epochs (``ti *= tmult`` at each restart) between ``lr_min`` and the current
+    warm-up peak; whenever validation improves, the NEXT peak is set to max(peak / lr_max_compression, current lr)."""
+
+    def __init__(self, lr_max, lr_min, lr_max_compression=5, t0=10, tmult=1, trigger_val_mae=9999, show_lr=True):
+        self.lr_max, self.lr_min = lr_max, lr_min
+        self.lr_max_compression = lr_max_compression
+        self.t0, self.tmult = t0, tmult
+        self.trigger_val_mae = trigger_val_mae
+        self.show_lr = show_lr
+        self.reset()
+
+    def reset(self):
+        self.triggered = False
+        self.peak_next = self.peak = self.lr = self.lr_max
+        self.ti, self.tcur = self.t0, 1
+        self.best_val_mae = 9999
+
+    on_train_begin = lambda self, logs=None: self.reset()  # noqa: E731
+
+    def on_epoch_end(self, epoch, logs):
+        val = logs["val_mae"]
+        if not self.triggered and val <= self.trigger_val_mae:
+            self.triggered = True
+        if self.triggered and val < self.best_val_mae:
+            self.best_val_mae = val
+            self.peak_next = max(self.peak / self.lr_max_compression, self.lr) if self.lr_max_compression > 0 else self.lr
+        if self.show_lr:
+            print("sgdr_triggered = %s, current_lr = %f, next_warmup_lr = %f, next_warmup = %d"
+                  % (self.triggered, self.lr, self.peak_next, self.ti - self.tcur))
+
+    def lr_scheduler(self, epoch):
+        if not self.triggered:
+            return self.lr
+        self.tcur += 1
+        if self.tcur > self.ti:
+            self.ti = int(self.tmult * self.ti)
+            self.tcur = 1
+            self.peak = self.peak_next
+        self.lr = float(self.lr_min + (self.peak - self.lr_min) * (1 + np.cos(self.tcur / self.ti * np.pi)) / 2.0)
+        return self.lr
+
+
+class Communicator:
+    """RCCL communicator of the training ranks (one process per GPU, launched by torch.distributed.run).  The 128-byte
+    ncclUniqueId travels through a gloo broadcast; torch never touches the GPU."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            buf = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = torch.frombuffer(bytearray(_hip.comm_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(buf, 0)
+            engine.comm_init(bytes(buf.numpy().tobytes()), self.rank, self.world)
+
+    def shard(self, packed):
+        if self.world == 1:
+            return packed, slice(0, packed.n_struct)
+        from ..parallel import split_packed  # contiguous structure ranges, one per rank
+
+        lo, hi = rank_slice(packed.n_struct, self.rank, self.world)
+        return _slice_packed(packed, lo, hi), slice(lo, hi)
+
+    def sum_pair(self, a, b):
+        return self.engine.allreduce_sse(a, b) if self.world > 1 else (a, b)
+
+
+def _slice_packed(pk, lo, hi):
+    mol = pk.mol_offset.astype(np.int64)
+    eoff = pk.edge_offset.astype(np.int64)
+    a0, a1 = int(mol[lo]), int(mol[hi])
+    e0, e1 = int(eoff[a0]), int(eoff[a1])
+    return _hip.PackedBatch(pk.atomic[a0:a1], mol[lo:hi + 1] - a0, eoff[a0:a1 + 1] - e0, pk.edge_col[e0:e1] - a0,
+                            pk.edge_dist[e0:e1], pk.edge_weight[e0:e1])
+
+
+def fit(scann, epochs=1000, dropout=0.1, verbose=True):
+    """``SCANN.train`` body.  Returns the history dict (keys as in Keras: loss, mae, r2_square, val_*, lr)."""
+    cfg = scann.config
+    hy = cfg["hyper"]
+    model = scann.model
+    eng = model.engine
+    eng.train_begin()
+    comm = Communicator(eng)
+    train_it, valid_it = scann.trainIter, scann.validIter
+    steps_per_epoch = len(train_it)
+    out_dir = "{}_{}".format(hy["save_path"], hy["target"])
+    ckpt = "{}/models/model_{}.h5".format(out_dir, hy["target"])
+    sgdr = None
+    if hy["scheduler"] == "sgdr":  # scann_model.py:181-193
+        sgdr = SGDRC(lr_min=hy["min_lr"], lr_max=hy["lr"], t0=50, tmult=2, lr_max_compression=1.2, trigger_val_mae=300)
+        sgdr.on_train_begin()
+    decay_steps = 0.5 * steps_per_epoch * epochs
+    alpha = hy["min_lr"] / hy["lr"]
+    hist = {k: [] for k in ("loss", "mae", "r2_square", "val_loss", "val_mae", "val_r2_square", "lr")}
+    best, wait, it = float("inf"), 0, 0
+    l2 = 1e-4
+
+    def run_epoch(iterator, training, epoch_lr):
+        nonlocal it
+        sse_t = sabs_t = sy = syy = 0.0
+        n_t = 0
+        loss_sum = 0.0
+        for b in range(len(iterator)):
+            inputs, target = iterator[b]
+            packed = _hip.pack_inputs(inputs)
+            shard, sl = comm.shard(packed)
+            tgt = np.asarray(target, dtype=np.float32)[sl]
+            rb = eng.upload(shard)
+            sse = eng.train_forward(rb, tgt, dropout=dropout if training else 0.0, seed=(it * 7919 + 17) & 0xFFFFFFFF)
+            y, _ = eng.download(rb, want_ga=False)
+            sse_g, cnt_g = comm.sum_pair(sse, shard.n_struct)
+            if training:
+                lr_t = (epoch_lr if sgdr is not None else cosine_decay(it, hy["lr"], decay_steps, alpha)) / (1.0 + 1e-5 * it)
+                eng.zero_grads()
+                eng.train_backward(rb, sse_g, cnt_g)
+                eng.allreduce_grads()
+                eng.adam_step(lr_t, l2=l2)
+                it += 1
+            rb.free()
+            loss_sum += math.sqrt(sse_g / cnt_g) * cnt_g
+            sabs, _ = comm.sum_pair(float(np.abs(y - tgt).sum()), 0)
+            s1, _ = comm.sum_pair(float(tgt.sum()), 0)
+            s2, _ = comm.sum_pair(float((tgt.astype(np.float64) ** 2).sum()), 0)
+            sse_t += sse_g; sabs_t += sabs; sy += s1; syy += s2; n_t += cnt_g
+        ss_tot = syy - sy * sy / max(n_t, 1)
+        return loss_sum / max(n_t, 1), sabs_t / max(n_t, 1), 1.0 - sse_t / (ss_tot + 1e-7)
+
+    for epoch in range(epochs):
+        t0 = time.time()
+        epoch_lr = sgdr.lr_scheduler(epoch) if sgdr is not None else None
+        loss, mae, r2 = run_epoch(train_it, True, epoch_lr)
+        if hasattr(train_it, "on_epoch_end"):
+            train_it.on_epoch_end()
+        vloss, vmae, vr2 = run_epoch(valid_it, False, None)
+        cur_lr = epoch_lr if sgdr is not None else cosine_decay(it, hy["lr"], decay_steps, alpha)
+        for k, v in zip(hist, (loss, mae, r2, vloss, vmae, vr2, cur_lr)):
+            hist[k].append(float(v))
+        if verbose and comm.rank == 0:
+            print("Epoch %d/%d - %.0fs - loss: %.4f - mae: %.4f - r2_square: %.4f - val_loss: %.4f - val_mae: %.4f - "
+                  "val_r2_square: %.4f" % (epoch + 1, epochs, time.time() - t0, loss, mae, r2, vloss, vmae, vr2))
+            if sgdr is None:
+                print("current_lr=", cur_lr)
+        if sgdr is not None:
+            sgdr.on_epoch_end(epoch, {"val_mae": vmae})
+        if vmae < best:  # ModelCheckpoint(monitor="val_mae", save_best_only=True), scann_model.py:166-177
+            best, wait = vmae, 0
+            if comm.rank == 0:
+                model._weights = eng.get_weights()
+                model.save(ckpt)
+        else:
+            wait += 1
+            if wait >= 200:  # EarlyStopping(monitor="val_mae", patience=200), scann_model.py:179
+                break
+    model._weights = eng.get_weights()
+    return hist

@@ -1,5 +1,7 @@
 """GPU tests of the training step: hand-written backward vs torch autograd (fp64, CPU) of the independent torch
 graph (tests/torch_ref.py), Adam + l2 regulariser vs a NumPy restatement of tf.keras Adam, dropout statistics."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,4 +138,69 @@ def test_loss_decreases_and_dropout_is_active(hip_lib):
         eng.adam_step(2e-3 / (1 + 1e-5 * step))
     final = eng.train_forward(rb, t2)
     assert final < 0.25 * s_start, (s_start, final)
+    rb.free()
+
+
+def _write_dataset(tmp_path, n=96, seed=5):
+    """A dataset in the reference's on-disk format (general.py:104-144) with a learnable target (carbon fraction)."""
+    de, dn = so.synth_dataset(n, seed)
+    full = np.empty(n, dtype=object)
+    for i in range(n):
+        Z = de[i][0]
+        full[i] = {"Atomic": Z, "Properties": {"homo": float(np.mean(np.asarray(Z) == 6) * 5.0 - 2.0)}}
+    np.save(tmp_path / "data_energy.npy", full, allow_pickle=True)
+    np.save(tmp_path / "data_nei.npy", dn, allow_pickle=True)
+    return str(tmp_path / "data_energy.npy"), str(tmp_path / "data_nei.npy")
+
+
+def test_scann_train_evaluate_roundtrip(hip_lib, tmp_path):
+    """SCANN.prepare_dataset -> train -> evaluate like train.py does: checkpoint, config.yaml, report.txt, hist_data.npy;
+    then infer mode from the checkpoint (predict_model.py path) reproduces the evaluation predictions."""
+    import yaml
+    from scann.models import SCANN
+
+    e_path, n_path = _write_dataset(tmp_path)
+    cfg = so.default_config("qm9")
+    cfg["model"]["n_attention"] = 2
+    cfg["hyper"].update(batch_size=16, test_percent=0.125, scaler=True, scheduler="cosine", train_size="", test_size="",
+                        data_size=96, data_nei_path=n_path, data_energy_path=e_path, lr=2e-3, min_lr=2e-4,
+                        save_path=str(tmp_path / "run"), pretrained="", use_ref=False, target="homo")
+    np.random.seed(0)
+    scann = SCANN(cfg, "")
+    scann.prepare_dataset()
+    scann.train(epochs=12)
+    h = scann.hist.history
+    assert len(h["val_mae"]) == 12 and h["mae"][-1] < 0.6 * h["mae"][0], h["mae"]
+    mae, r2 = scann.evaluate()  # reloads the best checkpoint, like the reference after training
+    out = str(tmp_path / "run_homo")
+    assert os.path.exists(out + "/models/model_homo.h5") and os.path.exists(out + "/config.yaml")
+    rep = open(out + "/report.txt").read()
+    assert "Training MAE" in rep and "Test MAE" in rep and os.path.exists(out + "/hist_data.npy")
+    saved = yaml.safe_load(open(out + "/config.yaml"))
+    assert "target_mean" in saved["hyper"] and saved["hyper"]["data_size"] == 96
+    infer = SCANN(saved, out + "/models/model_homo.h5", mode="infer")
+    inputs, tgt = scann.testIter[0]
+    y, ga = infer.predict_data(inputs)
+    assert y.shape == (len(tgt), 1) and ga.shape[:2] == inputs["atomic"].shape
+    assert abs(np.mean(np.abs((y[:, 0] - infer.mean) / infer.std - tgt)) * infer.std - mae) < 0.5 * mae + 1e-3
+
+
+def test_rccl_single_rank_communicator(hip_lib):
+    """world_size 1 RCCL communicator: the all-reduce entry points run and leave the gradients unchanged."""
+    from scann import _hip
+
+    cfg, w, pk, targets, model = setup(n=4)
+    eng = model.engine
+    eng.train_begin()
+    eng.comm_init(_hip.comm_unique_id(), 0, 1)
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    s2, c2 = eng.allreduce_sse(sse, pk.n_struct)
+    assert (s2, c2) == (sse, pk.n_struct)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    g1 = eng.get_grads()
+    eng.allreduce_grads()
+    g2 = eng.get_grads()
+    assert all(np.array_equal(g1[k], g2[k]) for k in g1)
     rb.free()

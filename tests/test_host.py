@@ -207,3 +207,79 @@ def test_concat_packed_equals_packing_the_union():
     cat = _hip.concat_packed(parts)
     for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
         assert np.array_equal(getattr(cat, f), getattr(whole, f)), f
+
+
+_DP_WORKER = r'''
+import os, sys, numpy as np
+sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import torch, torch.distributed as dist
+import scann_oracle as so
+from scann import _hip
+from scann.models.trainer import _slice_packed
+from scann.parallel import rank_slice
+import torch_ref
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = so.default_config("qm9"); cfg["model"]["n_attention"] = 1
+w = so.init_weights(cfg, 5, perturb=True)
+de, dn = so.synth_dataset(7, 12)
+inputs, targets = so.pad_batch(de, dn, True)
+pk = _hip.pack_inputs(inputs)
+lo, hi = rank_slice(pk.n_struct, rank, world)
+shard, t = _slice_packed(pk, lo, hi), targets[lo:hi]
+# what scann_train_forward / scann_allreduce_sse / scann_train_backward / scann_allreduce_grads do, on the CPU stand-in:
+W = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+y, _ = torch_ref.forward_packed(cfg, W, shard, "float64", as_tensor=True)
+tt = torch.tensor(t, dtype=torch.float64).reshape(-1, 1)
+pair = torch.tensor([float(((y - tt) ** 2).sum()), float(len(t))], dtype=torch.float64)
+dist.all_reduce(pair)                                  # exchange 1: scalar SSE / count
+rmse = (pair[0] / pair[1]).sqrt()
+dy = (y.detach() - tt) / (pair[1] * rmse)              # d rmse_global / d y_i
+y.backward(dy)
+flat = torch.cat([W[k].grad.reshape(-1) for k in sorted(W)])
+dist.all_reduce(flat)                                  # exchange 2: one flat gradient all-reduce
+if rank == 0:
+    _, rm, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED): ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+    want = np.concatenate([ref[k].reshape(-1) for k in sorted(ref)])
+    assert abs(float(rmse) - rm) < 1e-12
+    assert np.allclose(flat.numpy(), want, rtol=1e-9, atol=1e-12)
+    print("DP_TRAIN_OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_training_semantics_over_gloo(tmp_path):
+    """The loss is sqrt(mean over the GLOBAL batch) (losses.py:5-6), not a mean of shard losses: with the scalar SSE
+    exchanged first, the sum of the shard gradients equals the single-process gradient."""
+    pytest.importorskip("torch")
+    script = tmp_path / "dp_worker.py"
+    script.write_text("ROOT = %r\n" % ROOT + _DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "DP_TRAIN_OK" in outs[0]
+
+
+def test_learning_rate_schedules():
+    from scann.models.trainer import SGDRC, cosine_decay
+
+    # CosineDecay(lr, decay_steps, alpha): lr at 0, alpha*lr from decay_steps on (scann_model.py:203-208)
+    assert cosine_decay(0, 5e-4, 1000, 0.2) == pytest.approx(5e-4)
+    assert cosine_decay(500, 5e-4, 1000, 0.2) == pytest.approx(5e-4 * (0.8 * 0.5 + 0.2))
+    assert cosine_decay(5000, 5e-4, 1000, 0.2) == pytest.approx(1e-4)
+    s = SGDRC(lr_min=1e-4, lr_max=5e-4, t0=4, tmult=2, lr_max_compression=1.2, trigger_val_mae=1.0, show_lr=False)
+    s.on_train_begin()
+    assert s.lr_scheduler(0) == 5e-4
+    s.on_epoch_end(0, {"val_mae": 2.0})
+    assert not s.triggered and s.lr_scheduler(1) == 5e-4      # flat until val_mae <= trigger
+    s.on_epoch_end(1, {"val_mae": 0.9})
+    assert s.triggered
+    lrs = [s.lr_scheduler(e) for e in range(2, 6)]            # tcur 2,3,4 of the 4-epoch cycle, then restart
+    assert lrs[0] == pytest.approx(1e-4 + 4e-4 * (1 + np.cos(2 / 4 * np.pi)) / 2)
+    assert lrs[2] == pytest.approx(1e-4)                      # end of the cycle: lr_min
+    assert s.ti == 8 and s.tcur == 1                          # warm restart with a doubled period
+    assert lrs[3] <= 5e-4 and lrs[3] > lrs[2]
