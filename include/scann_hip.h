@@ -115,6 +115,15 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
  * y_out[n_struct]; ga_attn_out[n_atom] (packed GlobalAttention scores, attention.py:302) or NULL. */
 int scann_forward(scann_handle_t* h, const scann_batch_t* batch, float* y_out, float* ga_attn_out);
 
+/* The same on the PADDED Keras input dict itself (scann_model.py:338-357; DataIterator.__getitem__,
+ * datagenerator.py:123-133): atomic[B,M] int32, atom_mask[B,M] bytes (bool), neighbors[B,M,N] int32,
+ * neighbor_mask[B,M,N] bytes, neighbor_weight / neighbor_distance [B,M,N] float.  Packing to CSR (what gather_shape +
+ * the masks express, custom_layers.py:18-28) is done natively; ga_out[B*M] (or NULL) receives the GlobalAttention scores
+ * re-padded with exact zeros for padded atoms.  feature="atomic" without ring features only. */
+int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, const int32_t* atomic,
+                         const uint8_t* atom_mask, const int32_t* neighbors, const uint8_t* neighbor_mask,
+                         const float* neighbor_weight, const float* neighbor_distance, float* y_out, float* ga_out);
+
 /* Resident-batch path (inputs already in HBM; used for pipelined inference and by bench.py). */
 int scann_batch_upload(scann_handle_t* h, const scann_batch_t* batch, scann_dbatch_t** out);
 void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);

@@ -65,6 +65,12 @@ struct scann_handle {
   float train_drop_p = 0.f;            // > 0 only inside scann_train_forward
   unsigned long long train_seed = 0;
   ncclComm_t comm = nullptr;
+  // reusable scratch of the synchronous scann_forward path (grow-only device arena + pinned host staging)
+  char* sc_arena = nullptr;
+  size_t sc_cap = 0;
+  char* sc_host = nullptr;
+  size_t sc_host_cap = 0;
+  struct scann_dbatch* sc_db = nullptr;
   int comm_world = 1;
 };
 
@@ -83,6 +89,7 @@ struct scann_dbatch {
   unsigned long long* stamps = nullptr;  // diagnostic build only
   int dbg_layers = -1;
   int last_slot = 0;
+  bool owns_arena = true;  // false: the arena belongs to the handle's scratch (scann_forward)
 };
 
 namespace {
@@ -248,6 +255,14 @@ void scann_destroy(scann_handle_t* h) {
   for (void* q : {(void*)h->t_master, (void*)h->t_grad, (void*)h->t_m, (void*)h->t_v, (void*)h->t_l2, (void*)h->t_descs})
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
+  if (h->sc_db) {
+    if (h->sc_db->dbg_c) (void)hipFree(h->sc_db->dbg_c);
+    if (h->sc_db->dbg_g) (void)hipFree(h->sc_db->dbg_g);
+    if (h->sc_db->dbg_ctx) (void)hipFree(h->sc_db->dbg_ctx);
+    delete h->sc_db;
+  }
+  if (h->sc_arena) (void)hipFree(h->sc_arena);
+  if (h->sc_host) (void)hipHostFree(h->sc_host);
   delete h;
 }
 
@@ -464,7 +479,7 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   if (!db) return;
   if (h) (void)hipSetDevice(h->device);
   if (h) (void)hipDeviceSynchronize();
-  if (db->arena) (void)hipFree(db->arena);
+  if (db->arena && db->owns_arena) (void)hipFree(db->arena);
   if (db->dbg_c) (void)hipFree(db->dbg_c);
   if (db->dbg_g) (void)hipFree(db->dbg_g);
   if (db->dbg_ctx) (void)hipFree(db->dbg_ctx);
@@ -473,7 +488,7 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   delete db;
 }
 
-int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t** out) {
+static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t** out, bool scratch) {
   if (!h || !b || !out) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: null argument");
   *out = nullptr;
   const int32_t B = b->n_struct, A = b->n_atom, E = b->n_edge;
@@ -531,7 +546,21 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (tile_rows == want) break;  // no atom overflowed the requested tile size
   }
   HIPCHK(h, hipSetDevice(h->device));
-  scann_dbatch* db = new scann_dbatch();
+  scann_dbatch* db = nullptr;
+  if (scratch) {
+    if (!h->sc_db) h->sc_db = new scann_dbatch();
+    db = h->sc_db;
+    if (db->dbg_c || db->stamps) (void)hipStreamSynchronize(h->streams[0]);
+    if (db->dbg_c) (void)hipFree(db->dbg_c);
+    if (db->dbg_g) (void)hipFree(db->dbg_g);
+    if (db->dbg_ctx) (void)hipFree(db->dbg_ctx);
+    if (db->stamps) (void)hipFree(db->stamps);
+    free_train_ws(db);
+    *db = scann_dbatch();
+    db->owns_arena = false;
+  } else {
+    db = new scann_dbatch();
+  }
   db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows;
   // arena layout: inputs first (one H2D copy), then workspace
   size_t off = 0;
@@ -546,12 +575,34 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
-  hipError_t e = hipMalloc((void**)&db->arena, off);
+  hipError_t e = hipSuccess;
+  std::vector<char> img_vec;
+  char* img_ptr = nullptr;
+  if (scratch) {
+    if (off > h->sc_cap) {  // grow-only (dynamic M, N: SURVEY 8b "workspace sized on first call and grown monotonically")
+      if (h->sc_arena) { (void)hipStreamSynchronize(h->streams[0]); (void)hipFree(h->sc_arena); h->sc_arena = nullptr; h->sc_cap = 0; }
+      const size_t want = off + off / 2;
+      e = hipMalloc((void**)&h->sc_arena, want);
+      if (e == hipSuccess) h->sc_cap = want;
+    }
+    if (e == hipSuccess && in_bytes > h->sc_host_cap) {
+      if (h->sc_host) { (void)hipStreamSynchronize(h->streams[0]); (void)hipHostFree(h->sc_host); h->sc_host = nullptr; h->sc_host_cap = 0; }
+      const size_t want = in_bytes + in_bytes / 2;
+      e = hipHostMalloc((void**)&h->sc_host, want, hipHostMallocDefault);
+      if (e == hipSuccess) h->sc_host_cap = want;
+    }
+    db->arena = h->sc_arena;
+    img_ptr = h->sc_host;
+  } else {
+    e = hipMalloc((void**)&db->arena, off);
+    img_vec.assign(in_bytes, 0);
+    img_ptr = img_vec.data();
+  }
   if (e != hipSuccess) {
-    delete db;
+    if (!scratch) delete db;
     return fail(h, e == hipErrorOutOfMemory ? SCANN_ERR_OOM : SCANN_ERR_HIP, std::string("hipMalloc(batch arena): ") + hipGetErrorString(e));
   }
-  std::vector<char> img(in_bytes, 0);
+  struct ImgView { char* p; char* data() const { return p; } } img{img_ptr};
   if (b->atomic) memcpy(img.data() + o_atomic, b->atomic, (size_t)A * 4);
   if (h->cfg.use_ring) memcpy(img.data() + o_ring, b->ring, (size_t)A * 2 * 4);
   if (h->cfg.feature_cgcnn) memcpy(img.data() + o_cg, b->cgcnn, (size_t)A * 92 * 4);
@@ -564,10 +615,16 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     memcpy(img.data() + o_wgt, b->edge_weight, (size_t)E * 4);
   }
   memcpy(img.data() + o_tiles, tiles.data(), tiles.size() * sizeof(EdgeTile));
-  e = hipMemcpy(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice);
+  if (scratch) {  // pinned staging, ordered before the kernels on stream 0
+    e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->streams[0]);
+  } else {
+    e = hipMemcpy(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
-    (void)hipFree(db->arena);
-    delete db;
+    if (!scratch) {
+      (void)hipFree(db->arena);
+      delete db;
+    }
     return fail(h, SCANN_ERR_HIP, std::string("hipMemcpy(batch inputs): ") + hipGetErrorString(e));
   }
   char* a0 = db->arena;
@@ -582,6 +639,8 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   *out = db;
   return SCANN_OK;
 }
+
+int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t** out) { return upload_impl(h, b, out, false); }
 
 }  // extern "C"
 
@@ -732,15 +791,60 @@ int scann_sync(scann_handle_t* h) {
 }
 
 int scann_forward(scann_handle_t* h, const scann_batch_t* batch, float* y_out, float* ga_attn_out) {
+  // synchronous convenience path: the batch lives in the handle's reusable scratch (no hipMalloc per call)
   scann_dbatch_t* db = nullptr;
-  int r = scann_batch_upload(h, batch, &db);
+  int r = upload_impl(h, batch, &db, true);
   if (r) return r;
   r = scann_forward_resident(h, db, 0);
   if (!r) r = scann_batch_download(h, db, y_out, ga_attn_out);
-  const std::string keep = h->err;
-  scann_batch_free(h, db);
-  if (r) h->err = keep;
   return r;
+}
+
+int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, const int32_t* atomic, const uint8_t* atom_mask,
+                         const int32_t* neighbors, const uint8_t* neighbor_mask, const float* neighbor_weight,
+                         const float* neighbor_distance, float* y_out, float* ga_out) {
+  if (!h || B <= 0 || M <= 0 || N < 0 || !atomic || !atom_mask || !y_out || (N > 0 && (!neighbors || !neighbor_mask || !neighbor_weight || !neighbor_distance)))
+    return fail(h, SCANN_ERR_INVALID, "scann_forward_padded: bad argument");
+  if (h->cfg.use_ring || h->cfg.feature_cgcnn) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_forward_padded: atomic feature without ring only");
+  // real atoms (atom_mask) keep their order; gidx = packed row of (b, m)
+  std::vector<int32_t> gidx((size_t)B * M, -1), at, mol(1, 0), eoff(1, 0), col;
+  std::vector<float> dist, wgt;
+  at.reserve((size_t)B * M);
+  for (int b = 0; b < B; ++b) {
+    for (int m = 0; m < M; ++m)
+      if (atom_mask[(size_t)b * M + m]) {
+        gidx[(size_t)b * M + m] = (int32_t)at.size();
+        at.push_back(atomic[(size_t)b * M + m]);
+      }
+    if ((int32_t)at.size() == mol.back()) return fail(h, SCANN_ERR_INVALID, "scann_forward_padded: a structure has no atoms");
+    mol.push_back((int32_t)at.size());
+  }
+  col.reserve((size_t)at.size() * 8);
+  for (int b = 0; b < B; ++b)
+    for (int m = 0; m < M; ++m) {
+      if (!atom_mask[(size_t)b * M + m]) continue;
+      const size_t base = ((size_t)b * M + m) * N;
+      for (int n = 0; n < N; ++n) {
+        if (!neighbor_mask[base + n]) continue;
+        const int32_t t = neighbors[base + n];
+        if (t < 0 || t >= M || gidx[(size_t)b * M + t] < 0)
+          return fail(h, SCANN_ERR_INVALID, "scann_forward_padded: an unmasked neighbour slot points at a padded atom");
+        col.push_back(gidx[(size_t)b * M + t]);
+        dist.push_back(neighbor_distance[base + n]);
+        wgt.push_back(neighbor_weight[base + n]);
+      }
+      eoff.push_back((int32_t)col.size());
+    }
+  scann_batch_t pb{};
+  pb.n_struct = B; pb.n_atom = (int32_t)at.size(); pb.n_edge = (int32_t)col.size();
+  pb.atomic = at.data(); pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
+  pb.edge_col = col.data(); pb.edge_dist = dist.data(); pb.edge_weight = wgt.data();
+  std::vector<float> ga_packed(ga_out ? at.size() : 0);
+  const int r = scann_forward(h, &pb, y_out, ga_out ? ga_packed.data() : nullptr);
+  if (r) return r;
+  if (ga_out)
+    for (size_t i = 0; i < (size_t)B * M; ++i) ga_out[i] = gidx[i] >= 0 ? ga_packed[gidx[i]] : 0.f;  // softmax of -1e9 -> 0
+  return SCANN_OK;
 }
 
 int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t* prof) {

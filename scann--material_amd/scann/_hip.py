@@ -62,6 +62,7 @@ SYMBOLS = [
     ("scann_weight_name", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("scann_load_weights", C.c_int, [_P, _P, C.POINTER(TensorDesc), C.c_int]),
     ("scann_forward", C.c_int, [_P, C.POINTER(Batch), _P, _P]),
+    ("scann_forward_padded", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("scann_batch_upload", C.c_int, [_P, C.POINTER(Batch), C.POINTER(_P)]),
     ("scann_batch_free", None, [_P, _P]),
     ("scann_forward_resident", C.c_int, [_P, _P, C.c_int]),
@@ -301,6 +302,24 @@ class Engine:
         ga = np.empty(packed.n_atom, dtype=np.float32) if want_ga else None
         st = packed.as_struct()
         self._check(self.lib.scann_forward(self._h, C.byref(st), _ptr(y), _ptr(ga)))
+        return y, ga
+
+    def forward_padded(self, inputs, want_ga=True):
+        """The padded Keras dict straight through the C ABI (native CSR packing)."""
+        atomic = np.ascontiguousarray(inputs["atomic"], dtype=np.int32)
+        B, M = atomic.shape
+        amask = np.ascontiguousarray(np.asarray(inputs["atom_mask"]).reshape(B, M), dtype=np.uint8)
+        nbr = np.ascontiguousarray(inputs["neighbors"], dtype=np.int32)
+        N = nbr.shape[2]
+        nmask = np.ascontiguousarray(inputs["neighbor_mask"], dtype=np.uint8)
+        wgt = np.ascontiguousarray(inputs["neighbor_weight"], dtype=np.float32)
+        dst = np.ascontiguousarray(inputs["neighbor_distance"], dtype=np.float32)
+        if nbr.shape != (B, M, N) or nmask.shape != nbr.shape or wgt.shape != nbr.shape or dst.shape != nbr.shape:
+            raise ValueError("inconsistent input shapes")
+        y = np.empty(B, dtype=np.float32)
+        ga = np.empty((B, M, 1), dtype=np.float32) if want_ga else None
+        self._check(self.lib.scann_forward_padded(self._h, B, M, N, _ptr(atomic), _ptr(amask), _ptr(nbr), _ptr(nmask),
+                                                  _ptr(wgt), _ptr(dst), _ptr(y), _ptr(ga)))
         return y, ga
 
     def upload(self, packed):

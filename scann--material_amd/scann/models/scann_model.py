@@ -110,6 +110,10 @@ class HipModel:
     def predict(self, inputs, batch_size=None, verbose=0, **_):
         """``model.predict(inputs)`` (scann_model.py:266,316): ``[B,1]`` or, in infer mode,
         ``[[B,1], [B,M,1]]``."""
+        m = self.config["model"]
+        if not isinstance(inputs, _hip.PackedBatch) and m["feature"] == "atomic" and not m["use_ring"]:
+            y, ga = self.engine.forward_padded(inputs, want_ga=self.infer)  # native CSR packing
+            return [y.reshape(-1, 1), ga] if self.infer else y.reshape(-1, 1)
         packed = inputs if isinstance(inputs, _hip.PackedBatch) else _hip.pack_inputs(inputs)
         y, ga = self.engine.forward(packed, want_ga=self.infer)
         y = y.reshape(-1, 1)
@@ -118,6 +122,39 @@ class HipModel:
         return y
 
     __call__ = predict
+
+    def predict_dataset(self, dataset, group=4, want_ga=False):
+        """Pipelined inference over a whole ``PackedDataset`` (or any sequence of ``(PackedBatch | inputs dict, target)``):
+        batches are fused ``group`` at a time into one launch sequence, spread over the handle's streams, and fetched at
+        the end -- the throughput path behind ``SCANN.evaluate`` / ``predict_model.py``.  Returns ``(y [N], ga list | None,
+        targets [N])`` in dataset order."""
+        eng = self.engine
+        ns = eng.num_streams()
+        pending, ys, gas, ts = [], [], [], []
+
+        def drain():
+            for rb, sizes in pending:
+                y, ga = eng.download(rb, want_ga=want_ga)
+                ys.append(y)
+                if want_ga:
+                    gas.append(ga)
+                rb.free()
+            pending.clear()
+
+        n = len(dataset)
+        for g0 in range(0, n, group):
+            parts = []
+            for i in range(g0, min(n, g0 + group)):
+                item, tgt = dataset[i]
+                parts.append(item if isinstance(item, _hip.PackedBatch) else _hip.pack_inputs(item))
+                ts.append(np.asarray(tgt, dtype=np.float32))
+            rb = eng.upload(_hip.concat_packed(parts) if len(parts) > 1 else parts[0])
+            eng.forward_resident(rb, len(pending))
+            pending.append((rb, [p.n_struct for p in parts]))
+            if len(pending) >= ns:
+                drain()
+        drain()
+        return np.concatenate(ys), (np.concatenate(gas) if want_ga else None), np.concatenate(ts)
 
     def summary(self):
         print("SCANN HIP model: %d parameters, %d local-attention layers, g_update=%s" % (
@@ -185,9 +222,16 @@ class SCANN:
     def load_model(cls, path):
         return create_model_pretrained(path)
 
-    def prepare_dataset(self, split=True):
+    def prepare_dataset(self, split=True, packed=False):
+        """Reference behaviour (scann_model.py:98-161).  ``packed=True`` (extension) builds ``PackedDataset`` iterators:
+        the object arrays are converted once to flat CSR and batches become slices; they yield
+        ``(PackedBatch, target)`` instead of ``(inputs dict, target)``."""
         from ..utils.datagenerator import DataIterator
         from ..utils.general import load_dataset, split_data
+        from ..utils.packed_dataset import PackedDataset
+
+        if packed:
+            DataIterator = PackedDataset  # noqa: F811  (same constructor signature)
 
         hy, mo = self.config["hyper"], self.config["model"]
         data_energy, data_neighbor = load_dataset(
@@ -247,16 +291,8 @@ class SCANN:
             t = self.config["hyper"]["target"]
             self.model = load_model("{}/models/model_{}.h5".format(self._out_dir(), t))
         data = self.dataIter if hasattr(self, "dataIter") else self.testIter
-        y_predict, y = [], []
-        for i in range(len(data)):
-            inputs, target = data.__getitem__(i)
-            output = self.model.predict(inputs)
-            if isinstance(output, list):
-                output = output[0]
-            y.extend(list(target))
-            y_predict.extend(list(np.squeeze(output, -1)))
-            if i % 10 == 0:
-                print(f"{i}/{len(data)}")
+        yp, _, yt = self.model.predict_dataset(data)  # same per-batch results as the reference's predict loop (:264-271)
+        y_predict, y = list(yp), list(yt)
         mae = mean_absolute_error(y, y_predict) * self.std
         r2 = r2_score(y, y_predict)
         print("Result for testset ", self.config["hyper"]["target"], " : R2 score: ", r2, " and MAE: ", mae)

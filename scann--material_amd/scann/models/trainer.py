@@ -140,7 +140,7 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
         loss_sum = 0.0
         for b in range(len(iterator)):
             inputs, target = iterator[b]
-            packed = _hip.pack_inputs(inputs)
+            packed = inputs if isinstance(inputs, _hip.PackedBatch) else _hip.pack_inputs(inputs)
             shard, sl = comm.shard(packed)
             tgt = np.asarray(target, dtype=np.float32)[sl]
             rb = eng.upload(shard)

@@ -298,3 +298,18 @@ def test_full_size_properties(hip_lib):
     assert rel_err(outs[5][1], ga_ref[..., 0][inputs["atom_mask"][..., 0]]) <= RTOL
     for rb in rbs:
         rb.free()
+
+
+def test_predict_dataset_pipeline_equals_per_batch_predict(hip_lib):
+    """The pipelined / grouped dataset path (SCANN.evaluate, predict_model.py) returns the bytes of per-batch predict."""
+    from scann.utils import DataIterator, PackedDataset
+
+    cfg, w, _, model = make(n=2)
+    de, dn = so.synth_dataset(70, 41)
+    it = DataIterator(de, dn, batch_size=8, g_update=True)
+    pd_ = PackedDataset(de, dn, batch_size=8, g_update=True)
+    ref_y = np.concatenate([model.predict(it[i][0])[0][:, 0] for i in range(len(it))])
+    for data in (it, pd_):
+        for group in (1, 3):
+            y, ga, t = model.predict_dataset(data, group=group, want_ga=True)
+            assert np.array_equal(y, ref_y) and len(t) == 70 and ga.shape[0] == sum(len(e[0]) for e in de)

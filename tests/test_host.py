@@ -283,3 +283,24 @@ def test_learning_rate_schedules():
     assert lrs[2] == pytest.approx(1e-4)                      # end of the cycle: lr_min
     assert s.ti == 8 and s.tcur == 1                          # warm restart with a doubled period
     assert lrs[3] <= 5e-4 and lrs[3] > lrs[2]
+
+
+def test_packed_dataset_matches_data_iterator():
+    """One-time CSR conversion + slicing gives exactly what pack_inputs(DataIterator[i]) gives (f-1)."""
+    from scann import _hip
+    from scann.utils import DataIterator, PackedDataset
+
+    de, dn = so.synth_dataset(23, 17)
+    for g_update in (True, False):
+        np.random.seed(3)
+        it = DataIterator(de, dn, batch_size=5, g_update=g_update, shuffle=True)
+        np.random.seed(3)
+        pd_ = PackedDataset(de, dn, batch_size=5, g_update=g_update, shuffle=True)
+        assert len(it) == len(pd_) == 5
+        for i in range(len(it)):
+            inputs, t = it[i]
+            ref = _hip.pack_inputs(inputs)
+            pk, t2 = pd_[i]
+            assert np.array_equal(t, t2)
+            for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+                assert np.array_equal(getattr(pk, f), getattr(ref, f)), (f, i)
