@@ -1148,9 +1148,9 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
     float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
     launch_ln_bwd(eT, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
-    HIPCHK(h, hipMemsetAsync(dP1, 0, nA * 4, s));
     HIPCHK(h, hipMemsetAsync(dP3, 0, nA * 4, s));
-    launch_edge_dv(eV, dGnext, db->edge_row, db->edge_col, eU, dP1, dP3, E, s);  // dV (in eU), dP1[i] += dV, dP3[j] += dV
+    launch_edge_dv(eV, dGnext, db->edge_row, db->edge_col, eU, dP1, dP3, E, s);  // dV (in eU), dP3[j] += dV (atomics)
+    launch_segment_sum(eU, db->edge_offset, dP1, A, s);                           // dP1[i] = sum over the atom's edges
     float* fgk = g(la + "filter_geo/kernel");
     launch_wgrad(Gin, eU, fgk + (size_t)D * D, nullptr, E, s);                   // dW2
     launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                // dG += dV.W2^T

@@ -37,6 +37,7 @@ void launch_edge_v(const float* U, const float* P1, const float* P3, const int* 
                    float* T, int n_edge, hipStream_t s);
 void launch_edge_dv(const float* V, const float* dT, const int* ctr, const int* nb, float* dV, float* dP1, float* dP3,
                     int n_edge, hipStream_t s);
+void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s);
 void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
                      float* dK, float* dgamma, float* dbeta, int n_atom, hipStream_t s);
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);

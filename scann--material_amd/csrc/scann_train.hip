@@ -86,18 +86,19 @@ void launch_linear(const float* X, const float* Wp, const float* bias, float* Y,
 // A workgroup reduces a 256-row slab with MFMA (A = X^T read column-wise from LDS) and adds its 128x128 partial with
 // float atomics (order of the adds is not fixed: gradients are reproducible to rounding only).
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                    float* __restrict__ dW, float* __restrict__ db, int rows) {
+                                                    float* __restrict__ dW, float* __restrict__ db, int rows,
+                                                    int chunks) {
   __shared__ __attribute__((aligned(16))) float sX[64 * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sD[64 * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slab0 = blockIdx.x * 256;
+  const int slab0 = blockIdx.x * 64 * chunks;
   f32x16 acc[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
   float bsum = 0.f;  // thread tid < 128 owns column tid of db
-  for (int chunk = 0; chunk < 4; ++chunk) {
+  for (int chunk = 0; chunk < chunks; ++chunk) {
     const int row0 = slab0 + chunk * 64;
     if (row0 >= rows) break;
     const int nrows = min(64, rows - row0);
@@ -138,7 +139,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
 
 void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, X, dY, dW, db, rows);
+  // slab per workgroup: enough workgroups to fill the chip, few enough that the 64 KB of float atomics per workgroup
+  // (chip-wide ~1.3 TB/s of added bytes) stays below the MFMA time
+  const int chunks = rows >= 8192 ? 2 : 1;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((rows + 64 * chunks - 1) / (64 * chunks)), dim3(256), 0, s, X, dY, dW, db, rows, chunks);
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------
@@ -212,15 +216,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     dg.x += dyv.x * hx; dg.y += dyv.y * hy;
     dbt.x += dyv.x; dbt.y += dyv.y;
   }
-  atomicAdd(&dgamma[2 * lane], dg.x);
-  atomicAdd(&dgamma[2 * lane + 1], dg.y);
-  atomicAdd(&dbeta[2 * lane], dbt.x);
-  atomicAdd(&dbeta[2 * lane + 1], dbt.y);
+  // one set of atomics per workgroup (all workgroups hit the same 256 addresses)
+  __shared__ float sred[4][4 * 64];
+  sred[wave][lane] = dg.x; sred[wave][64 + lane] = dg.y; sred[wave][128 + lane] = dbt.x; sred[wave][192 + lane] = dbt.y;
+  __syncthreads();
+  const int t = threadIdx.x;  // 256 threads <-> 256 partial slots
+  const float tot = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+  const int ln = t & 63, which = t >> 6;  // 0: dg.x 1: dg.y 2: db.x 3: db.y
+  float* dst = (which < 2 ? dgamma : dbeta) + 2 * ln + (which & 1);
+  atomicAdd(dst, tot);
 }
 void launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
                    int accumulate, hipStream_t s) {
   if (rows <= 0) return;
-  const int rpw = 8;
+  const int rpw = rows >= 8192 ? 16 : 4;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 4 * rpw - 1) / (4 * rpw)), dim3(256), 0, s, x, gamma, dy, dx, dgamma,
                      dbeta, rows, rpw, accumulate);
 }
@@ -269,7 +278,26 @@ __global__ void edge_v_kernel(const float4* __restrict__ U, const float4* __rest
   V[i] = v;
   T[i] = make_float4(swish_(v.x) + g.x, swish_(v.y) + g.y, swish_(v.z) + g.z, swish_(v.w) + g.w);
 }
-// dV = dT * swish'(V);  dP1[ctr] += dV ; dP3[nb] += dV (atomics)
+// dP1[a] = sum over the CSR row of atom a of dV (the centre-indexed sum needs no atomics)
+__global__ void segment_sum_kernel(const float4* __restrict__ dV, const int* __restrict__ edge_offset, float4* __restrict__ out,
+                                   int n_atom) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_atom * 32) return;
+  const int a = (int)(i >> 5), c4 = (int)(i & 31);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = edge_offset[a]; e < edge_offset[a + 1]; ++e) {
+    const float4 v = dV[(size_t)e * 32 + c4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  out[i] = s;
+}
+void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s) {
+  if (n_atom > 0)
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)(((size_t)n_atom * 32 + 255) / 256)), dim3(256), 0, s,
+                       (const float4*)dV, edge_offset, (float4*)out, n_atom);
+}
+
+// dV = dT * swish'(V);  dP3[nb] += dV (atomics: neighbour-indexed)
 __global__ void edge_dv_kernel(const float4* __restrict__ V, const float4* __restrict__ dT, const int* __restrict__ ctr,
                                const int* __restrict__ nb, float4* __restrict__ dV, float* __restrict__ dP1,
                                float* __restrict__ dP3, int n_edge) {
@@ -279,9 +307,7 @@ __global__ void edge_dv_kernel(const float4* __restrict__ V, const float4* __res
   const float4 v = V[i], t = dT[i];
   const float4 d = make_float4(t.x * dswish_(v.x), t.y * dswish_(v.y), t.z * dswish_(v.z), t.w * dswish_(v.w));
   dV[i] = d;
-  float* p1 = dP1 + (size_t)ctr[e] * D + 4 * c4;
   float* p3 = dP3 + (size_t)nb[e] * D + 4 * c4;
-  atomicAdd(p1 + 0, d.x); atomicAdd(p1 + 1, d.y); atomicAdd(p1 + 2, d.z); atomicAdd(p1 + 3, d.w);
   atomicAdd(p3 + 0, d.x); atomicAdd(p3 + 1, d.y); atomicAdd(p3 + 2, d.z); atomicAdd(p3 + 3, d.w);
 }
 #define EDGE_GRID(n_edge) dim3((unsigned)(((size_t)(n_edge) * 32 + 255) / 256)), dim3(256)
