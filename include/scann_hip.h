@@ -135,6 +135,12 @@ int scann_num_streams(const scann_handle_t* h);
 /* Timed forward of a resident batch: HIP events around every kernel on its stream. */
 int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t* prof);
 
+/* Live kernel timing inside a pipelined run: while enabled, every `every`-th forward brackets each of its edge-kernel
+ * launches with HIP events on the launch stream.  scann_edge_timing_read (after scann_sync) returns the average launch
+ * duration in microseconds and the number of launches sampled, and clears the samples. */
+int scann_edge_timing(scann_handle_t* h, int every);
+int scann_edge_timing_read(scann_handle_t* h, double* avg_us, int64_t* n_launches, double* avg_edges);
+
 /* Test hook: copy an intermediate of the last forward of `db` to host.
  * what: 0 = centers after layer `layer` (0 = after dense_embed) [n_atom,128];
  *       1 = geometry features after layer `layer` [n_edge,128];

@@ -560,6 +560,228 @@ __global__ __launch_bounds__(256, RT == 1 ? EDGE_OCC32 : 2) void edge_kernel(Edg
   STAMP(a.stamps, 7);
 }
 
+// ---- 8-wave edge kernel: same 64-row tile, one 32x32 MFMA tile per wave ----------------------------------------
+//
+// Occupancy variant of edge_kernel<true, 2>: 512 threads, wave (rt, cb) = (wave >> 2, wave & 3) owns rows [32 rt, 32 rt+32)
+// x columns [32 cb, 32 cb+32).  Every VALU/LDS phase has twice the threads per tile (8 threads per edge row, one head per
+// thread in the logits, 16 atom groups), and the weight slab is streamed in two halves so the kernel fits 128 VGPRs:
+// 4 waves per SIMD, two workgroups per CU.
+__device__ __forceinline__ void load_w_half(const float* __restrict__ Wp, int cb, int lane, int half, float4 (&w)[8]) {
+  const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + cb * (16 * 64) + half * (8 * 64) + lane;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) w[t] = wsrc[t * 64];
+}
+__device__ __forceinline__ void mma_half(const float* __restrict__ sXrt, const float4 (&w)[8], int lane, int half, f32x16& acc) {
+  const float* xrow = sXrt + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5) + 64 * half;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * t);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
+  constexpr int TEK = 64;
+  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sB[TEK * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
+  __shared__ __attribute__((aligned(16))) float sPar[4 * D];
+  __shared__ int sCol[TEK], sCtr[TEK], sOff[TA + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rt = wave >> 2, cb = wave & 3;
+  const EdgeTile tile = a.tiles[blockIdx.x];
+  const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
+  const int col = 32 * cb + (lane & 31);
+  float* const sQ = sA;
+
+  float4 w[8];
+  load_w_half(a.p.W2p, cb, lane, 0, w);
+  if (tid < TEK) {
+    sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
+    sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
+  } else if (tid - TEK <= natom) {
+    sOff[tid - TEK] = a.edge_offset[tile.atom_begin + (tid - TEK)] - eb;
+  }
+  {
+    const float* src = tid < D ? a.p.lng_g : tid < 2 * D ? a.p.lng_b : tid < 3 * D ? a.p.ln_g : a.p.ln_b;
+    sPar[tid] = src[tid & (D - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 512 * i, r = idx >> 5, c4 = idx & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < ne) v = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
+    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = v;
+  }
+  __syncthreads();
+  // U = G . W2
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 0, acc);
+  load_w_half(a.p.W2p, cb, lane, 1, w);
+  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 1, acc);
+  load_w_half(a.p.Wkp, cb, lane, 0, w);  // first half of the key weights arrives during the row pass
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[i];
+  __syncthreads();
+
+  // row pass, 8 threads per edge row (attention.py:141-157)
+  {
+    const int r = tid >> 3, sub = tid & 7;
+    if (r < ne) {
+      const int ctr = sCtr[r], nb = sCol[r];
+      const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
+      const float4* p1 = reinterpret_cast<const float4*>(a.P1) + (size_t)ctr * 32;
+      const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
+      float4 t[4];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = sub + 8 * i;
+        const float4 u = *reinterpret_cast<const float4*>(&sB[r * LDS_STRIDE + 4 * c4]);
+        const float4 g = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
+        const float4 v = f4add(f4add(p1[c4], u), p3[c4]);
+        t[i] = f4add(f4swish(v), g);
+        s += f4sum(t[i]);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * (1.0f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = sub + 8 * i;
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
+        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
+        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
+        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
+        reinterpret_cast<float4*>(a.geom)[(size_t)(eb + r) * 32 + c4] = y;
+        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(crow[c4], y);
+      }
+    }
+  }
+  float4 qreg[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 512 * i, la = idx >> 5, c4 = idx & 31;
+    qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (la < natom) qreg[i] = reinterpret_cast<const float4*>(a.q)[(size_t)(tile.atom_begin + la) * 32 + c4];
+  }
+  __syncthreads();
+  // K = ang . Wk + bk
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 0, acc);
+  load_w_half(a.p.Wkp, cb, lane, 1, w);
+  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 1, acc);
+  {
+    const float b = a.p.bk[col];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[i] + b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 512 * i, la = idx >> 5, c4 = idx & 31;
+    *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
+  }
+  __syncthreads();
+  // logits: thread = (edge row, head)
+  {
+    const int n = tid >> 3, hh = tid & 7;
+    if (n < ne) {
+      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + HDIM * hh;
+      const float* krow = sB + n * LDS_STRIDE + HDIM * hh;
+      float e = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
+        e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
+      }
+      sE[n * NHEAD + hh] = e;
+    }
+  }
+  __syncthreads();
+  // softmax + context + residual: thread = (atom group of 16, float4 chunk)
+  {
+    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
+    for (int la = lgp; la < natom; la += 16) {
+      const int e0 = sOff[la], e1 = sOff[la + 1];
+      float m = -INFINITY;
+      for (int n = e0; n < e1; ++n) m = fmaxf(m, sE[n * NHEAD + h]);
+      float ssum = 0.f;
+      for (int n = e0; n < e1; ++n) ssum += fast_exp(sE[n * NHEAD + h] - m);
+      const float rs = __builtin_amdgcn_rcpf(ssum);
+      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int n = e0; n < e1; ++n) {
+        const float attn = fast_exp(sE[n * NHEAD + h] - m) * rs;
+        const float4 k4 = *reinterpret_cast<const float4*>(&sB[n * LDS_STRIDE + 4 * c4]);
+        cx.x += attn * k4.x; cx.y += attn * k4.y; cx.z += attn * k4.z; cx.w += attn * k4.w;
+      }
+      float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
+      *qp = f4add(cx, *qp);
+    }
+  }
+  __syncthreads();
+  // LayerNorm of the context rows: 16 threads per atom row
+  {
+    const int r = tid >> 4, sub = tid & 15;
+    if (r < natom) {
+      float4 t[2];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        t[i] = *reinterpret_cast<const float4*>(&sQ[r * LDS_STRIDE + 4 * (sub + 16 * i)]);
+        s += f4sum(t[i]);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+      const float mean = s * (1.0f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c4 = sub + 16 * i;
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
+        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
+        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
+        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
+        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + r) * 32 + c4] = y;
+      }
+    }
+  }
+}
+
 #ifdef SCANN_STAMPS
 #define STAMP_DECL()                                                                                             \
   unsigned long long acc_work[4] = {0, 0, 0, 0}, t_loop0 = 0, t_b = 0;                                           \
@@ -914,6 +1136,10 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.persistent_wgs > 0 && a.g_update && a.tile_rows == 64) {
     const int nwg = a.n_tile < a.persistent_wgs ? a.n_tile : a.persistent_wgs;
     hipLaunchKernelGGL(edge_kernel_persistent, dim3(nwg), dim3(P_THREADS), 0, s, a);
+    return;
+  }
+  if (a.waves8 && a.g_update && a.tile_rows == 64) {
+    hipLaunchKernelGGL(edge_kernel_w8, dim3(a.n_tile), dim3(512), 0, s, a);
     return;
   }
   const dim3 grid(a.n_tile), block(256);

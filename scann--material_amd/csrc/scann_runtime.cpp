@@ -42,6 +42,11 @@ struct scann_handle {
   bool debug = false;
   int edge_tile = 64;  // edge rows per tile (32 or 64); env SCANN_EDGE_TILE overrides
   int n_cu = 256;      // compute units of the device
+  int time_every = 0;  // > 0: sample edge-kernel launch durations on every n-th forward (scann_edge_timing)
+  int64_t time_count = 0;
+  std::vector<hipEvent_t> time_ev;  // pairs (start, stop)
+  std::vector<int> time_edges;
+  int edge_w8 = 1;     // 8-wave (512-thread) edge kernel for the g_update path; env SCANN_EDGE_W8=0 selects the 4-wave one
   int persist_min_tiles = 1 << 30;  // launches with at least this many edge tiles use edge_kernel_persistent (env SCANN_PERSIST_MIN)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
@@ -225,6 +230,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->device = device_id;
   h->specs = build_specs(*cfg);
   if (const char* et = getenv("SCANN_EDGE_TILE")) h->edge_tile = atoi(et) == 32 ? 32 : 64;
+  if (const char* w8 = getenv("SCANN_EDGE_W8")) h->edge_w8 = atoi(w8) != 0;
   if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
   {
     hipDeviceProp_t prop;
@@ -738,12 +744,26 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
     ea.c = db->c; ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = db->ctx;
     ea.p = h->layers[l];
+    const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (sample) {
+      (void)hipEventCreate(&ev0);
+      (void)hipEventCreate(&ev1);
+      (void)hipEventRecord(ev0, s);
+    }
+    ea.waves8 = h->edge_w8;
     ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles) ? h->n_cu : 0;
 #ifdef SCANN_STAMPS
     if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
     ea.stamps = db->stamps;
 #endif
     launch_edge(ea, s);
+    if (sample) {
+      (void)hipEventRecord(ev1, s);
+      h->time_ev.push_back(ev0);
+      h->time_ev.push_back(ev1);
+      h->time_edges.push_back(db->n_edge);
+    }
     if (tm) tm->mark(2);
     if (h->debug) {
       HIPCHK(h, hipMemcpyAsync(db->dbg_ctx + (size_t)l * db->n_atom * D, db->ctx, rowA, hipMemcpyDeviceToDevice, s));
@@ -751,6 +771,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
         HIPCHK(h, hipMemcpyAsync(db->dbg_g + (size_t)(l + 1) * db->n_edge * D, db->geom, rowE, hipMemcpyDeviceToDevice, s));
     }
   }
+  if (!tm) h->time_count++;
   ReadoutArgs r{};
   r.mol_offset = db->mol_offset; r.n_struct = db->n_struct; r.max_atoms = db->max_atoms;
   r.gq = db->gq; r.gk = db->gk; r.use_ga_norm = c.use_ga_norm; r.relu_out = c.relu_out;
@@ -868,6 +889,36 @@ int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t
   }
   if (tm.ev.size() >= 2) (void)hipEventElapsedTime(&prof->ms_total, tm.ev.front(), tm.ev.back());
   for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
+  return SCANN_OK;
+}
+
+int scann_edge_timing(scann_handle_t* h, int every) {
+  if (!h) return SCANN_ERR_INVALID;
+  h->time_every = every > 0 ? every : 0;
+  h->time_count = 0;
+  return SCANN_OK;
+}
+
+int scann_edge_timing_read(scann_handle_t* h, double* avg_us, int64_t* n_launches, double* avg_edges) {
+  if (!h || !avg_us || !n_launches) return SCANN_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  double tot = 0, edges = 0;
+  int64_t n = 0;
+  for (size_t i = 0; i + 1 < h->time_ev.size(); i += 2) {
+    float ms = 0.f;
+    if (hipEventSynchronize(h->time_ev[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->time_ev[i], h->time_ev[i + 1]) == hipSuccess) {
+      tot += ms * 1e3;
+      edges += h->time_edges[i / 2];
+      ++n;
+    }
+    (void)hipEventDestroy(h->time_ev[i]);
+    (void)hipEventDestroy(h->time_ev[i + 1]);
+  }
+  h->time_ev.clear();
+  h->time_edges.clear();
+  *avg_us = n ? tot / n : 0.0;
+  *n_launches = n;
+  if (avg_edges) *avg_edges = n ? edges / n : 0.0;
   return SCANN_OK;
 }
 

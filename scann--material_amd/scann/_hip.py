@@ -70,6 +70,8 @@ SYMBOLS = [
     ("scann_sync", C.c_int, [_P]),
     ("scann_num_streams", C.c_int, [_P]),
     ("scann_forward_profile", C.c_int, [_P, _P, C.POINTER(Profile)]),
+    ("scann_edge_timing", C.c_int, [_P, C.c_int]),
+    ("scann_edge_timing_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("scann_set_debug", C.c_int, [_P, C.c_int]),
     ("scann_debug_read", C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     ("scann_debug_stamps", C.c_int, [_P, _P, _P, C.c_int]),
@@ -398,6 +400,14 @@ class Engine:
 
     def comm_init(self, unique_id, rank, world):
         self._check(self.lib.scann_comm_init(self._h, unique_id, int(rank), int(world)))
+
+    def edge_timing(self, every):
+        self._check(self.lib.scann_edge_timing(self._h, int(every)))
+
+    def edge_timing_read(self):
+        us, n, ed = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.scann_edge_timing_read(self._h, C.byref(us), C.byref(n), C.byref(ed)))
+        return us.value, n.value, ed.value
 
     def set_debug(self, on):
         self._check(self.lib.scann_set_debug(self._h, int(bool(on))))

@@ -6,6 +6,7 @@ counts half the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section);
 16-B-per-lane (float4) read except the 8-B-per-edge index loads."""
 import collections, csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+group = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -23,8 +24,8 @@ for k, v in res.items():
 json.dump(res, open(os.path.join(root, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 ek = [v for k, v in res.items() if k.startswith("scann::edge_kernel")]
 if ek:
-    json.dump({"hbm_bytes_per_launch": ek[0]["hbm_bytes_per_launch_corrected"],
-               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 40 --pool 8, batch 128; "
+    json.dump({"hbm_bytes_per_launch": ek[0]["hbm_bytes_per_launch_corrected"], "batches_per_launch": group,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 64 --pool 16 (default --group), batch 128; "
                          "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, gfx950 FETCH_SIZE x2 correction for 16-B/lane reads",
                "fetch_KiB_raw": ek[0]["FETCH_SIZE_KiB_avg"], "write_KiB": ek[0]["WRITE_SIZE_KiB_avg"]},
               open(os.path.join(root, "profiles", "edge_kernel_traffic.json"), "w"), indent=1)
