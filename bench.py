@@ -36,6 +36,32 @@ QM9_MODEL = dict(n_atoms=10, embedding_dim=48, n_attention=7, local_dim=128, num
                  gaussian_d=4.0)  # configs/model_qm9.yaml:1-14
 
 
+MP2018_MODEL = dict(n_atoms=95, embedding_dim=128, n_attention=9, local_dim=128, num_head=8, global_dim=128,
+                    dense_out=128, scale=0.5, use_attn_norm=True, use_ga_norm=True, use_ring=False, g_update=True,
+                    gaussian_d=6.0)  # configs/model_mp2018.yaml:1-14
+
+
+def synth_packed_crystals(rng, n_struct):
+    """MP2018-shaped structures: A ~ clip(LogNormal(3.0, 0.8), 2, 300), neighbours per atom U[6, 24],
+    Z in [1, 94], distances U(1.5, 6.0)."""
+    atomic, mol_off, e_off, cols = [], [0], [0], []
+    for _ in range(n_struct):
+        A = int(np.clip(np.rint(rng.lognormal(3.0, 0.8)), 2, 300))
+        base = mol_off[-1]
+        atomic.append(rng.integers(1, 95, size=A))
+        lo, hi = min(6, A - 1), min(24, A - 1)
+        deg = rng.integers(lo, hi + 1, size=A)
+        for a in range(A):
+            others = rng.choice(A - 1, size=deg[a], replace=False)
+            cols.append(base + others + (others >= a))
+            e_off.append(e_off[-1] + int(deg[a]))
+        mol_off.append(base + A)
+    cols = np.concatenate(cols)
+    E = cols.shape[0]
+    return _hip.PackedBatch(np.concatenate(atomic), mol_off, e_off, cols, rng.uniform(1.5, 6.0, size=E),
+                            rng.uniform(0.4, 3.5, size=E))
+
+
 def synth_packed_batch(rng, n_mol, worst=False):
     """Synthetic QM9-shaped molecules straight into packed form: atoms ~ clip(round(N(18,2.9)),3,29),
     species {H .51, C .35, N .06, O .08, F .002}, neighbours per atom ~ U[3, min(12, A-1)] without replacement,
@@ -144,6 +170,8 @@ def main():
                     help="resident 128-molecule batches the engine fuses into one launch sequence (packed layout: a group is "
                          "the concatenation of its batches; 1 = one batch per launch)")
     ap.add_argument("--worst", action="store_true", help="Swc: every molecule 29 atoms x 12 neighbours")
+    ap.add_argument("--config", default="qm9", choices=["qm9", "mp2018"],
+                    help="qm9 = BASELINE configs[1] (the metric); mp2018 = configs[3] shapes (crystals, L=9, batch 64), extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-reps", type=int, default=20)
     args = ap.parse_args()
@@ -155,7 +183,10 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     os.environ["SCANN_STREAMS"] = str(max(1, args.streams))  # read by scann_create
-    cfg = normalize_config({"model": dict(QM9_MODEL), "hyper": {"target": "homo", "batch_size": args.batch}})
+    if args.config == "mp2018" and args.batch == 128:
+        args.batch = 64  # configs/model_mp2018.yaml:16
+    model_cfg = dict(QM9_MODEL) if args.config == "qm9" else dict(MP2018_MODEL)
+    cfg = normalize_config({"model": model_cfg, "hyper": {"target": "homo", "batch_size": args.batch}})
     ndev = _hip.load_library().scann_device_count()
     if ndev <= 0:
         raise SystemExit("bench.py needs a GPU: libscann_hip has no CPU fallback")
@@ -165,7 +196,10 @@ def main():
     G = max(1, args.group)
     n_groups = max(nstream, (max(args.pool // G, 1) + nstream - 1) // nstream * nstream)
     rng = np.random.default_rng(1000 + rank)
-    batches = [synth_packed_batch(rng, args.batch, args.worst) for _ in range(n_groups * G)]
+    if args.config == "mp2018":
+        batches = [synth_packed_crystals(rng, args.batch) for _ in range(n_groups * G)]
+    else:
+        batches = [synth_packed_batch(rng, args.batch, args.worst) for _ in range(n_groups * G)]
     # every step is one 128-molecule batch; the engine runs G of them per launch sequence
     pool = [eng.upload(_hip.concat_packed(batches[i * G:(i + 1) * G]) if G > 1 else batches[i]) for i in range(n_groups)]
     pool_n = n_groups
@@ -248,16 +282,19 @@ def main():
         A = float(np.mean([b.n_atom for b in batches]))
         E = float(np.mean([b.n_edge for b in batches]))
         value = world * args.steps * mols_per_step / elapsed
+        L_cfg, emb_cfg = model_cfg["n_attention"], model_cfg["embedding_dim"]
         out = {
-            "metric": "QM9 molecules/s forward", "value": value, "unit": "molecules/s", "n_gpus": world,
+            "metric": "QM9 molecules/s forward" if args.config == "qm9" else "MP2018-shaped structures/s forward", "value": value, "unit": "molecules/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: QM9-shaped%s, configs/model_qm9.yaml (SCANN+, L=7, d=128, H=8), "
-                                   "batch=128 per step, forward" % (" worst-case 29x12" if args.worst else ""),
+            "config": {"workload": ("configs[1]: QM9-shaped%s, configs/model_qm9.yaml (SCANN+, L=7, d=128, H=8), "
+                                    "batch=128 per step, forward" % (" worst-case 29x12" if args.worst else ""))
+                       if args.config == "qm9" else
+                       "configs[3] shapes: MP2018-shaped crystals, configs/model_mp2018.yaml (SCANN+, L=9), batch=64 per step, forward",
                        "batch": args.batch, "atoms_per_batch": A, "edges_per_batch": E,
                        "streams": nstream, "batches_fused_per_launch": G, "parallelism": "dp%d (independent shards, no collective)" % world},
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
-            "whole_path_tflops_min": world * args.steps * total_flops_min(A, E) / elapsed / 1e12,
+            "whole_path_tflops_min": world * args.steps * total_flops_min(A, E, L_cfg, emb_cfg) / elapsed / 1e12,
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -204,3 +204,30 @@ def test_rccl_single_rank_communicator(hip_lib):
     g2 = eng.get_grads()
     assert all(np.array_equal(g1[k], g2[k]) for k in g1)
     rb.free()
+
+
+def test_cli_train_then_predict_model(hip_lib, tmp_path):
+    """train.py (12 epochs) then predict_model.py on its output directory, as subprocesses like a user would run them."""
+    import subprocess
+    import sys
+
+    import yaml
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e_path, n_path = _write_dataset(tmp_path, n=64)
+    cfg = so.default_config("qm9")
+    cfg["model"]["n_attention"] = 1
+    cfg["hyper"].update(batch_size=16, test_percent=0.125, scaler=True, scheduler="sgdr", train_size="", test_size="",
+                        data_size=64, data_nei_path=n_path, data_energy_path=e_path, lr=2e-3, min_lr=2e-4,
+                        save_path=str(tmp_path / "cli"), pretrained="")
+    cfg["model"].pop("feature"); cfg["model"].pop("use_drop"); cfg["hyper"].pop("target")  # the CLI injects these
+    ypath = tmp_path / "cfg.yaml"
+    yaml.safe_dump(cfg, open(ypath, "w"))
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "homo", str(ypath), "--epochs", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = str(tmp_path / "cli_homo")
+    assert "Test MAE" in open(out + "/report.txt").read()
+    r = subprocess.run([sys.executable, os.path.join(root, "predict_model.py"), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(out + "/ga_scores_homo.pickle") and os.path.exists(out + "/energy_pre_homo.pickle")

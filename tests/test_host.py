@@ -304,3 +304,11 @@ def test_packed_dataset_matches_data_iterator():
             assert np.array_equal(t, t2)
             for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
                 assert np.array_equal(getattr(pk, f), getattr(ref, f)), (f, i)
+
+
+def test_input_output_names_match_the_reference_notebook():
+    """notebooks/qm9_pretrained.ipynb cell 5 records the Keras model's input names (SURVEY.md 8c pin 4)."""
+    from scann.models.scann_model import INPUT_NAMES
+
+    assert INPUT_NAMES + ["ring_aromatic"] == ["atomic", "atom_mask", "neighbors", "neighbor_mask", "neighbor_weight",
+                                               "neighbor_distance", "ring_aromatic"]
