@@ -583,6 +583,14 @@ __device__ __forceinline__ void mma_half(const float* __restrict__ sXrt, const f
   }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Consecutive tiles hold neighbouring
+// atoms of the same structures and gather the same centre rows, so give every XCD a CONTIGUOUS run of tiles
+// (bijective for any grid size).  Speed only: any placement is correct.
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return x * q + min(x, r) + i;
+}
+
 __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   constexpr int TEK = 64;
   __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   __shared__ int sCol[TEK], sCtr[TEK], sOff[TA + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rt = wave >> 2, cb = wave & 3;
-  const EdgeTile tile = a.tiles[blockIdx.x];
+  const EdgeTile tile = a.tiles[a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x];
   const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
   const int col = 32 * cb + (lane & 31);
   float* const sQ = sA;

@@ -46,6 +46,7 @@ struct scann_handle {
   int64_t time_count = 0;
   std::vector<hipEvent_t> time_ev;  // pairs (start, stop)
   std::vector<int> time_edges;
+  int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
   int edge_w8 = 1;     // 8-wave (512-thread) edge kernel for the g_update path; env SCANN_EDGE_W8=0 selects the 4-wave one
   int persist_min_tiles = 1 << 30;  // launches with at least this many edge tiles use edge_kernel_persistent (env SCANN_PERSIST_MIN)
   float* d_weights = nullptr;  // one arena with every device-side weight image
@@ -230,6 +231,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->device = device_id;
   h->specs = build_specs(*cfg);
   if (const char* et = getenv("SCANN_EDGE_TILE")) h->edge_tile = atoi(et) == 32 ? 32 : 64;
+  if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* w8 = getenv("SCANN_EDGE_W8")) h->edge_w8 = atoi(w8) != 0;
   if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
   {
@@ -752,6 +754,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       (void)hipEventRecord(ev0, s);
     }
     ea.waves8 = h->edge_w8;
+    ea.xcd_remap = h->xcd_remap;
     ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles) ? h->n_cu : 0;
 #ifdef SCANN_STAMPS
     if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));

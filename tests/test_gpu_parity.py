@@ -313,3 +313,39 @@ def test_predict_dataset_pipeline_equals_per_batch_predict(hip_lib):
         for group in (1, 3):
             y, ga, t = model.predict_dataset(data, group=group, want_ga=True)
             assert np.array_equal(y, ref_y) and len(t) == 70 and ga.shape[0] == sum(len(e[0]) for e in de)
+
+
+def test_degenerate_batches(hip_lib):
+    """No edges at all (every atom isolated: ctx = LN(q) in every layer), and atoms with the maximum 64 neighbours."""
+    from scann import _hip
+
+    cfg, w, _, model = make(n=2)
+    # (a) three structures, no edges
+    B, M, N = 3, 4, 2
+    atomic = np.array([[6, 1, 1, 0], [8, 1, 0, 0], [7, 6, 1, 1]], dtype="int32")
+    inputs = {"atomic": atomic, "atom_mask": (atomic != 0)[..., None], "neighbors": np.zeros((B, M, N), "int32"),
+              "neighbor_mask": np.zeros((B, M, N), bool), "neighbor_weight": np.zeros((B, M, N), "float32"),
+              "neighbor_distance": np.zeros((B, M, N), "float32")}
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+    # (b) one 70-atom structure whose atoms each have 64 neighbours, next to a small molecule
+    rng = np.random.default_rng(0)
+    A = 70
+    big = [[[6, int(j), float(rng.uniform(0.4, 3.5)), 1.0, float(rng.uniform(0.9, 4.0))]
+            for j in rng.choice(np.delete(np.arange(A), a), 64, replace=False)] for a in range(A)]
+    de, dn = so.synth_dataset(1, 3)
+    de2, dn2 = np.empty(2, dtype=object), np.empty(2, dtype=object)
+    de2[0], dn2[0] = [[6] * A, 0.0], big
+    de2[1], dn2[1] = de[0], dn[0]
+    inputs, _ = so.pad_batch(de2, dn2, True)
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+    # (c) 65 neighbours is refused with a clear error, not silently truncated
+    big[0].append([6, 1, 1.0, 1.0, 1.0])
+    de2[0], dn2[0] = [[6] * A, 0.0], big
+    inputs, _ = so.pad_batch(de2, dn2, True)
+    with pytest.raises(_hip.ScannHipError) as e:
+        model.predict(inputs)
+    assert e.value.code == -2 and "64 neighbours" in str(e.value)
