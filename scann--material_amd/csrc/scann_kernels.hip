@@ -605,6 +605,7 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   const int col = 32 * cb + (lane & 31);
   float* const sQ = sA;
 
+  STAMP(a.stamps, 0);
   float4 w[8];
   load_w_half(a.p.W2p, cb, lane, 0, w);
   if (tid < TEK) {
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
     *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = v;
   }
   __syncthreads();
+  STAMP(a.stamps, 1);
   // U = G . W2
   f32x16 acc;
 #pragma unroll
@@ -632,10 +634,12 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 0, acc);
   load_w_half(a.p.W2p, cb, lane, 1, w);
   mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 1, acc);
+  STAMP(a.stamps, 2);
   load_w_half(a.p.Wkp, cb, lane, 0, w);  // first half of the key weights arrives during the row pass
 #pragma unroll
   for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[i];
   __syncthreads();
+  STAMP(a.stamps, 3);
 
   // row pass, 8 threads per edge row (attention.py:141-157)
   {
@@ -694,12 +698,14 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
     if (la < natom) qreg[i] = reinterpret_cast<const float4*>(a.q)[(size_t)(tile.atom_begin + la) * 32 + c4];
   }
   __syncthreads();
+  STAMP(a.stamps, 4);
   // K = ang . Wk + bk
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 0, acc);
   load_w_half(a.p.Wkp, cb, lane, 1, w);
   mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 1, acc);
+  STAMP(a.stamps, 5);
   {
     const float b = a.p.bk[col];
 #pragma unroll
@@ -712,6 +718,7 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
     *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
   }
   __syncthreads();
+  STAMP(a.stamps, 6);
   // logits: thread = (edge row, head)
   {
     const int n = tid >> 3, hh = tid & 7;
@@ -729,27 +736,41 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
     }
   }
   __syncthreads();
-  // softmax + context + residual: thread = (atom group of 16, float4 chunk)
+  STAMP(a.stamps, 8);
+  // softmax + context + residual: thread = (atom group of 16, float4 chunk).  One pass over the atom's edges with a
+  // running maximum (online softmax: exp(e - max) / sum, the max-subtracted form of tf.nn.softmax, attention.py:189,
+  // evaluated with rescaling instead of three passes); two edges per iteration so their LDS reads overlap.
   {
     const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
     for (int la = lgp; la < natom; la += 16) {
       const int e0 = sOff[la], e1 = sOff[la + 1];
-      float m = -INFINITY;
-      for (int n = e0; n < e1; ++n) m = fmaxf(m, sE[n * NHEAD + h]);
-      float ssum = 0.f;
-      for (int n = e0; n < e1; ++n) ssum += fast_exp(sE[n * NHEAD + h] - m);
-      const float rs = __builtin_amdgcn_rcpf(ssum);
+      float m = -INFINITY, ssum = 0.f;
       float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int n = e0; n < e1; ++n) {
-        const float attn = fast_exp(sE[n * NHEAD + h] - m) * rs;
-        const float4 k4 = *reinterpret_cast<const float4*>(&sB[n * LDS_STRIDE + 4 * c4]);
-        cx.x += attn * k4.x; cx.y += attn * k4.y; cx.z += attn * k4.z; cx.w += attn * k4.w;
+      for (int n = e0; n < e1; n += 2) {
+        const bool two = n + 1 < e1;
+        const int n1 = two ? n + 1 : n;
+        const float ea = sE[n * NHEAD + h];
+        const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
+        const float4 ka = *reinterpret_cast<const float4*>(&sB[n * LDS_STRIDE + 4 * c4]);
+        const float4 kb = *reinterpret_cast<const float4*>(&sB[n1 * LDS_STRIDE + 4 * c4]);
+        const float mn = fmaxf(m, fmaxf(ea, eb2));
+        const float resc = fast_exp(m - mn);  // exp2(-inf) = 0 on the first iteration
+        const float pa = fast_exp(ea - mn), pb = fast_exp(eb2 - mn);
+        ssum = ssum * resc + (pa + pb);
+        cx.x = cx.x * resc + (pa * ka.x + pb * kb.x);
+        cx.y = cx.y * resc + (pa * ka.y + pb * kb.y);
+        cx.z = cx.z * resc + (pa * ka.z + pb * kb.z);
+        cx.w = cx.w * resc + (pa * ka.w + pb * kb.w);
+        m = mn;
       }
+      const float rs = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
       float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
-      *qp = f4add(cx, *qp);
+      const float4 q4 = *qp;
+      *qp = make_float4(cx.x * rs + q4.x, cx.y * rs + q4.y, cx.z * rs + q4.z, cx.w * rs + q4.w);  // + unscaled query (:212)
     }
   }
   __syncthreads();
+  STAMP(a.stamps, 9);
   // LayerNorm of the context rows: 16 threads per atom row
   {
     const int r = tid >> 4, sub = tid & 15;
@@ -788,6 +809,7 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
       }
     }
   }
+  STAMP(a.stamps, 7);
 }
 
 #ifdef SCANN_STAMPS
