@@ -84,7 +84,6 @@ typedef struct scann_handle scann_handle_t;
 typedef struct scann_dbatch scann_dbatch_t; /* a batch resident in HBM with its own workspace */
 
 /* Per-kernel device timing of one forward (HIP events on the handle's stream). */
-#define SCANN_PROF_SLOTS 8
 typedef struct scann_profile {
   float ms_basis;     /* embed + edge basis MLP            (scann_model.py:362-389) */
   float ms_atom;      /* sum over layers: atom-tile kernel (attention.py:37-40,160 + split filter_geo) */

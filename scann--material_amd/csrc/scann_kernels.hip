@@ -87,14 +87,6 @@ __device__ __forceinline__ void mma128(const float* __restrict__ sX, const float
 }
 
 template <int RT>
-__device__ __forceinline__ void gemm128(const float* __restrict__ sX, const float* __restrict__ Wp, int wave,
-                                        int lane, f32x16 (&acc)[RT]) {
-  float4 w[16];
-  load_w(Wp, wave, lane, w);
-  mma128<RT>(sX, w, lane, acc);
-}
-
-template <int RT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT]) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)

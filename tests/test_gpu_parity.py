@@ -349,3 +349,19 @@ def test_degenerate_batches(hip_lib):
     with pytest.raises(_hip.ScannHipError) as e:
         model.predict(inputs)
     assert e.value.code == -2 and "64 neighbours" in str(e.value)
+
+
+@pytest.mark.parametrize("env", [
+    {"SCANN_EDGE_W8": "0"},                              # 4-wave edge_kernel<true, 2>
+    {"SCANN_EDGE_W8": "0", "SCANN_EDGE_TILE": "32"},     # 32-row tiles, edge_kernel<true, 1>
+    {"SCANN_PERSIST_MIN": "1"},                          # persistent wave-specialised kernel for every launch
+    {"SCANN_XCD_REMAP": "0", "SCANN_STREAMS": "2"},
+], ids=["w4", "w4_tile32", "persistent", "no_remap_2streams"])
+def test_alternative_edge_kernels(hip_lib, env, monkeypatch):
+    """The opt-in kernel variants (selected by environment at scann_create) stay at parity."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg, w, inputs, model = make(n=40, seed=13)
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
