@@ -164,6 +164,9 @@ int scann_train_begin(scann_handle_t* h);
 int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, double* sse_out);
 /* accumulates d(rmse)/d(params) into the gradient vector; rmse = sqrt(sse_global / count_global) (losses.py:5-6) */
 int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_global, int64_t count_global);
+/* model.use_drop (train.py --use_drop): Dropout(0.05) on the local-attention weights during training forwards
+ * (attention.py:116,191); 0 disables.  g_update path only. */
+int scann_set_attention_dropout(scann_handle_t* h, float p);
 int scann_zero_grads(scann_handle_t* h);
 int scann_allreduce_grads(scann_handle_t* h);                 /* RCCL sum over the communicator; no-op without one */
 int scann_allreduce_sse(scann_handle_t* h, double* sse, int64_t* count); /* in-place sum over ranks */

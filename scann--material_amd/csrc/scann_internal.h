@@ -26,6 +26,7 @@ __host__ __device__ inline float drop_scale(unsigned long long seed, unsigned ta
   const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
   return u < p ? 0.f : 1.0f / (1.0f - p);
 }
+constexpr unsigned DROP_TAG_ATTN = 2000;   // + layer: Dropout(0.05) on attention weights, element = edge * 8 + head
 constexpr unsigned DROP_TAG_EMBED = 1000;  // Dropout(0.1) after dense_embed (scann_model.py:374); ResidualNorm l uses tag l
 
 // One tile of the edge kernel: a run of whole atoms whose CSR rows are contiguous, <= TE edges.
@@ -127,6 +128,10 @@ struct EdgeArgs {
   const float* edge_weight;    // [n_edge] (base)
   const float *c, *P1, *P3, *q;  // [n_atom,128]
   float* ctx;                  // [n_atom,128] out: LayerNorm(context)
+  // training with use_drop: Dropout(0.05) on the attention weights (attention.py:116,191); 0 in inference
+  float attn_drop_p;
+  uint32_t attn_drop_tag;
+  unsigned long long attn_drop_seed;
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS) only: [n_tile,16] phase clocks, else null
   LayerParams p;
 };

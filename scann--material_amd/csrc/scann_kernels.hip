@@ -747,8 +747,12 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
         const float4 kb = *reinterpret_cast<const float4*>(&sB[n1 * LDS_STRIDE + 4 * c4]);
         const float mn = fmaxf(m, fmaxf(ea, eb2));
         const float resc = fast_exp(m - mn);  // exp2(-inf) = 0 on the first iteration
-        const float pa = fast_exp(ea - mn), pb = fast_exp(eb2 - mn);
+        float pa = fast_exp(ea - mn), pb = fast_exp(eb2 - mn);
         ssum = ssum * resc + (pa + pb);
+        if (a.attn_drop_p > 0.f) {  // training only: dropout on the (normalised) attention weights, not on the sum
+          pa *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
+          pb *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
+        }
         cx.x = cx.x * resc + (pa * ka.x + pb * kb.x);
         cx.y = cx.y * resc + (pa * ka.y + pb * kb.y);
         cx.z = cx.z * resc + (pa * ka.z + pb * kb.z);

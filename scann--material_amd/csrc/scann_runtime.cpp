@@ -69,6 +69,8 @@ struct scann_handle {
   RepackDesc* t_descs = nullptr;
   int64_t t_step = 0;
   float train_drop_p = 0.f;            // > 0 only inside scann_train_forward
+  float attn_drop_p = 0.f;             // use_drop: Dropout(0.05) on attention weights (scann_set_attention_dropout)
+  bool in_train_forward = false;
   unsigned long long train_seed = 0;
   ncclComm_t comm = nullptr;
   // reusable scratch of the synchronous scann_forward path (grow-only device arena + pinned host staging)
@@ -755,6 +757,11 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
     ea.waves8 = h->edge_w8;
     ea.xcd_remap = h->xcd_remap;
+    if (h->in_train_forward && h->attn_drop_p > 0.f) {
+      ea.attn_drop_p = h->attn_drop_p;
+      ea.attn_drop_seed = h->train_seed;
+      ea.attn_drop_tag = DROP_TAG_ATTN + (unsigned)l;
+    }
     ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles) ? h->n_cu : 0;
 #ifdef SCANN_STAMPS
     if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
@@ -969,7 +976,7 @@ struct scann_train_ws {  // per resident batch, allocated on first use
   float *tE[10] = {};   // [n_edge,128] temporaries
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   double* sse = nullptr;
-  float drop_p = 0.f;
+  float drop_p = 0.f, attn_p = 0.f;
   unsigned long long seed = 0;
 };
 
@@ -1029,8 +1036,8 @@ int64_t scann_param_count(const scann_handle_t* h) {
 int scann_train_begin(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "scann_train_begin: weights not loaded");
-  if (!h->cfg.g_update || h->cfg.use_ring || h->cfg.feature_cgcnn)
-    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: the backward pass covers g_update=1, feature=atomic, use_ring=0");
+  if (h->cfg.use_ring || h->cfg.feature_cgcnn)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: the backward pass covers feature=atomic, use_ring=0");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t n = h->host_master.size();
   if (!h->t_master) {
@@ -1058,6 +1065,12 @@ int scann_train_begin(scann_handle_t* h) {
   }
   HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
   h->t_step = 0;
+  return SCANN_OK;
+}
+
+int scann_set_attention_dropout(scann_handle_t* h, float p) {
+  if (!h || !(p >= 0.f && p < 1.f)) return fail(h, SCANN_ERR_INVALID, "scann_set_attention_dropout: rate must be in [0, 1)");
+  h->attn_drop_p = p;
   return SCANN_OK;
 }
 
@@ -1102,9 +1115,14 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   w->seed = seed;
   const bool dbg = h->debug;
   h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)
+  if (h->attn_drop_p > 0.f && !(h->edge_w8 && h->cfg.g_update && db->tile_rows == 64 && db->n_tile < h->persist_min_tiles))
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_w8 only");
   h->train_drop_p = dropout;
   h->train_seed = seed;
+  h->in_train_forward = true;
+  w->attn_p = h->attn_drop_p;
   r = run_forward(h, db, s, nullptr);
+  h->in_train_forward = false;
   h->train_drop_p = 0.f;
   h->debug = dbg;
   if (r) return r;
@@ -1164,8 +1182,8 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     const std::string la = "local_attention_" + std::to_string(l) + "/", rn = "residual_norm_" + std::to_string(l) + "/";
     const float* c_in = db->dbg_c + (size_t)l * nA;        // centres entering LocalAttention l
     const float* ctx = db->dbg_ctx + (size_t)l * nA;       // LocalAttention output (after layer_norm)
-    const float* Gin = db->dbg_g + (size_t)l * nE;         // geometry entering layer l
-    const float* Gout = db->dbg_g + (size_t)(l + 1) * nE;  // geometry leaving layer l (= layer_norm_g output)
+    const float* Gin = c.g_update ? db->dbg_g + (size_t)l * nE : nullptr;         // geometry entering layer l
+    const float* Gout = c.g_update ? db->dbg_g + (size_t)(l + 1) * nE : nullptr;  // geometry leaving layer l (= layer_norm_g output)
 
     // ---- ResidualNorm backward (attention.py:37-40): c_{l+1} = LN(x + drop(W2 swish(W1 x + b1) + b2)), x = ctx ----
     if (c.use_attn_norm) {
@@ -1186,6 +1204,23 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     }
 
     // ---- LocalAttention backward (attention.py:118-216) ----
+    if (!c.g_update) {
+      // base SCANN (attention.py:155): geomL = swish(gd.Wf + bf) * weight from the raw basis, no geometry threading
+      launch_linear(c_in, p.Wqp, p.bq, db->q, nullptr, A, 0, s);
+      launch_base_geom(db->gd, p.Wfg, p.bfg, db->weight, eV, E, s);            // geomL (eV)
+      launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
+      launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
+      HIPCHK(h, hipMemsetAsync(dC, 0, nA * 4, s));
+      launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A,
+                    c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
+      launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
+      launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
+      launch_edge_dang(c_in, db->edge_col, eV, edAng, nullptr, dC, edGt, E, s);  // dC[j] += dang*geomL ; dgeomL = dang*c[j]
+      launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, edGt, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), s);
+      launch_wgrad(c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A, s);
+      launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
+      continue;
+    }
     // forward recompute of what the fused kernels do not keep
     launch_linear(c_in, p.W1p, p.bg, db->P1, nullptr, A, 0, s);
     launch_linear(c_in, p.W3p, nullptr, db->P3, nullptr, A, 0, s);
@@ -1193,7 +1228,8 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
     launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
     HIPCHK(h, hipMemsetAsync(dC, 0, nA * 4, s));                 // dC now collects d loss / d centres_l
-    launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, s);
+    launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A,
+                    c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
     launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
     launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, dC, edGt, E, s);  // dC[j] += dang*G' ; dG'tot

@@ -39,10 +39,14 @@ void launch_edge_dv(const float* V, const float* dT, const int* ctr, const int* 
                     int n_edge, hipStream_t s);
 void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s);
 void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
-                     float* dK, float* dgamma, float* dbeta, int n_atom, hipStream_t s);
+                     float* dK, float* dgamma, float* dbeta, int n_atom, float drop_p, unsigned drop_tag,
+                     unsigned long long drop_seed, hipStream_t s);
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);
 void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weight, const float* dgeom, int n_edge, float* dWd,
                       float* dbd, float* dWw, float* dbw, hipStream_t s);
+void launch_base_geom(const float* gd, const float* Wf, const float* bf, const float* wgt, float* geomL, int n_edge, hipStream_t s);
+void launch_base_geom_bwd(const float* gd, const float* Wf, const float* bf, const float* wgt, const float* dgeomL, int n_edge,
+                          float* dWf, float* dbf, hipStream_t s);
 void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const float* emb, const float* W, const float* b,
                       float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, hipStream_t s);
 void launch_sse(const float* y, const float* t, int n, double* out, hipStream_t s);

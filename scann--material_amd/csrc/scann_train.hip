@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dctx, const float* __restrict__ gamma,
                                                        float* __restrict__ dq, float* __restrict__ dK,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int n_atom,
-                                                       int atoms_per_wave) {
+                                                       int atoms_per_wave, float drop_p, unsigned drop_tag,
+                                                       unsigned long long drop_seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int a0 = (blockIdx.x * 4 + wave) * atoms_per_wave;
   const float2 g = reinterpret_cast<const float2*>(gamma)[lane];
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       const float2 k2 = reinterpret_cast<const float2*>(K)[(size_t)n * 64 + lane];
       float e = qx * k2.x + qy * k2.y;
       e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
-      const float attn = expf(e - m) / ssum;
+      float attn = expf(e - m) / ssum;
+      if (drop_p > 0.f) attn *= drop_scale(drop_seed, drop_tag, (size_t)n * NHEAD + (lane >> 3), drop_p);
       px += attn * k2.x; py += attn * k2.y;
     }
     px += q2.x; py += q2.y;
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       float e = qx * k2.x + qy * k2.y, da = dpx * k2.x + dpy * k2.y;
       e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
       da += __shfl_xor(da, 1); da += __shfl_xor(da, 2); da += __shfl_xor(da, 4);
+      if (drop_p > 0.f) da *= drop_scale(drop_seed, drop_tag, (size_t)n * NHEAD + (lane >> 3), drop_p);  // d(attn) through the mask
       dot += (expf(e - m) / ssum) * da;
     }
     float dqx = dpx, dqy = dpy;  // residual path (attention.py:212)
@@ -413,9 +416,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
       da += __shfl_xor(da, 1); da += __shfl_xor(da, 2); da += __shfl_xor(da, 4);
       const float attn = expf(e - m) / ssum;
-      const float de = attn * (da - dot);
+      const float keep = drop_p > 0.f ? drop_scale(drop_seed, drop_tag, (size_t)n * NHEAD + (lane >> 3), drop_p) : 1.0f;
+      const float de = attn * (da * keep - dot);
       reinterpret_cast<float2*>(dK)[(size_t)n * 64 + lane] =
-          make_float2(attn * dpx + 0.25f * de * q2.x, attn * dpy + 0.25f * de * q2.y);
+          make_float2(attn * keep * dpx + 0.25f * de * q2.x, attn * keep * dpy + 0.25f * de * q2.y);
       dqx += 0.25f * de * k2.x; dqy += 0.25f * de * k2.y;
     }
     reinterpret_cast<float2*>(dq)[(size_t)at * 64 + lane] = make_float2(dqx, dqy);
@@ -426,11 +430,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   atomicAdd(&dbeta[2 * lane + 1], dbt.y);
 }
 void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
-                     float* dK, float* dgamma, float* dbeta, int n_atom, hipStream_t s) {
+                     float* dK, float* dgamma, float* dbeta, int n_atom, float drop_p, unsigned drop_tag,
+                     unsigned long long drop_seed, hipStream_t s) {
   if (n_atom <= 0) return;
   const int apw = 2;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((n_atom + 4 * apw - 1) / (4 * apw)), dim3(256), 0, s, q, K, edge_offset, dctx,
-                     gamma, dq, dK, dgamma, dbeta, n_atom, apw);
+                     gamma, dq, dK, dgamma, dbeta, n_atom, apw, drop_p, drop_tag, drop_seed);
 }
 
 // ---- readout backward: one workgroup per structure ------------------------------------------------------------------
@@ -584,6 +589,59 @@ void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weig
   if (n_edge > 0)
     hipLaunchKernelGGL(basis_bwd_kernel, dim3((n_edge + 31) / 32), dim3(128), 0, s, p, dist, weight, dgeom, n_edge, dWd, dbd,
                        dWw, dbw);
+}
+
+// ---- base SCANN branch: geomL = swish(gd.Wf + bf) * weight  (attention.py:155; gd = raw Gaussian basis [E,20]) -------------
+// forward recompute: thread = (edge, column)
+__global__ void base_geom_kernel(const float* __restrict__ gd, const float* __restrict__ Wf, const float* __restrict__ bf,
+                                 const float* __restrict__ wgt, float* __restrict__ geomL, int n_edge) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_edge * D) return;
+  const int e = (int)(i / D), col = (int)(i % D);
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < NG; ++k) acc += gd[(size_t)e * NG + k] * Wf[k * D + col];
+  geomL[i] = swish_(acc + bf[col]) * wgt[e];
+}
+void launch_base_geom(const float* gd, const float* Wf, const float* bf, const float* wgt, float* geomL, int n_edge, hipStream_t s) {
+  if (n_edge > 0)
+    hipLaunchKernelGGL(base_geom_kernel, dim3((unsigned)(((size_t)n_edge * D + 255) / 256)), dim3(256), 0, s, gd, Wf, bf, wgt, geomL, n_edge);
+}
+// backward: dpre = dgeomL * weight * swish'(pre); dWf[k][col] += gd[e][k] dpre; dbf[col] += dpre   (32 edges per workgroup)
+__global__ __launch_bounds__(128) void base_geom_bwd_kernel(const float* __restrict__ gd, const float* __restrict__ Wf,
+                                                            const float* __restrict__ bf, const float* __restrict__ wgt,
+                                                            const float* __restrict__ dgeomL, int n_edge, float* dWf, float* dbf) {
+  __shared__ float sG[32][NG];
+  const int tid = threadIdx.x;
+  const int e0 = blockIdx.x * 32;
+  const int ne = min(32, n_edge - e0);
+  for (int i = tid; i < 32 * NG; i += 128) sG[i / NG][i % NG] = (i / NG) < ne ? gd[(size_t)(e0 + i / NG) * NG + (i % NG)] : 0.f;
+  __syncthreads();
+  float w[NG], gw[NG];
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    w[k] = Wf[k * D + tid];
+    gw[k] = 0.f;
+  }
+  const float b = bf[tid];
+  float gb = 0.f;
+  for (int e = 0; e < ne; ++e) {
+    float pre = b;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) pre += sG[e][k] * w[k];
+    const float dp = dgeomL[(size_t)(e0 + e) * D + tid] * wgt[e0 + e] * dswish_(pre);
+    gb += dp;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) gw[k] += sG[e][k] * dp;
+  }
+#pragma unroll
+  for (int k = 0; k < NG; ++k) atomicAdd(&dWf[k * D + tid], gw[k]);
+  atomicAdd(&dbf[tid], gb);
+}
+void launch_base_geom_bwd(const float* gd, const float* Wf, const float* bf, const float* wgt, const float* dgeomL, int n_edge,
+                          float* dWf, float* dbf, hipStream_t s) {
+  if (n_edge > 0)
+    hipLaunchKernelGGL(base_geom_bwd_kernel, dim3((n_edge + 31) / 32), dim3(128), 0, s, gd, Wf, bf, wgt, dgeomL, n_edge, dWf, dbf);
 }
 
 // ---- embedding backward (Embedding + dense_embed, scann_model.py:362,373) -------------------------------------------------

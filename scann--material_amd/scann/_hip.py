@@ -79,6 +79,7 @@ SYMBOLS = [
     ("scann_train_begin", C.c_int, [_P]),
     ("scann_train_forward", C.c_int, [_P, _P, _P, C.c_float, C.c_uint64, C.POINTER(C.c_double)]),
     ("scann_train_backward", C.c_int, [_P, _P, C.c_double, C.c_int64]),
+    ("scann_set_attention_dropout", C.c_int, [_P, C.c_float]),
     ("scann_zero_grads", C.c_int, [_P]),
     ("scann_allreduce_grads", C.c_int, [_P]),
     ("scann_allreduce_sse", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -373,6 +374,9 @@ class Engine:
 
     def train_backward(self, rb, sse_global, count_global):
         self._check(self.lib.scann_train_backward(self._h, rb._h, float(sse_global), int(count_global)))
+
+    def set_attention_dropout(self, p):
+        self._check(self.lib.scann_set_attention_dropout(self._h, float(p)))
 
     def zero_grads(self):
         self._check(self.lib.scann_zero_grads(self._h))

@@ -118,6 +118,7 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
     model = scann.model
     eng = model.engine
     eng.train_begin()
+    eng.set_attention_dropout(0.05 if cfg["model"].get("use_drop") else 0.0)  # attention.py:115-116
     comm = Communicator(eng)
     train_it, valid_it = scann.trainIter, scann.validIter
     steps_per_epoch = len(train_it)

@@ -19,7 +19,7 @@ def setup(n=6, L=2, seed=1, **model_over):
     cfg["model"].update(model_over)
     w = so.init_weights(cfg, 3, perturb=True)
     de, dn = so.synth_dataset(n, seed)
-    inputs, targets = so.pad_batch(de, dn, True)
+    inputs, targets = so.pad_batch(de, dn, cfg["model"]["g_update"])
     pk = _hip.pack_inputs(inputs)
     model = HipModel(cfg, w, device=0)
     return cfg, w, pk, targets, model
@@ -33,7 +33,8 @@ def grad_errors(got, ref):
     return out
 
 
-@pytest.mark.parametrize("over", [dict(), dict(use_attn_norm=False), dict(use_ga_norm=False)], ids=["qm9", "no_attn_norm", "no_ga_norm"])
+@pytest.mark.parametrize("over", [dict(), dict(use_attn_norm=False), dict(use_ga_norm=False), dict(g_update=False)],
+                         ids=["qm9", "no_attn_norm", "no_ga_norm", "base"])
 def test_gradients_match_autograd(hip_lib, over):
     import torch_ref
 
@@ -231,3 +232,43 @@ def test_cli_train_then_predict_model(hip_lib, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "predict_model.py"), out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert os.path.exists(out + "/ga_scores_homo.pickle") and os.path.exists(out + "/energy_pre_homo.pickle")
+
+
+def drop_scale_np(seed, tag, idx, p):
+    """NumPy twin of drop_scale() in scann_internal.h (64-bit mix, top 24 bits -> uniform)."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx.astype(np.uint64) + np.uint64(1)) + (np.uint64(tag) << np.uint64(48))) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float64) / 16777216.0
+    return np.where(u < np.float32(p), 0.0, 1.0 / (1.0 - float(np.float32(p))))
+
+
+def test_attention_dropout_gradients(hip_lib):
+    """use_drop: the GPU's counter-based attention mask, rebuilt on the host, is fed to the torch graph; gradients match."""
+    import torch_ref
+
+    cfg, w, pk, targets, model = setup(n=6, L=2, seed=2)
+    eng = model.engine
+    eng.train_begin()
+    eng.set_attention_dropout(0.3)  # large rate so that many weights are actually dropped
+    rb = eng.upload(pk)
+    seed = 12345
+    sse = eng.train_forward(rb, targets, dropout=0.0, seed=seed)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    idx = np.arange(pk.n_edge * 8, dtype=np.uint64)
+    scales = [drop_scale_np(seed, 2000 + l, idx, 0.3).reshape(pk.n_edge, 8) for l in range(2)]
+    assert 0.2 < np.mean(scales[0] == 0) < 0.4
+    loss, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=scales)
+    assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6)
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+    errs = grad_errors(got, ref)
+    assert max(errs.values()) <= 3e-3, {k: v for k, v in errs.items() if v > 3e-3}
+    eng.set_attention_dropout(0.0)
+    rb.free()

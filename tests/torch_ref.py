@@ -10,13 +10,13 @@ REGULARIZED = ("query/kernel", "key/kernel", "filter_geo/kernel", "dense_1/kerne
                "after_Lc/kernel", "bf_property/kernel")  # kernel_regularizer=l2(1e-4): attention.py:27-28,95-109,260-265; scann_model.py:428,441
 
 
-def loss_and_grads(config, weights, pk, targets):
+def loss_and_grads(config, weights, pk, targets, attn_scale=None):
     """Training loss of the reference (scann_model.py:210-214: RMSE + sum of l2(1e-4) kernel regularisers) and its
     gradient w.r.t. every tensor, by torch autograd in fp64.  Dropout layers are inactive (rate 0)."""
     import torch
 
     W = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in weights.items()}
-    y, _ = forward_packed(config, W, pk, "float64", as_tensor=True)
+    y, _ = forward_packed(config, W, pk, "float64", as_tensor=True, attn_scale=attn_scale)
     t = torch.tensor(np.asarray(targets), dtype=torch.float64).reshape(-1, 1)
     rmse = torch.sqrt(torch.mean((y - t) ** 2))  # losses.py:5-6
     reg = sum((W[k] ** 2).sum() for k in W if k.endswith(REGULARIZED)) * 1e-4
@@ -25,7 +25,8 @@ def loss_and_grads(config, weights, pk, targets):
     return float(loss), float(rmse), {k: v.grad.numpy() for k, v in W.items()}, y.detach().numpy()
 
 
-def forward_packed(config, weights, pk, dtype="float64", as_tensor=False):
+def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_scale=None):
+    """attn_scale: optional list (one [E, H] array per layer) of inverted-dropout factors for the attention weights."""
     import torch
     import torch.nn.functional as F
 
@@ -74,6 +75,8 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False):
         for a in range(A):  # per-atom softmax over its own edges
             if off[a + 1] > off[a]:
                 attn[off[a]:off[a + 1]] = F.softmax(e[off[a]:off[a + 1]], 0)
+        if attn_scale is not None:
+            attn = attn * torch.tensor(attn_scale[i], dtype=dt)
         ctx = torch.zeros(A, d, dtype=dt).index_add_(0, row, (attn[:, :, None] * k.view(E, H, hd)).reshape(E, d)) + q
         ctx = ln(ctx, p + "/layer_norm")
         if cfg["use_attn_norm"]:
