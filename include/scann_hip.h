@@ -154,7 +154,8 @@ int scann_debug_stamps(scann_handle_t* h, scann_dbatch_t* db, uint64_t* out, int
 
 /* ---- training step: replaces model.compile(loss=rmse, Adam(lr, decay=1e-5)) + model.fit (scann_model.py:199-241) ----
  * Gradients are hand-written derivatives of the forward graph; parameters, gradients and Adam moments are flat fp32
- * vectors in scann_weight_name() order.  Supported: g_update=1, feature="atomic", use_ring=0 (every shipped config).
+ * vectors in scann_weight_name() order.  Every architecture switch of create_model is covered (g_update on/off,
+ * use_attn_norm, use_ga_norm, use_ring, feature="cgcnn", target "e_b").
  * Data-parallel use: every rank calls forward on its shard, the SSE / count are summed over ranks (host side or
  * scann_allreduce_sse), then backward, scann_allreduce_grads (one flat RCCL all-reduce), scann_adam_step. */
 int64_t scann_param_count(const scann_handle_t* h);

@@ -1036,8 +1036,6 @@ int64_t scann_param_count(const scann_handle_t* h) {
 int scann_train_begin(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "scann_train_begin: weights not loaded");
-  if (h->cfg.use_ring || h->cfg.feature_cgcnn)
-    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: the backward pass covers feature=atomic, use_ring=0");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t n = h->host_master.size();
   if (!h->t_master) {
@@ -1258,9 +1256,20 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     launch_basis_bwd(h->basis, db->dist, db->weight, dG_in, E, g("neighbor_d/kernel"), g("neighbor_d/bias"),
                      g("neighbor_w/kernel"), g("neighbor_w/bias"), s);
   launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, s);
-  HIPCHK(h, hipMemsetAsync(w.dlut, 0, (size_t)c.n_atoms * D * 4, s));
-  launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
-                   c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), s);
+  if (c.use_ring || c.feature_cgcnn) {
+    EmbedArgs e = h->embed;
+    e.n_atom = A; e.atomic = db->atomic; e.c0 = db->c0;
+    e.ring = c.use_ring ? db->ring : nullptr;
+    e.cgcnn = c.feature_cgcnn ? db->cgcnn : nullptr;
+    launch_embed_general_bwd(e, dC, c.feature_cgcnn ? nullptr : g("embed_atom/embeddings"),
+                             c.feature_cgcnn ? g("embed_atom/kernel") : nullptr, c.feature_cgcnn ? g("embed_atom/bias") : nullptr,
+                             c.use_ring ? g("extra_embed/kernel") : nullptr, c.use_ring ? g("extra_embed/bias") : nullptr,
+                             g("dense_embed/kernel"), g("dense_embed/bias"), s);
+  } else {
+    HIPCHK(h, hipMemsetAsync(w.dlut, 0, (size_t)c.n_atoms * D * 4, s));
+    launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
+                     c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), s);
+  }
   HIPCHK(h, hipGetLastError());
   return SCANN_OK;
 }
@@ -1276,8 +1285,9 @@ int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, flo
   // t_l2 holds a 0/1 mask; fold the coefficient in by scaling through the kernel argument
   launch_adam(h->t_master, h->t_grad, h->t_m, h->t_v, h->t_l2, n, lr_hat, beta1, beta2, eps, l2, s);
   launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, s);
-  launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
-                   h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
+  if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
+    launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
+                     h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(s));
   return SCANN_OK;

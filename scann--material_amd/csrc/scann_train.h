@@ -49,6 +49,8 @@ void launch_base_geom_bwd(const float* gd, const float* Wf, const float* bf, con
                           float* dWf, float* dbf, hipStream_t s);
 void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const float* emb, const float* W, const float* b,
                       float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, hipStream_t s);
+void launch_embed_general_bwd(const EmbedArgs& a, const float* dc0, float* dEmb, float* dWe, float* dbe, float* dWr, float* dbr,
+                              float* dWde, float* dbde, hipStream_t s);
 void launch_sse(const float* y, const float* t, int n, double* out, hipStream_t s);
 void launch_dy(const float* y, const float* t, int n, float scale, float* dy, hipStream_t s);
 void launch_adam(float* w, const float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,

@@ -679,6 +679,83 @@ void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const flo
                      dEmb, dW, db);
 }
 
+// ---- general embedding backward (use_ring / feature="cgcnn", scann_model.py:361-374) --------------------------------------
+// forward: v = concat[E[Z] | X.We + be, ring.Wr + br] (cin values), c0 = swish(v.Wde + bde).  8 atoms per 128-thread workgroup;
+// dc0 already carries the dropout scale.  Small tensors: every gradient goes through float atomics.
+__global__ __launch_bounds__(128) void embed_general_bwd_kernel(EmbedArgs a, const float* __restrict__ dc0, float* dEmb, float* dWe,
+                                                                float* dbe, float* dWr, float* dbr, float* dWde, float* dbde) {
+  __shared__ float sV[8][160], sDp[8][D], sDv[8][160];
+  const int tid = threadIdx.x;
+  const int a0 = blockIdx.x * 8;
+  const int na = min(8, a.n_atom - a0);
+  const int cin = a.emb_dim + (a.ring ? 10 : 0);
+  for (int i = tid; i < na * cin; i += 128) {
+    const int la = i / cin, k = i % cin, at = a0 + la;
+    float v;
+    if (k < a.emb_dim) {
+      if (a.cgcnn) {
+        float acc = 0.f;
+        for (int j = 0; j < 92; ++j) acc += a.cgcnn[(size_t)at * 92 + j] * a.We[j * a.emb_dim + k];
+        v = acc + a.be[k];
+      } else {
+        v = a.emb[(size_t)a.atomic[at] * a.emb_dim + k];
+      }
+    } else {
+      const int r = k - a.emb_dim;
+      v = (a.ring[(size_t)at * 2] * a.Wr[r] + a.ring[(size_t)at * 2 + 1] * a.Wr[10 + r]) + a.br[r];
+    }
+    sV[la][k] = v;
+  }
+  __syncthreads();
+  float gb = 0.f;
+  for (int la = 0; la < na; ++la) {  // thread = output column
+    float pre = a.bde[tid];
+    for (int k = 0; k < cin; ++k) pre += sV[la][k] * a.Wde[k * D + tid];
+    const float dp = dc0[(size_t)(a0 + la) * D + tid] * dswish_(pre);
+    sDp[la][tid] = dp;
+    gb += dp;
+  }
+  atomicAdd(&dbde[tid], gb);
+  __syncthreads();
+  for (int k = 0; k < cin; ++k) {  // dWde[k][col] += sum_la v[la][k] dpre[la][col]
+    float g = 0.f;
+    for (int la = 0; la < na; ++la) g += sV[la][k] * sDp[la][tid];
+    atomicAdd(&dWde[k * D + tid], g);
+  }
+  for (int i = tid; i < na * cin; i += 128) {  // dv[la][k] = sum_col dpre[la][col] Wde[k][col]
+    const int la = i / cin, k = i % cin;
+    float acc = 0.f;
+    for (int c = 0; c < D; ++c) acc += sDp[la][c] * a.Wde[k * D + c];
+    sDv[la][k] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < na * cin; i += 128) {
+    const int la = i / cin, k = i % cin, at = a0 + la;
+    const float dv = sDv[la][k];
+    if (k < a.emb_dim) {
+      if (a.cgcnn) {
+        atomicAdd(&dbe[k], dv);
+        for (int j = 0; j < 92; ++j) {
+          const float x = a.cgcnn[(size_t)at * 92 + j];
+          if (x != 0.f) atomicAdd(&dWe[j * a.emb_dim + k], x * dv);
+        }
+      } else {
+        atomicAdd(&dEmb[(size_t)a.atomic[at] * a.emb_dim + k], dv);
+      }
+    } else {
+      const int r = k - a.emb_dim;
+      atomicAdd(&dbr[r], dv);
+      atomicAdd(&dWr[r], a.ring[(size_t)at * 2] * dv);
+      atomicAdd(&dWr[10 + r], a.ring[(size_t)at * 2 + 1] * dv);
+    }
+  }
+}
+void launch_embed_general_bwd(const EmbedArgs& a, const float* dc0, float* dEmb, float* dWe, float* dbe, float* dWr, float* dbr,
+                              float* dWde, float* dbde, hipStream_t s) {
+  if (a.n_atom > 0)
+    hipLaunchKernelGGL(embed_general_bwd_kernel, dim3((a.n_atom + 7) / 8), dim3(128), 0, s, a, dc0, dEmb, dWe, dbe, dWr, dbr, dWde, dbde);
+}
+
 // ---- loss ------------------------------------------------------------------------------------------------------------------
 __global__ void sse_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, double* __restrict__ out) {
   double s = 0.0;

@@ -272,3 +272,40 @@ def test_attention_dropout_gradients(hip_lib):
     assert max(errs.values()) <= 3e-3, {k: v for k, v in errs.items() if v > 3e-3}
     eng.set_attention_dropout(0.0)
     rb.free()
+
+
+@pytest.mark.parametrize("ring,cgcnn", [(True, False), (False, True), (True, True)], ids=["ring", "cgcnn", "ring+cgcnn"])
+def test_ring_cgcnn_embedding_gradients(hip_lib, ring, cgcnn):
+    """Backward of the general embedding path (use_ring / feature="cgcnn", scann_model.py:361-374)."""
+    import torch_ref
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    cfg["model"].update(n_attention=1, use_ring=ring, feature="cgcnn" if cgcnn else "atomic")
+    w = so.init_weights(cfg, 8, perturb=True)
+    de, dn = so.synth_dataset(6, 3, use_ring=ring)
+    inputs, targets = so.pad_batch(de, dn, True, use_ring=ring)
+    if cgcnn:
+        table = np.random.default_rng(5).integers(0, 2, size=(101, 92)).astype("float32")
+        inputs["atomic"] = table[inputs["atomic"]]
+    pk = _hip.pack_inputs(inputs)
+    model = HipModel(cfg, w, device=0)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    _, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6)
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+    errs = grad_errors(got, ref)
+    assert max(errs.values()) <= 2e-3, {k: v for k, v in errs.items() if v > 2e-3}
+    eng.adam_step(1e-3)  # also exercises the re-pack without the species LUT
+    s2 = eng.train_forward(rb, targets)
+    assert np.isfinite(s2)
+    rb.free()

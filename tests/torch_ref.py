@@ -46,7 +46,7 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_s
         c = torch.tensor(np.linspace(0, stop, 20, dtype="float32"), dtype=dt)
         return torch.exp(-((x[:, None] - c[None, :]) ** 2) / 0.25)
 
-    atomic = torch.tensor(pk.atomic, dtype=torch.long)
+    atomic = torch.tensor(pk.atomic, dtype=torch.long) if pk.atomic is not None else None
     col = torch.tensor(pk.edge_col, dtype=torch.long)
     deg = np.diff(pk.edge_offset)
     row = torch.tensor(np.repeat(np.arange(pk.n_atom), deg), dtype=torch.long)
@@ -54,7 +54,13 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_s
     wgt = torch.tensor(pk.edge_weight, dtype=dt)
     A, E = pk.n_atom, pk.n_edge
 
-    c = F.silu(lin(F.embedding(atomic, W["embed_atom/embeddings"]), "dense_embed"))
+    if cfg.get("feature", "atomic") == "cgcnn":  # scann_model.py:365
+        v = lin(torch.tensor(pk.cgcnn, dtype=dt), "embed_atom")
+    else:
+        v = F.embedding(atomic, W["embed_atom/embeddings"])
+    if cfg.get("use_ring", False):  # scann_model.py:367-371
+        v = torch.cat([v, lin(torch.tensor(pk.ring, dtype=dt), "extra_embed")], -1)
+    c = F.silu(lin(v, "dense_embed"))
     gd = gauss(dist, cfg["gaussian_d"])
     if cfg["g_update"]:
         geom = F.silu(lin(gd, "neighbor_d")) * F.silu(lin(gauss(wgt, math.pi * 2), "neighbor_w"))
