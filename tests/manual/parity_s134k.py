@@ -5,7 +5,7 @@ error of the predictions, of the GA scores, and the "HOMO MAE" the reference's e
 (scann_model.py:273-280) for both against the same synthetic targets.  ~2-3 minutes, dominated by the CPU side."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle"), ROOT]
 import bench
 os.environ.setdefault("OMP_NUM_THREADS", str(bench.host_cores()))

@@ -2,7 +2,7 @@
 """PCIe-inclusive rate of the drop-in call: model.predict(padded dict) = pack (NumPy) + upload + forward + download."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle"), ROOT]
 import scann_oracle as so   # only to build a padded dict the way DataIterator does
 from scann import _hip
