@@ -583,9 +583,12 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
   return x * q + min(x, r) + i;
 }
 
-__global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
-  constexpr int TEK = 64;
-  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];
+// RTW = 32-row MFMA row tiles per workgroup: 2 -> 64-edge tiles, 512 threads (default); 1 -> 32-edge tiles, 256 threads.
+template <int RTW>
+__global__ __launch_bounds__(256 * RTW, 4) void edge_kernel_w8(EdgeArgs a) {
+  constexpr int TEK = 32 * RTW;
+  constexpr int NT = 256 * RTW;  // threads
+  __shared__ __attribute__((aligned(16))) float sA[(TEK > TA ? TEK : TA) * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sB[TEK * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
   __shared__ __attribute__((aligned(16))) float sPar[4 * D];
@@ -606,13 +609,13 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   } else if (tid - TEK <= natom) {
     sOff[tid - TEK] = a.edge_offset[tile.atom_begin + (tid - TEK)] - eb;
   }
-  {
-    const float* src = tid < D ? a.p.lng_g : tid < 2 * D ? a.p.lng_b : tid < 3 * D ? a.p.ln_g : a.p.ln_b;
-    sPar[tid] = src[tid & (D - 1)];
+  for (int i = tid; i < 4 * D; i += NT) {
+    const float* src = i < D ? a.p.lng_g : i < 2 * D ? a.p.lng_b : i < 3 * D ? a.p.ln_g : a.p.ln_b;
+    sPar[i] = src[i & (D - 1)];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 512 * i, r = idx >> 5, c4 = idx & 31;
+    const int idx = tid + NT * i, r = idx >> 5, c4 = idx & 31;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < ne) v = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
     *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = v;
@@ -682,10 +685,11 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
       }
     }
   }
-  float4 qreg[2];
+  constexpr int NQ = 1024 / NT;
+  float4 qreg[NQ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = tid + 512 * i, la = idx >> 5, c4 = idx & 31;
+  for (int i = 0; i < NQ; ++i) {
+    const int idx = tid + NT * i, la = idx >> 5, c4 = idx & 31;
     qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (la < natom) qreg[i] = reinterpret_cast<const float4*>(a.q)[(size_t)(tile.atom_begin + la) * 32 + c4];
   }
@@ -705,8 +709,8 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = tid + 512 * i, la = idx >> 5, c4 = idx & 31;
+  for (int i = 0; i < NQ; ++i) {
+    const int idx = tid + NT * i, la = idx >> 5, c4 = idx & 31;
     *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
   }
   __syncthreads();
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   // evaluated with rescaling instead of three passes); two edges per iteration so their LDS reads overlap.
   {
     const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
-    for (int la = lgp; la < natom; la += 16) {
+    for (int la = lgp; la < natom; la += NT / 32) {
       const int e0 = sOff[la], e1 = sOff[la + 1];
       float m = -INFINITY, ssum = 0.f;
       float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -768,8 +772,8 @@ __global__ __launch_bounds__(512, 4) void edge_kernel_w8(EdgeArgs a) {
   __syncthreads();
   STAMP(a.stamps, 9);
   // LayerNorm of the context rows: 16 threads per atom row
-  {
-    const int r = tid >> 4, sub = tid & 15;
+  for (int r = tid >> 4; r < TA; r += NT / 16) {
+    const int sub = tid & 15;
     if (r < natom) {
       float4 t[2];
       float s = 0.f;
@@ -1164,8 +1168,12 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(edge_kernel_persistent, dim3(nwg), dim3(P_THREADS), 0, s, a);
     return;
   }
+  if (a.waves8 && a.g_update && a.tile_rows == 32) {
+    hipLaunchKernelGGL(edge_kernel_w8<1>, dim3(a.n_tile), dim3(256), 0, s, a);
+    return;
+  }
   if (a.waves8 && a.g_update && a.tile_rows == 64) {
-    hipLaunchKernelGGL(edge_kernel_w8, dim3(a.n_tile), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(edge_kernel_w8<2>, dim3(a.n_tile), dim3(512), 0, s, a);
     return;
   }
   const dim3 grid(a.n_tile), block(256);

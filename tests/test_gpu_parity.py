@@ -354,9 +354,10 @@ def test_degenerate_batches(hip_lib):
 @pytest.mark.parametrize("env", [
     {"SCANN_EDGE_W8": "0"},                              # 4-wave edge_kernel<true, 2>
     {"SCANN_EDGE_W8": "0", "SCANN_EDGE_TILE": "32"},     # 32-row tiles, edge_kernel<true, 1>
+    {"SCANN_EDGE_TILE": "32"},                           # edge_kernel_w8<1>: 32-row tiles, 4-wave workgroups
     {"SCANN_PERSIST_MIN": "1"},                          # persistent wave-specialised kernel for every launch
     {"SCANN_XCD_REMAP": "0", "SCANN_STREAMS": "2"},
-], ids=["w4", "w4_tile32", "persistent", "no_remap_2streams"])
+], ids=["w4", "w4_tile32", "w8_tile32", "persistent", "no_remap_2streams"])
 def test_alternative_edge_kernels(hip_lib, env, monkeypatch):
     """The opt-in kernel variants (selected by environment at scann_create) stay at parity."""
     for k, v in env.items():
