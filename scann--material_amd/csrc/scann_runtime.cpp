@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,74 @@ using namespace scann;
 namespace {
 
 constexpr int MAX_STREAM = 16;
+
+// Per-device cache of freed device blocks: resident batches, their keep/debug buffers and training workspaces are
+// allocated per batch, and pipelines (predict_dataset, the training loop) create and drop one per step -- reusing a
+// block of similar size avoids a hipMalloc/hipFree pair (hundreds of microseconds, and an implicit device sync) each time.
+struct BlockCache {
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> size_of;
+  size_t cached_bytes = 0;
+};
+std::map<int, BlockCache> g_block_cache;
+std::mutex g_block_mu;
+constexpr size_t BLOCK_CACHE_LIMIT = (size_t)16 << 30;  // per device
+
+hipError_t cached_malloc(void** p, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t gran = bytes >= ((size_t)1 << 20) ? ((size_t)1 << 20) : ((size_t)64 << 10);
+  const size_t want = (std::max<size_t>(bytes, 1) + gran - 1) / gran * gran;
+  {
+    std::lock_guard<std::mutex> lk(g_block_mu);
+    BlockCache& c = g_block_cache[dev];
+    auto it = c.free_blocks.lower_bound(want);
+    if (it != c.free_blocks.end() && it->first <= 2 * want) {
+      *p = it->second;
+      c.cached_bytes -= it->first;
+      c.free_blocks.erase(it);
+      return hipSuccess;
+    }
+  }
+  const hipError_t e = hipMalloc(p, want);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(g_block_mu);
+    g_block_cache[dev].size_of[*p] = want;
+  }
+  return e;
+}
+
+// The caller guarantees no kernel still uses the block (scann_batch_free synchronises first).
+void cached_free(void* p) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_block_mu);
+  BlockCache& c = g_block_cache[dev];
+  auto it = c.size_of.find(p);
+  if (it == c.size_of.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  if (c.cached_bytes + it->second > BLOCK_CACHE_LIMIT) {
+    c.size_of.erase(it);
+    (void)hipFree(p);
+    return;
+  }
+  c.free_blocks.emplace(it->second, p);
+  c.cached_bytes += it->second;
+}
+
+void cache_release(int dev) {  // at handle destruction: give the idle blocks of this device back
+  std::lock_guard<std::mutex> lk(g_block_mu);
+  BlockCache& c = g_block_cache[dev];
+  for (auto& kv : c.free_blocks) {
+    c.size_of.erase(kv.second);
+    (void)hipFree(kv.second);
+  }
+  c.free_blocks.clear();
+  c.cached_bytes = 0;
+}
 thread_local std::string g_create_error;
 
 struct WeightSpec {
@@ -99,6 +168,8 @@ struct scann_dbatch {
   int last_slot = 0;
   bool owns_arena = true;  // false: the arena belongs to the handle's scratch (scann_forward)
 };
+
+static void free_train_ws(scann_dbatch* db);
 
 namespace {
 
@@ -266,13 +337,15 @@ void scann_destroy(scann_handle_t* h) {
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->sc_db) {
-    if (h->sc_db->dbg_c) (void)hipFree(h->sc_db->dbg_c);
-    if (h->sc_db->dbg_g) (void)hipFree(h->sc_db->dbg_g);
-    if (h->sc_db->dbg_ctx) (void)hipFree(h->sc_db->dbg_ctx);
+    cached_free(h->sc_db->dbg_c);
+    cached_free(h->sc_db->dbg_g);
+    cached_free(h->sc_db->dbg_ctx);
+    free_train_ws(h->sc_db);
     delete h->sc_db;
   }
   if (h->sc_arena) (void)hipFree(h->sc_arena);
   if (h->sc_host) (void)hipHostFree(h->sc_host);
+  cache_release(h->device);
   delete h;
 }
 
@@ -489,10 +562,10 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   if (!db) return;
   if (h) (void)hipSetDevice(h->device);
   if (h) (void)hipDeviceSynchronize();
-  if (db->arena && db->owns_arena) (void)hipFree(db->arena);
-  if (db->dbg_c) (void)hipFree(db->dbg_c);
-  if (db->dbg_g) (void)hipFree(db->dbg_g);
-  if (db->dbg_ctx) (void)hipFree(db->dbg_ctx);
+  if (db->arena && db->owns_arena) cached_free(db->arena);
+  cached_free(db->dbg_c);
+  cached_free(db->dbg_g);
+  cached_free(db->dbg_ctx);
   if (db->stamps) (void)hipFree(db->stamps);
   free_train_ws(db);
   delete db;
@@ -561,9 +634,9 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (!h->sc_db) h->sc_db = new scann_dbatch();
     db = h->sc_db;
     if (db->dbg_c || db->stamps) (void)hipStreamSynchronize(h->streams[0]);
-    if (db->dbg_c) (void)hipFree(db->dbg_c);
-    if (db->dbg_g) (void)hipFree(db->dbg_g);
-    if (db->dbg_ctx) (void)hipFree(db->dbg_ctx);
+    cached_free(db->dbg_c);
+    cached_free(db->dbg_g);
+    cached_free(db->dbg_ctx);
     if (db->stamps) (void)hipFree(db->stamps);
     free_train_ws(db);
     *db = scann_dbatch();
@@ -604,7 +677,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     db->arena = h->sc_arena;
     img_ptr = h->sc_host;
   } else {
-    e = hipMalloc((void**)&db->arena, off);
+    e = cached_malloc((void**)&db->arena, off);
     img_vec.assign(in_bytes, 0);
     img_ptr = img_vec.data();
   }
@@ -632,7 +705,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   }
   if (e != hipSuccess) {
     if (!scratch) {
-      (void)hipFree(db->arena);
+      cached_free(db->arena);
       delete db;
     }
     return fail(h, SCANN_ERR_HIP, std::string("hipMemcpy(batch inputs): ") + hipGetErrorString(e));
@@ -674,9 +747,9 @@ struct Timer {
 int ensure_debug(scann_handle* h, scann_dbatch* db) {
   const int L = h->cfg.n_attention;
   if (db->dbg_layers == L) return SCANN_OK;
-  HIPCHK(h, hipMalloc((void**)&db->dbg_c, (size_t)(L + 1) * db->n_atom * D * 4));
-  HIPCHK(h, hipMalloc((void**)&db->dbg_ctx, (size_t)std::max(L, 1) * db->n_atom * D * 4));
-  if (h->cfg.g_update) HIPCHK(h, hipMalloc((void**)&db->dbg_g, (size_t)(L + 1) * std::max(db->n_edge, 1) * D * 4));
+  HIPCHK(h, cached_malloc((void**)&db->dbg_c, (size_t)(L + 1) * db->n_atom * D * 4));
+  HIPCHK(h, cached_malloc((void**)&db->dbg_ctx, (size_t)std::max(L, 1) * db->n_atom * D * 4));
+  if (h->cfg.g_update) HIPCHK(h, cached_malloc((void**)&db->dbg_g, (size_t)(L + 1) * std::max(db->n_edge, 1) * D * 4));
   db->dbg_layers = L;
   return SCANN_OK;
 }
@@ -992,7 +1065,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   const size_t rowB = align_up((size_t)db->n_struct * D * 4);
   const size_t total = 10 * rowA + 10 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
                        align_up((size_t)h->cfg.n_atoms * D * 4) + 256;
-  HIPCHK(h, hipMalloc((void**)&w.arena, total));
+  HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   for (int i = 0; i < 10; ++i) { w.tA[i] = (float*)p; p += rowA; }
   for (int i = 0; i < 10; ++i) { w.tE[i] = (float*)p; p += rowE; }
@@ -1010,7 +1083,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
 static void free_train_ws(scann_dbatch* db) {
   auto it = g_train_ws.find(db);
   if (it == g_train_ws.end()) return;
-  if (it->second.arena) (void)hipFree(it->second.arena);
+  cached_free(it->second.arena);
   g_train_ws.erase(it);
 }
 
