@@ -67,3 +67,40 @@ def load_dataset(dataset, dataset_neighbor, target_prop, use_ref=False, use_ring
     data_energy = np.array(rows, dtype="object") if len(rows) else data_energy
     data_neighbor = np.array(np.load(dataset_neighbor, allow_pickle=True), dtype="object")
     return data_energy, data_neighbor
+
+
+def prepare_input_from_neighbors(atomic_numbers, neighbors, angle=True):
+    """Input dict for ONE structure from its per-atom neighbour lists -- the second half of the reference's
+    ``prepare_input_pmt`` (general.py:220-244).  ``neighbors[a]`` is the list the Voronoi step produces for atom ``a``:
+    ``[species, index, solid_angle, ratio, distance]`` entries (voronoi_neighbor.py:38-47); ``angle`` selects the raw solid
+    angle (SCANN+, g_update) or the normalised ratio, as in the reference."""
+    local_neighbor = np.array([pad_sequence([[n[1] for n in lc] for lc in neighbors], value=1000)], "int32")
+    mask_local = local_neighbor != 1000
+    local_neighbor[~mask_local] = 0
+    wi = 2 if angle else 3
+    local_weight = np.array([pad_sequence([[n[wi] for n in lc] for lc in neighbors], dtype="float32")])
+    local_distance = np.array([pad_sequence([[n[-1] for n in lc] for lc in neighbors], dtype="float32")])
+    atomics = np.array([list(atomic_numbers)], "int32")
+    return {
+        "atomic": atomics,
+        "atom_mask": np.expand_dims(atomics != 0, -1),
+        "neighbors": local_neighbor,
+        "neighbor_mask": mask_local,
+        "neighbor_weight": local_weight,
+        "neighbor_distance": local_distance,
+    }
+
+
+def prepare_input_pmt(struct, d_t=4.0, w_t=0.4, angle=True):
+    """README entry point (general.py:206-246).  The Voronoi neighbour search itself (pymatgen ``VoronoiNN``,
+    voronoi_neighbor.py:11-61) is outside the accelerated path and not re-implemented: with pymatgen installed this
+    delegates to it, otherwise it says so."""
+    try:
+        from pymatgen.analysis.local_env import VoronoiNN  # noqa: F401
+    except ImportError as e:  # pragma: no cover - pymatgen is absent in this image
+        raise ImportError("prepare_input_pmt needs pymatgen for the Voronoi neighbour search; build the neighbour lists "
+                          "elsewhere and call prepare_input_from_neighbors(atomic_numbers, neighbors, angle)") from e
+    from .voronoi import compute_voronoi_neighbor  # pragma: no cover
+
+    neighbors = compute_voronoi_neighbor(struct, d_thresh=d_t, w_thresh=w_t)  # pragma: no cover
+    return prepare_input_from_neighbors(struct.atomic_numbers, neighbors, angle)  # pragma: no cover

@@ -312,3 +312,16 @@ def test_input_output_names_match_the_reference_notebook():
 
     assert INPUT_NAMES + ["ring_aromatic"] == ["atomic", "atom_mask", "neighbors", "neighbor_mask", "neighbor_weight",
                                                "neighbor_distance", "ring_aromatic"]
+
+
+def test_prepare_input_from_neighbors_matches_batch_of_one():
+    from scann import _hip
+    from scann.utils import prepare_input_from_neighbors
+
+    de, dn = so.synth_dataset(1, 33)
+    for angle in (True, False):
+        got = prepare_input_from_neighbors(de[0][0], dn[0], angle=angle)
+        ref, _ = so.pad_batch(de, dn, g_update=angle)
+        for k in ref:
+            assert np.array_equal(got[k], ref[k]), k
+        assert _hip.pack_inputs(got).n_edge == int(ref["neighbor_mask"].sum())
