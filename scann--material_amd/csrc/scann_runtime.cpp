@@ -336,6 +336,7 @@ void scann_destroy(scann_handle_t* h) {
   for (void* q : {(void*)h->t_master, (void*)h->t_grad, (void*)h->t_m, (void*)h->t_v, (void*)h->t_l2, (void*)h->t_descs})
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
+  for (hipEvent_t e : h->time_ev) (void)hipEventDestroy(e);
   if (h->sc_db) {
     cached_free(h->sc_db->dbg_c);
     cached_free(h->sc_db->dbg_g);
@@ -1056,9 +1057,15 @@ struct scann_train_ws {  // per resident batch, allocated on first use
 namespace {
 
 std::map<scann_dbatch*, scann_train_ws> g_train_ws;  // keyed by batch; freed with the batch
+std::mutex g_train_mu;                               // handles may live on different threads
 
 int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
-  scann_train_ws& w = g_train_ws[db];
+  scann_train_ws* wp = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_train_mu);
+    wp = &g_train_ws[db];  // std::map nodes are stable: the pointer stays valid after the lock is dropped
+  }
+  scann_train_ws& w = *wp;
   *out = &w;
   if (w.arena) return SCANN_OK;
   const size_t rowA = align_up((size_t)db->n_atom * D * 4), rowE = align_up((size_t)std::max(db->n_edge, 1) * D * 4);
@@ -1081,6 +1088,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
 }  // namespace
 
 static void free_train_ws(scann_dbatch* db) {
+  std::lock_guard<std::mutex> lk(g_train_mu);
   auto it = g_train_ws.find(db);
   if (it == g_train_ws.end()) return;
   cached_free(it->second.arena);
@@ -1206,10 +1214,16 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
 
 int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_global, int64_t count_global) {
   if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_train_backward: null argument");
-  if (!h->t_grad || g_train_ws.find(db) == g_train_ws.end() || db->dbg_layers != h->cfg.n_attention)
+  scann_train_ws* wp = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_train_mu);
+    auto it = g_train_ws.find(db);
+    if (it != g_train_ws.end()) wp = &it->second;
+  }
+  if (!h->t_grad || !wp || db->dbg_layers != h->cfg.n_attention)
     return fail(h, SCANN_ERR_INVALID, "scann_train_backward: run scann_train_forward on this batch first");
   HIPCHK(h, hipSetDevice(h->device));
-  scann_train_ws& w = g_train_ws[db];
+  scann_train_ws& w = *wp;
   hipStream_t s = h->streams[0];
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
@@ -1402,15 +1416,15 @@ int scann_allreduce_sse(scann_handle_t* h, double* sse, int64_t* count) {
   if (!h->comm || h->comm_world == 1) return SCANN_OK;
   HIPCHK(h, hipSetDevice(h->device));
   double* d = nullptr;
-  HIPCHK(h, hipMalloc((void**)&d, 2 * sizeof(double)));
+  HIPCHK(h, cached_malloc((void**)&d, 2 * sizeof(double)));
   const double v[2] = {*sse, (double)*count};
   HIPCHK(h, hipMemcpy(d, v, sizeof(v), hipMemcpyHostToDevice));
   const ncclResult_t r = ncclAllReduce(d, d, 2, ncclDouble, ncclSum, h->comm, h->streams[0]);
-  if (r != ncclSuccess) { (void)hipFree(d); return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+  if (r != ncclSuccess) { cached_free(d); return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
   double o[2];
   HIPCHK(h, hipStreamSynchronize(h->streams[0]));
   HIPCHK(h, hipMemcpy(o, d, sizeof(o), hipMemcpyDeviceToHost));
-  (void)hipFree(d);
+  cached_free(d);
   *sse = o[0];
   *count = (int64_t)(o[1] + 0.5);
   return SCANN_OK;

@@ -93,8 +93,6 @@ class Communicator:
     def shard(self, packed):
         if self.world == 1:
             return packed, slice(0, packed.n_struct)
-        from ..parallel import split_packed  # contiguous structure ranges, one per rank
-
         lo, hi = rank_slice(packed.n_struct, self.rank, self.world)
         return _slice_packed(packed, lo, hi), slice(lo, hi)
 
