@@ -99,9 +99,11 @@ __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (
 
 // ---- atom-tile kernel ------------------------------------------------------------------------------
 
-// Weights are double-buffered in registers: the slab for GEMM g+1 is requested before the MFMAs of GEMM g.
+// One weight slab (64 VGPRs) is live at a time: each slab is requested right after the previous GEMM's MFMAs and pinned
+// there with sched_barrier (hipcc otherwise hoists it above them and keeps two slabs live: 202 VGPRs, 2 waves/SIMD).
+// 158 VGPRs -> 3 waves per SIMD = 3 workgroups per CU; +1.7 % end to end.  (4 waves/SIMD spills.)
 template <bool FFN, int MODE>
-__global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
+__global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[TA * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sH[TA * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
   // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
   const float* const firstW = MODE == 1 ? a.WCp : a.WAp;
 
-  float4 wA[16], wB[16];
+  float4 wA[16];
   if (FFN) load_w(a.Wf1p, wave, lane, wA);
   else load_w(firstW, wave, lane, wA);
 
@@ -138,9 +140,11 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
   f32x16 acc[1];
   if (FFN) {
     // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
-    load_w(a.Wf2p, wave, lane, wB);
     zero_acc(acc);
     mma128<1>(sX, wA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(a.Wf2p, wave, lane, wA);
+    __builtin_amdgcn_sched_barrier(0);
     {
       const float b = a.bf1[col];
 #pragma unroll
@@ -148,9 +152,11 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
     }
     __syncthreads();
     // y = h W2 + b2 ; t = x + y
-    load_w(firstW, wave, lane, wA);
     zero_acc(acc);
-    mma128<1>(sH, wB, lane, acc);
+    mma128<1>(sH, wA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(firstW, wave, lane, wA);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave is done reading sH
     {
       const float b = a.bf2[col];
@@ -206,9 +212,11 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
   }
 
   if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
-    load_w(a.WBp, wave, lane, wB);
     zero_acc(acc);
     mma128<1>(sX, wA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(a.WBp, wave, lane, wA);
+    __builtin_amdgcn_sched_barrier(0);
     {
       const float b = a.bA[col];
 #pragma unroll
@@ -217,9 +225,11 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
         if (r < nrows) a.oA[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
       }
     }
-    load_w(a.WCp, wave, lane, wA);
     zero_acc(acc);
-    mma128<1>(sX, wB, lane, acc);
+    mma128<1>(sX, wA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(a.WCp, wave, lane, wA);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = acc_row(i, lane);
@@ -237,18 +247,22 @@ __global__ __launch_bounds__(256) void atom_kernel(AtomArgs a) {
     }
   }
   if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
-    load_w(a.WCp, wave, lane, wB);
     zero_acc(acc);
     mma128<1>(sX, wA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(a.WCp, wave, lane, wA);
+    __builtin_amdgcn_sched_barrier(0);
     {
       const float b = a.bA[col];
 #pragma unroll
       for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b);
     }
     __syncthreads();
-    load_w(a.WDp, wave, lane, wA);
     zero_acc(acc);
-    mma128<1>(sH, wB, lane, acc);
+    mma128<1>(sH, wA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(a.WDp, wave, lane, wA);
+    __builtin_amdgcn_sched_barrier(0);
     {
       const float b = a.bC[col];
 #pragma unroll
