@@ -152,7 +152,7 @@ struct scann_handle {
 };
 
 struct scann_dbatch {
-  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0, tile_rows = 64;
+  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0, tile_rows = 64, max_degree = 0;
   char* arena = nullptr;  // inputs + workspace, one allocation
   // inputs
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
@@ -598,6 +598,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   if (h->cfg.use_ring && !b->ring) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: use_ring needs batch.ring [n_atom,2]");
   std::vector<int32_t> edge_row((size_t)E);
   std::vector<EdgeTile> tiles;
+  int32_t max_degree = 0;
   int tile_rows = h->edge_tile;
   for (int pass = 0; pass < 2; ++pass) {
     const int want = tile_rows;
@@ -610,6 +611,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
       if (e1 < e0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: edge_offset not monotone");
       if (e1 - e0 > TE_MAX)
         return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: an atom has more than 64 neighbours (edge-tile limit)");
+      max_degree = std::max(max_degree, e1 - e0);
       if (e1 - e0 > tile_rows) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom: fall back to 64-row tiles
       for (int e = e0; e < e1; ++e) {
         if (b->edge_col[e] < b->mol_offset[s] || b->edge_col[e] >= b->mol_offset[s + 1])
@@ -645,7 +647,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   } else {
     db = new scann_dbatch();
   }
-  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows;
+  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows; db->max_degree = max_degree;
   // arena layout: inputs first (one H2D copy), then workspace
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
@@ -1296,7 +1298,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
       launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
       HIPCHK(h, hipMemsetAsync(dC, 0, nA * 4, s));
-      launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A,
+      launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
       launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
       launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
@@ -1307,13 +1309,17 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       continue;
     }
     // forward recompute of what the fused kernels do not keep
-    launch_linear(c_in, p.W1p, p.bg, db->P1, nullptr, A, 0, s);
-    launch_linear(c_in, p.W3p, nullptr, db->P3, nullptr, A, 0, s);
-    launch_linear(c_in, p.Wqp, p.bq, db->q, nullptr, A, 0, s);
+    {  // P1, P3, q recomputed by the forward kernel itself (one launch; its copy of the input rows goes to a scratch)
+      AtomArgs ra2{};
+      ra2.x = c_in; ra2.n_atom = A; ra2.ffn = 0; ra2.c = t4; ra2.mode = 0;
+      ra2.WAp = p.W1p; ra2.bA = p.bg; ra2.WBp = p.W3p; ra2.WCp = p.Wqp; ra2.bC = p.bq;
+      ra2.oA = db->P1; ra2.oB = db->P3; ra2.oC = db->q;
+      launch_atom(ra2, s);
+    }
     launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
     launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
     HIPCHK(h, hipMemsetAsync(dC, 0, nA * 4, s));                 // dC now collects d loss / d centres_l
-    launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A,
+    launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
     launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang

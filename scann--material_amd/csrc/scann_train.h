@@ -39,7 +39,7 @@ void launch_edge_dv(const float* V, const float* dT, const int* ctr, const int* 
                     int n_edge, hipStream_t s);
 void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s);
 void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
-                     float* dK, float* dgamma, float* dbeta, int n_atom, float drop_p, unsigned drop_tag,
+                     float* dK, float* dgamma, float* dbeta, int n_atom, int max_degree, float drop_p, unsigned drop_tag,
                      unsigned long long drop_seed, hipStream_t s);
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);
 void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weight, const float* dgeom, int n_edge, float* dWd,

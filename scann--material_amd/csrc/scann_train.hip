@@ -24,34 +24,36 @@ __device__ __forceinline__ int acc_row_(int i, int lane) { return (i & 3) + 8 * 
 
 // ---- linear: Y = act(X . W + b) on 64-row tiles (same MFMA fragment scheme as the forward kernels) -----------------
 // flags: bit0 accumulate into Y, bit1 swish.  P (optional) receives the pre-activation X.W + b.
+template <int RT>  // 32-row MFMA row tiles per workgroup: 2 for edge-sized inputs, 1 for atom-sized ones (more workgroups)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                      const float* __restrict__ bias, float* __restrict__ Y,
                                                      float* __restrict__ P, int rows, int flags) {
-  __shared__ __attribute__((aligned(16))) float sX[64 * LDS_STRIDE];
+  constexpr int TR = 32 * RT;
+  __shared__ __attribute__((aligned(16))) float sX[TR * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * 64;
-  const int nrows = min(64, rows - row0);
+  const int row0 = blockIdx.x * TR;
+  const int nrows = min(TR, rows - row0);
   const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + wave * (16 * 64) + lane;
   float4 w[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) w[t] = wsrc[t * 64];
-  for (int i = tid; i < 64 * 32; i += 256) {
+  for (int i = tid; i < TR * 32; i += 256) {
     const int r = i >> 5, c4 = i & 31;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < nrows) v = reinterpret_cast<const float4*>(X)[(size_t)(row0 + r) * 32 + c4];
     *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
   }
   __syncthreads();
-  f32x16 acc[2];
+  f32x16 acc[RT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
   const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
 #pragma unroll
   for (int t = 0; t < 16; ++t)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[rt], 0, 0, 0);
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[rt], 0, 0, 0);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
   const int col = 32 * wave + (lane & 31);
   const float b = bias ? bias[col] : 0.f;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = 32 * rt + acc_row_(i, lane);
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
 void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags,
                    hipStream_t s) {
   if (rows <= 0) return;
-  hipLaunchKernelGGL(linear_kernel, dim3((rows + 63) / 64), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
+  if (rows >= 8192) hipLaunchKernelGGL(linear_kernel<2>, dim3((rows + 63) / 64), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
+  else hipLaunchKernelGGL(linear_kernel<1>, dim3((rows + 31) / 32), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
 }
 
 // ---- weight gradient: dW[i][j] += sum_rows X[row][i] dY[row][j];  db[j] += sum_rows dY[row][j] ---------------------
@@ -429,10 +432,108 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   atomicAdd(&dbeta[2 * lane], dbt.x);
   atomicAdd(&dbeta[2 * lane + 1], dbt.y);
 }
+// Fast path when no atom of the batch has more than 16 neighbours (QM9: <= 12): the atom's key rows, logits and
+// attention gradients live in registers, so K is read once and the 8-lane dot-product reductions run once per edge.
+__global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict__ q, const float* __restrict__ K,
+                                                         const int* __restrict__ edge_offset,
+                                                         const float* __restrict__ dctx, const float* __restrict__ gamma,
+                                                         float* __restrict__ dq, float* __restrict__ dK,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int n_atom,
+                                                         float drop_p, unsigned drop_tag, unsigned long long drop_seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int at = blockIdx.x * 4 + wave;
+  const float2 g = reinterpret_cast<const float2*>(gamma)[lane];
+  float2 dg = make_float2(0.f, 0.f), dbt = dg;
+  if (at < n_atom) {
+    const int e0 = edge_offset[at], deg = edge_offset[at + 1] - e0;
+    const float2 q2 = reinterpret_cast<const float2*>(q)[(size_t)at * 64 + lane];
+    const float qx = q2.x * 0.25f, qy = q2.y * 0.25f;
+    float2 k2[16];
+    float ev[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      k2[n] = n < deg ? reinterpret_cast<const float2*>(K)[(size_t)(e0 + n) * 64 + lane] : make_float2(0.f, 0.f);
+      float e = qx * k2[n].x + qy * k2[n].y;
+      e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
+      ev[n] = n < deg ? e : -INFINITY;
+      m = fmaxf(m, ev[n]);
+    }
+    float ssum = 0.f;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      ev[n] = n < deg ? expf(ev[n] - m) : 0.f;
+      ssum += ev[n];
+    }
+    float px = q2.x, py = q2.y;
+    float keep[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      ev[n] = deg > 0 ? ev[n] / ssum : 0.f;  // attention weight
+      keep[n] = (drop_p > 0.f && n < deg) ? drop_scale(drop_seed, drop_tag, (size_t)(e0 + n) * NHEAD + (lane >> 3), drop_p) : 1.0f;
+      px += ev[n] * keep[n] * k2[n].x;
+      py += ev[n] * keep[n] * k2[n].y;
+    }
+    float s = px + py;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / D);
+    const float cx = px - mean, cy = py - mean;
+    float v = cx * cx + cy * cy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+    const float hx = cx * rstd, hy = cy * rstd;
+    const float2 dyv = reinterpret_cast<const float2*>(dctx)[(size_t)at * 64 + lane];
+    const float ax = dyv.x * g.x, ay = dyv.y * g.y;
+    float m1 = ax + ay, m2 = ax * hx + ay * hy;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      m1 += __shfl_xor(m1, o);
+      m2 += __shfl_xor(m2, o);
+    }
+    m1 *= (1.0f / D); m2 *= (1.0f / D);
+    const float dpx = rstd * (ax - m1 - hx * m2), dpy = rstd * (ay - m1 - hy * m2);
+    dg.x = dyv.x * hx; dg.y = dyv.y * hy; dbt.x = dyv.x; dbt.y = dyv.y;
+    float da[16];
+    float dot = 0.f;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      float d = dpx * k2[n].x + dpy * k2[n].y;
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      da[n] = d * keep[n];
+      dot += ev[n] * da[n];
+    }
+    float dqx = dpx, dqy = dpy;
+#pragma unroll
+    for (int n = 0; n < 16; ++n)
+      if (n < deg) {
+        const float de = ev[n] * (da[n] - dot);
+        reinterpret_cast<float2*>(dK)[(size_t)(e0 + n) * 64 + lane] =
+            make_float2(ev[n] * keep[n] * dpx + 0.25f * de * q2.x, ev[n] * keep[n] * dpy + 0.25f * de * q2.y);
+        dqx += 0.25f * de * k2[n].x;
+        dqy += 0.25f * de * k2[n].y;
+      }
+    reinterpret_cast<float2*>(dq)[(size_t)at * 64 + lane] = make_float2(dqx, dqy);
+  }
+  __shared__ float sred[4][4 * 64];
+  sred[wave][lane] = dg.x; sred[wave][64 + lane] = dg.y; sred[wave][128 + lane] = dbt.x; sred[wave][192 + lane] = dbt.y;
+  __syncthreads();
+  const int t = threadIdx.x;
+  const float tot = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+  const int ln = t & 63, which = t >> 6;
+  atomicAdd((which < 2 ? dgamma : dbeta) + 2 * ln + (which & 1), tot);
+}
+
 void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
-                     float* dK, float* dgamma, float* dbeta, int n_atom, float drop_p, unsigned drop_tag,
+                     float* dK, float* dgamma, float* dbeta, int n_atom, int max_degree, float drop_p, unsigned drop_tag,
                      unsigned long long drop_seed, hipStream_t s) {
   if (n_atom <= 0) return;
+  if (max_degree <= 16) {
+    hipLaunchKernelGGL(attn_bwd16_kernel, dim3((n_atom + 3) / 4), dim3(256), 0, s, q, K, edge_offset, dctx, gamma, dq, dK,
+                       dgamma, dbeta, n_atom, drop_p, drop_tag, drop_seed);
+    return;
+  }
   const int apw = 2;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((n_atom + 4 * apw - 1) / (4 * apw)), dim3(256), 0, s, q, K, edge_offset, dctx,
                      gamma, dq, dK, dgamma, dbeta, n_atom, apw, drop_p, drop_tag, drop_seed);

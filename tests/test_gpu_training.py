@@ -309,3 +309,33 @@ def test_ring_cgcnn_embedding_gradients(hip_lib, ring, cgcnn):
     s2 = eng.train_forward(rb, targets)
     assert np.isfinite(s2)
     rb.free()
+
+
+def test_gradients_mp2018_shapes(hip_lib):
+    """Crystal-shaped batch (up to 24 neighbours per atom): exercises the general attention backward (degree > 16)."""
+    import torch_ref
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("mp2018")
+    cfg["model"]["n_attention"] = 2
+    w = so.init_weights(cfg, 21, perturb=True)
+    de, dn = so.synth_dataset(4, 6, "mp2018")
+    inputs, targets = so.pad_batch(de, dn, True)
+    pk = _hip.pack_inputs(inputs)
+    assert np.diff(pk.edge_offset).max() > 16
+    model = HipModel(cfg, w, device=0)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    _, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+    errs = grad_errors(got, ref)
+    assert max(errs.values()) <= 3e-3, {k: v for k, v in errs.items() if v > 3e-3}
+    rb.free()
