@@ -155,6 +155,64 @@ def cpu_baseline(seconds_budget=12.0):
                       "padded-dense graph (BLAS threads = host cores)" % n}
 
 
+def train_bench(args, eng, rank, world):
+    """Weak-scaling training throughput: every rank trains on its own --batch molecules per step; the ranks exchange the
+    scalar SSE/count and one flat fp32 gradient all-reduce per step over RCCL."""
+    from scann.models.trainer import Communicator
+
+    eng.train_begin()
+    comm = Communicator(eng)  # gloo only carries the 128-byte ncclUniqueId; gradients go over RCCL
+    rng = np.random.default_rng(2000 + rank)
+    pool = [eng.upload(synth_packed_batch(rng, args.batch)) for _ in range(8)]
+    targets = [rng.normal(size=args.batch).astype(np.float32) for _ in pool]
+
+    def step(i):
+        rb, t = pool[i % 8], targets[i % 8]
+        sse = eng.train_forward(rb, t, dropout=0.1, seed=i)
+        sse_g, cnt_g = comm.sum_pair(sse, args.batch)
+        eng.zero_grads()
+        eng.train_backward(rb, sse_g, cnt_g)
+        eng.allreduce_grads()
+        eng.adam_step(5e-4 / (1.0 + 1e-5 * i))
+
+    steps, warm = min(args.steps, 400), min(args.warmup, 20)
+    for i in range(warm):
+        step(i)
+    eng.sync()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "QM9 molecules/s training (forward + backward + Adam)", "value": world * steps * args.batch / elapsed,
+            "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: QM9 training, configs/model_qm9.yaml, %d molecules per GPU per step, dropout 0.1, "
+                                   "RCCL flat gradient all-reduce (%d floats)" % (args.batch, eng.param_count()),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world}}))
+    for rb in pool:
+        rb.free()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +231,10 @@ def main():
     ap.add_argument("--config", default="qm9", choices=["qm9", "mp2018"],
                     help="qm9 = BASELINE configs[1] (the metric); mp2018 = configs[3] shapes (crystals, L=9, batch 64), extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="extra (BASELINE configs[2]): time data-parallel TRAINING steps instead of the forward metric -- "
+                         "forward(train, dropout 0.1) + SSE all-reduce + backward + flat RCCL gradient all-reduce + Adam; "
+                         "--batch molecules per GPU per step")
     ap.add_argument("--profile-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -192,6 +254,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: libscann_hip has no CPU fallback")
     model = HipModel(cfg, device=local % ndev, seed=1234)  # random-init weights of the QM9 architecture
     eng = model.engine
+    if args.train:
+        return train_bench(args, eng, rank, world)
     nstream = eng.num_streams()
     G = max(1, args.group)
     n_groups = max(nstream, (max(args.pool // G, 1) + nstream - 1) // nstream * nstream)
