@@ -361,6 +361,21 @@ def main():
             "whole_path_tflops_min": world * args.steps * total_flops_min(A, E, L_cfg, emb_cfg) / elapsed / 1e12,
             "roofline": roof,
         }
+        if world == 1 and G > 1 and not args.worst:
+            # the same engine with exactly ONE 128-molecule batch per launch sequence (no fusing), for reference
+            singles = [eng.upload(b) for b in batches[:min(len(batches), 4 * nstream, 32)]]
+            n1 = 400
+            for i in range(40):
+                eng.forward_resident(singles[i % len(singles)], i % nstream)
+            eng.sync()
+            t1 = time.perf_counter()
+            for i in range(n1):
+                eng.forward_resident(singles[i % len(singles)], i % nstream)
+            eng.sync()
+            out["one_batch_per_launch"] = {"value": n1 * mols_per_step / (time.perf_counter() - t1), "unit": "molecules/s",
+                                           "steps": n1, "streams": nstream}
+            for rb in singles:
+                rb.free()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -325,3 +325,14 @@ def test_prepare_input_from_neighbors_matches_batch_of_one():
         for k in ref:
             assert np.array_equal(got[k], ref[k]), k
         assert _hip.pack_inputs(got).n_edge == int(ref["neighbor_mask"].sum())
+
+
+def test_keras_hdf5_checkpoint_is_refused_with_a_clear_message(tmp_path):
+    """Keras .h5 import is not available; the loader must say so instead of mis-parsing."""
+    from scann.models.scann_model import _read_container
+
+    p = tmp_path / "model_homo.h5"
+    p.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(NotImplementedError) as e:
+        _read_container(str(p))
+    assert "HDF5" in str(e.value)
