@@ -179,6 +179,33 @@ int scann_get_weights(scann_handle_t* h, float* out);         /* current master 
 int scann_comm_unique_id(char* out128);                       /* ncclGetUniqueId on rank 0; broadcast by the caller */
 int scann_comm_init(scann_handle_t* h, const char* id128, int rank, int world);
 
+/* ---- host batch packers (no GPU work) --------------------------------------------------------------
+ * Replace DataIterator.__getitem__ + pad_sequence / pad_nested_sequences (datagenerator.py:69-135, general.py:14-50).
+ * All arrays are caller-allocated; on error the return is SCANN_ERR_INVALID and scann_pack_last_error() has the text
+ * (thread-local). */
+const char* scann_pack_last_error(void);
+/* Padded Keras input dict (scann_model.py:338-357) -> packed CSR.  atomic[B,M] or NULL with cgcnn[B,M,92];
+ * ring[B,M,2] or NULL; masks as bytes.  Outputs sized for the worst case: out_atomic[B*M], out_cgcnn[B*M*92],
+ * out_ring[B*M*2], out_mol_offset[B+1], out_edge_offset[B*M+1], out_edge_col/dist/weight[B*M*N];
+ * out_row_of[B*M] = packed row of (b, m) or -1 for padded atoms (used to re-pad the GlobalAttention scores). */
+int scann_pack_padded(int32_t B, int32_t M, int32_t N, const int32_t* atomic, const float* cgcnn,
+                      const uint8_t* atom_mask, const int32_t* neighbors, const uint8_t* neighbor_mask,
+                      const float* neighbor_weight, const float* neighbor_distance, const float* ring,
+                      int32_t* out_atomic, float* out_cgcnn, float* out_ring, int32_t* out_mol_offset,
+                      int32_t* out_edge_offset, int32_t* out_edge_col, float* out_edge_dist,
+                      float* out_edge_weight, int32_t* out_row_of, int32_t* n_atom, int32_t* n_edge);
+/* A whole dataset kept in CSR form (ds_mol_offset[n_struct_total+1] atoms per structure, ds_edge_offset[atoms+1],
+ * ds_edge_local = neighbour index INSIDE its structure as stored by the preprocessing, voronoi_neighbor.py:38-47):
+ * the batch made of structures sel[0..n_sel) in that order (the structures DataIterator.__getitem__(idx) would hold).
+ * scann_slice_count gives the output sizes first. */
+int scann_slice_count(const int64_t* ds_mol_offset, const int64_t* ds_edge_offset, const int64_t* sel, int32_t n_sel,
+                      int64_t n_struct_total, int64_t* n_atom, int64_t* n_edge);
+int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offset, const int32_t* ds_atomic,
+                      const float* ds_ring, const int32_t* ds_edge_local, const float* ds_edge_dist,
+                      const float* ds_edge_weight, const int64_t* sel, int32_t n_sel, int64_t n_struct_total,
+                      int32_t* out_atomic, float* out_ring, int32_t* out_mol_offset, int32_t* out_edge_offset,
+                      int32_t* out_edge_col, float* out_edge_dist, float* out_edge_weight);
+
 #ifdef __cplusplus
 }
 #endif

@@ -913,44 +913,23 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
   if (!h || B <= 0 || M <= 0 || N < 0 || !atomic || !atom_mask || !y_out || (N > 0 && (!neighbors || !neighbor_mask || !neighbor_weight || !neighbor_distance)))
     return fail(h, SCANN_ERR_INVALID, "scann_forward_padded: bad argument");
   if (h->cfg.use_ring || h->cfg.feature_cgcnn) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_forward_padded: atomic feature without ring only");
-  // real atoms (atom_mask) keep their order; gidx = packed row of (b, m)
-  std::vector<int32_t> gidx((size_t)B * M, -1), at, mol(1, 0), eoff(1, 0), col;
-  std::vector<float> dist, wgt;
-  at.reserve((size_t)B * M);
-  for (int b = 0; b < B; ++b) {
-    for (int m = 0; m < M; ++m)
-      if (atom_mask[(size_t)b * M + m]) {
-        gidx[(size_t)b * M + m] = (int32_t)at.size();
-        at.push_back(atomic[(size_t)b * M + m]);
-      }
-    if ((int32_t)at.size() == mol.back()) return fail(h, SCANN_ERR_INVALID, "scann_forward_padded: a structure has no atoms");
-    mol.push_back((int32_t)at.size());
-  }
-  col.reserve((size_t)at.size() * 8);
-  for (int b = 0; b < B; ++b)
-    for (int m = 0; m < M; ++m) {
-      if (!atom_mask[(size_t)b * M + m]) continue;
-      const size_t base = ((size_t)b * M + m) * N;
-      for (int n = 0; n < N; ++n) {
-        if (!neighbor_mask[base + n]) continue;
-        const int32_t t = neighbors[base + n];
-        if (t < 0 || t >= M || gidx[(size_t)b * M + t] < 0)
-          return fail(h, SCANN_ERR_INVALID, "scann_forward_padded: an unmasked neighbour slot points at a padded atom");
-        col.push_back(gidx[(size_t)b * M + t]);
-        dist.push_back(neighbor_distance[base + n]);
-        wgt.push_back(neighbor_weight[base + n]);
-      }
-      eoff.push_back((int32_t)col.size());
-    }
+  const size_t BM = (size_t)B * M;
+  std::vector<int32_t> gidx(BM), at(BM), mol((size_t)B + 1), eoff(BM + 1), col(BM * N);
+  std::vector<float> dist(BM * N), wgt(BM * N);
+  int32_t na = 0, ne = 0;
+  if (scann_pack_padded(B, M, N, atomic, nullptr, atom_mask, neighbors, neighbor_mask, neighbor_weight, neighbor_distance,
+                        nullptr, at.data(), nullptr, nullptr, mol.data(), eoff.data(), col.data(), dist.data(), wgt.data(),
+                        gidx.data(), &na, &ne))
+    return fail(h, SCANN_ERR_INVALID, std::string("scann_forward_padded: ") + scann_pack_last_error());
   scann_batch_t pb{};
-  pb.n_struct = B; pb.n_atom = (int32_t)at.size(); pb.n_edge = (int32_t)col.size();
+  pb.n_struct = B; pb.n_atom = na; pb.n_edge = ne;
   pb.atomic = at.data(); pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
   pb.edge_col = col.data(); pb.edge_dist = dist.data(); pb.edge_weight = wgt.data();
-  std::vector<float> ga_packed(ga_out ? at.size() : 0);
+  std::vector<float> ga_packed(ga_out ? (size_t)na : 0);
   const int r = scann_forward(h, &pb, y_out, ga_out ? ga_packed.data() : nullptr);
   if (r) return r;
   if (ga_out)
-    for (size_t i = 0; i < (size_t)B * M; ++i) ga_out[i] = gidx[i] >= 0 ? ga_packed[gidx[i]] : 0.f;  // softmax of -1e9 -> 0
+    for (size_t i = 0; i < BM; ++i) ga_out[i] = gidx[i] >= 0 ? ga_packed[gidx[i]] : 0.f;  // softmax of -1e9 -> 0
   return SCANN_OK;
 }
 

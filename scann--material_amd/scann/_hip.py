@@ -88,6 +88,10 @@ SYMBOLS = [
     ("scann_get_weights", C.c_int, [_P, _P]),
     ("scann_comm_unique_id", C.c_int, [C.c_char_p]),
     ("scann_comm_init", C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
+    ("scann_pack_last_error", C.c_char_p, []),
+    ("scann_pack_padded", C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 17 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("scann_slice_count", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("scann_slice_batch", C.c_int, [_P] * 8 + [C.c_int32, C.c_int64] + [_P] * 7),
 ]
 
 _lib = None
@@ -125,7 +129,7 @@ def comm_unique_id():
 
 
 def _ptr(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    return a.ctypes.data if a is not None else None  # plain address: c_void_p argtypes / fields take ints
 
 
 class PackedBatch:
@@ -193,38 +197,68 @@ def pack_inputs(inputs):
     -> PackedBatch.  Real atoms are those with atom_mask set; real edges the unmasked neighbour
     slots of real atoms, kept in slot order; neighbour ids become global atom rows (what
     gather_shape + tf.gather_nd do in the reference, custom_layers.py:18-28, attention.py:136)."""
+    lib = load_library()
     atomic = np.asarray(inputs["atomic"])
     cgcnn = None
     if atomic.ndim == 3:  # feature="cgcnn": [B, M, 92] float features instead of atomic numbers (scann_model.py:334)
-        cgcnn, atomic = atomic, None
-    amask = np.asarray(inputs["atom_mask"]).astype(bool)
+        cgcnn, atomic = np.ascontiguousarray(atomic, dtype=np.float32), None
+        if cgcnn.shape[2] != 92:
+            raise ValueError("cgcnn features must be [B, M, 92]")
+    else:
+        atomic = np.ascontiguousarray(atomic, dtype=np.int32)
+    amask = np.asarray(inputs["atom_mask"])
     if amask.ndim == 3:
         amask = amask[..., 0]
-    nbr = np.asarray(inputs["neighbors"]).astype(np.int64)
-    nmask = np.asarray(inputs["neighbor_mask"]).astype(bool)
+    amask = np.ascontiguousarray(amask != 0)
+    nbr = np.ascontiguousarray(inputs["neighbors"], dtype=np.int32)
+    nmask = np.ascontiguousarray(np.asarray(inputs["neighbor_mask"]) != 0)
     B, M = amask.shape
-    if nbr.shape[:2] != (B, M) or nmask.shape != nbr.shape or amask.shape != (B, M):
+    if nbr.ndim != 3 or nbr.shape[:2] != (B, M) or nmask.shape != nbr.shape or \
+            (atomic is not None and atomic.shape != (B, M)) or (cgcnn is not None and cgcnn.shape[:2] != (B, M)):
         raise ValueError("inconsistent input shapes")
-    counts = amask.sum(1)
-    if (counts == 0).any():
-        raise ValueError("a structure in the batch has no atoms")
-    mol_offset = np.zeros(B + 1, dtype=np.int64)
-    np.cumsum(counts, out=mol_offset[1:])
-    gidx = (np.cumsum(amask, 1) - 1) + mol_offset[:-1, None]  # global row of every real atom
-    emask = nmask & amask[:, :, None]
-    bsel = np.broadcast_to(np.arange(B)[:, None, None], nbr.shape)[emask]
-    tgt = nbr[emask]
-    if tgt.size and ((tgt < 0).any() or (tgt >= M).any() or not amask[bsel, tgt].all()):
-        raise ValueError("an unmasked neighbour slot points at a padded atom")
-    edge_col = gidx[bsel, tgt]
-    deg = emask.sum(2)[amask]
-    edge_offset = np.zeros(deg.shape[0] + 1, dtype=np.int64)
-    np.cumsum(deg, out=edge_offset[1:])
-    dist = np.asarray(inputs["neighbor_distance"], dtype=np.float32)[emask]
-    wgt = np.asarray(inputs["neighbor_weight"], dtype=np.float32)[emask]
-    ring = np.asarray(inputs["ring_aromatic"], dtype=np.float32)[amask] if "ring_aromatic" in inputs else None
-    return PackedBatch(atomic[amask] if atomic is not None else None, mol_offset, edge_offset, edge_col, dist, wgt,
-                       pad_shape=(B, M), gidx=amask, ring=ring, cgcnn=cgcnn[amask] if cgcnn is not None else None)
+    N = nbr.shape[2]
+    dist = np.ascontiguousarray(inputs["neighbor_distance"], dtype=np.float32)
+    wgt = np.ascontiguousarray(inputs["neighbor_weight"], dtype=np.float32)
+    ring = np.ascontiguousarray(inputs["ring_aromatic"], dtype=np.float32) if "ring_aromatic" in inputs else None
+    if dist.shape != nbr.shape or wgt.shape != nbr.shape or (ring is not None and ring.shape != (B, M, 2)):
+        raise ValueError("inconsistent input shapes")
+    o_atomic = np.empty(B * M, np.int32) if atomic is not None else None
+    o_cgcnn = np.empty((B * M, 92), np.float32) if cgcnn is not None else None
+    o_ring = np.empty((B * M, 2), np.float32) if ring is not None else None
+    o_mol, o_eoff = np.empty(B + 1, np.int32), np.empty(B * M + 1, np.int32)
+    o_col, o_dist, o_wgt = np.empty(B * M * N, np.int32), np.empty(B * M * N, np.float32), np.empty(B * M * N, np.float32)
+    row_of = np.empty(B * M, np.int32)
+    na, ne = C.c_int32(0), C.c_int32(0)
+    rc = lib.scann_pack_padded(B, M, N, _ptr(atomic), _ptr(cgcnn), _ptr(amask), _ptr(nbr), _ptr(nmask), _ptr(wgt), _ptr(dist),
+                               _ptr(ring), _ptr(o_atomic), _ptr(o_cgcnn), _ptr(o_ring), _ptr(o_mol), _ptr(o_eoff), _ptr(o_col),
+                               _ptr(o_dist), _ptr(o_wgt), _ptr(row_of), C.byref(na), C.byref(ne))
+    if rc != SCANN_OK:
+        raise ValueError((lib.scann_pack_last_error() or b"").decode())
+    na, ne = na.value, ne.value
+    return PackedBatch(o_atomic[:na] if o_atomic is not None else None, o_mol, o_eoff[:na + 1], o_col[:ne], o_dist[:ne],
+                       o_wgt[:ne], pad_shape=(B, M), gidx=amask, ring=o_ring[:na] if o_ring is not None else None,
+                       cgcnn=o_cgcnn[:na] if o_cgcnn is not None else None)
+
+
+def slice_dataset(ds_mol_offset, ds_edge_offset, ds_atomic, ds_ring, ds_edge_local, ds_edge_dist, ds_edge_weight, sel):
+    """Structures `sel` of a dataset kept in CSR form -> PackedBatch (scann_slice_batch; the batch that
+    DataIterator.__getitem__, datagenerator.py:69-135, would assemble from nested lists)."""
+    lib = load_library()
+    sel = np.ascontiguousarray(sel, dtype=np.int64)
+    n_total = int(ds_mol_offset.shape[0] - 1)
+    na, ne = C.c_int64(0), C.c_int64(0)
+    if lib.scann_slice_count(_ptr(ds_mol_offset), _ptr(ds_edge_offset), _ptr(sel), len(sel), n_total, C.byref(na), C.byref(ne)) != SCANN_OK:
+        raise ValueError((lib.scann_pack_last_error() or b"").decode())
+    na, ne = na.value, ne.value
+    o_atomic, o_mol, o_eoff = np.empty(na, np.int32), np.empty(len(sel) + 1, np.int32), np.empty(na + 1, np.int32)
+    o_ring = np.empty((na, 2), np.float32) if ds_ring is not None else None
+    o_col, o_dist, o_wgt = np.empty(ne, np.int32), np.empty(ne, np.float32), np.empty(ne, np.float32)
+    rc = lib.scann_slice_batch(_ptr(ds_mol_offset), _ptr(ds_edge_offset), _ptr(ds_atomic), _ptr(ds_ring), _ptr(ds_edge_local),
+                               _ptr(ds_edge_dist), _ptr(ds_edge_weight), _ptr(sel), len(sel), n_total, _ptr(o_atomic),
+                               _ptr(o_ring), _ptr(o_mol), _ptr(o_eoff), _ptr(o_col), _ptr(o_dist), _ptr(o_wgt))
+    if rc != SCANN_OK:
+        raise ValueError((lib.scann_pack_last_error() or b"").decode())
+    return PackedBatch(o_atomic, o_mol, o_eoff, o_col, o_dist, o_wgt, ring=o_ring)
 
 
 class ResidentBatch:

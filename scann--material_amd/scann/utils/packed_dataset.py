@@ -11,7 +11,8 @@ from math import ceil
 
 import numpy as np
 
-from .._hip import PackedBatch
+from .. import _listwalk  # native walker, built by csrc/Makefile (no Python fallback)
+from .._hip import slice_dataset
 
 
 class PackedDataset:
@@ -27,14 +28,13 @@ class PackedDataset:
         np.cumsum(sizes, out=self.mol_offset[1:])
         self.atomic = np.concatenate([np.asarray(d[0], dtype=np.int32) for d in data_energy]) if n else np.zeros(0, np.int32)
         self.target = np.array([float(d[1]) * (1000 if converter else 1.0) for d in data_energy], dtype=np.float32)
-        deg = np.fromiter((len(lst) for c in data_neighbor for lst in c), dtype=np.int64, count=int(sizes.sum()))
+        per_struct, deg, local, weight, dist = (np.frombuffer(b, dtype=t) for b, t in zip(
+            _listwalk.convert(data_neighbor, wi), (np.int64, np.int64, np.int32, np.float32, np.float32)))
+        if not np.array_equal(per_struct, sizes):
+            raise ValueError("data_energy and data_neighbor disagree on the number of atoms per structure")
         self.edge_offset = np.zeros(deg.shape[0] + 1, dtype=np.int64)
         np.cumsum(deg, out=self.edge_offset[1:])
-        flat = [e for c in data_neighbor for lst in c for e in lst]
-        arr = np.asarray([(e[1], e[wi], e[-1]) for e in flat], dtype=np.float64).reshape(-1, 3)
-        self.edge_local = arr[:, 0].astype(np.int32)  # neighbour index INSIDE its structure
-        self.edge_weight = arr[:, 1].astype(np.float32)
-        self.edge_dist = arr[:, 2].astype(np.float32)
+        self.edge_local, self.edge_weight, self.edge_dist = local, weight, dist  # edge_local: index INSIDE its structure
         self.ring = np.concatenate([np.asarray(d[2], dtype=np.float32).reshape(-1, 2) for d in data_energy]) if use_ring else None
         self.on_epoch_end()
 
@@ -49,20 +49,8 @@ class PackedDataset:
     def batch(self, idx):
         """-> (PackedBatch, targets) of batch `idx` (the structures DataIterator.__getitem__(idx) would hold)."""
         sel = self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size]
-        a0, a1 = self.mol_offset[sel], self.mol_offset[sel + 1]
-        n_at = a1 - a0
-        new_mol = np.zeros(len(sel) + 1, dtype=np.int64)
-        np.cumsum(n_at, out=new_mol[1:])
-        atom_idx = np.repeat(a0 - new_mol[:-1], n_at) + np.arange(new_mol[-1])  # source atom row of every packed atom
-        e0, e1 = self.edge_offset[atom_idx], self.edge_offset[atom_idx + 1]
-        deg = e1 - e0
-        new_eoff = np.zeros(len(atom_idx) + 1, dtype=np.int64)
-        np.cumsum(deg, out=new_eoff[1:])
-        edge_idx = np.repeat(e0 - new_eoff[:-1], deg) + np.arange(new_eoff[-1])
-        base = np.repeat(np.repeat(new_mol[:-1], n_at), deg)  # first packed atom row of the edge's structure
-        pk = PackedBatch(self.atomic[atom_idx], new_mol, new_eoff, self.edge_local[edge_idx] + base,
-                         self.edge_dist[edge_idx], self.edge_weight[edge_idx],
-                         ring=self.ring[atom_idx] if self.ring is not None else None)
+        pk = slice_dataset(self.mol_offset, self.edge_offset, self.atomic, self.ring, self.edge_local, self.edge_dist,
+                           self.edge_weight, sel)
         return pk, self.target[sel]
 
     def __getitem__(self, idx):

@@ -336,3 +336,80 @@ def test_keras_hdf5_checkpoint_is_refused_with_a_clear_message(tmp_path):
     with pytest.raises(NotImplementedError) as e:
         _read_container(str(p))
     assert "HDF5" in str(e.value)
+
+
+def test_native_packers_ring_cgcnn_masks_and_errors():
+    """scann_pack_padded / scann_slice_batch (host C++, f-1): optional inputs, float masks, garbage in masked slots, errors."""
+    from scann import _hip
+    from scann.utils import PackedDataset
+
+    de, dn = so.synth_dataset(9, 21, use_ring=True)
+    inputs, _ = so.pad_batch(de, dn, True, use_ring=True)
+    ref = _hip.pack_inputs(inputs)
+    am = inputs["atom_mask"][..., 0].astype(bool)
+    assert np.array_equal(ref.ring, inputs["ring_aromatic"][am]) and np.array_equal(ref.atomic, inputs["atomic"][am])
+    # float masks (Keras casts the bool masks to fp32, scann_model.py:339,343) and garbage under the masks change nothing
+    noisy = {k: np.array(v) for k, v in inputs.items()}
+    nm = inputs["neighbor_mask"].astype(bool)
+    rng = np.random.default_rng(0)
+    noisy["neighbors"][~nm] = rng.integers(-5, 999, size=int((~nm).sum()))
+    noisy["neighbor_distance"][~nm] = 77.0
+    noisy["neighbor_weight"][~nm] = -3.0
+    noisy["atomic"][~am] = 5
+    noisy["atom_mask"] = inputs["atom_mask"].astype(np.float32)
+    noisy["neighbor_mask"] = inputs["neighbor_mask"].astype(np.float32)
+    got = _hip.pack_inputs(noisy)
+    for f in ("atomic", "ring", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+        assert np.array_equal(getattr(got, f), getattr(ref, f)), f
+    # cgcnn: [B, M, 92] float features in place of atomic numbers (scann_model.py:334)
+    feats = rng.standard_normal(inputs["atomic"].shape + (92,)).astype(np.float32)
+    cg = dict(inputs, atomic=feats)
+    pk = _hip.pack_inputs(cg)
+    assert pk.atomic is None and np.array_equal(pk.cgcnn, feats[am])
+    # a structure without atoms is rejected
+    bad = {k: np.array(v) for k, v in inputs.items()}
+    bad["atom_mask"][3] = False
+    with pytest.raises(ValueError, match="no atoms"):
+        _hip.pack_inputs(bad)
+    # dataset slicing: arbitrary order with repeats equals packing those structures; errors are reported
+    ds = PackedDataset(de, dn, batch_size=4, g_update=True, use_ring=True)
+    sel = np.array([7, 2, 2, 0])
+    pk = _hip.slice_dataset(ds.mol_offset, ds.edge_offset, ds.atomic, ds.ring, ds.edge_local, ds.edge_dist, ds.edge_weight, sel)
+    sub_e, sub_n = [de[i] for i in sel], [dn[i] for i in sel]
+    want = _hip.pack_inputs(so.pad_batch(sub_e, sub_n, True, use_ring=True)[0])
+    for f in ("atomic", "ring", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+        assert np.array_equal(getattr(pk, f), getattr(want, f)), f
+    empty = _hip.slice_dataset(ds.mol_offset, ds.edge_offset, ds.atomic, ds.ring, ds.edge_local, ds.edge_dist, ds.edge_weight, [])
+    assert empty.n_struct == 0 and empty.n_atom == 0 and empty.n_edge == 0
+    with pytest.raises(ValueError, match="out of range"):
+        _hip.slice_dataset(ds.mol_offset, ds.edge_offset, ds.atomic, ds.ring, ds.edge_local, ds.edge_dist, ds.edge_weight, [9])
+    broken = ds.edge_local.copy()
+    broken[0] = 10 ** 6
+    with pytest.raises(ValueError, match="outside its structure"):
+        _hip.slice_dataset(ds.mol_offset, ds.edge_offset, ds.atomic, ds.ring, broken, ds.edge_dist, ds.edge_weight, [0])
+
+
+def test_listwalk_matches_python_walk_of_the_nested_lists():
+    """scann._listwalk (CPython extension, f-1) against a plain Python walk of the reference's nested-list format."""
+    from scann import _listwalk
+    from scann.utils import PackedDataset
+
+    de, dn = so.synth_dataset(31, 8)
+    dn_obj = np.empty(len(dn), dtype=object)  # the reference loads object arrays (general.py:127-137)
+    for i, c in enumerate(dn):
+        dn_obj[i] = [tuple(r) if k % 2 else list(r) for k, r in enumerate(c)] if i % 3 == 0 else c
+    for wi in (2, 3):
+        per, deg, loc, w, d = (np.frombuffer(b, dtype=t) for b, t in zip(
+            _listwalk.convert(dn_obj, wi), (np.int64, np.int64, np.int32, np.float32, np.float32)))
+        flat = [e for c in dn for lst in c for e in lst]
+        assert np.array_equal(per, [len(c) for c in dn]) and np.array_equal(deg, [len(lst) for c in dn for lst in c])
+        assert np.array_equal(loc, np.array([e[1] for e in flat], dtype=np.int32))
+        assert np.array_equal(w, np.array([e[wi] for e in flat], dtype=np.float32))
+        assert np.array_equal(d, np.array([e[-1] for e in flat], dtype=np.float32))
+    with pytest.raises(ValueError, match="no column"):
+        _listwalk.convert([[[[1, 0]]]], 3)
+    with pytest.raises(TypeError):
+        _listwalk.convert([[[["C", "x", 1.0, 1.0, 1.0]]]], 2)
+    with pytest.raises(ValueError, match="disagree"):
+        PackedDataset(de[:4], dn[1:5], batch_size=2)
+    assert len(PackedDataset([], [], batch_size=2)) == 0
