@@ -13,6 +13,7 @@ constexpr int NG = 20;           // Gaussian basis size (scann_model.py:378)
 constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict-free b128 A-fragment reads)
 constexpr int TE_MAX = 64;       // edge rows per edge tile: 32 or 64 (one or two 32-row MFMA row tiles)
 constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row tile)
+constexpr int TQ = 24;           // atoms per EDGE tile when edge_kernel_lean runs (its query-row buffer)
 constexpr int TB = 16;           // edges per basis-kernel workgroup
 constexpr int WPACK = D * D;     // floats in one packed 128x128 weight
 
@@ -119,6 +120,7 @@ struct EdgeArgs {
   int32_t persistent_wgs;      // > 0: run edge_kernel_persistent with this many workgroups (one per CU)
   int32_t xcd_remap;           // contiguous run of tiles per XCD (edge_kernel_w8)
   int32_t waves8;              // run the 8-wave (512-thread) variant edge_kernel_w8
+  int32_t lean;                // run edge_kernel_lean (tiles must hold <= TQ atoms)
   int32_t g_update;
   const int32_t* edge_offset;  // [n_atom+1]
   const int32_t* edge_col;     // [n_edge]

@@ -33,8 +33,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
       (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
     }                                                                                         \
   } while (0)
+#define STAMP_IF(buf, slot, cond)                                                             \
+  do {                                                                                        \
+    if ((buf) && (cond)) {                                                                    \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
+    }                                                                                         \
+  } while (0)
 #else
 #define STAMP(buf, slot) do {} while (0)
+#define STAMP_IF(buf, slot, cond) do {} while (0)
 #endif
 
 // swish(x) = x * sigmoid(x) on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each.
@@ -826,6 +835,280 @@ __global__ __launch_bounds__(256 * RTW, 4) void edge_kernel_w8(EdgeArgs a) {
   STAMP(a.stamps, 7);
 }
 
+// ---- lean-LDS edge kernel: three workgroups per CU ---------------------------------------------------------------
+//
+// Phase clocks of edge_kernel_w8 show the two GEMM phases saturating the MFMA pipe (8.2 k cycles each per tile) and the
+// other phases being latency chains (35 k cycles per tile), so MFMA utilisation is set by how many tiles a CU keeps in
+// flight: 2 x 16.4 k / 51.6 k = 62 %.  This variant keeps ONE 64 x 128 LDS buffer per workgroup -- G, U, ang and K
+// take turns in it; the thread that stages a piece of G keeps it in registers for the residual -- plus the query
+// rows of <= TQ atoms: 51 KB, so three workgroups (of 4 waves, <= 168 VGPRs) fit a CU.
+__device__ __forceinline__ void mma_half2(const float* __restrict__ sX, const float4 (&w)[8], int lane, int half,
+                                          f32x16 (&acc)[2]) {
+  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5) + 64 * half;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[rt], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void load_q(const float* __restrict__ q, int atom_begin, int natom, int tid, float4 (&qreg)[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
+    qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (la < natom) qreg[i] = reinterpret_cast<const float4*>(q)[(size_t)(atom_begin + la) * 32 + c4];
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
+  constexpr int TEK = 64;
+  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];  // G -> U -> ang = c[j]*geom' -> K
+  __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];   // P1 rows, then query rows of the tile's atoms, then context
+  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
+  __shared__ __attribute__((aligned(16))) float sPar[4 * D];
+  __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const EdgeTile tile = a.tiles[a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x];
+  const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
+  const int col = 32 * wave + (lane & 31);
+  const int r = tid >> 2, sub = tid & 3;  // row-pass mapping: 4 threads per edge row, float4 chunks sub, sub+4, ...
+
+  STAMP(a.stamps, 0);
+  STAMP_IF(a.stamps, 10 + wave, lane == 0 && wave > 0);  // diagnostic: start time of the sibling waves
+  float4 wA[8], wB[8];
+  load_w_half(a.p.W2p, wave, lane, 0, wA);
+  load_w_half(a.p.W2p, wave, lane, 1, wB);
+  if (tid < TEK) {
+    sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
+    sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
+  } else if (tid - TEK <= natom) {
+    sOff[tid - TEK] = a.edge_offset[tile.atom_begin + (tid - TEK)] - eb;
+  }
+  for (int i = tid; i < 4 * D; i += 256) {
+    const float* src = i < D ? a.p.lng_g : i < 2 * D ? a.p.lng_b : i < 3 * D ? a.p.ln_g : a.p.ln_b;
+    sPar[i] = src[i & (D - 1)];
+  }
+  // centre thirds P1 = c_i W1 + bg of the tile's atoms: staged once in the query buffer (an atom's edges share the row)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
+    if (la < natom)
+      *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) =
+          reinterpret_cast<const float4*>(a.P1)[(size_t)(tile.atom_begin + la) * 32 + c4];
+  }
+  float4 greg[8];  // this thread's pieces of G stay in registers for the residual (attention.py:153)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = sub + 4 * i;
+    greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < ne) greg[i] = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
+    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = greg[i];
+  }
+  STAMP(a.stamps, 10);  // diagnostic: this wave's loads have landed
+  __syncthreads();
+  STAMP(a.stamps, 1);
+  // U = G . W2
+  f32x16 acc[2];
+  zero_acc(acc);
+  mma_half2(sA, wA, lane, 0, acc);
+  mma_half2(sA, wB, lane, 1, acc);
+  STAMP(a.stamps, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w_half(a.p.Wkp, wave, lane, 0, wA);  // first half of the key weights arrives during the row pass
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();  // every wave is done reading G
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sA[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i];
+  __syncthreads();
+  STAMP(a.stamps, 3);
+
+  // row pass (attention.py:141-157): u read and ang written at the thread's own positions of sA
+  if (r < ne) {
+    const int ctr = sCtr[r], nb = sCol[r];
+    const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
+    const float* p1 = sQ + (ctr - tile.atom_begin) * LDS_STRIDE;
+    const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
+    float s = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {  // two groups of four chunks: bounds the gathered rows in flight (register budget)
+#pragma unroll
+      for (int i = 4 * hf; i < 4 * hf + 4; ++i) {
+        const int c4 = sub + 4 * i;
+        const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
+        const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3[c4]);
+        greg[i] = f4add(f4swish(v), greg[i]);
+        s += f4sum(greg[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float4 cn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cn[i] = crow[sub + 4 * i];  // neighbour centre row (attention.py:136), in flight over the statistics
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s * (1.0f / D);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float dx = greg[i].x - mean, dy = greg[i].y - mean, dz = greg[i].z - mean, dw = greg[i].w - mean;
+      v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = sub + 4 * i;
+      const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
+      const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
+      float4 y;
+      float inv;
+      inv = rstd * g.x; y.x = greg[i].x * inv + (be.x - mean * inv);
+      inv = rstd * g.y; y.y = greg[i].y * inv + (be.y - mean * inv);
+      inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
+      inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
+      reinterpret_cast<float4*>(a.geom)[(size_t)(eb + r) * 32 + c4] = y;
+      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)  // ragged tail rows: U of the zero rows is 0 already, keep ang = 0 explicit
+      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  load_w_half(a.p.Wkp, wave, lane, 1, wB);
+  float4 qreg[3];
+  load_q(a.q, tile.atom_begin, natom, tid, qreg);
+  __syncthreads();
+  STAMP(a.stamps, 4);
+  // K = ang . Wk + bk
+  zero_acc(acc);
+  mma_half2(sA, wA, lane, 0, acc);
+  mma_half2(sA, wB, lane, 1, acc);
+  STAMP(a.stamps, 5);
+  __syncthreads();  // every wave is done reading ang
+  {
+    const float b = a.p.bk[col];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sA[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + b;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
+    *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
+  }
+  __syncthreads();
+  STAMP(a.stamps, 6);
+  // logits: thread = (edge row, pair of heads)
+  {
+    const int n = tid >> 2, hh = tid & 3;
+    if (n < ne) {
+      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + 2 * HDIM * hh;
+      const float* krow = sA + n * LDS_STRIDE + 2 * HDIM * hh;
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        float e = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qrow + HDIM * hp + 4 * j);
+          const float4 k4 = *reinterpret_cast<const float4*>(krow + HDIM * hp + 4 * j);
+          e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
+        }
+        sE[n * NHEAD + 2 * hh + hp] = e;
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(a.stamps, 8);
+  // softmax + context + residual, one pass with a running maximum (see edge_kernel_w8)
+  {
+    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
+    for (int la = lgp; la < natom; la += 8) {
+      const int e0 = sOff[la], e1 = sOff[la + 1];
+      float m = -INFINITY, ssum = 0.f;
+      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int n = e0; n < e1; n += 2) {
+        const bool two = n + 1 < e1;
+        const int n1 = two ? n + 1 : n;
+        const float ea = sE[n * NHEAD + h];
+        const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
+        const float4 ka = *reinterpret_cast<const float4*>(&sA[n * LDS_STRIDE + 4 * c4]);
+        const float4 kb = *reinterpret_cast<const float4*>(&sA[n1 * LDS_STRIDE + 4 * c4]);
+        const float mn = fmaxf(m, fmaxf(ea, eb2));
+        const float resc = fast_exp(m - mn);
+        float pa = fast_exp(ea - mn), pb = fast_exp(eb2 - mn);
+        ssum = ssum * resc + (pa + pb);
+        if (a.attn_drop_p > 0.f) {
+          pa *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
+          pb *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
+        }
+        cx.x = cx.x * resc + (pa * ka.x + pb * kb.x);
+        cx.y = cx.y * resc + (pa * ka.y + pb * kb.y);
+        cx.z = cx.z * resc + (pa * ka.z + pb * kb.z);
+        cx.w = cx.w * resc + (pa * ka.w + pb * kb.w);
+        m = mn;
+      }
+      const float rs = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+      float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
+      const float4 q4 = *qp;
+      *qp = make_float4(cx.x * rs + q4.x, cx.y * rs + q4.y, cx.z * rs + q4.z, cx.w * rs + q4.w);
+    }
+  }
+  __syncthreads();
+  STAMP(a.stamps, 9);
+  // LayerNorm of the context rows: 8 threads per atom row
+  {
+    const int rr = tid >> 3, sb = tid & 7;
+    if (rr < natom) {
+      float4 t[4];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        t[i] = *reinterpret_cast<const float4*>(&sQ[rr * LDS_STRIDE + 4 * (sb + 8 * i)]);
+        s += f4sum(t[i]);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * (1.0f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = sb + 8 * i;
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
+        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
+        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
+        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
+        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + rr) * 32 + c4] = y;
+      }
+    }
+  }
+  STAMP(a.stamps, 7);
+}
+
 #ifdef SCANN_STAMPS
 #define STAMP_DECL()                                                                                             \
   unsigned long long acc_work[4] = {0, 0, 0, 0}, t_loop0 = 0, t_b = 0;                                           \
@@ -1180,6 +1463,10 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.persistent_wgs > 0 && a.g_update && a.tile_rows == 64) {
     const int nwg = a.n_tile < a.persistent_wgs ? a.n_tile : a.persistent_wgs;
     hipLaunchKernelGGL(edge_kernel_persistent, dim3(nwg), dim3(P_THREADS), 0, s, a);
+    return;
+  }
+  if (a.lean && a.g_update && a.tile_rows == 64) {
+    hipLaunchKernelGGL(edge_kernel_lean, dim3(a.n_tile), dim3(256), 0, s, a);
     return;
   }
   if (a.waves8 && a.g_update && a.tile_rows == 32) {

@@ -110,6 +110,8 @@ struct scann_handle {
   bool loaded = false;
   bool debug = false;
   int edge_tile = 64;  // edge rows per tile (32 or 64); env SCANN_EDGE_TILE overrides
+  bool edge_lean = false;  // env SCANN_EDGE_LEAN=1: edge_kernel_lean (3 workgroups per CU), tiles of <= TQ atoms
+  int tile_atoms = TA;     // atoms per edge tile the tile builder allows
   int n_cu = 256;      // compute units of the device
   int time_every = 0;  // > 0: sample edge-kernel launch durations on every n-th forward (scann_edge_timing)
   int64_t time_count = 0;
@@ -152,7 +154,7 @@ struct scann_handle {
 };
 
 struct scann_dbatch {
-  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0, tile_rows = 64, max_degree = 0;
+  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0, tile_rows = 64, max_degree = 0, tile_atoms = TA;
   char* arena = nullptr;  // inputs + workspace, one allocation
   // inputs
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
@@ -306,6 +308,8 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* et = getenv("SCANN_EDGE_TILE")) h->edge_tile = atoi(et) == 32 ? 32 : 64;
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* w8 = getenv("SCANN_EDGE_W8")) h->edge_w8 = atoi(w8) != 0;
+  if (const char* ln = getenv("SCANN_EDGE_LEAN")) h->edge_lean = atoi(ln) != 0;
+  if (h->edge_lean) h->tile_atoms = TQ;
   if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
   {
     hipDeviceProp_t prop;
@@ -619,7 +623,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
         edge_row[e] = a;
       }
       // greedy tiling: whole atoms, <= TE edges and <= TA atoms per tile
-      if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= TA) {
+      if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= h->tile_atoms) {
         cur.atom_end = a;
         cur.edge_end = e0;
         tiles.push_back(cur);
@@ -647,7 +651,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   } else {
     db = new scann_dbatch();
   }
-  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows; db->max_degree = max_degree;
+  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows; db->max_degree = max_degree; db->tile_atoms = h->tile_atoms;
   // arena layout: inputs first (one H2D copy), then workspace
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
@@ -832,6 +836,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       (void)hipEventRecord(ev0, s);
     }
     ea.waves8 = h->edge_w8;
+    ea.lean = h->edge_lean && db->tile_atoms <= TQ;
     ea.xcd_remap = h->xcd_remap;
     if (h->in_train_forward && h->attn_drop_p > 0.f) {
       ea.attn_drop_p = h->attn_drop_p;

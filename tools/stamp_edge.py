@@ -25,3 +25,7 @@ for n, (i, j) in zip(names, zip(order[:-1], order[1:])):
     col = st[:, j] - st[:, i]
     print("%-10s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))
 print("kernel span (first start -> last end) cycles:", st[:, 7].max() - st[:, 0].min(), "(s_memtime ticks at 100MHz? see guide: tick = shader cycle)")
+if os.environ.get("SCANN_EDGE_LEAN") == "1":
+    print("lean diagnostics: own loads landed after %.0f cycles (mean), barrier wait %.0f; sibling wave start offsets (mean) %s max %s" % (
+        (st[:, 10] - st[:, 0]).mean(), (st[:, 1] - st[:, 10]).mean(),
+        [(st[:, 10 + w] - st[:, 0]).mean() for w in (1, 2, 3)], [(st[:, 10 + w] - st[:, 0]).max() for w in (1, 2, 3)]))
