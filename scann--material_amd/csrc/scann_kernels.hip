@@ -882,9 +882,21 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
 
   STAMP(a.stamps, 0);
   STAMP_IF(a.stamps, 10 + wave, lane == 0 && wave > 0);  // diagnostic: start time of the sibling waves
+#ifdef SCANN_DIAG_PROBE
+  {  // diagnostic: latency of one small L2-resident load, then of one load from this tile's geometry rows
+    const float pr = a.p.bk[lane];
+    sE[tid] = pr;
+    STAMP(a.stamps, 14);
+    const float pg = a.geom[(size_t)eb * D + tid];
+    sE[256 + tid] = pg;
+    STAMP(a.stamps, 15);
+  }
+#endif
   float4 wA[8], wB[8];
+#ifndef SCANN_DIAG_NOW
   load_w_half(a.p.W2p, wave, lane, 0, wA);
   load_w_half(a.p.W2p, wave, lane, 1, wB);
+#endif
   if (tid < TEK) {
     sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
     sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
@@ -908,12 +920,18 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   for (int i = 0; i < 8; ++i) {
     const int c4 = sub + 4 * i;
     greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef SCANN_DIAG_NOG
     if (r < ne) greg[i] = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
+#endif
     *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = greg[i];
   }
   STAMP(a.stamps, 10);  // diagnostic: this wave's loads have landed
   __syncthreads();
   STAMP(a.stamps, 1);
+#ifdef SCANN_DIAG_NOW
+  load_w_half(a.p.W2p, wave, lane, 0, wA);
+  load_w_half(a.p.W2p, wave, lane, 1, wB);
+#endif
   // U = G . W2
   f32x16 acc[2];
   zero_acc(acc);
