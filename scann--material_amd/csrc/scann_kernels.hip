@@ -858,15 +858,6 @@ __device__ __forceinline__ void mma_half2(const float* __restrict__ sX, const fl
   }
 }
 
-__device__ __forceinline__ void load_q(const float* __restrict__ q, int atom_begin, int natom, int tid, float4 (&qreg)[3]) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
-    qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (la < natom) qreg[i] = reinterpret_cast<const float4*>(q)[(size_t)(atom_begin + la) * 32 + c4];
-  }
-}
-
 __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   constexpr int TEK = 64;
   __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];  // G -> U -> ang = c[j]*geom' -> K
@@ -882,56 +873,53 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
 
   STAMP(a.stamps, 0);
   STAMP_IF(a.stamps, 10 + wave, lane == 0 && wave > 0);  // diagnostic: start time of the sibling waves
-#ifdef SCANN_DIAG_PROBE
-  {  // diagnostic: latency of one small L2-resident load, then of one load from this tile's geometry rows
-    const float pr = a.p.bk[lane];
-    sE[tid] = pr;
-    STAMP(a.stamps, 14);
-    const float pg = a.geom[(size_t)eb * D + tid];
-    sE[256 + tid] = pg;
-    STAMP(a.stamps, 15);
-  }
-#endif
+  // Every load of the prologue is issued UNCONDITIONALLY (rows clamped into the tile, values selected afterwards): a load
+  // under a per-thread guard is compiled as branch + load + s_waitcnt vmcnt(0) + store, i.e. one full memory round trip
+  // per guard (16 in a row here before: 22 k cycles per tile).
+  const int nem1 = ne > 0 ? ne - 1 : 0;
+  const int rs = r < ne ? r : nem1;
   float4 wA[8], wB[8];
-#ifndef SCANN_DIAG_NOW
   load_w_half(a.p.W2p, wave, lane, 0, wA);
   load_w_half(a.p.W2p, wave, lane, 1, wB);
-#endif
-  if (tid < TEK) {
-    sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
-    sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
-  } else if (tid - TEK <= natom) {
-    sOff[tid - TEK] = a.edge_offset[tile.atom_begin + (tid - TEK)] - eb;
-  }
-  for (int i = tid; i < 4 * D; i += 256) {
-    const float* src = i < D ? a.p.lng_g : i < 2 * D ? a.p.lng_b : i < 3 * D ? a.p.ln_g : a.p.ln_b;
-    sPar[i] = src[i & (D - 1)];
-  }
-  // centre thirds P1 = c_i W1 + bg of the tile's atoms: staged once in the query buffer (an atom's edges share the row)
+  const int32_t* pa = tid < TEK ? (ne > 0 ? a.edge_col + eb + min(tid, nem1) : a.edge_offset)
+                                : a.edge_offset + tile.atom_begin + min(tid - TEK, natom);
+  const int32_t* pb = ne > 0 ? a.edge_row + eb + min(tid & (TEK - 1), nem1) : a.edge_offset;
+  const int va = *pa, vb = *pb;
+  const float par0 = (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)];
+  const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
+  float4 p1reg[3];  // centre thirds P1 = c_i W1 + bg of the tile's atoms (an atom's edges share the row)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
-    if (la < natom)
-      *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) =
-          reinterpret_cast<const float4*>(a.P1)[(size_t)(tile.atom_begin + la) * 32 + c4];
+    const int idx = tid + 256 * i, la = min(idx >> 5, natom - 1), c4 = idx & 31;
+    p1reg[i] = reinterpret_cast<const float4*>(a.P1)[(size_t)(tile.atom_begin + la) * 32 + c4];
   }
   float4 greg[8];  // this thread's pieces of G stay in registers for the residual (attention.py:153)
+  {
+    const float4* grow = reinterpret_cast<const float4*>(ne > 0 ? a.geom + (size_t)(eb + rs) * D : a.P1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) greg[i] = grow[sub + 4 * i];
+  }
+  if (tid < TEK) {
+    sCol[tid] = tid < ne ? va : 0;
+    sCtr[tid] = tid < ne ? vb : 0;
+  } else if (tid - TEK <= natom) {
+    sOff[tid - TEK] = va - eb;
+  }
+  sPar[tid] = par0;
+  sPar[2 * D + tid] = par1;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i;
+    *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c4 = sub + 4 * i;
-    greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef SCANN_DIAG_NOG
-    if (r < ne) greg[i] = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
-#endif
-    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = greg[i];
+    if (r >= ne) greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = greg[i];
   }
   STAMP(a.stamps, 10);  // diagnostic: this wave's loads have landed
   __syncthreads();
   STAMP(a.stamps, 1);
-#ifdef SCANN_DIAG_NOW
-  load_w_half(a.p.W2p, wave, lane, 0, wA);
-  load_w_half(a.p.W2p, wave, lane, 1, wB);
-#endif
   // U = G . W2
   f32x16 acc[2];
   zero_acc(acc);
@@ -1003,9 +991,17 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
       *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   load_w_half(a.p.Wkp, wave, lane, 1, wB);
-  float4 qreg[3];
-  load_q(a.q, tile.atom_begin, natom, tid, qreg);
-  __syncthreads();
+  // query rows: fetched here, parked in sQ as soon as the P1 rows are dead (rows clamped, never guarded: see the prologue)
+  const float4* const q4p = reinterpret_cast<const float4*>(a.q) + (size_t)tile.atom_begin * 32 + (tid & 31);
+  const int qa = tid >> 5;  // atom rows qa, qa + 8, qa + 16
+  const float4 q0 = q4p[(size_t)min(qa, natom - 1) * 32];
+  const float4 q1 = q4p[(size_t)min(qa + 8, natom - 1) * 32];
+  const float4 q2 = q4p[(size_t)min(qa + 16, natom - 1) * 32];
+  __syncthreads();  // ang complete; nobody reads the P1 rows any more
+  *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * (tid & 31)]) = q0;
+  *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * (tid & 31)]) = q1;
+  *reinterpret_cast<float4*>(&sQ[(qa + 16) * LDS_STRIDE + 4 * (tid & 31)]) = q2;
+  __builtin_amdgcn_sched_barrier(0);  // keep the stores here: sunk below the GEMM the rows get parked in scratch
   STAMP(a.stamps, 4);
   // K = ang . Wk + bk
   zero_acc(acc);
@@ -1019,11 +1015,6 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) sA[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + b;
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
-    *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
   }
   __syncthreads();
   STAMP(a.stamps, 6);

@@ -110,7 +110,7 @@ struct scann_handle {
   bool loaded = false;
   bool debug = false;
   int edge_tile = 64;  // edge rows per tile (32 or 64); env SCANN_EDGE_TILE overrides
-  bool edge_lean = false;  // env SCANN_EDGE_LEAN=1: edge_kernel_lean (3 workgroups per CU), tiles of <= TQ atoms
+  bool edge_lean = true;   // edge_kernel_lean (3 workgroups per CU, tiles of <= TQ atoms) on the g_update path; env SCANN_EDGE_LEAN=0: edge_kernel_w8
   int tile_atoms = TA;     // atoms per edge tile the tile builder allows
   int n_cu = 256;      // compute units of the device
   int time_every = 0;  // > 0: sample edge-kernel launch durations on every n-th forward (scann_edge_timing)
@@ -309,6 +309,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* w8 = getenv("SCANN_EDGE_W8")) h->edge_w8 = atoi(w8) != 0;
   if (const char* ln = getenv("SCANN_EDGE_LEAN")) h->edge_lean = atoi(ln) != 0;
+  h->edge_lean = h->edge_lean && cfg->g_update && h->edge_tile == 64;
   if (h->edge_lean) h->tile_atoms = TQ;
   if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
   {
@@ -1180,8 +1181,9 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   w->seed = seed;
   const bool dbg = h->debug;
   h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)
-  if (h->attn_drop_p > 0.f && !(h->edge_w8 && h->cfg.g_update && db->tile_rows == 64 && db->n_tile < h->persist_min_tiles))
-    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_w8 only");
+  if (h->attn_drop_p > 0.f && !((h->edge_w8 || (h->edge_lean && db->tile_atoms <= TQ)) && h->cfg.g_update && db->tile_rows == 64 &&
+                                db->n_tile < h->persist_min_tiles))
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
   h->train_drop_p = dropout;
   h->train_seed = seed;
   h->in_train_forward = true;

@@ -29,6 +29,3 @@ if os.environ.get("SCANN_EDGE_LEAN") == "1":
     print("lean diagnostics: own loads landed after %.0f cycles (mean), barrier wait %.0f; sibling wave start offsets (mean) %s max %s" % (
         (st[:, 10] - st[:, 0]).mean(), (st[:, 1] - st[:, 10]).mean(),
         [(st[:, 10 + w] - st[:, 0]).mean() for w in (1, 2, 3)], [(st[:, 10 + w] - st[:, 0]).max() for w in (1, 2, 3)]))
-    if st[:, 14].any():
-        print("probe: first small load landed after %.0f cycles (median %.0f), geometry probe after a further %.0f (median %.0f)" % (
-            (st[:, 14] - st[:, 0]).mean(), np.median(st[:, 14] - st[:, 0]), (st[:, 15] - st[:, 14]).mean(), np.median(st[:, 15] - st[:, 14])))
