@@ -126,23 +126,35 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   if (FFN) load_w(a.Wf1p, wave, lane, wA);
   else load_w(firstW, wave, lane, wA);
 
-  // stage x rows (zero-fill the ragged tail so the MFMAs see defined data)
-  for (int i = tid; i < TA * 32; i += 256) {
-    const int r = i >> 5, c4 = i & 31;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nrows) {
-      const int src = a.x_index ? a.x_index[row0 + r] : (row0 + r);
-      v = reinterpret_cast<const float4*>(a.x)[(size_t)src * 32 + c4];
-      if (!FFN && a.drop_p > 0.f) {  // training: Dropout after dense_embed (scann_model.py:374)
-        const size_t e = (size_t)(row0 + r) * D + 4 * c4;
-        v.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
-        v.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
-        v.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
-        v.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
-      }
-      if (!FFN) reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] = v;  // centres = staged rows (layer 0 / no ResidualNorm)
+  // stage x rows (zero-fill the ragged tail so the MFMAs see defined data).  The four row loads of a thread are issued
+  // together from clamped rows and masked afterwards: a load under a per-thread guard costs a full memory round trip each.
+  {
+    const int c4 = tid & 31, r0 = tid >> 5;  // rows r0, r0 + 8, r0 + 16, r0 + 24
+    int src[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rc = min(r0 + 8 * k, nrows - 1);
+      src[k] = a.x_index ? a.x_index[row0 + rc] : (row0 + rc);
     }
-    *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
+    float4 xv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = reinterpret_cast<const float4*>(a.x)[(size_t)src[k] * 32 + c4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + 8 * k;
+      float4 v = r < nrows ? xv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nrows) {
+        if (!FFN && a.drop_p > 0.f) {  // training: Dropout after dense_embed (scann_model.py:374)
+          const size_t e = (size_t)(row0 + r) * D + 4 * c4;
+          v.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
+          v.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
+          v.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
+          v.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
+        }
+        if (!FFN) reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] = v;  // centres = staged rows (layer 0 / no ResidualNorm)
+      }
+      *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
+    }
   }
   __syncthreads();
 
