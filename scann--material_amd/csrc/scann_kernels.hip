@@ -938,9 +938,6 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   mma_half2(sA, wA, lane, 0, acc);
   mma_half2(sA, wB, lane, 1, acc);
   STAMP(a.stamps, 2);
-  __builtin_amdgcn_sched_barrier(0);
-  load_w_half(a.p.Wkp, wave, lane, 0, wA);  // first half of the key weights arrives during the row pass
-  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();  // every wave is done reading G
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -955,22 +952,25 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
     const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
     const float* p1 = sQ + (ctr - tile.atom_begin) * LDS_STRIDE;
     const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
+    // all sixteen gathered pieces (P3 and centre row of the neighbour, attention.py:136) are requested at once: one memory
+    // round trip for the row pass (the key weights are fetched after it, so the registers are free here)
+    float4 p3r[8], cn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p3r[i] = p3[sub + 4 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cn[i] = crow[sub + 4 * i];
     float s = 0.f;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {  // two groups of four chunks: bounds the gathered rows in flight (register budget)
-#pragma unroll
-      for (int i = 4 * hf; i < 4 * hf + 4; ++i) {
-        const int c4 = sub + 4 * i;
-        const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
-        const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3[c4]);
-        greg[i] = f4add(f4swish(v), greg[i]);
-        s += f4sum(greg[i]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = sub + 4 * i;
+      const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
+      const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3r[i]);
+      greg[i] = f4add(f4swish(v), greg[i]);
+      s += f4sum(greg[i]);
     }
-    float4 cn[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) cn[i] = crow[sub + 4 * i];  // neighbour centre row (attention.py:136), in flight over the statistics
+    __builtin_amdgcn_sched_barrier(0);
+    load_w_half(a.p.Wkp, wave, lane, 0, wA);  // the P3 registers are free: first half of the key weights lands over the statistics
+    __builtin_amdgcn_sched_barrier(0);
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     const float mean = s * (1.0f / D);
@@ -1001,6 +1001,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)  // ragged tail rows: U of the zero rows is 0 already, keep ang = 0 explicit
       *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_w_half(a.p.Wkp, wave, lane, 0, wA);
   }
   load_w_half(a.p.Wkp, wave, lane, 1, wB);
   // query rows: fetched here, parked in sQ as soon as the P1 rows are dead (rows clamped, never guarded: see the prologue)
