@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--config", default="qm9", choices=["qm9", "mp2018"],
                     help="qm9 = BASELINE configs[1] (the metric); mp2018 = configs[3] shapes (crystals, L=9, batch 64), extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-batch-ref", action="store_true",
+                    help="also time single-batch launch sequences (reported as one_batch_per_launch)")
     ap.add_argument("--train", action="store_true",
                     help="extra (BASELINE configs[2]): time data-parallel TRAINING steps instead of the forward metric -- "
                          "forward(train, dropout 0.1) + SSE all-reduce + backward + flat RCCL gradient all-reduce + Adam; "
@@ -333,7 +335,7 @@ def main():
             tj = json.load(open(tfile))
             if tj.get("batches_per_launch") == G and not args.worst:  # PMC passes were taken at this launch size
                 traffic = tj.get("hbm_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "edge_kernel_w8 (scann_kernels.hip), %d batches per launch" % G, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+        roof = {"bound": "mfma", "kernel": "%s (scann_kernels.hip), %d batches per launch" % ("edge_kernel_lean" if os.environ.get("SCANN_EDGE_LEAN", "1") != "0" else "edge_kernel_w8", G), "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                 "avg_launch_us": live_us if live_n else avg_ms * 1e3, "launches_sampled": live_n,
                 "note": "achieved = HIP events around sampled edge-kernel launches inside the timed region (with 1 stream "
@@ -361,8 +363,9 @@ def main():
             "whole_path_tflops_min": world * args.steps * total_flops_min(A, E, L_cfg, emb_cfg) / elapsed / 1e12,
             "roofline": roof,
         }
-        if world == 1 and G > 1 and not args.worst:
-            # the same engine with exactly ONE 128-molecule batch per launch sequence (no fusing), for reference
+        if args.one_batch_ref and world == 1 and G > 1 and not args.worst:
+            # the same engine with exactly ONE 128-molecule batch per launch sequence (no fusing), for reference; opt-in so that
+            # the default command's rocprofv3 per-kernel averages cover the fused launches only
             singles = [eng.upload(b) for b in batches[:min(len(batches), 4 * nstream, 32)]]
             n1 = 400
             for i in range(40):

@@ -41,9 +41,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
       (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
     }                                                                                         \
   } while (0)
+#define STAMP_REAL(buf, slot)                                                                 \
+  do {                                                                                        \
+    if ((buf) && threadIdx.x == 0) {                                                          \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
+    }                                                                                         \
+  } while (0)
 #else
 #define STAMP(buf, slot) do {} while (0)
 #define STAMP_IF(buf, slot, cond) do {} while (0)
+#define STAMP_REAL(buf, slot) do {} while (0)
 #endif
 
 // swish(x) = x * sigmoid(x) on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each.
@@ -884,7 +893,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   const int r = tid >> 2, sub = tid & 3;  // row-pass mapping: 4 threads per edge row, float4 chunks sub, sub+4, ...
 
   STAMP(a.stamps, 0);
-  STAMP_IF(a.stamps, 10 + wave, lane == 0 && wave > 0);  // diagnostic: start time of the sibling waves
+  STAMP_REAL(a.stamps, 12);  // 100 MHz reference clock at entry and exit: shader clock = cycles / ticks * 100 MHz
   // Every load of the prologue is issued UNCONDITIONALLY (rows clamped into the tile, values selected afterwards): a load
   // under a per-thread guard is compiled as branch + load + s_waitcnt vmcnt(0) + store, i.e. one full memory round trip
   // per guard (16 in a row here before: 22 k cycles per tile).
@@ -929,7 +938,6 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
     if (r >= ne) greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = greg[i];
   }
-  STAMP(a.stamps, 10);  // diagnostic: this wave's loads have landed
   __syncthreads();
   STAMP(a.stamps, 1);
   // U = G . W2
@@ -1129,6 +1137,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
     }
   }
   STAMP(a.stamps, 7);
+  STAMP_REAL(a.stamps, 13);
 }
 
 #ifdef SCANN_STAMPS

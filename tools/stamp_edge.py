@@ -25,7 +25,9 @@ for n, (i, j) in zip(names, zip(order[:-1], order[1:])):
     col = st[:, j] - st[:, i]
     print("%-10s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))
 print("kernel span (first start -> last end) cycles:", st[:, 7].max() - st[:, 0].min(), "(s_memtime ticks at 100MHz? see guide: tick = shader cycle)")
-if os.environ.get("SCANN_EDGE_LEAN") == "1":
-    print("lean diagnostics: own loads landed after %.0f cycles (mean), barrier wait %.0f; sibling wave start offsets (mean) %s max %s" % (
-        (st[:, 10] - st[:, 0]).mean(), (st[:, 1] - st[:, 10]).mean(),
-        [(st[:, 10 + w] - st[:, 0]).mean() for w in (1, 2, 3)], [(st[:, 10 + w] - st[:, 0]).max() for w in (1, 2, 3)]))
+if st[:, 12].any() and st[:, 13].any():
+    ticks = (st[:, 13] - st[:, 12]).astype(np.float64)
+    cyc = (st[:, 7] - st[:, 0]).astype(np.float64)
+    ok = ticks > 0
+    print("shader clock while the kernel runs: %.0f MHz (sum of s_memtime cycles / sum of s_memrealtime ticks x 100 MHz over %d tiles)"
+          % (cyc[ok].sum() / ticks[ok].sum() * 100.0, int(ok.sum())))
