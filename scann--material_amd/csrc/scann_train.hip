@@ -37,11 +37,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
   float4 w[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) w[t] = wsrc[t * 64];
-  for (int i = tid; i < TR * 32; i += 256) {
-    const int r = i >> 5, c4 = i & 31;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nrows) v = reinterpret_cast<const float4*>(X)[(size_t)(row0 + r) * 32 + c4];
-    *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
+  {  // all row pieces of a thread are requested together from clamped rows and masked afterwards: a load under a
+     // per-thread guard costs one full memory round trip each (branch + load + s_waitcnt vmcnt(0) + store)
+    const int c4 = tid & 31, r0 = tid >> 5;
+    float4 xv[4 * RT];
+#pragma unroll
+    for (int k = 0; k < 4 * RT; ++k)
+      xv[k] = reinterpret_cast<const float4*>(X)[(size_t)(row0 + min(r0 + 8 * k, nrows - 1)) * 32 + c4];
+#pragma unroll
+    for (int k = 0; k < 4 * RT; ++k) {
+      const int r = r0 + 8 * k;
+      *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = r < nrows ? xv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   __syncthreads();
   f32x16 acc[RT];
@@ -62,6 +69,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
     }
   const int col = 32 * wave + (lane & 31);
   const float b = bias ? bias[col] : 0.f;
+  float yold[RT][16];  // accumulate mode: the old values, requested together (clamped rows) before any of them is used
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) yold[rt][i] = 0.f;
+  if (flags & 1) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        yold[rt][i] = Y[(size_t)(row0 + min(32 * rt + acc_row_(i, lane), nrows - 1)) * D + col];
+  }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -72,7 +91,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
         float v = acc[rt][i] + b;
         if (P) P[o] = v;
         if (flags & 2) v = swish_(v);
-        if (flags & 1) v += Y[o];
+        if (flags & 1) v += yold[rt][i];
         Y[o] = v;
       }
     }
@@ -106,15 +125,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
     if (row0 >= rows) break;
     const int nrows = min(64, rows - row0);
     __syncthreads();
-    for (int i = tid; i < 64 * 32; i += 256) {
-      const int r = i >> 5, c4 = i & 31;
-      float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vd = vx;
-      if (r < nrows) {
-        vx = reinterpret_cast<const float4*>(X)[(size_t)(row0 + r) * 32 + c4];
-        vd = reinterpret_cast<const float4*>(dY)[(size_t)(row0 + r) * 32 + c4];
+    {  // sixteen row pieces requested together from clamped rows, masked afterwards (see linear_kernel)
+      const int c4 = tid & 31, rb = tid >> 5;
+      float4 vx[8], vd[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t o = (size_t)(row0 + min(rb + 8 * k, nrows - 1)) * 32 + c4;
+        vx[k] = reinterpret_cast<const float4*>(X)[o];
+        vd[k] = reinterpret_cast<const float4*>(dY)[o];
       }
-      *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = vx;
-      *reinterpret_cast<float4*>(&sD[r * LDS_STRIDE + 4 * c4]) = vd;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = rb + 8 * k;
+        const float keep = r < nrows ? 1.f : 0.f;  // rows past the end contribute exact zeros
+        *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = make_float4(vx[k].x * keep, vx[k].y * keep, vx[k].z * keep, vx[k].w * keep);
+        *reinterpret_cast<float4*>(&sD[r * LDS_STRIDE + 4 * c4]) = make_float4(vd[k].x * keep, vd[k].y * keep, vd[k].z * keep, vd[k].w * keep);
+      }
     }
     __syncthreads();
     if (db && tid < D)
@@ -186,38 +212,53 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   const int r0 = (blockIdx.x * 4 + wave) * rows_per_wave;
   const float2 g = reinterpret_cast<const float2*>(gamma)[lane];
   float2 dg = make_float2(0.f, 0.f), dbt = dg;
-  for (int r = r0; r < min(rows, r0 + rows_per_wave); ++r) {
-    const float2 xv = reinterpret_cast<const float2*>(x)[(size_t)r * 64 + lane];
-    const float2 dyv = reinterpret_cast<const float2*>(dy)[(size_t)r * 64 + lane];
-    float s = xv.x + xv.y;
+  const int rend = min(rows, r0 + rows_per_wave);
+  for (int rg = r0; rg < rend; rg += 4) {  // four rows per trip, their loads requested together (clamped rows)
+    float2 xv4[4], dyv4[4], old4[4];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / D);
-    const float cx = xv.x - mean, cy = xv.y - mean;
-    float v = cx * cx + cy * cy;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-    const float hx = cx * rstd, hy = cy * rstd;
-    const float ax = dyv.x * g.x, ay = dyv.y * g.y;
-    float m1 = ax + ay, m2 = ax * hx + ay * hy;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      m1 += __shfl_xor(m1, o);
-      m2 += __shfl_xor(m2, o);
+    for (int j = 0; j < 4; ++j) {
+      const size_t o = (size_t)min(rg + j, rend - 1) * 64 + lane;
+      xv4[j] = reinterpret_cast<const float2*>(x)[o];
+      dyv4[j] = reinterpret_cast<const float2*>(dy)[o];
+      old4[j] = make_float2(0.f, 0.f);
     }
-    m1 *= (1.0f / D);
-    m2 *= (1.0f / D);
-    float2 out = make_float2(rstd * (ax - m1 - hx * m2), rstd * (ay - m1 - hy * m2));
-    float2* dst = reinterpret_cast<float2*>(dx) + (size_t)r * 64 + lane;
     if (accumulate) {
-      const float2 old = *dst;
-      out.x += old.x;
-      out.y += old.y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) old4[j] = reinterpret_cast<const float2*>(dx)[(size_t)min(rg + j, rend - 1) * 64 + lane];
     }
-    *dst = out;
-    dg.x += dyv.x * hx; dg.y += dyv.y * hy;
-    dbt.x += dyv.x; dbt.y += dyv.y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = rg + j;
+      if (r >= rend) break;
+      const float2 xv = xv4[j], dyv = dyv4[j];
+      float s = xv.x + xv.y;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+      const float mean = s * (1.0f / D);
+      const float cx = xv.x - mean, cy = xv.y - mean;
+      float v = cx * cx + cy * cy;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+      const float hx = cx * rstd, hy = cy * rstd;
+      const float ax = dyv.x * g.x, ay = dyv.y * g.y;
+      float m1 = ax + ay, m2 = ax * hx + ay * hy;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        m1 += __shfl_xor(m1, o);
+        m2 += __shfl_xor(m2, o);
+      }
+      m1 *= (1.0f / D);
+      m2 *= (1.0f / D);
+      float2 out = make_float2(rstd * (ax - m1 - hx * m2), rstd * (ay - m1 - hy * m2));
+      if (accumulate) {
+        out.x += old4[j].x;
+        out.y += old4[j].y;
+      }
+      reinterpret_cast<float2*>(dx)[(size_t)r * 64 + lane] = out;
+      dg.x += dyv.x * hx; dg.y += dyv.y * hy;
+      dbt.x += dyv.x; dbt.y += dyv.y;
+    }
   }
   // one set of atomics per workgroup (all workgroups hit the same 256 addresses)
   __shared__ float sred[4][4 * 64];
