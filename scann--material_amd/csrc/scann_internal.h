@@ -110,6 +110,7 @@ struct AtomArgs {
   const float *WCp, *bC;   // mode 0/1: Wq,bq  | mode 2: ga query
   const float *WDp, *bD;   // mode 2: ga key
   float *oA, *oB, *oC;     // mode 0: P1,P3,q | mode 1: -, -, q | mode 2: -, gk, gq
+  unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS, env SCANN_STAMP_ATOM=1) only: [n_tiles,16] phase clocks
 };
 void launch_atom(const AtomArgs& a, hipStream_t s);
 

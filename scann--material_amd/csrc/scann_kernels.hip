@@ -131,6 +131,13 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
   const float* const firstW = MODE == 1 ? a.WCp : a.WAp;
 
+  STAMP(a.stamps, 0);
+  // vmcnt retires in issue order: a bias or LayerNorm parameter requested after a weight slab waits for the whole slab,
+  // and one requested after output stores waits for their acknowledgements.  So every small operand is fetched here, first.
+  __shared__ float sLN[2 * D];
+  const float b_f1 = FFN ? a.bf1[col] : 0.f, b_f2 = FFN ? a.bf2[col] : 0.f;
+  const float b_A = MODE != 1 ? a.bA[col] : 0.f, b_C = a.bC[col], b_D = MODE == 2 ? a.bD[col] : 0.f;
+  if (FFN) sLN[tid] = (tid < D ? a.lnr_g : a.lnr_b)[tid & (D - 1)];
   float4 wA[16];
   if (FFN) load_w(a.Wf1p, wave, lane, wA);
   else load_w(firstW, wave, lane, wA);
@@ -166,39 +173,40 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
     }
   }
   __syncthreads();
+  STAMP(a.stamps, 1);
 
   f32x16 acc[1];
   if (FFN) {
     // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
     zero_acc(acc);
     mma128<1>(sX, wA, lane, acc);
+    STAMP(a.stamps, 2);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.Wf2p, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const float b = a.bf1[col];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b);
-    }
+    for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b_f1);
     __syncthreads();
+    STAMP(a.stamps, 3);
     // y = h W2 + b2 ; t = x + y
     zero_acc(acc);
     mma128<1>(sH, wA, lane, acc);
+    STAMP(a.stamps, 4);
     __builtin_amdgcn_sched_barrier(0);
     load_w(firstW, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave is done reading sH
     {
-      const float b = a.bf2[col];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = acc_row(i, lane);
-        float y = acc[0][i] + b;
+        float y = acc[0][i] + b_f2;
         if (a.drop_p > 0.f) y *= drop_scale(a.drop_seed, a.drop_tag, (size_t)(row0 + r) * D + col, a.drop_p);  // attention.py:29 (training)
         sH[r * LDS_STRIDE + col] = sX[r * LDS_STRIDE + col] + y;
       }
     }
     __syncthreads();
+    STAMP(a.stamps, 5);
     // c = LayerNorm(t): 8 threads per row, 4 float4 each
     {
       const int r = tid >> 3, sub = tid & 7;
@@ -226,8 +234,8 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c4 = sub + 8 * i;
-        const float4 g = reinterpret_cast<const float4*>(a.lnr_g)[c4];
-        const float4 be = reinterpret_cast<const float4*>(a.lnr_b)[c4];
+        const float4 g = *reinterpret_cast<const float4*>(&sLN[4 * c4]);
+        const float4 be = *reinterpret_cast<const float4*>(&sLN[D + 4 * c4]);
         float4 y;
         float inv;
         inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
@@ -239,42 +247,48 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
       }
     }
     __syncthreads();
+    STAMP(a.stamps, 6);
   }
 
+  // The projections stay in registers until the last weight slab has been requested; their stores go out together at
+  // the end so that no load of this workgroup ever queues behind a store acknowledgement.
+  f32x16 accP1, accP3;
   if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
     zero_acc(acc);
     mma128<1>(sX, wA, lane, acc);
+    STAMP(a.stamps, 7);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WBp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const float b = a.bA[col];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = acc_row(i, lane);
-        if (r < nrows) a.oA[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
-      }
-    }
+    accP1 = acc[0];
+    STAMP(a.stamps, 8);
     zero_acc(acc);
     mma128<1>(sX, wA, lane, acc);
+    STAMP(a.stamps, 9);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WCp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = acc_row(i, lane);
-      if (r < nrows) a.oB[(size_t)(row0 + r) * D + col] = acc[0][i];
-    }
+    accP3 = acc[0];
   }
   if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
+    STAMP(a.stamps, 10);
     zero_acc(acc);
     mma128<1>(sX, wA, lane, acc);
-    const float b = a.bC[col];
+    STAMP(a.stamps, 11);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = acc_row(i, lane);
-      if (r < nrows) a.oC[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+      if (r < nrows) {
+        const size_t o = (size_t)(row0 + r) * D + col;
+        if (MODE == 0) {
+          a.oA[o] = accP1[i] + b_A;
+          a.oB[o] = accP3[i];
+        }
+        a.oC[o] = acc[0][i] + b_C;
+      }
     }
+    STAMP(a.stamps, 12);
   }
   if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
     zero_acc(acc);
@@ -282,33 +296,25 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WCp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const float b = a.bA[col];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b);
-    }
+    for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b_A);
     __syncthreads();
     zero_acc(acc);
     mma128<1>(sH, wA, lane, acc);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WDp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const float b = a.bC[col];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = acc_row(i, lane);
-        if (r < nrows) a.oC[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
-      }
-    }
+    accP1 = acc[0];
     zero_acc(acc);
     mma128<1>(sH, wA, lane, acc);
-    {
-      const float b = a.bD[col];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = acc_row(i, lane);
-        if (r < nrows) a.oB[(size_t)(row0 + r) * D + col] = acc[0][i] + b;
+    for (int i = 0; i < 16; ++i) {
+      const int r = acc_row(i, lane);
+      if (r < nrows) {
+        const size_t o = (size_t)(row0 + r) * D + col;
+        a.oC[o] = accP1[i] + b_C;
+        a.oB[o] = acc[0][i] + b_D;
       }
     }
   }

@@ -166,6 +166,7 @@ struct scann_dbatch {
   // debug copies (allocated on demand)
   float *dbg_c = nullptr, *dbg_g = nullptr, *dbg_ctx = nullptr;
   unsigned long long* stamps = nullptr;  // diagnostic build only
+  int n_stamp = 0;
   int dbg_layers = -1;
   int last_slot = 0;
   bool owns_arena = true;  // false: the arena belongs to the handle's scratch (scann_forward)
@@ -819,6 +820,14 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       a.WAp = h->head.Wap; a.bA = h->head.ba; a.WCp = h->head.Wgqp; a.bC = h->head.bgq; a.WDp = h->head.Wgkp; a.bD = h->head.bgk;
       a.oB = db->gk; a.oC = db->gq;
     }
+#ifdef SCANN_STAMPS
+    if (getenv("SCANN_STAMP_ATOM") && l >= 1 && l < L) {  // phase clocks of atom_kernel<true, 0> (the last such launch wins)
+      const int nt = (db->n_atom + TA - 1) / TA;
+      if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)nt * 16 * sizeof(unsigned long long)));
+      a.stamps = db->stamps;
+      db->n_stamp = nt;
+    }
+#endif
     launch_atom(a, s);
     if (tm) tm->mark(l < L ? 1 : 3);
     if (h->debug) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
@@ -846,8 +855,11 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
     ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles) ? h->n_cu : 0;
 #ifdef SCANN_STAMPS
-    if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
-    ea.stamps = db->stamps;
+    if (!getenv("SCANN_STAMP_ATOM")) {
+      if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
+      ea.stamps = db->stamps;
+      db->n_stamp = db->n_tile;
+    }
 #endif
     launch_edge(ea, s);
     if (sample) {
@@ -999,7 +1011,7 @@ int scann_debug_stamps(scann_handle_t* h, scann_dbatch_t* db, uint64_t* out, int
   if (!db->stamps) return fail(h, SCANN_ERR_INVALID, "scann_debug_stamps: no forward has run");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipDeviceSynchronize());
-  const int n = std::min(max_tiles, db->n_tile);
+  const int n = std::min(max_tiles, db->n_stamp);
   HIPCHK(h, hipMemcpy(out, db->stamps, (size_t)n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return n;
 #else

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic: phase clocks of atom_kernel<true, 0> (ResidualNorm + P1/P3/q projections of a 32-atom tile).
+Run with SCANN_HIP_LIB=.../libscann_hip_stamps.so SCANN_STAMP_ATOM=1 (make -C scann--material_amd/csrc stamps)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scann--material_amd")); sys.path.insert(0, ROOT)
+from scann.models.scann_model import HipModel, normalize_config
+import bench
+
+cfg = normalize_config({"model": dict(bench.QM9_MODEL), "hyper": {"target": "homo"}})
+model = HipModel(cfg, device=0, seed=1234)
+eng = model.engine
+rng = np.random.default_rng(0)
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+rb = eng.upload(bench.synth_packed_batch(rng, nb))
+for _ in range(5):
+    eng.forward_resident(rb, 0)
+eng.sync()
+st = eng.debug_stamps(rb).astype(np.int64)
+names = ["stage x", "GEMM ffn1", "dump+barrier", "GEMM ffn2", "residual+barrier", "LayerNorm+barrier", "GEMM W1", "store P1 (+W3 wait)",
+         "GEMM W3", "store P3 (+Wq wait)", "GEMM Wq", "store q"]
+print("tiles", st.shape[0], "total cycles/tile mean", (st[:, 12] - st[:, 0]).mean())
+for i, n in enumerate(names):
+    col = st[:, i + 1] - st[:, i]
+    print("%-22s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))
