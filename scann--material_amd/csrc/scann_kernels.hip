@@ -912,6 +912,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
                                 : a.edge_offset + tile.atom_begin + min(tid - TEK, natom);
   const int32_t* pb = ne > 0 ? a.edge_row + eb + min(tid & (TEK - 1), nem1) : a.edge_offset;
   const int va = *pa, vb = *pb;
+  const float bkc = a.p.bk[col];  // key bias: fetched with the prologue so that its wait never queues behind the geometry stores
   const float par0 = (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)];
   const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
   float4 p1reg[3];  // centre thirds P1 = c_i W1 + bg of the tile's atoms (an atom's edges share the row)
@@ -1036,13 +1037,10 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   mma_half2(sA, wB, lane, 1, acc);
   STAMP(a.stamps, 5);
   __syncthreads();  // every wave is done reading ang
-  {
-    const float b = a.p.bk[col];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sA[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + b;
-  }
+    for (int i = 0; i < 16; ++i) sA[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + bkc;
   __syncthreads();
   STAMP(a.stamps, 6);
   // logits: thread = (edge row, pair of heads)
