@@ -352,17 +352,43 @@ def test_degenerate_batches(hip_lib):
 
 
 @pytest.mark.parametrize("env", [
-    {"SCANN_EDGE_W8": "0"},                              # 4-wave edge_kernel<true, 2>
-    {"SCANN_EDGE_W8": "0", "SCANN_EDGE_TILE": "32"},     # 32-row tiles, edge_kernel<true, 1>
-    {"SCANN_EDGE_TILE": "32"},                           # edge_kernel_w8<1>: 32-row tiles, 4-wave workgroups
-    {"SCANN_PERSIST_MIN": "1"},                          # persistent wave-specialised kernel for every launch
-    {"SCANN_XCD_REMAP": "0", "SCANN_STREAMS": "2"},
-], ids=["w4", "w4_tile32", "w8_tile32", "persistent", "no_remap_2streams"])
+    {"SCANN_EDGE_LEAN": "0"},                                    # edge_kernel_w8<2>: 8 waves, two LDS buffers
+    {"SCANN_EDGE_LEAN": "0", "SCANN_EDGE_W8": "0"},              # 4-wave edge_kernel<true, 2>
+    {"SCANN_EDGE_W8": "0", "SCANN_EDGE_TILE": "32"},             # 32-row tiles, edge_kernel<true, 1>
+    {"SCANN_EDGE_TILE": "32"},                                   # edge_kernel_w8<1>: 32-row tiles, 4-wave workgroups
+    {"SCANN_PERSIST_MIN": "1"},                                  # persistent wave-specialised kernel for every launch
+    {"SCANN_XCD_REMAP": "0", "SCANN_STREAMS": "2"},              # default edge_kernel_lean without the XCD tile order
+], ids=["w8", "w4", "w4_tile32", "w8_tile32", "persistent", "lean_no_remap_2streams"])
 def test_alternative_edge_kernels(hip_lib, env, monkeypatch):
     """The opt-in kernel variants (selected by environment at scann_create) stay at parity."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cfg, w, inputs, model = make(n=40, seed=13)
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+
+
+def test_sparse_graphs_hit_the_atoms_per_tile_limit(hip_lib):
+    """Chains and stars: atoms with one or two neighbours, so an edge tile is closed by its atom count (TQ = 24 for
+    edge_kernel_lean) long before it holds 64 edges; includes atoms without any neighbour between them."""
+    cfg, w, _, model = make(n=2)
+    rng = np.random.default_rng(5)
+    de, dn = np.empty(4, dtype=object), np.empty(4, dtype=object)
+    for s, A in enumerate((29, 27, 29, 3)):
+        nb = []
+        for a in range(A):
+            if s == 0:    # chain: both chain neighbours
+                js = [j for j in (a - 1, a + 1) if 0 <= j < A]
+            elif s == 1:  # star: everybody sees atom 0 only, atom 0 sees three of them
+                js = [0] if a else [1, 2, 3]
+            elif s == 2:  # every third atom isolated, the others see one neighbour
+                js = [] if a % 3 == 0 else [a - 1]
+            else:
+                js = [(a + 1) % A]
+            nb.append([[6, int(j), float(rng.uniform(0.4, 3.5)), 1.0, float(rng.uniform(0.9, 4.0))] for j in js])
+        de[s], dn[s] = [[int(z) for z in rng.choice([1, 6, 7, 8], A)], 0.0], nb
+    inputs, _ = so.pad_batch(de, dn, True)
     y, ga = model.predict(inputs)
     y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
     assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
