@@ -877,11 +877,27 @@ __device__ __forceinline__ void mma_half2(const float* __restrict__ sX, const fl
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[rt], 0, 0, 0);
+      // operands swapped (weights as A, rows as B): the product comes out transposed, i.e. lane l holds ROW l & 31 and the
+      // sixteen columns (i & 3) + 8 (i >> 2) + 4 (l >> 5) of the wave's 32 -- four runs of four consecutive columns, so the
+      // tile is written back with ds_write_b128 instead of sixteen ds_write_b32
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, a.x, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, a.y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, a.z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, a.w, acc[rt], 0, 0, 0);
     }
+  }
+}
+// write the transposed accumulators of mma_half2 (+ a per-column bias row, or null) to a [64][LDS_STRIDE] tile
+__device__ __forceinline__ void dump_t2(float* __restrict__ sT, const f32x16 (&acc)[2], int wave, int lane, const float* __restrict__ sBias) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 32 * wave + 8 * j + 4 * (lane >> 5);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sBias) bv = *reinterpret_cast<const float4*>(sBias + c);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      *reinterpret_cast<float4*>(&sT[(32 * rt + (lane & 31)) * LDS_STRIDE + c]) =
+          make_float4(acc[rt][4 * j] + bv.x, acc[rt][4 * j + 1] + bv.y, acc[rt][4 * j + 2] + bv.z, acc[rt][4 * j + 3] + bv.w);
   }
 }
 
@@ -890,12 +906,11 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];  // G -> U -> ang = c[j]*geom' -> K
   __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];   // P1 rows, then query rows of the tile's atoms, then context
   __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
-  __shared__ __attribute__((aligned(16))) float sPar[4 * D];
+  __shared__ __attribute__((aligned(16))) float sPar[5 * D];  // layer_norm_g gamma/beta, layer_norm gamma/beta, key bias
   __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const EdgeTile tile = a.tiles[a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x];
   const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
-  const int col = 32 * wave + (lane & 31);
   const int r = tid >> 2, sub = tid & 3;  // row-pass mapping: 4 threads per edge row, float4 chunks sub, sub+4, ...
 
   STAMP(a.stamps, 0);
@@ -912,7 +927,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
                                 : a.edge_offset + tile.atom_begin + min(tid - TEK, natom);
   const int32_t* pb = ne > 0 ? a.edge_row + eb + min(tid & (TEK - 1), nem1) : a.edge_offset;
   const int va = *pa, vb = *pb;
-  const float bkc = a.p.bk[col];  // key bias: fetched with the prologue so that its wait never queues behind the geometry stores
+  const float bkc = a.p.bk[tid & (D - 1)];  // key bias row (-> sPar): fetched with the prologue so that its wait never queues behind the geometry stores
   const float par0 = (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)];
   const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
   float4 p1reg[3];  // centre thirds P1 = c_i W1 + bg of the tile's atoms (an atom's edges share the row)
@@ -935,6 +950,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   }
   sPar[tid] = par0;
   sPar[2 * D + tid] = par1;
+  if (tid < D) sPar[4 * D + tid] = bkc;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int idx = tid + 256 * i;
@@ -954,10 +970,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   mma_half2(sA, wB, lane, 1, acc);
   STAMP(a.stamps, 2);
   __syncthreads();  // every wave is done reading G
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sA[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i];
+  dump_t2(sA, acc, wave, lane, nullptr);
   __syncthreads();
   STAMP(a.stamps, 3);
 
@@ -1037,10 +1050,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   mma_half2(sA, wB, lane, 1, acc);
   STAMP(a.stamps, 5);
   __syncthreads();  // every wave is done reading ang
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sA[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + bkc;
+  dump_t2(sA, acc, wave, lane, sPar + 4 * D);
   __syncthreads();
   STAMP(a.stamps, 6);
   // logits: thread = (edge row, pair of heads)
