@@ -112,6 +112,23 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT]) {
     for (int i = 0; i < 16; ++i) acc[rt][i] = 0.0f;
 }
 
+// Operands swapped (weights as A, rows as B): the product comes out transposed -- lane l holds ROW l & 31 and the sixteen
+// columns (i & 3) + 8 (i >> 2) + 4 (l >> 5) of the wave's 32, four runs of four consecutive columns -- so every epilogue
+// moves 16-byte pieces (ds_write_b128 / global_store_dwordx4) instead of sixteen 4-byte ones.  Same k order, same sums.
+__device__ __forceinline__ void mma128T(const float* __restrict__ sX, const float4 (&w)[16], int lane, f32x16& acc) {
+  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * t);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, a.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, a.w, acc, 0, 0, 0);
+  }
+}
+// column of the j-th run of a lane in the transposed layout
+__device__ __forceinline__ int tcol(int wave, int lane, int j) { return 32 * wave + 8 * j + 4 * (lane >> 5); }
+
 // C/D map of the 32x32 MFMA: register i of lane l holds row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31.
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
@@ -124,20 +141,30 @@ template <bool FFN, int MODE>
 __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[TA * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sH[TA * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sLN[2 * D];  // ResidualNorm LayerNorm gamma, beta
+  __shared__ __attribute__((aligned(16))) float sBias[5 * D];  // rows: bf1, bf2, bA, bC, bD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * TA;
   const int nrows = min(TA, a.n_atom - row0);
-  const int col = 32 * wave + (lane & 31);
+  const int trow = lane & 31;  // this lane's row in the transposed accumulator layout (mma128T)
   // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
   const float* const firstW = MODE == 1 ? a.WCp : a.WAp;
 
   STAMP(a.stamps, 0);
   // vmcnt retires in issue order: a bias or LayerNorm parameter requested after a weight slab waits for the whole slab,
   // and one requested after output stores waits for their acknowledgements.  So every small operand is fetched here, first.
-  __shared__ float sLN[2 * D];
-  const float b_f1 = FFN ? a.bf1[col] : 0.f, b_f2 = FFN ? a.bf2[col] : 0.f;
-  const float b_A = MODE != 1 ? a.bA[col] : 0.f, b_C = a.bC[col], b_D = MODE == 2 ? a.bD[col] : 0.f;
-  if (FFN) sLN[tid] = (tid < D ? a.lnr_g : a.lnr_b)[tid & (D - 1)];
+  {
+    const int j = tid & (D - 1);
+    const bool lo = tid < D;
+    const float v0 = FFN ? (lo ? a.bf1 : a.bf2)[j] : 0.f;
+    const float v1 = MODE == 1 ? a.bC[j] : (lo ? a.bA : a.bC)[j];
+    const float v2 = MODE == 2 ? a.bD[j] : 0.f;
+    const float v3 = FFN ? (lo ? a.lnr_g : a.lnr_b)[j] : 0.f;
+    sBias[tid] = v0;                              // bf1 | bf2
+    sBias[2 * D + tid] = v1;                      // bA | bC   (mode 1: bC in both halves)
+    if (lo) sBias[4 * D + j] = v2;                // bD
+    sLN[tid] = v3;
+  }
   float4 wA[16];
   if (FFN) load_w(a.Wf1p, wave, lane, wA);
   else load_w(firstW, wave, lane, wA);
@@ -175,35 +202,48 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   __syncthreads();
   STAMP(a.stamps, 1);
 
-  f32x16 acc[1];
+  f32x16 acc;
   if (FFN) {
     // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
-    zero_acc(acc);
-    mma128<1>(sX, wA, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    mma128T(sX, wA, lane, acc);
     STAMP(a.stamps, 2);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.Wf2p, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b_f1);
+    for (int j = 0; j < 4; ++j) {
+      const int c = tcol(wave, lane, j);
+      const float4 bv = *reinterpret_cast<const float4*>(&sBias[c]);
+      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) =
+          make_float4(swishf(acc[4 * j] + bv.x), swishf(acc[4 * j + 1] + bv.y), swishf(acc[4 * j + 2] + bv.z), swishf(acc[4 * j + 3] + bv.w));
+    }
     __syncthreads();
     STAMP(a.stamps, 3);
     // y = h W2 + b2 ; t = x + y
-    zero_acc(acc);
-    mma128<1>(sH, wA, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    mma128T(sH, wA, lane, acc);
     STAMP(a.stamps, 4);
     __builtin_amdgcn_sched_barrier(0);
     load_w(firstW, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave is done reading sH
-    {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = acc_row(i, lane);
-        float y = acc[0][i] + b_f2;
-        if (a.drop_p > 0.f) y *= drop_scale(a.drop_seed, a.drop_tag, (size_t)(row0 + r) * D + col, a.drop_p);  // attention.py:29 (training)
-        sH[r * LDS_STRIDE + col] = sX[r * LDS_STRIDE + col] + y;
+    for (int j = 0; j < 4; ++j) {
+      const int c = tcol(wave, lane, j);
+      const float4 bv = *reinterpret_cast<const float4*>(&sBias[D + c]);
+      const float4 xv = *reinterpret_cast<const float4*>(&sX[trow * LDS_STRIDE + c]);
+      float4 y = make_float4(acc[4 * j] + bv.x, acc[4 * j + 1] + bv.y, acc[4 * j + 2] + bv.z, acc[4 * j + 3] + bv.w);
+      if (a.drop_p > 0.f) {  // attention.py:29 (training)
+        const size_t e = (size_t)(row0 + trow) * D + c;
+        y.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
+        y.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
+        y.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
+        y.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
       }
+      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) = f4add(xv, y);
     }
     __syncthreads();
     STAMP(a.stamps, 5);
@@ -251,70 +291,82 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   }
 
   // The projections stay in registers until the last weight slab has been requested; their stores go out together at
-  // the end so that no load of this workgroup ever queues behind a store acknowledgement.
+  // the end (16-byte pieces) so that no load of this workgroup ever queues behind a store acknowledgement.
   f32x16 accP1, accP3;
   if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
-    zero_acc(acc);
-    mma128<1>(sX, wA, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accP1[i] = 0.f;
+    mma128T(sX, wA, lane, accP1);
     STAMP(a.stamps, 7);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WBp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-    accP1 = acc[0];
     STAMP(a.stamps, 8);
-    zero_acc(acc);
-    mma128<1>(sX, wA, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accP3[i] = 0.f;
+    mma128T(sX, wA, lane, accP3);
     STAMP(a.stamps, 9);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WCp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-    accP3 = acc[0];
   }
   if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
     STAMP(a.stamps, 10);
-    zero_acc(acc);
-    mma128<1>(sX, wA, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    mma128T(sX, wA, lane, acc);
     STAMP(a.stamps, 11);
     __builtin_amdgcn_sched_barrier(0);
+    if (trow < nrows) {
+      const size_t o = (size_t)(row0 + trow) * D;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = acc_row(i, lane);
-      if (r < nrows) {
-        const size_t o = (size_t)(row0 + r) * D + col;
+      for (int j = 0; j < 4; ++j) {
+        const int c = tcol(wave, lane, j);
+        const float4 bq = *reinterpret_cast<const float4*>(&sBias[(MODE == 0 ? 3 : 2) * D + c]);
         if (MODE == 0) {
-          a.oA[o] = accP1[i] + b_A;
-          a.oB[o] = accP3[i];
+          const float4 bg = *reinterpret_cast<const float4*>(&sBias[2 * D + c]);
+          *reinterpret_cast<float4*>(a.oA + o + c) = make_float4(accP1[4 * j] + bg.x, accP1[4 * j + 1] + bg.y, accP1[4 * j + 2] + bg.z, accP1[4 * j + 3] + bg.w);
+          *reinterpret_cast<float4*>(a.oB + o + c) = make_float4(accP3[4 * j], accP3[4 * j + 1], accP3[4 * j + 2], accP3[4 * j + 3]);
         }
-        a.oC[o] = acc[0][i] + b_C;
+        *reinterpret_cast<float4*>(a.oC + o + c) = make_float4(acc[4 * j] + bq.x, acc[4 * j + 1] + bq.y, acc[4 * j + 2] + bq.z, acc[4 * j + 3] + bq.w);
       }
     }
     STAMP(a.stamps, 12);
   }
   if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
-    zero_acc(acc);
-    mma128<1>(sX, wA, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    mma128T(sX, wA, lane, acc);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WCp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sH[acc_row(i, lane) * LDS_STRIDE + col] = swishf(acc[0][i] + b_A);
+    for (int j = 0; j < 4; ++j) {
+      const int c = tcol(wave, lane, j);
+      const float4 bv = *reinterpret_cast<const float4*>(&sBias[2 * D + c]);
+      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) =
+          make_float4(swishf(acc[4 * j] + bv.x), swishf(acc[4 * j + 1] + bv.y), swishf(acc[4 * j + 2] + bv.z), swishf(acc[4 * j + 3] + bv.w));
+    }
     __syncthreads();
-    zero_acc(acc);
-    mma128<1>(sH, wA, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accP1[i] = 0.f;
+    mma128T(sH, wA, lane, accP1);
     __builtin_amdgcn_sched_barrier(0);
     load_w(a.WDp, wave, lane, wA);
     __builtin_amdgcn_sched_barrier(0);
-    accP1 = acc[0];
-    zero_acc(acc);
-    mma128<1>(sH, wA, lane, acc);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = acc_row(i, lane);
-      if (r < nrows) {
-        const size_t o = (size_t)(row0 + r) * D + col;
-        a.oC[o] = accP1[i] + b_C;
-        a.oB[o] = acc[0][i] + b_D;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    mma128T(sH, wA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (trow < nrows) {
+      const size_t o = (size_t)(row0 + trow) * D;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = tcol(wave, lane, j);
+        const float4 bq = *reinterpret_cast<const float4*>(&sBias[3 * D + c]);
+        const float4 bk = *reinterpret_cast<const float4*>(&sBias[4 * D + c]);
+        *reinterpret_cast<float4*>(a.oC + o + c) = make_float4(accP1[4 * j] + bq.x, accP1[4 * j + 1] + bq.y, accP1[4 * j + 2] + bq.z, accP1[4 * j + 3] + bq.w);
+        *reinterpret_cast<float4*>(a.oB + o + c) = make_float4(acc[4 * j] + bk.x, acc[4 * j + 1] + bk.y, acc[4 * j + 2] + bk.z, acc[4 * j + 3] + bk.w);
       }
     }
   }
