@@ -1612,11 +1612,20 @@ __global__ __launch_bounds__(256) void basis_kernel(BasisParams p, const float* 
     ww[k] = p.Ww[k * D + col];
   }
   const float bd = p.bd[col], bw = p.bw[col];
-  for (int i = tid; i < TB * 2 * NG; i += 256) {
-    const int e = i / (2 * NG), k = i % (2 * NG);
-    float v = 0.f;
-    if (e < ne) v = k < NG ? gauss_fast(dist[e0 + e], p.cd[k]) : gauss_fast(weight[e0 + e], p.cw[k - NG]);
-    sG[e][k] = v;
+  {  // Gaussian expansions of the tile's edges; operands requested together from clamped rows, values masked afterwards
+    constexpr int NV = (TB * 2 * NG + 255) / 256;
+    float x[NV], cc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = min(tid + 256 * j, TB * 2 * NG - 1), e = min(i / (2 * NG), ne - 1), k = i % (2 * NG);
+      x[j] = (k < NG ? dist : weight)[e0 + e];
+      cc[j] = k < NG ? p.cd[k] : p.cw[k - NG];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + 256 * j;
+      if (i < TB * 2 * NG) sG[i / (2 * NG)][i % (2 * NG)] = i / (2 * NG) < ne ? gauss_fast(x[j], cc[j]) : 0.f;
+    }
   }
   __syncthreads();
 #pragma unroll 2
