@@ -122,6 +122,11 @@ struct EdgeArgs {
   int32_t xcd_remap;           // contiguous run of tiles per XCD (edge_kernel_w8)
   int32_t waves8;              // run the 8-wave (512-thread) variant edge_kernel_w8
   int32_t lean;                // run edge_kernel_lean (tiles must hold <= TQ atoms)
+  // atoms with more than 64 neighbours (edge_kernel_lean only): their edges are cut into chunk tiles of one atom each;
+  // tile_part[tile] = partial slot of a chunk tile, -1 for ordinary tiles (null: no such atom in the batch); a chunk tile
+  // leaves (running max, sum, unnormalised context) per column in part_buf[slot][3][128] for edge_merge_kernel
+  const int32_t* tile_part;
+  float* part_buf;
   int32_t g_update;
   const int32_t* edge_offset;  // [n_atom+1]
   const int32_t* edge_col;     // [n_edge]
@@ -139,6 +144,9 @@ struct EdgeArgs {
   LayerParams p;
 };
 void launch_edge(const EdgeArgs& a, hipStream_t s);
+// softmax merge of the chunk tiles of every big atom (+ unscaled-query residual + LayerNorm, attention.py:189-214)
+void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,
+                       const float* ln_b, float* ctx, hipStream_t s);
 
 struct ReadoutArgs {
   const int32_t* mol_offset;  // [n_struct+1]

@@ -961,7 +961,9 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   __shared__ __attribute__((aligned(16))) float sPar[5 * D];  // layer_norm_g gamma/beta, layer_norm gamma/beta, key bias
   __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const EdgeTile tile = a.tiles[a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x];
+  const int tix = a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+  const EdgeTile tile = a.tiles[tix];
+  const int part = a.tile_part ? a.tile_part[tix] : -1;  // >= 0: one <= 64-edge chunk of an atom with more than 64 neighbours
   const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
   const int r = tid >> 2, sub = tid & 3;  // row-pass mapping: 4 threads per edge row, float4 chunks sub, sub+4, ...
 
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
     sCol[tid] = tid < ne ? va : 0;
     sCtr[tid] = tid < ne ? vb : 0;
   } else if (tid - TEK <= natom) {
-    sOff[tid - TEK] = va - eb;
+    sOff[tid - TEK] = part >= 0 ? (tid == TEK ? 0 : ne) : va - eb;  // a chunk tile holds edges [0, ne) of its single atom
   }
   sPar[tid] = par0;
   sPar[2 * D + tid] = par1;
@@ -1154,10 +1156,17 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
         cx.w = cx.w * resc + (pa * ka.w + pb * kb.w);
         m = mn;
       }
-      const float rs = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
-      float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
-      const float4 q4 = *qp;
-      *qp = make_float4(cx.x * rs + q4.x, cx.y * rs + q4.y, cx.z * rs + q4.z, cx.w * rs + q4.w);
+      if (part >= 0) {  // chunk tile: leave the softmax state of this chunk for edge_merge_kernel
+        float* pb = a.part_buf + (size_t)part * 3 * D + 4 * c4;
+        *reinterpret_cast<float4*>(pb) = make_float4(m, m, m, m);
+        *reinterpret_cast<float4*>(pb + D) = make_float4(ssum, ssum, ssum, ssum);
+        *reinterpret_cast<float4*>(pb + 2 * D) = cx;
+      } else {
+        const float rs = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+        float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
+        const float4 q4 = *qp;
+        *qp = make_float4(cx.x * rs + q4.x, cx.y * rs + q4.y, cx.z * rs + q4.z, cx.w * rs + q4.w);
+      }
     }
   }
   __syncthreads();
@@ -1165,7 +1174,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   // LayerNorm of the context rows: 8 threads per atom row
   {
     const int rr = tid >> 3, sb = tid & 7;
-    if (rr < natom) {
+    if (rr < natom && part < 0) {
       float4 t[4];
       float s = 0.f;
 #pragma unroll
@@ -1204,6 +1213,46 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   }
   STAMP(a.stamps, 7);
   STAMP_REAL(a.stamps, 13);
+}
+
+// Atoms with more than 64 neighbours: combine the per-chunk softmax states (running max m, sum s, unnormalised context x per
+// column) exactly as the online softmax combines edges -- M = max m_i, s = sum s_i e^(m_i - M), x = sum x_i e^(m_i - M) -- then
+// add the unscaled query and apply the LayerNorm (attention.py:189-214).  One workgroup of 128 threads per such atom.
+__global__ __launch_bounds__(128) void edge_merge_kernel(const int32_t* __restrict__ big_tab, const float* __restrict__ part_buf,
+                                                         const float* __restrict__ q, const float* __restrict__ ln_g,
+                                                         const float* __restrict__ ln_b, float* __restrict__ ctx) {
+  __shared__ float sRed[2][2];
+  const int c = threadIdx.x, atom = big_tab[3 * blockIdx.x], s0 = big_tab[3 * blockIdx.x + 1], ns = big_tab[3 * blockIdx.x + 2];
+  const float* pb = part_buf + (size_t)s0 * 3 * D + c;
+  float M = -INFINITY;
+  for (int i = 0; i < ns; ++i) M = fmaxf(M, pb[(size_t)i * 3 * D]);
+  float S = 0.f, X = 0.f;
+  for (int i = 0; i < ns; ++i) {
+    const float wgt = fast_exp(pb[(size_t)i * 3 * D] - M);
+    S += pb[(size_t)i * 3 * D + D] * wgt;
+    X += pb[(size_t)i * 3 * D + 2 * D] * wgt;
+  }
+  const float t = X * __builtin_amdgcn_rcpf(S) + q[(size_t)atom * D + c];
+  float s = t;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+  if ((c & 63) == 0) sRed[0][c >> 6] = s;
+  __syncthreads();
+  const float mean = (sRed[0][0] + sRed[0][1]) * (1.0f / D);
+  const float d = t - mean;
+  float v = d * d;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+  if ((c & 63) == 0) sRed[1][c >> 6] = v;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((sRed[1][0] + sRed[1][1]) * (1.0f / D) + 1e-6f);
+  const float inv = rstd * ln_g[c];
+  ctx[(size_t)atom * D + c] = t * inv + (ln_b[c] - mean * inv);
+}
+
+void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,
+                       const float* ln_b, float* ctx, hipStream_t s) {
+  if (n_big > 0) hipLaunchKernelGGL(edge_merge_kernel, dim3(n_big), dim3(128), 0, s, big_tab, part_buf, q, ln_g, ln_b, ctx);
 }
 
 #ifdef SCANN_STAMPS

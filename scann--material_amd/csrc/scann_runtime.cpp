@@ -160,6 +160,10 @@ struct scann_dbatch {
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
   float *dist = nullptr, *weight = nullptr, *ring = nullptr, *cgcnn = nullptr, *c0 = nullptr;
   EdgeTile* tiles = nullptr;
+  int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
+  int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
+  float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
+  int32_t n_big = 0, n_slot = 0;
   // workspace
   float *geom = nullptr, *gd = nullptr, *c = nullptr, *ctx = nullptr, *P1 = nullptr, *P3 = nullptr, *q = nullptr;
   float *gq = nullptr, *gk = nullptr, *ga = nullptr, *y = nullptr;
@@ -604,39 +608,62 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   if (h->cfg.use_ring && !b->ring) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: use_ring needs batch.ring [n_atom,2]");
   std::vector<int32_t> edge_row((size_t)E);
   std::vector<EdgeTile> tiles;
+  std::vector<int32_t> tile_part, big_tab;  // atoms with more than TE_MAX neighbours (edge_kernel_lean only)
+  int32_t n_slot = 0;
   int32_t max_degree = 0;
   int tile_rows = h->edge_tile;
   for (int pass = 0; pass < 2; ++pass) {
     const int want = tile_rows;
-    tiles.clear();
+    tiles.clear(); tile_part.clear(); big_tab.clear(); n_slot = 0;
     int s = 0;
     EdgeTile cur{0, 0, 0, 0};
     for (int a = 0; a < A; ++a) {
       while (a >= b->mol_offset[s + 1]) ++s;
       const int32_t e0 = b->edge_offset[a], e1 = b->edge_offset[a + 1];
       if (e1 < e0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: edge_offset not monotone");
-      if (e1 - e0 > TE_MAX)
-        return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: an atom has more than 64 neighbours (edge-tile limit)");
+      if (e1 - e0 > TE_MAX && !h->edge_lean)
+        return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: an atom has more than 64 neighbours (edge-tile limit of the selected edge kernel; "
+                                              "edge_kernel_lean, the default on the g_update path, has none)");
       max_degree = std::max(max_degree, e1 - e0);
-      if (e1 - e0 > tile_rows) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom: fall back to 64-row tiles
+      if (e1 - e0 > tile_rows && e1 - e0 <= TE_MAX) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom: fall back to 64-row tiles
       for (int e = e0; e < e1; ++e) {
         if (b->edge_col[e] < b->mol_offset[s] || b->edge_col[e] >= b->mol_offset[s + 1])
           return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: neighbour index outside its structure");
         edge_row[e] = a;
       }
-      // greedy tiling: whole atoms, <= TE edges and <= TA atoms per tile
+      if (e1 - e0 > TE_MAX) {  // big atom: close the open tile, then one chunk tile per <= 64 of its edges
+        if (a > cur.atom_begin) {
+          cur.atom_end = a;
+          cur.edge_end = e0;
+          tiles.push_back(cur);
+          tile_part.push_back(-1);
+        }
+        big_tab.push_back(a); big_tab.push_back(n_slot); big_tab.push_back((e1 - e0 + TE_MAX - 1) / TE_MAX);
+        for (int c0 = e0; c0 < e1; c0 += TE_MAX) {
+          tiles.push_back(EdgeTile{a, a + 1, c0, std::min(c0 + TE_MAX, e1)});
+          tile_part.push_back(n_slot++);
+        }
+        cur = EdgeTile{a + 1, a + 1, e1, e1};
+        continue;
+      }
+      // greedy tiling: whole atoms, <= TE edges and <= tile_atoms atoms per tile
       if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= h->tile_atoms) {
         cur.atom_end = a;
         cur.edge_end = e0;
         tiles.push_back(cur);
+        tile_part.push_back(-1);
         cur = EdgeTile{a, a, e0, e0};
       }
     }
-    cur.atom_end = A;
-    cur.edge_end = E;
-    tiles.push_back(cur);
+    if (cur.atom_begin < A || tiles.empty()) {
+      cur.atom_end = A;
+      cur.edge_end = E;
+      tiles.push_back(cur);
+      tile_part.push_back(-1);
+    }
     if (tile_rows == want) break;  // no atom overflowed the requested tile size
   }
+  const int32_t n_big = (int32_t)big_tab.size() / 3;
   HIPCHK(h, hipSetDevice(h->device));
   scann_dbatch* db = nullptr;
   if (scratch) {
@@ -653,13 +680,14 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   } else {
     db = new scann_dbatch();
   }
-  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows; db->max_degree = max_degree; db->tile_atoms = h->tile_atoms;
+  db->n_struct = B; db->n_atom = A; db->n_edge = E; db->n_tile = (int32_t)tiles.size(); db->max_atoms = max_atoms; db->tile_rows = tile_rows; db->max_degree = max_degree; db->tile_atoms = h->tile_atoms; db->n_big = n_big; db->n_slot = n_slot;
   // arena layout: inputs first (one H2D copy), then workspace
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
   const size_t o_atomic = take((size_t)A * 4), o_mol = take((size_t)(B + 1) * 4), o_eoff = take((size_t)(A + 1) * 4);
   const size_t o_col = take((size_t)E * 4), o_row = take((size_t)E * 4), o_dist = take((size_t)E * 4), o_wgt = take((size_t)E * 4);
   const size_t o_tiles = take(tiles.size() * sizeof(EdgeTile));
+  const size_t o_tpart = take(n_big ? tiles.size() * 4 : 0), o_big = take((size_t)n_big * 3 * 4);
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
@@ -667,6 +695,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
+  const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4);
   hipError_t e = hipSuccess;
   std::vector<char> img_vec;
   char* img_ptr = nullptr;
@@ -707,6 +736,10 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     memcpy(img.data() + o_wgt, b->edge_weight, (size_t)E * 4);
   }
   memcpy(img.data() + o_tiles, tiles.data(), tiles.size() * sizeof(EdgeTile));
+  if (n_big) {
+    memcpy(img.data() + o_tpart, tile_part.data(), tiles.size() * 4);
+    memcpy(img.data() + o_big, big_tab.data(), (size_t)n_big * 3 * 4);
+  }
   if (scratch) {  // pinned staging, ordered before the kernels on stream 0
     e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->streams[0]);
   } else {
@@ -728,6 +761,9 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->c = (float*)(a0 + o_c); db->ctx = (float*)(a0 + o_ctx); db->P1 = (float*)(a0 + o_P1); db->P3 = (float*)(a0 + o_P3);
   db->q = (float*)(a0 + o_q); db->gq = (float*)(a0 + o_gq); db->gk = (float*)(a0 + o_gk);
   db->ga = (float*)(a0 + o_ga); db->y = (float*)(a0 + o_y);
+  if (n_big) {
+    db->tile_part = (int32_t*)(a0 + o_tpart); db->big_tab = (int32_t*)(a0 + o_big); db->part_buf = (float*)(a0 + o_pbuf);
+  }
   *out = db;
   return SCANN_OK;
 }
@@ -847,13 +883,14 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
     ea.waves8 = h->edge_w8;
     ea.lean = h->edge_lean && db->tile_atoms <= TQ;
+    ea.tile_part = db->tile_part; ea.part_buf = db->part_buf;
     ea.xcd_remap = h->xcd_remap;
     if (h->in_train_forward && h->attn_drop_p > 0.f) {
       ea.attn_drop_p = h->attn_drop_p;
       ea.attn_drop_seed = h->train_seed;
       ea.attn_drop_tag = DROP_TAG_ATTN + (unsigned)l;
     }
-    ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles) ? h->n_cu : 0;
+    ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles && db->n_big == 0) ? h->n_cu : 0;
 #ifdef SCANN_STAMPS
     if (!getenv("SCANN_STAMP_ATOM")) {
       if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
@@ -862,6 +899,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
 #endif
     launch_edge(ea, s);
+    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, db->q, ea.p.ln_g, ea.p.ln_b, db->ctx, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);
@@ -1191,11 +1229,13 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   db->last_slot = 0;
   w->drop_p = dropout;
   w->seed = seed;
-  const bool dbg = h->debug;
-  h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)
   if (h->attn_drop_p > 0.f && !((h->edge_w8 || (h->edge_lean && db->tile_atoms <= TQ)) && h->cfg.g_update && db->tile_rows == 64 &&
                                 db->n_tile < h->persist_min_tiles))
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
+  if (db->n_big > 0)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: the backward pass handles at most 64 neighbours per atom");
+  const bool dbg = h->debug;
+  h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)
   h->train_drop_p = dropout;
   h->train_seed = seed;
   h->in_train_forward = true;

@@ -342,12 +342,50 @@ def test_degenerate_batches(hip_lib):
     y, ga = model.predict(inputs)
     y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
     assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
-    # (c) 65 neighbours is refused with a clear error, not silently truncated
+    # (c) 65 neighbours: one more than an edge tile holds -- two chunk tiles merged by edge_merge_kernel
     big[0].append([6, 1, 1.0, 1.0, 1.0])
     de2[0], dn2[0] = [[6] * A, 0.0], big
     inputs, _ = so.pad_batch(de2, dn2, True)
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+
+
+def test_more_than_64_neighbours(hip_lib, monkeypatch):
+    """Atoms with 65 ... 219 neighbours (chunk tiles + softmax merge), between ordinary atoms and next to small molecules;
+    the two-buffer kernels refuse such a batch with a clear error instead of truncating."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg, w, _, model = make(n=2)
+    rng = np.random.default_rng(11)
+    A = 220
+    degs = {0: 219, 1: 65, 7: 128, 8: 129, 9: 64, 100: 200, 219: 70}
+    nb = []
+    for a in range(A):
+        d = degs.get(a, int(rng.integers(0, 9)))
+        js = rng.choice(np.delete(np.arange(A), a), d, replace=False)
+        nb.append([[6, int(j), float(rng.uniform(0.4, 3.5)), 1.0, float(rng.uniform(0.9, 4.0))] for j in js])
+    de, dn = so.synth_dataset(2, 3)
+    de3, dn3 = np.empty(3, dtype=object), np.empty(3, dtype=object)
+    de3[0], dn3[0] = de[0], dn[0]
+    de3[1], dn3[1] = [[int(z) for z in rng.choice([1, 6, 7, 8], A)], 0.0], nb
+    de3[2], dn3[2] = de[1], dn[1]
+    inputs, _ = so.pad_batch(de3, dn3, True)
+    y, ga = model.predict(inputs)
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+    # the same batch through the resident / multi-stream path
+    pk = _hip.pack_inputs(inputs)
+    rb = model.engine.upload(pk)
+    model.engine.forward_resident(rb, 1)
+    y2, ga2 = model.engine.download(rb)
+    assert np.array_equal(y2, y[:, 0]) and np.array_equal(pk.repad_ga(ga2), ga)
+    rb.free()
+    monkeypatch.setenv("SCANN_EDGE_LEAN", "0")
+    other = HipModel(cfg, w, device=0, infer=True)
     with pytest.raises(_hip.ScannHipError) as e:
-        model.predict(inputs)
+        other.predict(inputs)
     assert e.value.code == -2 and "64 neighbours" in str(e.value)
 
 

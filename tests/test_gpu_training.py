@@ -339,3 +339,25 @@ def test_gradients_mp2018_shapes(hip_lib):
     errs = grad_errors(got, ref)
     assert max(errs.values()) <= 3e-3, {k: v for k, v in errs.items() if v > 3e-3}
     rb.free()
+
+
+def test_training_refuses_more_than_64_neighbours(hip_lib):
+    """Inference handles any neighbour count; the backward pass stops at 64 and says so."""
+    from scann import _hip
+
+    cfg, w, pk, targets, model = setup(n=2, L=1, seed=3)
+    A = 70
+    mol_offset = np.array([0, A])
+    edge_offset = np.concatenate([[0], np.cumsum([A - 1] + [1] * (A - 1))])
+    edge_col = np.concatenate([np.arange(1, A), np.zeros(A - 1, dtype=np.int64)])
+    E = edge_col.shape[0]
+    big = _hip.PackedBatch(np.full(A, 6), mol_offset, edge_offset, edge_col, np.full(E, 1.5), np.full(E, 1.0))
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(big)
+    with pytest.raises(_hip.ScannHipError) as e:
+        eng.train_forward(rb, np.zeros(1, dtype=np.float32))
+    assert e.value.code == -2 and "64 neighbours" in str(e.value)
+    eng.forward_resident(rb, 0)  # the inference path takes the same resident batch
+    y, _ = eng.download(rb)
+    assert np.isfinite(y).all()
