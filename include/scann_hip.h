@@ -205,6 +205,13 @@ int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offse
                       const float* ds_edge_weight, const int64_t* sel, int32_t n_sel, int64_t n_struct_total,
                       int32_t* out_atomic, float* out_ring, int32_t* out_mol_offset, int32_t* out_edge_offset,
                       int32_t* out_edge_col, float* out_edge_dist, float* out_edge_weight);
+/* The edge-tile plan scann_batch_upload builds for a packed batch (host only; exposed so that it can be checked without a
+ * GPU): whole atoms per tile, <= tile_rows (32 | 64) edges and <= tile_atoms (<= 32) atoms; with allow_chunks an atom with
+ * more than 64 neighbours becomes ceil(deg/64) single-atom chunk tiles, part_out[tile] = its softmax-merge slot (-1 for
+ * ordinary tiles), otherwise such a batch is SCANN_ERR_UNSUPPORTED.  tiles_out[cap][4] = atom_begin, atom_end, edge_begin,
+ * edge_end.  Returns the planned edge rows per tile (32 | 64) or a negative status (text: scann_pack_last_error). */
+int scann_plan_tiles(const scann_batch_t* batch, int32_t tile_rows, int32_t tile_atoms, int32_t allow_chunks, int32_t cap,
+                     int32_t* tiles_out, int32_t* part_out, int32_t* n_tiles, int32_t* n_slots);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,11 @@
 #include <cstring>
 #include <string>
 
+#include <algorithm>
+#include <vector>
+
 #include "../../include/scann_hip.h"
+#include "scann_internal.h"
 
 namespace {
 thread_local std::string t_pack_error;
@@ -19,6 +23,76 @@ int pack_fail(const char* msg) {
   return SCANN_ERR_INVALID;
 }
 }  // namespace
+
+namespace scann {
+
+int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset, const int32_t* edge_col, int32_t A, int32_t E,
+               int tile_rows_req, int tile_atoms, bool allow_chunks, std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part,
+               std::vector<int32_t>& big_tab, std::vector<int32_t>& edge_row, int* tile_rows_out, int32_t* max_degree,
+               int32_t* n_slot_out, std::string& err) {
+  (void)B;
+  edge_row.assign((size_t)E, 0);
+  int32_t n_slot = 0, maxdeg = 0;
+  int tile_rows = tile_rows_req;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int want = tile_rows;
+    tiles.clear(); tile_part.clear(); big_tab.clear(); n_slot = 0;
+    int s = 0;
+    EdgeTile cur{0, 0, 0, 0};
+    for (int a = 0; a < A; ++a) {
+      while (a >= mol_offset[s + 1]) ++s;
+      const int32_t e0 = edge_offset[a], e1 = edge_offset[a + 1];
+      if (e1 < e0) { err = "edge_offset not monotone"; return SCANN_ERR_INVALID; }
+      if (e1 - e0 > TE_MAX && !allow_chunks) {
+        err = "an atom has more than 64 neighbours (edge-tile limit of the selected edge kernel; edge_kernel_lean, the default on "
+              "the g_update path, has none)";
+        return SCANN_ERR_UNSUPPORTED;
+      }
+      maxdeg = std::max(maxdeg, e1 - e0);
+      if (e1 - e0 > tile_rows) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom (or its 64-edge chunks): fall back to 64-row tiles
+      for (int e = e0; e < e1; ++e) {
+        if (edge_col[e] < mol_offset[s] || edge_col[e] >= mol_offset[s + 1]) { err = "neighbour index outside its structure"; return SCANN_ERR_INVALID; }
+        edge_row[e] = a;
+      }
+      if (e1 - e0 > TE_MAX) {  // big atom: close the open tile, then one chunk tile per <= 64 of its edges
+        if (a > cur.atom_begin) {
+          cur.atom_end = a;
+          cur.edge_end = e0;
+          tiles.push_back(cur);
+          tile_part.push_back(-1);
+        }
+        big_tab.push_back(a); big_tab.push_back(n_slot); big_tab.push_back((e1 - e0 + TE_MAX - 1) / TE_MAX);
+        for (int c0 = e0; c0 < e1; c0 += TE_MAX) {
+          tiles.push_back(EdgeTile{a, a + 1, c0, std::min(c0 + TE_MAX, e1)});
+          tile_part.push_back(n_slot++);
+        }
+        cur = EdgeTile{a + 1, a + 1, e1, e1};
+        continue;
+      }
+      // greedy tiling: whole atoms, <= tile_rows edges and <= tile_atoms atoms per tile
+      if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= tile_atoms) {
+        cur.atom_end = a;
+        cur.edge_end = e0;
+        tiles.push_back(cur);
+        tile_part.push_back(-1);
+        cur = EdgeTile{a, a, e0, e0};
+      }
+    }
+    if (cur.atom_begin < A || tiles.empty()) {
+      cur.atom_end = A;
+      cur.edge_end = E;
+      tiles.push_back(cur);
+      tile_part.push_back(-1);
+    }
+    if (tile_rows == want) break;  // no atom overflowed the requested tile size
+  }
+  *tile_rows_out = tile_rows;
+  *max_degree = maxdeg;
+  *n_slot_out = n_slot;
+  return SCANN_OK;
+}
+
+}  // namespace scann
 
 extern "C" {
 
@@ -131,6 +205,37 @@ int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offse
     out_mol_offset[i + 1] = (int32_t)na;
   }
   return SCANN_OK;
+}
+
+int scann_plan_tiles(const scann_batch_t* b, int32_t tile_rows, int32_t tile_atoms, int32_t allow_chunks, int32_t cap,
+                     int32_t* tiles_out, int32_t* part_out, int32_t* n_tiles, int32_t* n_slots) {
+  if (!b || !n_tiles || !n_slots || !b->mol_offset || !b->edge_offset || (b->n_edge > 0 && !b->edge_col) || b->n_struct <= 0 ||
+      b->n_atom <= 0 || b->n_edge < 0 || (tile_rows != 32 && tile_rows != 64) || tile_atoms <= 0 || tile_atoms > scann::TA)
+    return pack_fail("scann_plan_tiles: bad argument");
+  if (b->mol_offset[0] != 0 || b->mol_offset[b->n_struct] != b->n_atom || b->edge_offset[0] != 0 || b->edge_offset[b->n_atom] != b->n_edge)
+    return pack_fail("scann_plan_tiles: offsets do not cover the batch");
+  for (int s = 0; s < b->n_struct; ++s)
+    if (b->mol_offset[s + 1] <= b->mol_offset[s]) return pack_fail("scann_plan_tiles: structure without atoms");
+  std::vector<scann::EdgeTile> tiles;
+  std::vector<int32_t> part, big, row;
+  int rows = 0;
+  int32_t maxdeg = 0, nslot = 0;
+  std::string err;
+  const int r = scann::plan_tiles(b->mol_offset, b->n_struct, b->edge_offset, b->edge_col, b->n_atom, b->n_edge, tile_rows, tile_atoms,
+                                  allow_chunks != 0, tiles, part, big, row, &rows, &maxdeg, &nslot, err);
+  if (r) {
+    t_pack_error = "scann_plan_tiles: " + err;
+    return r;
+  }
+  *n_tiles = (int32_t)tiles.size();
+  *n_slots = nslot;
+  if ((int32_t)tiles.size() > cap || !tiles_out || !part_out) return tiles_out ? pack_fail("scann_plan_tiles: output capacity too small") : SCANN_OK;
+  for (size_t i = 0; i < tiles.size(); ++i) {
+    tiles_out[4 * i] = tiles[i].atom_begin; tiles_out[4 * i + 1] = tiles[i].atom_end;
+    tiles_out[4 * i + 2] = tiles[i].edge_begin; tiles_out[4 * i + 3] = tiles[i].edge_end;
+    part_out[i] = part[i];
+  }
+  return rows;  // 32 or 64: the edge rows per tile actually planned
 }
 
 }  // extern "C"

@@ -606,62 +606,16 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: feature=cgcnn needs batch.cgcnn [n_atom,92]");
   }
   if (h->cfg.use_ring && !b->ring) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: use_ring needs batch.ring [n_atom,2]");
-  std::vector<int32_t> edge_row((size_t)E);
+  std::vector<int32_t> edge_row;
   std::vector<EdgeTile> tiles;
   std::vector<int32_t> tile_part, big_tab;  // atoms with more than TE_MAX neighbours (edge_kernel_lean only)
-  int32_t n_slot = 0;
-  int32_t max_degree = 0;
+  int32_t n_slot = 0, max_degree = 0;
   int tile_rows = h->edge_tile;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int want = tile_rows;
-    tiles.clear(); tile_part.clear(); big_tab.clear(); n_slot = 0;
-    int s = 0;
-    EdgeTile cur{0, 0, 0, 0};
-    for (int a = 0; a < A; ++a) {
-      while (a >= b->mol_offset[s + 1]) ++s;
-      const int32_t e0 = b->edge_offset[a], e1 = b->edge_offset[a + 1];
-      if (e1 < e0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: edge_offset not monotone");
-      if (e1 - e0 > TE_MAX && !h->edge_lean)
-        return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: an atom has more than 64 neighbours (edge-tile limit of the selected edge kernel; "
-                                              "edge_kernel_lean, the default on the g_update path, has none)");
-      max_degree = std::max(max_degree, e1 - e0);
-      if (e1 - e0 > tile_rows && e1 - e0 <= TE_MAX) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom: fall back to 64-row tiles
-      for (int e = e0; e < e1; ++e) {
-        if (b->edge_col[e] < b->mol_offset[s] || b->edge_col[e] >= b->mol_offset[s + 1])
-          return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: neighbour index outside its structure");
-        edge_row[e] = a;
-      }
-      if (e1 - e0 > TE_MAX) {  // big atom: close the open tile, then one chunk tile per <= 64 of its edges
-        if (a > cur.atom_begin) {
-          cur.atom_end = a;
-          cur.edge_end = e0;
-          tiles.push_back(cur);
-          tile_part.push_back(-1);
-        }
-        big_tab.push_back(a); big_tab.push_back(n_slot); big_tab.push_back((e1 - e0 + TE_MAX - 1) / TE_MAX);
-        for (int c0 = e0; c0 < e1; c0 += TE_MAX) {
-          tiles.push_back(EdgeTile{a, a + 1, c0, std::min(c0 + TE_MAX, e1)});
-          tile_part.push_back(n_slot++);
-        }
-        cur = EdgeTile{a + 1, a + 1, e1, e1};
-        continue;
-      }
-      // greedy tiling: whole atoms, <= TE edges and <= tile_atoms atoms per tile
-      if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= h->tile_atoms) {
-        cur.atom_end = a;
-        cur.edge_end = e0;
-        tiles.push_back(cur);
-        tile_part.push_back(-1);
-        cur = EdgeTile{a, a, e0, e0};
-      }
-    }
-    if (cur.atom_begin < A || tiles.empty()) {
-      cur.atom_end = A;
-      cur.edge_end = E;
-      tiles.push_back(cur);
-      tile_part.push_back(-1);
-    }
-    if (tile_rows == want) break;  // no atom overflowed the requested tile size
+  {
+    std::string err;
+    const int r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, h->edge_tile, h->tile_atoms, h->edge_lean, tiles,
+                             tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err);
+    if (r) return fail(h, r, "scann_batch_upload: " + err);
   }
   const int32_t n_big = (int32_t)big_tab.size() / 3;
   HIPCHK(h, hipSetDevice(h->device));

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("scann_pack_padded", C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 17 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("scann_slice_count", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("scann_slice_batch", C.c_int, [_P] * 8 + [C.c_int32, C.c_int64] + [_P] * 7),
+    ("scann_plan_tiles", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 ]
 
 _lib = None
@@ -238,6 +239,19 @@ def pack_inputs(inputs):
     return PackedBatch(o_atomic[:na] if o_atomic is not None else None, o_mol, o_eoff[:na + 1], o_col[:ne], o_dist[:ne],
                        o_wgt[:ne], pad_shape=(B, M), gidx=amask, ring=o_ring[:na] if o_ring is not None else None,
                        cgcnn=o_cgcnn[:na] if o_cgcnn is not None else None)
+
+
+def plan_tiles(packed, tile_rows=64, tile_atoms=24, allow_chunks=True):
+    """The edge-tile plan scann_batch_upload would build for `packed` (host only): (rows_per_tile, tiles[n,4], part[n], n_slots)."""
+    lib = load_library()
+    cap = packed.n_atom + packed.n_edge // 32 + 2
+    tiles, part = np.empty((cap, 4), np.int32), np.empty(cap, np.int32)
+    nt, ns = C.c_int32(0), C.c_int32(0)
+    st = packed.as_struct()
+    rc = lib.scann_plan_tiles(C.byref(st), tile_rows, tile_atoms, int(allow_chunks), cap, _ptr(tiles), _ptr(part), C.byref(nt), C.byref(ns))
+    if rc < 0:
+        raise ScannHipError(rc, (lib.scann_pack_last_error() or b"").decode())
+    return rc, tiles[:nt.value].copy(), part[:nt.value].copy(), ns.value
 
 
 def slice_dataset(ds_mol_offset, ds_edge_offset, ds_atomic, ds_ring, ds_edge_local, ds_edge_dist, ds_edge_weight, sel):

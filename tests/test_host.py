@@ -413,3 +413,51 @@ def test_listwalk_matches_python_walk_of_the_nested_lists():
     with pytest.raises(ValueError, match="disagree"):
         PackedDataset(de[:4], dn[1:5], batch_size=2)
     assert len(PackedDataset([], [], batch_size=2)) == 0
+
+
+def test_edge_tile_plan_invariants(hip_lib):
+    """scann_plan_tiles (host only): the tile table scann_batch_upload builds.  Tiles partition atoms and edges in order,
+    hold whole atoms within the edge / atom limits, atoms with more than 64 neighbours become single-atom chunk tiles with
+    consecutive merge slots, and malformed CSR input is refused."""
+    from scann import _hip
+
+    rng = np.random.default_rng(2)
+    de, dn = so.synth_dataset(40, 6)
+    pk = _hip.pack_inputs(so.pad_batch(de, dn, True)[0])
+
+    def check(pk, rows, atoms, chunks=True):
+        got_rows, tiles, part, n_slots = _hip.plan_tiles(pk, rows, atoms, chunks)
+        assert tiles[0, 0] == 0 and tiles[0, 2] == 0 and tiles[-1, 1] == pk.n_atom and tiles[-1, 3] == pk.n_edge
+        assert np.array_equal(tiles[1:, 2], tiles[:-1, 3])  # edges: consecutive tiles are adjacent
+        same_atom = (part[1:] >= 0) & (part[:-1] >= 0) & (tiles[1:, 0] == tiles[:-1, 0])  # next chunk of the same big atom
+        assert np.array_equal(tiles[1:, 0][~same_atom], tiles[:-1, 1][~same_atom])
+        assert np.array_equal(tiles[:, 2][part < 0], pk.edge_offset[tiles[:, 0]][part < 0]) and np.array_equal(tiles[:, 3][part < 0], pk.edge_offset[tiles[:, 1]][part < 0])
+        ne, na = tiles[:, 3] - tiles[:, 2], tiles[:, 1] - tiles[:, 0]
+        assert (na >= 1).all() and (ne <= got_rows).all() and (na[part < 0] <= atoms).all() and (na[part >= 0] == 1).all()
+        assert np.array_equal(np.sort(part[part >= 0]), np.arange(n_slots))
+        return got_rows, tiles, part, n_slots
+
+    for rows, atoms in ((64, 24), (64, 32), (32, 32)):
+        got_rows, tiles, part, n_slots = check(pk, rows, atoms)
+        assert got_rows == rows and n_slots == 0 and (part < 0).all()
+    # sparse graph: the atom limit closes the tiles
+    A = 100
+    chain = _hip.PackedBatch(np.full(A, 6), [0, A], np.arange(A + 1), (np.arange(A) + 1) % A, np.ones(A), np.ones(A))
+    _, tiles, _, _ = check(chain, 64, 24)
+    assert (tiles[:, 1] - tiles[:, 0]).max() == 24 and len(tiles) == 5
+    # atoms with 65, 130 and 12 neighbours: chunk tiles of <= 64 edges, slots in order; 32-row request falls back to 64
+    deg = np.array([3, 65, 12, 130, 0, 5])
+    A = 140
+    eoff = np.concatenate([[0], np.cumsum(np.concatenate([deg, np.zeros(A - len(deg), dtype=np.int64)]))])
+    col = np.concatenate([rng.choice(np.delete(np.arange(A), a), d, replace=False) for a, d in enumerate(deg)])
+    big = _hip.PackedBatch(np.full(A, 6), [0, A], eoff, col, np.ones(len(col)), np.ones(len(col)))
+    got_rows, tiles, part, n_slots = check(big, 32, 24)
+    assert got_rows == 64 and n_slots == 2 + 3
+    assert [int(t[3] - t[2]) for t, p in zip(tiles, part) if p >= 0] == [64, 1, 64, 64, 2]
+    with pytest.raises(_hip.ScannHipError) as e:
+        _hip.plan_tiles(big, 64, 32, allow_chunks=False)
+    assert e.value.code == -2 and "64 neighbours" in str(e.value)
+    bad = _hip.PackedBatch(np.full(4, 6), [0, 2, 4], [0, 1, 2, 3, 4], [1, 0, 1, 2], np.ones(4), np.ones(4))  # edge 2 leaves its structure
+    with pytest.raises(_hip.ScannHipError) as e:
+        _hip.plan_tiles(bad)
+    assert e.value.code == -1 and "outside its structure" in str(e.value)
