@@ -24,7 +24,7 @@ __device__ __forceinline__ int acc_row_(int i, int lane) { return (i & 3) + 8 * 
 
 // ---- linear: Y = act(X . W + b) on 64-row tiles (same MFMA fragment scheme as the forward kernels) -----------------
 // flags: bit0 accumulate into Y, bit1 swish.  P (optional) receives the pre-activation X.W + b.
-template <int RT>  // 32-row MFMA row tiles per workgroup: 2 for edge-sized inputs, 1 for atom-sized ones (more workgroups)
+template <int RT>  // 32-row MFMA row tiles per workgroup: 2 for large inputs, 1 otherwise (more workgroups)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                      const float* __restrict__ bias, float* __restrict__ Y,
                                                      float* __restrict__ P, int rows, int flags) {
@@ -61,46 +61,51 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
   for (int t = 0; t < 16; ++t)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
+      // operands swapped (weights as A, rows as B): transposed product -- lane l holds row l & 31 of the row tile and the
+      // columns 32 wave + 8 j + 4 (l >> 5) + 0..3, j = 0..3 -- so the epilogue moves 16-byte pieces (same k order, same sums)
       const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, a.x, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, a.y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, a.z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, a.w, acc[rt], 0, 0, 0);
     }
-  const int col = 32 * wave + (lane & 31);
-  const float b = bias ? bias[col] : 0.f;
-  float yold[RT][16];  // accumulate mode: the old values, requested together (clamped rows) before any of them is used
+  const int cb = 32 * wave + 4 * (lane >> 5);  // first column of run j: cb + 8 j
+  float4 bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = bias ? *reinterpret_cast<const float4*>(bias + cb + 8 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 yold[RT][4];  // accumulate mode: the old values, requested together (clamped rows) before any of them is used
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) yold[rt][i] = 0.f;
+    for (int j = 0; j < 4; ++j) yold[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (flags & 1) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        yold[rt][i] = Y[(size_t)(row0 + min(32 * rt + acc_row_(i, lane), nrows - 1)) * D + col];
+      for (int j = 0; j < 4; ++j)
+        yold[rt][j] = *reinterpret_cast<const float4*>(Y + (size_t)(row0 + min(32 * rt + (lane & 31), nrows - 1)) * D + cb + 8 * j);
   }
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt) {
+    const int r = 32 * rt + (lane & 31);
+    if (r < nrows) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = 32 * rt + acc_row_(i, lane);
-      if (r < nrows) {
-        const size_t o = (size_t)(row0 + r) * D + col;
-        float v = acc[rt][i] + b;
-        if (P) P[o] = v;
-        if (flags & 2) v = swish_(v);
-        if (flags & 1) v += yold[rt][i];
-        Y[o] = v;
+      for (int j = 0; j < 4; ++j) {
+        const size_t o = (size_t)(row0 + r) * D + cb + 8 * j;
+        float4 v = make_float4(acc[rt][4 * j] + bv[j].x, acc[rt][4 * j + 1] + bv[j].y, acc[rt][4 * j + 2] + bv[j].z, acc[rt][4 * j + 3] + bv[j].w);
+        if (P) *reinterpret_cast<float4*>(P + o) = v;
+        if (flags & 2) v = make_float4(swish_(v.x), swish_(v.y), swish_(v.z), swish_(v.w));
+        if (flags & 1) v = make_float4(v.x + yold[rt][j].x, v.y + yold[rt][j].y, v.z + yold[rt][j].z, v.w + yold[rt][j].w);
+        *reinterpret_cast<float4*>(Y + o) = v;
       }
     }
+  }
 }
 
 void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags,
                    hipStream_t s) {
   if (rows <= 0) return;
-  if (rows >= 8192) hipLaunchKernelGGL(linear_kernel<2>, dim3((rows + 63) / 64), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
+  if (rows >= 65536) hipLaunchKernelGGL(linear_kernel<2>, dim3((rows + 63) / 64), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
   else hipLaunchKernelGGL(linear_kernel<1>, dim3((rows + 31) / 32), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
 }
 
