@@ -1246,10 +1246,9 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   ra.dwo = g("predict_property/kernel"); ra.dbo = g("predict_property/bias");
   launch_readout_bwd(ra, s);
   launch_wgrad(w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B, s);
-  launch_wgrad(t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), A, s);
-  launch_wgrad(t1, t3, g("global_attention/key/kernel"), g("global_attention/key/bias"), A, s);
-  launch_linear(t2, h->WgqT, nullptr, t4, nullptr, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
-  launch_linear(t3, h->WgkT, nullptr, t4, nullptr, A, 1, s);
+  launch_wgrad3(t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), t3, g("global_attention/key/kernel"),
+                g("global_attention/key/bias"), nullptr, nullptr, nullptr, A, s);
+  launch_linear_sum(t2, h->WgqT, t3, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
   launch_swish_bwd(t0, t4, t2, nA, s);                        // dpreA
   launch_wgrad(cL, t2, g("after_Lc/kernel"), g("after_Lc/bias"), A, s);
   launch_linear(t2, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
@@ -1328,12 +1327,9 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     launch_wgrad(Gin, eU, fgk + (size_t)D * D, nullptr, E, s);                   // dW2
     launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                // dG += dV.W2^T
     // per-atom projections
-    launch_wgrad(c_in, dP1, fgk, g(la + "filter_geo/bias"), A, s);
-    launch_wgrad(c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A, s);
-    launch_wgrad(c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A, s);
-    launch_linear(dP1, pt.W1T, nullptr, dC, nullptr, A, 1, s);
-    launch_linear(dP3, pt.W3T, nullptr, dC, nullptr, A, 1, s);
-    launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
+    launch_wgrad3(c_in, dP1, fgk, g(la + "filter_geo/bias"), dP3, fgk + (size_t)2 * D * D, nullptr, dQ, g(la + "query/kernel"),
+                  g(la + "query/bias"), A, s);
+    launch_linear_sum(dP1, pt.W1T, dP3, pt.W3T, dQ, pt.WqT, dC, A, 1, s);  // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T
     dG_in = dGnext;
   }
   // ---- basis MLP and embedding (scann_model.py:362-389) ----

@@ -25,6 +25,12 @@ struct RepackDesc {
 
 void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags, hipStream_t s);
 void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s);
+// up to three weight gradients that share the left operand X in one launch (null dY1 / dY2: fewer)
+void launch_wgrad3(const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
+                   const float* dY2, float* dW2, float* db2, int rows, hipStream_t s);
+// Y (+)= X0.W0 + X1.W1 + X2.W2 (packed [128,128] kernels; null X1 / X2: fewer terms)
+void launch_linear_sum(const float* X0, const float* W0, const float* X1, const float* W1, const float* X2, const float* W2, float* Y,
+                       int rows, int accumulate, hipStream_t s);
 void launch_swish_bwd(const float* pre, const float* dout, float* dpre, size_t n, hipStream_t s);
 void launch_add(float* dst, const float* src, size_t n, hipStream_t s);
 void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s);

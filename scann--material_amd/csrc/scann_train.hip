@@ -109,12 +109,86 @@ void launch_linear(const float* X, const float* Wp, const float* bias, float* Y,
   else hipLaunchKernelGGL(linear_kernel<1>, dim3((rows + 31) / 32), dim3(256), 0, s, X, Wp, bias, Y, P, rows, flags);
 }
 
+// ---- Y (+)= sum_i X_i . W_i for up to three (X_i, W_i) pairs on 32-row tiles: the data gradients that meet in one
+// tensor (d centres = dP1.W1^T + dP3.W3^T + dq.Wq^T, attention.py:142-160) in one launch and one pass over Y -----------------
+struct LinearSumArgs {
+  const float* X[3];
+  const float* Wp[3];
+  int n;
+};
+__global__ __launch_bounds__(256) void linear_sum_kernel(LinearSumArgs a, float* __restrict__ Y, int rows, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float sX[32 * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * 32;
+  const int nrows = min(32, rows - row0);
+  const int c4 = tid & 31, r0 = tid >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int cb = 32 * wave + 4 * (lane >> 5);
+  float4 yold[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) yold[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (accumulate) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      yold[j] = *reinterpret_cast<const float4*>(Y + (size_t)(row0 + min(lane & 31, nrows - 1)) * D + cb + 8 * j);
+  }
+  for (int p = 0; p < a.n; ++p) {
+    const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(a.Wp[p]) + wave * (16 * 64) + lane;
+    float4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = wsrc[t * 64];
+    float4 xv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      xv[k] = reinterpret_cast<const float4*>(a.X[p])[(size_t)(row0 + min(r0 + 8 * k, nrows - 1)) * 32 + c4];
+    if (p) __syncthreads();  // every wave is done with the previous operand tile
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + 8 * k;
+      *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = r < nrows ? xv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * t);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, x4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, x4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, x4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, x4.w, acc, 0, 0, 0);
+    }
+  }
+  if ((lane & 31) < nrows) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(Y + (size_t)(row0 + (lane & 31)) * D + cb + 8 * j) =
+          make_float4(acc[4 * j] + yold[j].x, acc[4 * j + 1] + yold[j].y, acc[4 * j + 2] + yold[j].z, acc[4 * j + 3] + yold[j].w);
+  }
+}
+void launch_linear_sum(const float* X0, const float* W0, const float* X1, const float* W1, const float* X2, const float* W2, float* Y,
+                       int rows, int accumulate, hipStream_t s) {
+  if (rows <= 0) return;
+  LinearSumArgs a{};
+  a.X[0] = X0; a.Wp[0] = W0; a.X[1] = X1; a.Wp[1] = W1; a.X[2] = X2; a.Wp[2] = W2;
+  a.n = X2 ? 3 : (X1 ? 2 : 1);
+  hipLaunchKernelGGL(linear_sum_kernel, dim3((rows + 31) / 32), dim3(256), 0, s, a, Y, rows, accumulate);
+}
+
 // ---- weight gradient: dW[i][j] += sum_rows X[row][i] dY[row][j];  db[j] += sum_rows dY[row][j] ---------------------
 // A workgroup reduces a 256-row slab with MFMA (A = X^T read column-wise from LDS) and adds its 128x128 partial with
 // float atomics (order of the adds is not fixed: gradients are reproducible to rounding only).
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                    float* __restrict__ dW, float* __restrict__ db, int rows,
-                                                    int chunks) {
+struct WgradSet {
+  const float* dY[3];
+  float* dW[3];
+  float* db[3];
+};
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, WgradSet set, int rows, int chunks) {
+  // blockIdx.y selects one of up to three gradients that share the left operand X (c^T.[dP1 | dP3 | dq], attention.py:142-160)
+  const float* __restrict__ dY = set.dY[blockIdx.y];
+  float* __restrict__ dW = set.dW[blockIdx.y];
+  float* __restrict__ db = set.db[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float sX[64 * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sD[64 * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,12 +245,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
   if (db && tid < D) atomicAdd(&db[tid], bsum);
 }
 
-void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
+void launch_wgrad3(const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
+                   const float* dY2, float* dW2, float* db2, int rows, hipStream_t s) {
   if (rows <= 0) return;
   // slab per workgroup: enough workgroups to fill the chip, few enough that the 64 KB of float atomics per workgroup
   // (chip-wide ~1.3 TB/s of added bytes) stays below the MFMA time
   const int chunks = rows >= 8192 ? 2 : 1;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((rows + 64 * chunks - 1) / (64 * chunks)), dim3(256), 0, s, X, dY, dW, db, rows, chunks);
+  WgradSet set{};
+  set.dY[0] = dY0; set.dW[0] = dW0; set.db[0] = db0;
+  set.dY[1] = dY1; set.dW[1] = dW1; set.db[1] = db1;
+  set.dY[2] = dY2; set.dW[2] = dW2; set.db[2] = db2;
+  const int ny = dY2 ? 3 : (dY1 ? 2 : 1);
+  hipLaunchKernelGGL(wgrad_kernel, dim3((rows + 64 * chunks - 1) / (64 * chunks), ny), dim3(256), 0, s, X, set, rows, chunks);
+}
+void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
+  launch_wgrad3(X, dY, dW, db, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, s);
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------
