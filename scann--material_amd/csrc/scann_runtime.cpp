@@ -160,6 +160,7 @@ struct scann_dbatch {
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
   float *dist = nullptr, *weight = nullptr, *ring = nullptr, *cgcnn = nullptr, *c0 = nullptr;
   EdgeTile* tiles = nullptr;
+  int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
   int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
   float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
@@ -642,6 +643,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_col = take((size_t)E * 4), o_row = take((size_t)E * 4), o_dist = take((size_t)E * 4), o_wgt = take((size_t)E * 4);
   const size_t o_tiles = take(tiles.size() * sizeof(EdgeTile));
   const size_t o_tpart = take(n_big ? tiles.size() * 4 : 0), o_big = take((size_t)n_big * 3 * 4);
+  const size_t o_inoff = take((size_t)(A + 1) * 4), o_inedge = take((size_t)E * 4);
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
@@ -690,6 +692,15 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     memcpy(img.data() + o_wgt, b->edge_weight, (size_t)E * 4);
   }
   memcpy(img.data() + o_tiles, tiles.data(), tiles.size() * sizeof(EdgeTile));
+  {  // reverse adjacency (counting sort of the edges by neighbour atom, stable): the backward pass sums per neighbour without atomics
+    int32_t* in_off = reinterpret_cast<int32_t*>(img.data() + o_inoff);
+    int32_t* in_edge = reinterpret_cast<int32_t*>(img.data() + o_inedge);
+    memset(in_off, 0, (size_t)(A + 1) * 4);
+    for (int e = 0; e < E; ++e) ++in_off[b->edge_col[e] + 1];
+    for (int a = 0; a < A; ++a) in_off[a + 1] += in_off[a];
+    std::vector<int32_t> fill(in_off, in_off + A);
+    for (int e = 0; e < E; ++e) in_edge[fill[b->edge_col[e]]++] = e;
+  }
   if (n_big) {
     memcpy(img.data() + o_tpart, tile_part.data(), tiles.size() * 4);
     memcpy(img.data() + o_big, big_tab.data(), (size_t)n_big * 3 * 4);
@@ -710,6 +721,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->atomic = (int32_t*)(a0 + o_atomic); db->mol_offset = (int32_t*)(a0 + o_mol); db->edge_offset = (int32_t*)(a0 + o_eoff);
   db->edge_col = (int32_t*)(a0 + o_col); db->edge_row = (int32_t*)(a0 + o_row);
   db->dist = (float*)(a0 + o_dist); db->weight = (float*)(a0 + o_wgt); db->tiles = (EdgeTile*)(a0 + o_tiles);
+  db->in_off = (int32_t*)(a0 + o_inoff); db->in_edge = (int32_t*)(a0 + o_inedge);
   db->ring = (float*)(a0 + o_ring); db->cgcnn = (float*)(a0 + o_cg); db->c0 = (float*)(a0 + o_c0);
   db->geom = (float*)(a0 + o_geom); db->gd = (float*)(a0 + o_gd);
   db->c = (float*)(a0 + o_c); db->ctx = (float*)(a0 + o_ctx); db->P1 = (float*)(a0 + o_P1); db->P3 = (float*)(a0 + o_P3);
@@ -1288,12 +1300,12 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_base_geom(db->gd, p.Wfg, p.bfg, db->weight, eV, E, s);            // geomL (eV)
       launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
       launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
-      HIPCHK(h, hipMemsetAsync(dC, 0, nA * 4, s));
       launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
       launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
       launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
-      launch_edge_dang(c_in, db->edge_col, eV, edAng, nullptr, dC, edGt, E, s);  // dC[j] += dang*geomL ; dgeomL = dang*c[j]
+      launch_edge_dang(c_in, db->edge_col, eV, edAng, nullptr, eAng, edGt, E, s);  // per edge dang*geomL (in eAng) ; dgeomL = dang*c[j]
+      launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);              // dC[j] = sum over the edges that point at j
       launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, edGt, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), s);
       launch_wgrad(c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A, s);
       launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
@@ -1309,20 +1321,20 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     }
     launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
     launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
-    HIPCHK(h, hipMemsetAsync(dC, 0, nA * 4, s));                 // dC now collects d loss / d centres_l
     launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
     launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
-    launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, dC, edGt, E, s);  // dC[j] += dang*G' ; dG'tot
+    launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, eAng, edGt, E, s);  // per edge dang*G' (in eAng) ; dG'tot
+    launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);               // dC now collects d loss / d centres_l: dC[j] = sum over the edges that point at j
     // geometry update: G' = LN_g(swish(V) + G), V = G.W2 + P1[i] + P3[j]
     launch_linear(Gin, p.W2p, nullptr, eU, nullptr, E, 0, s);
     launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
     float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
     launch_ln_bwd(eT, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
-    HIPCHK(h, hipMemsetAsync(dP3, 0, nA * 4, s));
-    launch_edge_dv(eV, dGnext, db->edge_row, db->edge_col, eU, dP1, dP3, E, s);  // dV (in eU), dP3[j] += dV (atomics)
-    launch_segment_sum(eU, db->edge_offset, dP1, A, s);                           // dP1[i] = sum over the atom's edges
+    launch_edge_dv(eV, dGnext, eU, E, s);                                         // dV (in eU)
+    launch_segment_sum(eU, db->edge_offset, dP1, A, s);                           // dP1[i] = sum over the atom's own edges
+    launch_gather_sum(eU, db->in_off, db->in_edge, dP3, A, 0, s);                 // dP3[j] = sum over the edges that point at j
     float* fgk = g(la + "filter_geo/kernel");
     launch_wgrad(Gin, eU, fgk + (size_t)D * D, nullptr, E, s);                   // dW2
     launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                // dG += dV.W2^T

@@ -37,12 +37,14 @@ void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, f
 void launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
                    int accumulate, hipStream_t s);
 void launch_edge_ang(const float* c, const int* nb, const float* g, float* ang, int n_edge, hipStream_t s);
-void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dc,
+// dcn[e] = dang[e] * g[e] (per edge; summed per neighbour atom with launch_gather_sum), dg_tot = dang * c[nb] (+ dg_in)
+void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dcn,
                       float* dg_tot, int n_edge, hipStream_t s);
+// out[a] (+)= sum of val[e] over the edges whose neighbour is atom a (reverse adjacency in_off / in_edge); fixed order, no atomics
+void launch_gather_sum(const float* val, const int* in_off, const int* in_edge, float* out, int n_atom, int accumulate, hipStream_t s);
 void launch_edge_v(const float* U, const float* P1, const float* P3, const int* ctr, const int* nb, const float* G, float* V,
                    float* T, int n_edge, hipStream_t s);
-void launch_edge_dv(const float* V, const float* dT, const int* ctr, const int* nb, float* dV, float* dP1, float* dP3,
-                    int n_edge, hipStream_t s);
+void launch_edge_dv(const float* V, const float* dT, float* dV, int n_edge, hipStream_t s);
 void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s);
 void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
                      float* dK, float* dgamma, float* dbeta, int n_atom, int max_degree, float drop_p, unsigned drop_tag,

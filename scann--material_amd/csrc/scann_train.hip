@@ -377,10 +377,11 @@ __global__ void edge_ang_kernel(const float4* __restrict__ c, const int* __restr
   const float4 a = c[(size_t)nb[e] * 32 + c4], b = g[i];
   ang[i] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 }
-// backward of ang = cn * G':  dc[nb] += dang * G' (atomic),  dG'(total) = dang * cn + dG'(from the next layer)
+// backward of ang = cn * G':  dcn (per edge; summed over the edges that point AT an atom by gather_sum_kernel) = dang * G',
+// dG'(total) = dang * cn + dG'(from the next layer)
 __global__ void edge_dang_kernel(const float4* __restrict__ c, const int* __restrict__ nb, const float4* __restrict__ g,
                                  const float4* __restrict__ dang, const float4* __restrict__ dg_in,
-                                 float* __restrict__ dc, float4* __restrict__ dg_tot, int n_edge) {
+                                 float4* __restrict__ dcn, float4* __restrict__ dg_tot, int n_edge) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n_edge * 32) return;
   const int e = (int)(i >> 5), c4 = (int)(i & 31);
@@ -392,11 +393,27 @@ __global__ void edge_dang_kernel(const float4* __restrict__ c, const int* __rest
     t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
   }
   dg_tot[i] = t;
-  float* d = dc + (size_t)j * D + 4 * c4;
-  atomicAdd(d + 0, da.x * gg.x);
-  atomicAdd(d + 1, da.y * gg.y);
-  atomicAdd(d + 2, da.z * gg.z);
-  atomicAdd(d + 3, da.w * gg.w);
+  dcn[i] = make_float4(da.x * gg.x, da.y * gg.y, da.z * gg.z, da.w * gg.w);
+}
+// out[a] (+)= sum of val[e] over the edges e whose NEIGHBOUR is atom a (reverse adjacency built at upload: in_off, in_edge):
+// the neighbour-indexed sums of the backward pass in a fixed order, without float atomics
+__global__ void gather_sum_kernel(const float4* __restrict__ val, const int* __restrict__ in_off, const int* __restrict__ in_edge,
+                                  float4* __restrict__ out, int n_atom, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_atom * 32) return;
+  const int a = (int)(i >> 5), c4 = (int)(i & 31);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (accumulate) s = out[i];
+  for (int k = in_off[a]; k < in_off[a + 1]; ++k) {
+    const float4 v = val[(size_t)in_edge[k] * 32 + c4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  out[i] = s;
+}
+void launch_gather_sum(const float* val, const int* in_off, const int* in_edge, float* out, int n_atom, int accumulate, hipStream_t s) {
+  if (n_atom > 0)
+    hipLaunchKernelGGL(gather_sum_kernel, dim3((unsigned)(((size_t)n_atom * 32 + 255) / 256)), dim3(256), 0, s, (const float4*)val,
+                       in_off, in_edge, (float4*)out, n_atom, accumulate);
 }
 // V = U + P1[ctr] + P3[nb] ; T = swish(V) + G   (attention.py:142-153)
 __global__ void edge_v_kernel(const float4* __restrict__ U, const float4* __restrict__ P1, const float4* __restrict__ P3,
@@ -429,29 +446,23 @@ void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int
                        (const float4*)dV, edge_offset, (float4*)out, n_atom);
 }
 
-// dV = dT * swish'(V);  dP3[nb] += dV (atomics: neighbour-indexed)
-__global__ void edge_dv_kernel(const float4* __restrict__ V, const float4* __restrict__ dT, const int* __restrict__ ctr,
-                               const int* __restrict__ nb, float4* __restrict__ dV, float* __restrict__ dP1,
-                               float* __restrict__ dP3, int n_edge) {
+// dV = dT * swish'(V)   (dP1 = centre-indexed sum, dP3 = neighbour-indexed sum of dV: segment_sum / gather_sum)
+__global__ void edge_dv_kernel(const float4* __restrict__ V, const float4* __restrict__ dT, float4* __restrict__ dV, int n_edge) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n_edge * 32) return;
-  const int e = (int)(i >> 5), c4 = (int)(i & 31);
   const float4 v = V[i], t = dT[i];
-  const float4 d = make_float4(t.x * dswish_(v.x), t.y * dswish_(v.y), t.z * dswish_(v.z), t.w * dswish_(v.w));
-  dV[i] = d;
-  float* p3 = dP3 + (size_t)nb[e] * D + 4 * c4;
-  atomicAdd(p3 + 0, d.x); atomicAdd(p3 + 1, d.y); atomicAdd(p3 + 2, d.z); atomicAdd(p3 + 3, d.w);
+  dV[i] = make_float4(t.x * dswish_(v.x), t.y * dswish_(v.y), t.z * dswish_(v.z), t.w * dswish_(v.w));
 }
 #define EDGE_GRID(n_edge) dim3((unsigned)(((size_t)(n_edge) * 32 + 255) / 256)), dim3(256)
 void launch_edge_ang(const float* c, const int* nb, const float* g, float* ang, int n_edge, hipStream_t s) {
   if (n_edge > 0)
     hipLaunchKernelGGL(edge_ang_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)c, nb, (const float4*)g, (float4*)ang, n_edge);
 }
-void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dc,
+void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dcn,
                       float* dg_tot, int n_edge, hipStream_t s) {
   if (n_edge > 0)
     hipLaunchKernelGGL(edge_dang_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)c, nb, (const float4*)g,
-                       (const float4*)dang, (const float4*)dg_in, dc, (float4*)dg_tot, n_edge);
+                       (const float4*)dang, (const float4*)dg_in, (float4*)dcn, (float4*)dg_tot, n_edge);
 }
 void launch_edge_v(const float* U, const float* P1, const float* P3, const int* ctr, const int* nb, const float* G, float* V,
                    float* T, int n_edge, hipStream_t s) {
@@ -459,11 +470,9 @@ void launch_edge_v(const float* U, const float* P1, const float* P3, const int* 
     hipLaunchKernelGGL(edge_v_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)U, (const float4*)P1, (const float4*)P3, ctr,
                        nb, (const float4*)G, (float4*)V, (float4*)T, n_edge);
 }
-void launch_edge_dv(const float* V, const float* dT, const int* ctr, const int* nb, float* dV, float* dP1, float* dP3,
-                    int n_edge, hipStream_t s) {
+void launch_edge_dv(const float* V, const float* dT, float* dV, int n_edge, hipStream_t s) {
   if (n_edge > 0)
-    hipLaunchKernelGGL(edge_dv_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)V, (const float4*)dT, ctr, nb, (float4*)dV,
-                       dP1, dP3, n_edge);
+    hipLaunchKernelGGL(edge_dv_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)V, (const float4*)dT, (float4*)dV, n_edge);
 }
 
 // ---- attention backward: one wave per atom, lane l owns features 2l, 2l+1 (head l>>3) -----------------------------
