@@ -585,13 +585,20 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict
   if (at < n_atom) {
     const int e0 = edge_offset[at], deg = edge_offset[at + 1] - e0;
     const float2 q2 = reinterpret_cast<const float2*>(q)[(size_t)at * 64 + lane];
+    const float2 dyv = reinterpret_cast<const float2*>(dctx)[(size_t)at * 64 + lane];
     const float qx = q2.x * 0.25f, qy = q2.y * 0.25f;
     float2 k2[16];
     float ev[16];
     float m = -INFINITY;
+    // the sixteen key rows are requested together from clamped edge rows and masked afterwards (a load under a per-lane
+    // guard is compiled as one full memory round trip each)
+    if (deg > 0) {
+#pragma unroll
+      for (int n = 0; n < 16; ++n) k2[n] = reinterpret_cast<const float2*>(K)[(size_t)(e0 + min(n, deg - 1)) * 64 + lane];
+    }
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      k2[n] = n < deg ? reinterpret_cast<const float2*>(K)[(size_t)(e0 + n) * 64 + lane] : make_float2(0.f, 0.f);
+      if (n >= deg) k2[n] = make_float2(0.f, 0.f);
       float e = qx * k2[n].x + qy * k2[n].y;
       e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
       ev[n] = n < deg ? e : -INFINITY;
@@ -622,7 +629,6 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict
     for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
     const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
     const float hx = cx * rstd, hy = cy * rstd;
-    const float2 dyv = reinterpret_cast<const float2*>(dctx)[(size_t)at * 64 + lane];
     const float ax = dyv.x * g.x, ay = dyv.y * g.y;
     float m1 = ax + ay, m2 = ax * hx + ay * hy;
 #pragma unroll
