@@ -289,81 +289,96 @@ void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, f
   if (n && p > 0.f) hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, seed, tag, p);
 }
 
-// ---- LayerNorm backward (rows of 128; one wave per row) ---------------------------------------------------------------
+// ---- LayerNorm backward (rows of 128; 8 threads per row) ---------------------------------------------------------------
 // y = xhat*gamma + beta, xhat = (x - mean) * rstd  (attention.py:35,111,113; eps 1e-6)
 // dxhat = dy*gamma ; dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)) ; dgamma += dy*xhat ; dbeta += dy
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     int rows_per_wave, int accumulate) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r0 = (blockIdx.x * 4 + wave) * rows_per_wave;
-  const float2 g = reinterpret_cast<const float2*>(gamma)[lane];
-  float2 dg = make_float2(0.f, 0.f), dbt = dg;
-  const int rend = min(rows, r0 + rows_per_wave);
-  for (int rg = r0; rg < rend; rg += 4) {  // four rows per trip, their loads requested together (clamped rows)
-    float2 xv4[4], dyv4[4], old4[4];
+                                                     int groups, int accumulate) {
+  // 8 threads per row (float4 chunks sub, sub+8, sub+16, sub+24 like the forward LayerNorm), 32 rows per pass, `groups`
+  // passes per workgroup; all loads of a pass are requested together from clamped rows.
+  const int tid = threadIdx.x, r_in = tid >> 3, sub = tid & 7;
+  const int row_base = blockIdx.x * 32 * groups;
+  float4 g4[4], dg[4], dbt[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const size_t o = (size_t)min(rg + j, rend - 1) * 64 + lane;
-      xv4[j] = reinterpret_cast<const float2*>(x)[o];
-      dyv4[j] = reinterpret_cast<const float2*>(dy)[o];
-      old4[j] = make_float2(0.f, 0.f);
+  for (int i = 0; i < 4; ++i) {
+    g4[i] = reinterpret_cast<const float4*>(gamma)[sub + 8 * i];
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dbt[i] = dg[i];
+  }
+  for (int gi = 0; gi < groups; ++gi) {
+    const int r = row_base + 32 * gi + r_in;
+    if (row_base + 32 * gi >= rows) break;
+    const int rc = min(r, rows - 1);
+    float4 xv[4], dv[4], old[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xv[i] = reinterpret_cast<const float4*>(x)[(size_t)rc * 32 + sub + 8 * i];
+      dv[i] = reinterpret_cast<const float4*>(dy)[(size_t)rc * 32 + sub + 8 * i];
+      old[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (accumulate) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) old4[j] = reinterpret_cast<const float2*>(dx)[(size_t)min(rg + j, rend - 1) * 64 + lane];
+      for (int i = 0; i < 4; ++i) old[i] = reinterpret_cast<const float4*>(dx)[(size_t)rc * 32 + sub + 8 * i];
     }
+    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = rg + j;
-      if (r >= rend) break;
-      const float2 xv = xv4[j], dyv = dyv4[j];
-      float s = xv.x + xv.y;
+    for (int i = 0; i < 4; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    const float mean = s * (1.0f / D);
+    float v = 0.f;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
-      const float mean = s * (1.0f / D);
-      const float cx = xv.x - mean, cy = xv.y - mean;
-      float v = cx * cx + cy * cy;
+    for (int i = 0; i < 4; ++i) {
+      xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+      v += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+    }
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+    float m1 = 0.f, m2 = 0.f;
+    float4 ax[4];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-      const float hx = cx * rstd, hy = cy * rstd;
-      const float ax = dyv.x * g.x, ay = dyv.y * g.y;
-      float m1 = ax + ay, m2 = ax * hx + ay * hy;
+    for (int i = 0; i < 4; ++i) {
+      xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;  // xhat
+      ax[i] = make_float4(dv[i].x * g4[i].x, dv[i].y * g4[i].y, dv[i].z * g4[i].z, dv[i].w * g4[i].w);
+      m1 += (ax[i].x + ax[i].y) + (ax[i].z + ax[i].w);
+      m2 += (ax[i].x * xv[i].x + ax[i].y * xv[i].y) + (ax[i].z * xv[i].z + ax[i].w * xv[i].w);
+    }
+    m1 += __shfl_xor(m1, 1); m1 += __shfl_xor(m1, 2); m1 += __shfl_xor(m1, 4);
+    m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 4);
+    m1 *= (1.0f / D);
+    m2 *= (1.0f / D);
+    if (r < rows) {
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        m1 += __shfl_xor(m1, o);
-        m2 += __shfl_xor(m2, o);
+      for (int i = 0; i < 4; ++i) {
+        reinterpret_cast<float4*>(dx)[(size_t)r * 32 + sub + 8 * i] =
+            make_float4(rstd * (ax[i].x - m1 - xv[i].x * m2) + old[i].x, rstd * (ax[i].y - m1 - xv[i].y * m2) + old[i].y,
+                        rstd * (ax[i].z - m1 - xv[i].z * m2) + old[i].z, rstd * (ax[i].w - m1 - xv[i].w * m2) + old[i].w);
+        dg[i].x += dv[i].x * xv[i].x; dg[i].y += dv[i].y * xv[i].y; dg[i].z += dv[i].z * xv[i].z; dg[i].w += dv[i].w * xv[i].w;
+        dbt[i].x += dv[i].x; dbt[i].y += dv[i].y; dbt[i].z += dv[i].z; dbt[i].w += dv[i].w;
       }
-      m1 *= (1.0f / D);
-      m2 *= (1.0f / D);
-      float2 out = make_float2(rstd * (ax - m1 - hx * m2), rstd * (ay - m1 - hy * m2));
-      if (accumulate) {
-        out.x += old4[j].x;
-        out.y += old4[j].y;
-      }
-      reinterpret_cast<float2*>(dx)[(size_t)r * 64 + lane] = out;
-      dg.x += dyv.x * hx; dg.y += dyv.y * hy;
-      dbt.x += dyv.x; dbt.y += dyv.y;
     }
   }
-  // one set of atomics per workgroup (all workgroups hit the same 256 addresses)
-  __shared__ float sred[4][4 * 64];
-  sred[wave][lane] = dg.x; sred[wave][64 + lane] = dg.y; sred[wave][128 + lane] = dbt.x; sred[wave][192 + lane] = dbt.y;
+  // column sums over the 32 row slots of the workgroup, then one set of atomics per workgroup
+  __shared__ float sred[2][32][D + 4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<float4*>(&sred[0][r_in][4 * (sub + 8 * i)]) = dg[i];
+    *reinterpret_cast<float4*>(&sred[1][r_in][4 * (sub + 8 * i)]) = dbt[i];
+  }
   __syncthreads();
-  const int t = threadIdx.x;  // 256 threads <-> 256 partial slots
-  const float tot = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
-  const int ln = t & 63, which = t >> 6;  // 0: dg.x 1: dg.y 2: db.x 3: db.y
-  float* dst = (which < 2 ? dgamma : dbeta) + 2 * ln + (which & 1);
-  atomicAdd(dst, tot);
+  const int which = tid >> 7, col = tid & (D - 1);
+  float tot = 0.f;
+#pragma unroll 8
+  for (int rr = 0; rr < 32; ++rr) tot += sred[which][rr][col];
+  atomicAdd((which ? dbeta : dgamma) + col, tot);
 }
 void launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
                    int accumulate, hipStream_t s) {
   if (rows <= 0) return;
-  const int rpw = rows >= 8192 ? 16 : 4;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 4 * rpw - 1) / (4 * rpw)), dim3(256), 0, s, x, gamma, dy, dx, dgamma,
-                     dbeta, rows, rpw, accumulate);
+  const int groups = rows >= 8192 ? 2 : 1;  // 64 / 32 rows per workgroup
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 32 * groups - 1) / (32 * groups)), dim3(256), 0, s, x, gamma, dy, dx, dgamma,
+                     dbeta, rows, groups, accumulate);
 }
 
 // ---- edge elementwise kernels (thread = float4 chunk of an edge row) -------------------------------------------------
