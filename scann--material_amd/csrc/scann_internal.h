@@ -135,6 +135,7 @@ struct EdgeArgs {
   const int32_t* edge_col;     // [n_edge]
   const int32_t* edge_row;     // [n_edge] centre atom of each edge
   float* geom;                 // [n_edge,128] in/out (g_update)
+  float* geom_out;             // edge_kernel_lean only: where geom' goes (null: in place) -- keep-mode writes each layer's geometry to its own slice
   const float* gd;             // [n_edge,20] raw distance basis (base)
   const float* edge_weight;    // [n_edge] (base)
   const float *c, *P1, *P3, *q;  // [n_atom,128]

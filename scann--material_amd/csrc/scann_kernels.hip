@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
       inv = rstd * g.y; y.y = greg[i].y * inv + (be.y - mean * inv);
       inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
       inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
-      reinterpret_cast<float4*>(a.geom)[(size_t)(eb + r) * 32 + c4] = y;
+      reinterpret_cast<float4*>(a.geom_out ? a.geom_out : a.geom)[(size_t)(eb + r) * 32 + c4] = y;
       *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);
     }
   } else {

@@ -776,11 +776,19 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     const int r = ensure_debug(h, db);
     if (r) return r;
   }
+  // keep-mode (training / scann_set_debug): with edge_kernel_lean every layer writes its centres, context and geometry straight
+  // into its slice of the per-layer buffers; the other edge kernels update the geometry in place and the slices are copies
+  const bool direct = h->debug && h->edge_lean && c.g_update && db->tile_atoms <= TQ && db->tile_rows == 64 &&
+                      db->n_tile < h->persist_min_tiles;
+  const size_t nA_ = (size_t)db->n_atom * D, nE_ = (size_t)db->n_edge * D;
+  auto c_of = [&](int l) { return direct ? db->dbg_c + (size_t)l * nA_ : db->c; };
+  auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
+  auto g_of = [&](int l) { return direct ? db->dbg_g + (size_t)l * nE_ : db->geom; };
   if (tm) tm->mark(-1);
-  if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, db->geom, s);
+  if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
   else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
   if (tm) tm->mark(0);
-  if (h->debug && c.g_update && db->n_edge) HIPCHK(h, hipMemcpyAsync(db->dbg_g, db->geom, rowE, hipMemcpyDeviceToDevice, s));
+  if (h->debug && !direct && c.g_update && db->n_edge) HIPCHK(h, hipMemcpyAsync(db->dbg_g, db->geom, rowE, hipMemcpyDeviceToDevice, s));
 
   const bool general_embed = c.use_ring || c.feature_cgcnn;
   if (general_embed) {
@@ -800,13 +808,13 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       a.x_index = general_embed ? nullptr : db->atomic;
       a.ffn = 0;
     } else {
-      a.x = db->ctx;
+      a.x = ctx_of(l - 1);
       a.x_index = nullptr;
       a.ffn = c.use_attn_norm ? 1 : 0;
       const LayerParams& pp = h->layers[l - 1];
       a.Wf1p = pp.Wf1p; a.bf1 = pp.bf1; a.Wf2p = pp.Wf2p; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
     }
-    a.c = db->c;
+    a.c = c_of(l);
     if (h->train_drop_p > 0.f) {  // training-mode Dropout(0.1) layers (scann_model.py:374, attention.py:29)
       a.drop_p = (l == 0 || c.use_attn_norm) ? h->train_drop_p : 0.f;
       a.drop_seed = h->train_seed;
@@ -832,13 +840,13 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
 #endif
     launch_atom(a, s);
     if (tm) tm->mark(l < L ? 1 : 3);
-    if (h->debug) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
+    if (h->debug && !direct) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
     if (l == L) break;
     EdgeArgs ea{};
     ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.tile_rows = db->tile_rows; ea.g_update = c.g_update;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
-    ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
-    ea.c = db->c; ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = db->ctx;
+    ea.geom = g_of(l); ea.geom_out = direct ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
+    ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = ctx_of(l);
     ea.p = h->layers[l];
     const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -865,7 +873,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
 #endif
     launch_edge(ea, s);
-    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, db->q, ea.p.ln_g, ea.p.ln_b, db->ctx, s);
+    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, db->q, ea.p.ln_g, ea.p.ln_b, ea.ctx, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);
@@ -873,7 +881,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       h->time_edges.push_back(db->n_edge);
     }
     if (tm) tm->mark(2);
-    if (h->debug) {
+    if (h->debug && !direct) {
       HIPCHK(h, hipMemcpyAsync(db->dbg_ctx + (size_t)l * db->n_atom * D, db->ctx, rowA, hipMemcpyDeviceToDevice, s));
       if (c.g_update && db->n_edge)
         HIPCHK(h, hipMemcpyAsync(db->dbg_g + (size_t)(l + 1) * db->n_edge * D, db->geom, rowE, hipMemcpyDeviceToDevice, s));
