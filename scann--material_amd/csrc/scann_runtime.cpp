@@ -1206,8 +1206,6 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   if (h->attn_drop_p > 0.f && !((h->edge_w8 || (h->edge_lean && db->tile_atoms <= TQ)) && h->cfg.g_update && db->tile_rows == 64 &&
                                 db->n_tile < h->persist_min_tiles))
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
-  if (db->n_big > 0)
-    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: the backward pass handles at most 64 neighbours per atom");
   const bool dbg = h->debug;
   h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)
   h->train_drop_p = dropout;

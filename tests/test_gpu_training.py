@@ -341,23 +341,41 @@ def test_gradients_mp2018_shapes(hip_lib):
     rb.free()
 
 
-def test_training_refuses_more_than_64_neighbours(hip_lib):
-    """Inference handles any neighbour count; the backward pass stops at 64 and says so."""
+def test_gradients_with_more_than_64_neighbours(hip_lib):
+    """Atoms with 70 and 130 neighbours (chunk tiles + softmax merge in the keep-mode forward, the degree-agnostic attention
+    backward) next to ordinary molecules: gradients against autograd."""
+    import torch_ref
     from scann import _hip
 
-    cfg, w, pk, targets, model = setup(n=2, L=1, seed=3)
-    A = 70
-    mol_offset = np.array([0, A])
-    edge_offset = np.concatenate([[0], np.cumsum([A - 1] + [1] * (A - 1))])
-    edge_col = np.concatenate([np.arange(1, A), np.zeros(A - 1, dtype=np.int64)])
-    E = edge_col.shape[0]
-    big = _hip.PackedBatch(np.full(A, 6), mol_offset, edge_offset, edge_col, np.full(E, 1.5), np.full(E, 1.0))
+    cfg, w, _, _, model = setup(n=2, L=2, seed=3)
+    rng = np.random.default_rng(4)
+    A = 140
+    deg = {0: 70, 5: 130, 139: 65}
+    nb = []
+    for a in range(A):
+        d = deg.get(a, int(rng.integers(1, 7)))
+        js = rng.choice(np.delete(np.arange(A), a), d, replace=False)
+        nb.append([[6, int(j), float(rng.uniform(0.4, 3.5)), 1.0, float(rng.uniform(0.9, 4.0))] for j in js])
+    de, dn = so.synth_dataset(2, 3)
+    de3, dn3 = np.empty(3, dtype=object), np.empty(3, dtype=object)
+    de3[0], dn3[0] = de[0], dn[0]
+    de3[1], dn3[1] = [[int(z) for z in rng.choice([1, 6, 7, 8], A)], 0.3], nb
+    de3[2], dn3[2] = de[1], dn[1]
+    inputs, targets = so.pad_batch(de3, dn3, True)
+    pk = _hip.pack_inputs(inputs)
     eng = model.engine
     eng.train_begin()
-    rb = eng.upload(big)
-    with pytest.raises(_hip.ScannHipError) as e:
-        eng.train_forward(rb, np.zeros(1, dtype=np.float32))
-    assert e.value.code == -2 and "64 neighbours" in str(e.value)
-    eng.forward_resident(rb, 0)  # the inference path takes the same resident batch
-    y, _ = eng.download(rb)
-    assert np.isfinite(y).all()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    loss, rmse, ref, y_ref = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 1e-5 * max(rmse, 1e-6)
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+    errs = grad_errors(got, ref)
+    bad = {k: v for k, v in errs.items() if not v <= 2e-3}
+    assert not bad, bad
+    rb.free()
