@@ -245,7 +245,8 @@ class SCANN:
         hy["target_mean"] = str(self.mean)
         hy["target_std"] = str(self.std)
         hy["data_size"] = len(data_energy)
-        kw = dict(batch_size=hy["batch_size"], use_ring=mo["use_ring"], feature=mo["feature"], g_update=mo["g_update"])
+        kw = dict(batch_size=hy["batch_size"], use_ring=mo["use_ring"], feature=mo["feature"], g_update=mo["g_update"],
+                  atomic_features=hy.get("cgcnn_table"))  # cgcnn: path of the element table (else SCANN_CGCNN_TABLE)
         if split:
             train, valid, test, extra = split_data(len_data=len(data_energy), test_percent=hy["test_percent"],
                                                    train_size=hy["train_size"], test_size=hy["test_size"])

@@ -5,7 +5,35 @@ from math import ceil
 
 import numpy as np
 
+import json
+import os
+
 from .general import pad_sequence
+
+
+def load_cgcnn_table(table=None):
+    """The 92-d CGCNN element descriptors the reference keeps as a Python dict (scann/utils/atomic_data.py, used at
+    datagenerator.py:109-110).  That table is not shipped here: pass a mapping {Z: 92 floats} or the path of a JSON file in
+    the public CGCNN `atom_init.json` format (keys "1", "2", ...), or point SCANN_CGCNN_TABLE at one.  -> float32 [Zmax+1, 92]
+    with row 0 = zeros (padding), and the mask of the elements present."""
+    if table is None:
+        table = os.environ.get("SCANN_CGCNN_TABLE")
+        if not table:
+            raise FileNotFoundError(
+                "feature='cgcnn' needs the CGCNN element table: pass atomic_features={Z: [92 floats]} (or a path to a JSON "
+                "file in atom_init.json format) or set SCANN_CGCNN_TABLE")
+    if isinstance(table, (str, os.PathLike)):
+        with open(table) as f:
+            table = json.load(f)
+    items = {int(k): np.asarray(v, dtype=np.float32) for k, v in table.items()}
+    if not items or any(v.shape != (92,) for v in items.values()):
+        raise ValueError("CGCNN table: every element needs 92 values")
+    out = np.zeros((max(items) + 1, 92), dtype=np.float32)
+    has = np.zeros(max(items) + 1, dtype=bool)
+    for z, v in items.items():
+        out[z] = v
+        has[z] = True
+    return out, has
 
 
 class DataIterator:
@@ -14,7 +42,7 @@ class DataIterator:
     ``g_update`` else 3 (normalised); ``atom_mask = atomic != 0``."""
 
     def __init__(self, data_energy, data_neighbor, batch_size=32, converter=False, use_ring=False,
-                 shuffle=False, feature="atomic", g_update=False):
+                 shuffle=False, feature="atomic", g_update=False, atomic_features=None):
         self.batch_size = batch_size
         self.shuffle = shuffle
         self.data_neighbor = data_neighbor
@@ -22,6 +50,7 @@ class DataIterator:
         self.use_ring = use_ring
         self.weight_index = 2 if g_update else 3
         self.feature = feature
+        self.cgcnn_table, self.cgcnn_has = load_cgcnn_table(atomic_features) if feature == "cgcnn" else (None, None)
         self.converter = 1000 if converter else 1.0
         self.on_epoch_end()
 
@@ -57,8 +86,12 @@ class DataIterator:
         nbr[~mask_local] = 0
         pad_atom = pad_sequence([c[0] for c in batch_atom], padding="post", maxlen=M, value=0, dtype="int32")
         mask_atom = pad_atom != 0
-        if self.feature == "cgcnn":
-            raise NotImplementedError("feature='cgcnn' needs the CGCNN table (atomic_data.py) -- not in this round")
+        if self.feature == "cgcnn":  # [B, M, 92] element descriptors instead of atomic numbers (datagenerator.py:109-110)
+            zs = pad_atom[mask_atom]
+            if zs.size and (zs.max() >= self.cgcnn_table.shape[0] or not self.cgcnn_has[zs].all()):
+                missing = sorted({int(z) for z in zs if z >= self.cgcnn_table.shape[0] or not self.cgcnn_has[z]})
+                raise KeyError("atomic numbers %s are not in the CGCNN table" % missing)
+            pad_atom = self.cgcnn_table[pad_atom]
         inputs = {
             "atomic": pad_atom,
             "atom_mask": np.expand_dims(mask_atom, -1),

@@ -461,3 +461,41 @@ def test_edge_tile_plan_invariants(hip_lib):
     with pytest.raises(_hip.ScannHipError) as e:
         _hip.plan_tiles(bad)
     assert e.value.code == -1 and "outside its structure" in str(e.value)
+
+
+def test_data_iterator_cgcnn_features(tmp_path, monkeypatch):
+    """feature='cgcnn' (datagenerator.py:109-110): atomic numbers replaced by rows of a user-supplied 92-d element table."""
+    import json
+    from scann import _hip
+    from scann.utils import DataIterator
+
+    de, dn = so.synth_dataset(6, 2)
+    rng = np.random.default_rng(0)
+    table = {str(z): [float(x) for x in rng.standard_normal(92)] for z in (1, 6, 7, 8, 9)}
+    path = tmp_path / "atom_init.json"
+    path.write_text(json.dumps(table))
+    monkeypatch.delenv("SCANN_CGCNN_TABLE", raising=False)
+    with pytest.raises(FileNotFoundError):
+        DataIterator(de, dn, batch_size=3, feature="cgcnn")
+    ref = DataIterator(de, dn, batch_size=3, g_update=True)
+    for it in (DataIterator(de, dn, batch_size=3, feature="cgcnn", g_update=True, atomic_features=str(path)),
+               DataIterator(de, dn, batch_size=3, feature="cgcnn", g_update=True, atomic_features={int(k): v for k, v in table.items()})):
+        for i in range(len(it)):
+            inputs, t = it[i]
+            base, t0 = ref[i]
+            assert inputs["atomic"].shape == base["atomic"].shape + (92,) and inputs["atomic"].dtype == np.float32
+            for b, m in np.ndindex(*base["atomic"].shape):
+                z = int(base["atomic"][b, m])
+                want = np.zeros(92, np.float32) if z == 0 else np.asarray(table[str(z)], np.float32)
+                assert np.array_equal(inputs["atomic"][b, m], want)
+            assert np.array_equal(inputs["atom_mask"], base["atom_mask"]) and np.array_equal(t, t0)
+            pk = _hip.pack_inputs(inputs)
+            assert pk.atomic is None and pk.cgcnn.shape == (int(base["atom_mask"].sum()), 92)
+    monkeypatch.setenv("SCANN_CGCNN_TABLE", str(path))
+    assert DataIterator(de, dn, batch_size=3, feature="cgcnn")[0][0]["atomic"].shape[-1] == 92
+    bad = dict(table)
+    del bad["9"], bad["8"]
+    with pytest.raises(KeyError):
+        it = DataIterator(de, dn, batch_size=6, feature="cgcnn", atomic_features={int(k): v for k, v in bad.items()})
+        for i in range(len(it)):
+            it[i]
