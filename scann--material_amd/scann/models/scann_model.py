@@ -282,9 +282,10 @@ class SCANN:
         self.hist.history = fit(self, epochs)
         del self.model
 
-    def evaluate(self):
+    def evaluate(self, gpus=None):
         """Test-set loop of the reference (scann_model.py:247-313): predict every batch, report
-        R2 and MAE * std, write report.txt."""
+        R2 and MAE * std, write report.txt.  ``gpus`` (or ``hyper.gpus``) > 1 spreads the batches over that many
+        devices of the node from this process (scann.parallel.MultiGpuPredictor; no collective)."""
         from sklearn.metrics import mean_absolute_error, r2_score
 
         if not hasattr(self, "model") or self.model is None:
@@ -292,7 +293,13 @@ class SCANN:
             t = self.config["hyper"]["target"]
             self.model = load_model("{}/models/model_{}.h5".format(self._out_dir(), t))
         data = self.dataIter if hasattr(self, "dataIter") else self.testIter
-        yp, _, yt = self.model.predict_dataset(data)  # same per-batch results as the reference's predict loop (:264-271)
+        runner = self.model
+        n_gpu = int(gpus if gpus is not None else self.config["hyper"].get("gpus", 1))
+        if n_gpu > 1:
+            from ..parallel import MultiGpuPredictor
+
+            runner = MultiGpuPredictor(self.config, self.model.get_weights(), devices=list(range(n_gpu)))
+        yp, _, yt = runner.predict_dataset(data)  # same per-batch results as the reference's predict loop (:264-271)
         y_predict, y = list(yp), list(yt)
         mae = mean_absolute_error(y, y_predict) * self.std
         r2 = r2_score(y, y_predict)

@@ -1,0 +1,75 @@
+"""All GPUs of one node from ONE process: one handle (scann_handle_t) per device, one host thread per handle.
+
+Inference shards by structure with no collective: handles are independent ("thread-safe across handles"),
+ctypes releases the GIL during every library call, so N threads keep N GPUs busy; outputs come back in dataset order."""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+
+from .. import _hip
+
+
+class MultiGpuPredictor:
+    """``MultiGpuPredictor(config, weights).predict_dataset(dataset)``: the batches of ``dataset`` are dealt to the devices
+    in contiguous runs (one run per device, sized by edge count) and every device runs ``HipModel.predict_dataset`` on its
+    run.  ``devices`` defaults to every visible GPU; repeating an id (``[0, 0]``) puts two handles on one GPU."""
+
+    def __init__(self, config, weights=None, devices=None, infer=False, seed=None):
+        from ..models.scann_model import HipModel
+
+        if devices is None:
+            devices = list(range(_hip.load_library().scann_device_count()))
+        if not devices:
+            raise RuntimeError("MultiGpuPredictor: no HIP device visible (there is no CPU fallback)")
+        first = HipModel(config, weights, device=devices[0], infer=infer, seed=seed)
+        w = first.get_weights()  # every replica runs the same parameters
+        self.models = [first] + [HipModel(config, w, device=d, infer=infer) for d in devices[1:]]
+        self.devices = list(devices)
+
+    def get_weights(self):
+        return self.models[0].get_weights()
+
+    def set_weights(self, weights):
+        for m in self.models:
+            m.set_weights(weights)
+
+    @staticmethod
+    def _runs(costs, n):
+        """Contiguous runs of batches with balanced total cost -> list of (lo, hi)."""
+        n = max(1, min(n, len(costs)))
+        cum = np.concatenate([[0.0], np.cumsum(np.asarray(costs, dtype=np.float64))])
+        cuts = [0]
+        for s in range(1, n):
+            c = int(np.searchsorted(cum, cum[-1] * s / n))
+            cuts.append(min(max(c, cuts[-1] + 1), len(costs) - (n - s)))
+        cuts.append(len(costs))
+        return list(zip(cuts[:-1], cuts[1:]))
+
+    def predict_dataset(self, dataset, group=4, want_ga=False):
+        """-> (y [N], ga | None, targets [N]) in dataset order, like ``HipModel.predict_dataset``."""
+        n = len(dataset)
+        if n == 0:
+            return np.zeros(0, np.float32), (np.zeros(0, np.float32) if want_ga else None), np.zeros(0, np.float32)
+        items = [dataset[i] for i in range(n)]
+        costs = [(it.n_edge + 8 * it.n_atom) if isinstance(it, _hip.PackedBatch) else 1 for it, _ in items]
+        runs = self._runs(costs, len(self.models))
+        out, err = [None] * len(runs), []
+
+        def work(k, lo, hi):
+            try:
+                out[k] = self.models[k].predict_dataset(items[lo:hi], group=group, want_ga=want_ga)
+            except BaseException as e:  # surfaced in the caller's thread
+                err.append(e)
+
+        threads = [threading.Thread(target=work, args=(k, lo, hi)) for k, (lo, hi) in enumerate(runs)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            raise err[0]
+        y = np.concatenate([o[0] for o in out])
+        ga = np.concatenate([o[1] for o in out]) if want_ga else None
+        return y, ga, np.concatenate([o[2] for o in out])

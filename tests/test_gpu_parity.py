@@ -430,3 +430,20 @@ def test_sparse_graphs_hit_the_atoms_per_tile_limit(hip_lib):
     y, ga = model.predict(inputs)
     y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
     assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
+
+
+def test_multi_gpu_predictor_matches_single_handle(hip_lib):
+    """One process, one handle + host thread per device (two handles on the one GPU of this box): same numbers, same order."""
+    from scann.parallel import MultiGpuPredictor
+    from scann.utils import PackedDataset
+
+    cfg, w, _, model = make(n=2)
+    de, dn = so.synth_dataset(90, 21)
+    ds = PackedDataset(de, dn, batch_size=8, g_update=True)
+    y1, ga1, t1 = model.predict_dataset(ds, group=3, want_ga=True)
+    multi = MultiGpuPredictor(cfg, w, devices=[0, 0])
+    y2, ga2, t2 = multi.predict_dataset(ds, group=3, want_ga=True)
+    assert np.array_equal(t1, t2) and y1.shape == y2.shape == (90,)
+    assert rel_err(y2, y1) <= 1e-6 and rel_err(ga2, ga1) <= 1e-6
+    runs = MultiGpuPredictor._runs([5, 1, 1, 1, 5, 5], 3)
+    assert runs[0][0] == 0 and runs[-1][1] == 6 and all(hi > lo for lo, hi in runs) and len(runs) == 3
