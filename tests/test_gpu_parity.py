@@ -242,7 +242,7 @@ def test_errors_are_reported(hip_lib):
         model.engine.load_weights(w2)
 
 
-@pytest.mark.parametrize("name", ["qm9_plus", "qm9_base", "qm9_no_norms", "qm9_e_b", "mp2018"])
+@pytest.mark.parametrize("name", ["qm9_plus", "qm9_base", "qm9_no_norms", "qm9_e_b", "mp2018", "dense_and_sparse"])
 def test_golden_vectors(hip_lib, name):
     """Committed fixtures (tests/golden/*.npz, written by make_golden.py from the oracle)."""
     import importlib.util
