@@ -17,6 +17,7 @@ constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict
 constexpr int TE_MAX = 64;       // edge rows per edge tile: 32 or 64 (one or two 32-row MFMA row tiles)
 constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row tile)
 constexpr int TQ = 24;           // atoms per EDGE tile when edge_kernel_lean runs (its query-row buffer)
+constexpr int TQ32H = 16;        // the same for edge_kernel_lean32 (32-edge tiles)
 constexpr int TB = 16;           // edges per basis-kernel workgroup (64 measured slower: 0.095 vs 0.088 ms per 16-batch forward)
 constexpr int WPACK = D * D;     // floats in one packed 128x128 weight
 

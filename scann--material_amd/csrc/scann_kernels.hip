@@ -1255,6 +1255,292 @@ void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf,
   if (n_big > 0) hipLaunchKernelGGL(edge_merge_kernel, dim3(n_big), dim3(128), 0, s, big_tab, part_buf, q, ln_g, ln_b, ctx);
 }
 
+// ---- lean-LDS edge kernel on 32-edge tiles: five workgroups per CU ----------------------------------------------------
+//
+// Same phases as edge_kernel_lean on one 32 x 128 buffer (29 KB of LDS, <= 96 VGPRs): the launch time of the edge path is
+// (rounds of tiles) x (tile latency) and the latency is a dependency chain, not matrix work, so more, smaller tiles in
+// flight per CU trade weight traffic (the kernels are re-read per tile) for matrix-pipe occupancy.  Weights stream in
+// quarter slabs through two 4 x float4 buffers.
+constexpr int TQ32 = 16;  // atoms per 32-edge tile
+__device__ __forceinline__ void load_w_quarter(const float* __restrict__ Wp, int cb, int lane, int qt, float4 (&w)[4]) {
+  const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + cb * (16 * 64) + qt * (4 * 64) + lane;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w[t] = wsrc[t * 64];
+}
+__device__ __forceinline__ void mma_quarter1(const float* __restrict__ sX, const float4 (&w)[4], int lane, int qt, f32x16& acc) {
+  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5) + 32 * qt;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * t);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, a.x, acc, 0, 0, 0);  // transposed product (see mma_half2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, a.w, acc, 0, 0, 0);
+  }
+}
+// acc (+)= X[32 x 128] . W[:, 32 wave .. +32]; wa / wb hold quarters 0 / 1 on entry; `next` (or null): the kernel whose
+// quarters 0 / 1 are requested as soon as the buffers free up
+__device__ __forceinline__ void gemm32(const float* __restrict__ sX, const float* __restrict__ Wp, const float* __restrict__ next,
+                                       int wave, int lane, float4 (&wa)[4], float4 (&wb)[4], f32x16& acc) {
+  mma_quarter1(sX, wa, lane, 0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w_quarter(Wp, wave, lane, 2, wa);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_quarter1(sX, wb, lane, 1, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w_quarter(Wp, wave, lane, 3, wb);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_quarter1(sX, wa, lane, 2, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if (next) load_w_quarter(next, wave, lane, 0, wa);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_quarter1(sX, wb, lane, 3, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if (next) load_w_quarter(next, wave, lane, 1, wb);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void dump_t1(float* __restrict__ sT, const f32x16& acc, int wave, int lane, const float* __restrict__ sBias) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 32 * wave + 8 * j + 4 * (lane >> 5);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sBias) bv = *reinterpret_cast<const float4*>(sBias + c);
+    *reinterpret_cast<float4*>(&sT[(lane & 31) * LDS_STRIDE + c]) =
+        make_float4(acc[4 * j] + bv.x, acc[4 * j + 1] + bv.y, acc[4 * j + 2] + bv.z, acc[4 * j + 3] + bv.w);
+  }
+}
+
+__global__ __launch_bounds__(256, 5) void edge_kernel_lean32(EdgeArgs a) {
+  constexpr int TEK = 32;
+  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];   // G -> U -> ang = c[j]*geom' -> K
+  __shared__ __attribute__((aligned(16))) float sQ[TQ32 * LDS_STRIDE];  // P1 rows, then query rows of the tile's atoms, then context
+  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
+  __shared__ __attribute__((aligned(16))) float sPar[5 * D];
+  __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ32 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tix = a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+  const EdgeTile tile = a.tiles[tix];
+  const int part = a.tile_part ? a.tile_part[tix] : -1;
+  const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
+  const int r = tid >> 3, sub = tid & 7;  // row-pass mapping: 8 threads per edge row, float4 chunks sub, sub+8, sub+16, sub+24
+
+  // prologue: every load unguarded from clamped rows (see edge_kernel_lean)
+  const int nem1 = ne > 0 ? ne - 1 : 0;
+  const int rs = r < ne ? r : nem1;
+  float4 wa[4], wb[4];
+  load_w_quarter(a.p.W2p, wave, lane, 0, wa);
+  load_w_quarter(a.p.W2p, wave, lane, 1, wb);
+  const int32_t* pa = tid < TEK ? (ne > 0 ? a.edge_col + eb + min(tid, nem1) : a.edge_offset)
+                                : a.edge_offset + tile.atom_begin + min(tid - TEK, natom);
+  const int32_t* pb = ne > 0 ? a.edge_row + eb + min(tid & (TEK - 1), nem1) : a.edge_offset;
+  const int va = *pa, vb = *pb;
+  const float bkc = a.p.bk[tid & (D - 1)];
+  const float par0 = (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)];
+  const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
+  const int qa = tid >> 5, qc = tid & 31;  // atom rows qa, qa + 8 of the P1 / query staging
+  const float4* const p14 = reinterpret_cast<const float4*>(a.P1) + (size_t)tile.atom_begin * 32 + qc;
+  const float4 p1a = p14[(size_t)min(qa, natom - 1) * 32], p1b = p14[(size_t)min(qa + 8, natom - 1) * 32];
+  float4 greg[4];
+  {
+    const float4* grow = reinterpret_cast<const float4*>(ne > 0 ? a.geom + (size_t)(eb + rs) * D : a.P1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) greg[i] = grow[sub + 8 * i];
+  }
+  if (tid < TEK) {
+    sCol[tid] = tid < ne ? va : 0;
+    sCtr[tid] = tid < ne ? vb : 0;
+  } else if (tid - TEK <= natom) {
+    sOff[tid - TEK] = part >= 0 ? (tid == TEK ? 0 : ne) : va - eb;
+  }
+  sPar[tid] = par0;
+  sPar[2 * D + tid] = par1;
+  if (tid < D) sPar[4 * D + tid] = bkc;
+  *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * qc]) = p1a;
+  *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * qc]) = p1b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (r >= ne) greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 8 * i)]) = greg[i];
+  }
+  __syncthreads();
+  // U = G . W2
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  gemm32(sA, a.p.W2p, nullptr, wave, lane, wa, wb, acc);
+  __syncthreads();  // every wave is done reading G
+  dump_t1(sA, acc, wave, lane, nullptr);
+  __syncthreads();
+
+  // row pass (attention.py:141-157)
+  if (r < ne) {
+    const int ctr = sCtr[r], nb = sCol[r];
+    const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
+    const float* p1 = sQ + (ctr - tile.atom_begin) * LDS_STRIDE;
+    const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
+    float4 p3r[4], cn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p3r[i] = p3[sub + 8 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cn[i] = crow[sub + 8 * i];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c4 = sub + 8 * i;
+      const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
+      const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3r[i]);
+      greg[i] = f4add(f4swish(v), greg[i]);
+      s += f4sum(greg[i]);
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    const float mean = s * (1.0f / D);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dx = greg[i].x - mean, dy = greg[i].y - mean, dz = greg[i].z - mean, dw = greg[i].w - mean;
+      v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c4 = sub + 8 * i;
+      const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
+      const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
+      float4 y;
+      float inv;
+      inv = rstd * g.x; y.x = greg[i].x * inv + (be.x - mean * inv);
+      inv = rstd * g.y; y.y = greg[i].y * inv + (be.y - mean * inv);
+      inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
+      inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
+      reinterpret_cast<float4*>(a.geom_out ? a.geom_out : a.geom)[(size_t)(eb + r) * 32 + c4] = y;
+      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 8 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  load_w_quarter(a.p.Wkp, wave, lane, 0, wa);
+  load_w_quarter(a.p.Wkp, wave, lane, 1, wb);
+  const float4* const q4p = reinterpret_cast<const float4*>(a.q) + (size_t)tile.atom_begin * 32 + qc;
+  const float4 q0 = q4p[(size_t)min(qa, natom - 1) * 32], q1 = q4p[(size_t)min(qa + 8, natom - 1) * 32];
+  __syncthreads();  // ang complete; nobody reads the P1 rows any more
+  *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * qc]) = q0;
+  *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * qc]) = q1;
+  __builtin_amdgcn_sched_barrier(0);
+  // K = ang . Wk + bk
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  gemm32(sA, a.p.Wkp, nullptr, wave, lane, wa, wb, acc);
+  __syncthreads();  // every wave is done reading ang
+  dump_t1(sA, acc, wave, lane, sPar + 4 * D);
+  __syncthreads();
+  // logits: thread = (edge row, head)
+  {
+    const int n = tid >> 3, hh = tid & 7;
+    if (n < ne) {
+      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + HDIM * hh;
+      const float* krow = sA + n * LDS_STRIDE + HDIM * hh;
+      float e = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
+        e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
+      }
+      sE[n * NHEAD + hh] = e;
+    }
+  }
+  __syncthreads();
+  // softmax + context + residual (online form, see edge_kernel_w8)
+  {
+    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
+    for (int la = lgp; la < natom; la += 8) {
+      const int e0 = sOff[la], e1 = sOff[la + 1];
+      float m = -INFINITY, ssum = 0.f;
+      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int n = e0; n < e1; n += 2) {
+        const bool two = n + 1 < e1;
+        const int n1 = two ? n + 1 : n;
+        const float ea = sE[n * NHEAD + h];
+        const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
+        const float4 ka = *reinterpret_cast<const float4*>(&sA[n * LDS_STRIDE + 4 * c4]);
+        const float4 kb = *reinterpret_cast<const float4*>(&sA[n1 * LDS_STRIDE + 4 * c4]);
+        const float mn = fmaxf(m, fmaxf(ea, eb2));
+        const float resc = fast_exp(m - mn);
+        float pa2 = fast_exp(ea - mn), pb2 = fast_exp(eb2 - mn);
+        ssum = ssum * resc + (pa2 + pb2);
+        if (a.attn_drop_p > 0.f) {
+          pa2 *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
+          pb2 *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
+        }
+        cx.x = cx.x * resc + (pa2 * ka.x + pb2 * kb.x);
+        cx.y = cx.y * resc + (pa2 * ka.y + pb2 * kb.y);
+        cx.z = cx.z * resc + (pa2 * ka.z + pb2 * kb.z);
+        cx.w = cx.w * resc + (pa2 * ka.w + pb2 * kb.w);
+        m = mn;
+      }
+      if (part >= 0) {
+        float* pbuf = a.part_buf + (size_t)part * 3 * D + 4 * c4;
+        *reinterpret_cast<float4*>(pbuf) = make_float4(m, m, m, m);
+        *reinterpret_cast<float4*>(pbuf + D) = make_float4(ssum, ssum, ssum, ssum);
+        *reinterpret_cast<float4*>(pbuf + 2 * D) = cx;
+      } else {
+        const float rs2 = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+        float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
+        const float4 q4 = *qp;
+        *qp = make_float4(cx.x * rs2 + q4.x, cx.y * rs2 + q4.y, cx.z * rs2 + q4.z, cx.w * rs2 + q4.w);
+      }
+    }
+  }
+  __syncthreads();
+  // LayerNorm of the context rows: 8 threads per atom row
+  {
+    const int rr = tid >> 3, sb = tid & 7;
+    if (rr < natom && part < 0) {
+      float4 t[4];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        t[i] = *reinterpret_cast<const float4*>(&sQ[rr * LDS_STRIDE + 4 * (sb + 8 * i)]);
+        s += f4sum(t[i]);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * (1.0f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
+        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = sb + 8 * i;
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
+        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
+        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
+        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
+        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + rr) * 32 + c4] = y;
+      }
+    }
+  }
+}
+
 #ifdef SCANN_STAMPS
 #define STAMP_DECL()                                                                                             \
   unsigned long long acc_work[4] = {0, 0, 0, 0}, t_loop0 = 0, t_b = 0;                                           \
@@ -1613,6 +1899,10 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
   }
   if (a.lean && a.g_update && a.tile_rows == 64) {
     hipLaunchKernelGGL(edge_kernel_lean, dim3(a.n_tile), dim3(256), 0, s, a);
+    return;
+  }
+  if (a.lean && a.g_update && a.tile_rows == 32) {
+    hipLaunchKernelGGL(edge_kernel_lean32, dim3(a.n_tile), dim3(256), 0, s, a);
     return;
   }
   if (a.waves8 && a.g_update && a.tile_rows == 32) {

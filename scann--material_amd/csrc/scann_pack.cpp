@@ -49,21 +49,21 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
         return SCANN_ERR_UNSUPPORTED;
       }
       maxdeg = std::max(maxdeg, e1 - e0);
-      if (e1 - e0 > tile_rows) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom (or its 64-edge chunks): fall back to 64-row tiles
+      if (e1 - e0 > tile_rows && !allow_chunks) tile_rows = TE_MAX;  // a 32-row tile cannot hold this atom: fall back to 64-row tiles
       for (int e = e0; e < e1; ++e) {
         if (edge_col[e] < mol_offset[s] || edge_col[e] >= mol_offset[s + 1]) { err = "neighbour index outside its structure"; return SCANN_ERR_INVALID; }
         edge_row[e] = a;
       }
-      if (e1 - e0 > TE_MAX) {  // big atom: close the open tile, then one chunk tile per <= 64 of its edges
+      if (allow_chunks && e1 - e0 > want) {  // big atom: close the open tile, then one chunk tile per <= tile_rows of its edges
         if (a > cur.atom_begin) {
           cur.atom_end = a;
           cur.edge_end = e0;
           tiles.push_back(cur);
           tile_part.push_back(-1);
         }
-        big_tab.push_back(a); big_tab.push_back(n_slot); big_tab.push_back((e1 - e0 + TE_MAX - 1) / TE_MAX);
-        for (int c0 = e0; c0 < e1; c0 += TE_MAX) {
-          tiles.push_back(EdgeTile{a, a + 1, c0, std::min(c0 + TE_MAX, e1)});
+        big_tab.push_back(a); big_tab.push_back(n_slot); big_tab.push_back((e1 - e0 + want - 1) / want);
+        for (int c0 = e0; c0 < e1; c0 += want) {
+          tiles.push_back(EdgeTile{a, a + 1, c0, std::min(c0 + want, e1)});
           tile_part.push_back(n_slot++);
         }
         cur = EdgeTile{a + 1, a + 1, e1, e1};

@@ -315,8 +315,8 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* w8 = getenv("SCANN_EDGE_W8")) h->edge_w8 = atoi(w8) != 0;
   if (const char* ln = getenv("SCANN_EDGE_LEAN")) h->edge_lean = atoi(ln) != 0;
-  h->edge_lean = h->edge_lean && cfg->g_update && h->edge_tile == 64;
-  if (h->edge_lean) h->tile_atoms = TQ;
+  h->edge_lean = h->edge_lean && cfg->g_update;
+  if (h->edge_lean) h->tile_atoms = h->edge_tile == 32 ? TQ32H : TQ;  // edge_kernel_lean32 / edge_kernel_lean
   if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
   {
     hipDeviceProp_t prop;
@@ -778,8 +778,8 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   }
   // keep-mode (training / scann_set_debug): with edge_kernel_lean every layer writes its centres, context and geometry straight
   // into its slice of the per-layer buffers; the other edge kernels update the geometry in place and the slices are copies
-  const bool direct = h->debug && h->edge_lean && c.g_update && db->tile_atoms <= TQ && db->tile_rows == 64 &&
-                      db->n_tile < h->persist_min_tiles;
+  const bool direct = h->debug && h->edge_lean && c.g_update && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ) &&
+                      (db->tile_rows == 32 || db->n_tile < h->persist_min_tiles);
   const size_t nA_ = (size_t)db->n_atom * D, nE_ = (size_t)db->n_edge * D;
   auto c_of = [&](int l) { return direct ? db->dbg_c + (size_t)l * nA_ : db->c; };
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
@@ -856,7 +856,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       (void)hipEventRecord(ev0, s);
     }
     ea.waves8 = h->edge_w8;
-    ea.lean = h->edge_lean && db->tile_atoms <= TQ;
+    ea.lean = h->edge_lean && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ);
     ea.tile_part = db->tile_part; ea.part_buf = db->part_buf;
     ea.xcd_remap = h->xcd_remap;
     if (h->in_train_forward && h->attn_drop_p > 0.f) {
@@ -1203,8 +1203,8 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   db->last_slot = 0;
   w->drop_p = dropout;
   w->seed = seed;
-  if (h->attn_drop_p > 0.f && !((h->edge_w8 || (h->edge_lean && db->tile_atoms <= TQ)) && h->cfg.g_update && db->tile_rows == 64 &&
-                                db->n_tile < h->persist_min_tiles))
+  if (h->attn_drop_p > 0.f && !(h->cfg.g_update && ((h->edge_lean && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ)) ||
+                                                    (h->edge_w8 && db->tile_rows == 64 && db->n_tile < h->persist_min_tiles))))
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
   const bool dbg = h->debug;
   h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)

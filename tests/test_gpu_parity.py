@@ -382,6 +382,11 @@ def test_more_than_64_neighbours(hip_lib, monkeypatch):
     y2, ga2 = model.engine.download(rb)
     assert np.array_equal(y2, y[:, 0]) and np.array_equal(pk.repad_ga(ga2), ga)
     rb.free()
+    monkeypatch.setenv("SCANN_EDGE_TILE", "32")  # edge_kernel_lean32: chunks of 32 edges
+    small = HipModel(cfg, w, device=0, infer=True)
+    y3, ga3 = small.predict(inputs)
+    assert rel_err(y3, y_ref) <= RTOL and rel_err(ga3, ga_ref) <= RTOL
+    monkeypatch.delenv("SCANN_EDGE_TILE")
     monkeypatch.setenv("SCANN_EDGE_LEAN", "0")
     other = HipModel(cfg, w, device=0, infer=True)
     with pytest.raises(_hip.ScannHipError) as e:
@@ -390,13 +395,14 @@ def test_more_than_64_neighbours(hip_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [
-    {"SCANN_EDGE_LEAN": "0"},                                    # edge_kernel_w8<2>: 8 waves, two LDS buffers
-    {"SCANN_EDGE_LEAN": "0", "SCANN_EDGE_W8": "0"},              # 4-wave edge_kernel<true, 2>
-    {"SCANN_EDGE_W8": "0", "SCANN_EDGE_TILE": "32"},             # 32-row tiles, edge_kernel<true, 1>
-    {"SCANN_EDGE_TILE": "32"},                                   # edge_kernel_w8<1>: 32-row tiles, 4-wave workgroups
-    {"SCANN_PERSIST_MIN": "1"},                                  # persistent wave-specialised kernel for every launch
-    {"SCANN_XCD_REMAP": "0", "SCANN_STREAMS": "2"},              # default edge_kernel_lean without the XCD tile order
-], ids=["w8", "w4", "w4_tile32", "w8_tile32", "persistent", "lean_no_remap_2streams"])
+    {"SCANN_EDGE_LEAN": "0"},                                                # edge_kernel_w8<2>: 8 waves, two LDS buffers
+    {"SCANN_EDGE_LEAN": "0", "SCANN_EDGE_W8": "0"},                          # 4-wave edge_kernel<true, 2>
+    {"SCANN_EDGE_LEAN": "0", "SCANN_EDGE_W8": "0", "SCANN_EDGE_TILE": "32"},  # 32-row tiles, edge_kernel<true, 1>
+    {"SCANN_EDGE_LEAN": "0", "SCANN_EDGE_TILE": "32"},                       # edge_kernel_w8<1>: 32-row tiles, 4-wave workgroups
+    {"SCANN_EDGE_TILE": "32"},                                               # edge_kernel_lean32: 32-edge tiles, five workgroups per CU
+    {"SCANN_PERSIST_MIN": "1"},                                              # persistent wave-specialised kernel for every launch
+    {"SCANN_XCD_REMAP": "0", "SCANN_STREAMS": "2"},                          # default edge_kernel_lean without the XCD tile order
+], ids=["w8", "w4", "w4_tile32", "w8_tile32", "lean32", "persistent", "lean_no_remap_2streams"])
 def test_alternative_edge_kernels(hip_lib, env, monkeypatch):
     """The opt-in kernel variants (selected by environment at scann_create) stay at parity."""
     for k, v in env.items():

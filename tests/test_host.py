@@ -445,15 +445,21 @@ def test_edge_tile_plan_invariants(hip_lib):
     chain = _hip.PackedBatch(np.full(A, 6), [0, A], np.arange(A + 1), (np.arange(A) + 1) % A, np.ones(A), np.ones(A))
     _, tiles, _, _ = check(chain, 64, 24)
     assert (tiles[:, 1] - tiles[:, 0]).max() == 24 and len(tiles) == 5
-    # atoms with 65, 130 and 12 neighbours: chunk tiles of <= 64 edges, slots in order; 32-row request falls back to 64
+    # atoms with 65, 130 and 12 neighbours: chunk tiles of <= tile_rows edges, slots in order
     deg = np.array([3, 65, 12, 130, 0, 5])
     A = 140
     eoff = np.concatenate([[0], np.cumsum(np.concatenate([deg, np.zeros(A - len(deg), dtype=np.int64)]))])
     col = np.concatenate([rng.choice(np.delete(np.arange(A), a), d, replace=False) for a, d in enumerate(deg)])
     big = _hip.PackedBatch(np.full(A, 6), [0, A], eoff, col, np.ones(len(col)), np.ones(len(col)))
-    got_rows, tiles, part, n_slots = check(big, 32, 24)
+    got_rows, tiles, part, n_slots = check(big, 64, 24)
     assert got_rows == 64 and n_slots == 2 + 3
     assert [int(t[3] - t[2]) for t, p in zip(tiles, part) if p >= 0] == [64, 1, 64, 64, 2]
+    got_rows, tiles, part, n_slots = check(big, 32, 16)  # 32-edge tiles (edge_kernel_lean32): chunks of 32
+    assert got_rows == 32 and n_slots == 3 + 5
+    assert [int(t[3] - t[2]) for t, p in zip(tiles, part) if p >= 0] == [32, 32, 1, 32, 32, 32, 32, 2]
+    got_rows, _, part, _ = _hip.plan_tiles(_hip.PackedBatch(np.full(3, 6), [0, 3], [0, 2, 42, 44], np.concatenate([[1, 2], np.arange(40) % 2 + 1 - (np.arange(40) % 2) * 2 + 0 * np.arange(40), [0, 1]]) % 3,
+                                                            np.ones(44), np.ones(44)), 32, 32, allow_chunks=False)
+    assert got_rows == 64 and (part < 0).all()  # without chunking a 40-neighbour atom forces 64-edge tiles
     with pytest.raises(_hip.ScannHipError) as e:
         _hip.plan_tiles(big, 64, 32, allow_chunks=False)
     assert e.value.code == -2 and "64 neighbours" in str(e.value)
