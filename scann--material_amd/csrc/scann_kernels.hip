@@ -1028,6 +1028,20 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   __syncthreads();
   STAMP(a.stamps, 3);
 
+#ifdef SCANN_DIAG_GEMMONLY
+  // diagnostic (wrong results): prologue + the two GEMMs + their write-backs only -- the rate the matrix work alone reaches
+  load_w_half(a.p.Wkp, wave, lane, 0, wA);
+  load_w_half(a.p.Wkp, wave, lane, 1, wB);
+  __syncthreads();
+  zero_acc(acc);
+  mma_half2(sA, wA, lane, 0, acc);
+  mma_half2(sA, wB, lane, 1, acc);
+  __syncthreads();
+  dump_t2(sA, acc, wave, lane, sPar + 4 * D);
+  __syncthreads();
+  if (r < ne) reinterpret_cast<float4*>(a.geom_out ? a.geom_out : a.geom)[(size_t)(eb + r) * 32 + sub] = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * sub]);
+  return;
+#endif
   // row pass (attention.py:141-157): u read and ang written at the thread's own positions of sA
   if (r < ne) {
     const int ctr = sCtr[r], nb = sCol[r];
