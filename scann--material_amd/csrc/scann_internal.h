@@ -126,6 +126,7 @@ struct EdgeArgs {
   int32_t xcd_remap;           // contiguous run of tiles per XCD (edge_kernel_w8)
   int32_t waves8;              // run the 8-wave (512-thread) variant edge_kernel_w8
   int32_t lean;                // run edge_kernel_lean (tiles must hold <= TQ atoms)
+  int32_t lean_wgs;            // > 0: edge_kernel_leanp, the persistent form, with this many workgroups (a multiple of 8)
   // atoms with more than 64 neighbours (edge_kernel_lean only): their edges are cut into chunk tiles of one atom each;
   // tile_part[tile] = partial slot of a chunk tile, -1 for ordinary tiles (null: no such atom in the batch); a chunk tile
   // leaves (running max, sum, unnormalised context) per column in part_buf[slot][3][128] for edge_merge_kernel

@@ -1269,6 +1269,305 @@ void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf,
   if (n_big > 0) hipLaunchKernelGGL(edge_merge_kernel, dim3(n_big), dim3(128), 0, s, big_tab, part_buf, q, ln_g, ln_b, ctx);
 }
 
+// ---- persistent form of edge_kernel_lean: the next tile's inputs are requested before the attention phases ------------
+//
+// Occupancy bound of the tile structure: N T_mfma / (T_other + T_mfma) with N = 3 tiles per CU; the prologue (13.5 k of the
+// 52 k cycles of T_other) is pure waiting for the tile's geometry rows, P1 rows, indices and first weight slab.  Here a
+// workgroup walks tiles blockIdx.x, + gridDim.x, ... and issues tile k+1's prologue loads into registers right after tile
+// k's logits, so they land under the softmax / LayerNorm phases; LayerNorm parameters and the key bias are staged once.
+// One tile's inputs, requested into plain locals of the kernel (a struct passed by reference stays a stack object here:
+// every fetched value went through scratch).  VT = virtual block index of the tile.
+#define LEAN_FETCH(VT)                                                                                                  \
+  do {                                                                                                                  \
+    const int tix_ = xr ? xcd_tile((VT), n_tile) : (VT);                                                                \
+    const EdgeTile tile_ = g_tiles[tix_];                                                                               \
+    t_part = g_part ? g_part[tix_] : -1;                                                                                \
+    t_eb = tile_.edge_begin; t_ne = tile_.edge_end - tile_.edge_begin; t_natom = tile_.atom_end - tile_.atom_begin;      \
+    t_abeg = tile_.atom_begin;                                                                                          \
+    const int nem1_ = t_ne > 0 ? t_ne - 1 : 0;                                                                          \
+    const int rs_ = r < t_ne ? r : nem1_;                                                                               \
+    const int32_t* pa_ = tid < 64 ? (t_ne > 0 ? g_col + t_eb + min(tid, nem1_) : g_eoff)                                \
+                                  : g_eoff + t_abeg + min(tid - 64, t_natom);                                           \
+    const int32_t* pb_ = t_ne > 0 ? g_row + t_eb + min(tid & 63, nem1_) : g_eoff;                                       \
+    t_va = *pa_; t_vb = *pb_;                                                                                           \
+    {                                                                                                                   \
+      const float4* p14_ = reinterpret_cast<const float4*>(g_P1) + (size_t)t_abeg * 32 + (tid & 31);                    \
+      const int qa_ = tid >> 5;                                                                                         \
+      t_p1a = p14_[(size_t)min(qa_, t_natom - 1) * 32];                                                                 \
+      t_p1b = p14_[(size_t)min(qa_ + 8, t_natom - 1) * 32];                                                             \
+      t_p1c = p14_[(size_t)min(qa_ + 16, t_natom - 1) * 32];                                                            \
+    }                                                                                                                   \
+    const float4* grow_ = reinterpret_cast<const float4*>(t_ne > 0 ? g_geom + (size_t)(t_eb + rs_) * D : g_P1);          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) t_g[i_] = grow_[sub + 4 * i_];                                     \
+  } while (0)
+
+__global__ __launch_bounds__(256, 3) void edge_kernel_leanp(EdgeArgs a) {
+  constexpr int TEK = 64;
+  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
+  __shared__ __attribute__((aligned(16))) float sPar[5 * D];
+  __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ + 1];
+  const int tid0 = threadIdx.x;
+  // kernel-argument fields used inside the loop, hoisted (the argument struct itself is never address-taken)
+  const EdgeTile* const g_tiles = a.tiles;
+  const int32_t* const g_part = a.tile_part;
+  const int32_t* const g_col = a.edge_col;
+  const int32_t* const g_row = a.edge_row;
+  const int32_t* const g_eoff = a.edge_offset;
+  float* const g_geom = a.geom;
+  float* const g_geom_out = a.geom_out ? a.geom_out : a.geom;
+  const float* const g_c = a.c;
+  const float* const g_P1 = a.P1;
+  const float* const g_P3 = a.P3;
+  const float* const g_q = a.q;
+  float* const g_ctx = a.ctx;
+  float* const g_pbuf = a.part_buf;
+  const float* const g_W2p = a.p.W2p;
+  const float* const g_Wkp = a.p.Wkp;
+  const int n_tile = a.n_tile, xr = a.xcd_remap, nwg = gridDim.x;
+  const float drop_p = a.attn_drop_p;
+  const unsigned drop_tag = a.attn_drop_tag;
+  const unsigned long long drop_seed = a.attn_drop_seed;
+
+  sPar[tid0] = (tid0 < D ? a.p.lng_g : a.p.lng_b)[tid0 & (D - 1)];
+  sPar[2 * D + tid0] = (tid0 < D ? a.p.ln_g : a.p.ln_b)[tid0 & (D - 1)];
+  if (tid0 < D) sPar[4 * D + tid0] = a.p.bk[tid0];
+
+  float4 t_g[8], t_p1a, t_p1b, t_p1c;
+  int t_va, t_vb, t_eb, t_ne, t_natom, t_abeg, t_part;
+  {
+    const int tid = tid0, r = tid >> 2, sub = tid & 3;
+    LEAN_FETCH((int)blockIdx.x);
+  }
+  for (int vt = blockIdx.x;;) {
+    // the thread index is re-materialised per iteration behind an opaque barrier: otherwise every per-thread address of the
+    // body (LDS rows, weight fragments, staging slots) is hoisted out of the loop and kept in registers across it (156 spills)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, r = tid >> 2, sub = tid & 3;
+    const int eb = t_eb, ne = t_ne, natom = t_natom, abeg = t_abeg, part = t_part;
+    float4 wA[8], wB[8];  // the weight slabs are L2-resident: requested here, they land while the tile is staged
+    load_w_half(g_W2p, wave, lane, 0, wA);
+    load_w_half(g_W2p, wave, lane, 1, wB);
+    if (tid < TEK) {
+      sCol[tid] = tid < ne ? t_va : 0;
+      sCtr[tid] = tid < ne ? t_vb : 0;
+    } else if (tid - TEK <= natom) {
+      sOff[tid - TEK] = part >= 0 ? (tid == TEK ? 0 : ne) : t_va - eb;
+    }
+    *reinterpret_cast<float4*>(&sQ[(tid >> 5) * LDS_STRIDE + 4 * (tid & 31)]) = t_p1a;
+    *reinterpret_cast<float4*>(&sQ[((tid >> 5) + 8) * LDS_STRIDE + 4 * (tid & 31)]) = t_p1b;
+    *reinterpret_cast<float4*>(&sQ[((tid >> 5) + 16) * LDS_STRIDE + 4 * (tid & 31)]) = t_p1c;
+    float4 greg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      greg[i] = r < ne ? t_g[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = greg[i];
+    }
+    __syncthreads();
+    // U = G . W2
+    f32x16 acc[2];
+    zero_acc(acc);
+    mma_half2(sA, wA, lane, 0, acc);
+    mma_half2(sA, wB, lane, 1, acc);
+    __syncthreads();  // every wave is done reading G
+    dump_t2(sA, acc, wave, lane, nullptr);
+    __syncthreads();
+    // row pass (attention.py:141-157)
+    if (r < ne) {
+      const int ctr = sCtr[r], nb = sCol[r];
+      const float4* crow = reinterpret_cast<const float4*>(g_c) + (size_t)nb * 32;
+      const float* p1 = sQ + (ctr - abeg) * LDS_STRIDE;
+      const float4* p3 = reinterpret_cast<const float4*>(g_P3) + (size_t)nb * 32;
+      float4 cn[8];
+      float s = 0.f;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {  // P3 pieces in two groups of four (register budget of the persistent form)
+        float4 p3r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p3r[i] = p3[sub + 4 * (4 * hf + i)];
+        if (hf == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cn[i] = crow[sub + 4 * i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c4 = sub + 4 * (4 * hf + i);
+          const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
+          const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3r[i]);
+          greg[4 * hf + i] = f4add(f4swish(v), greg[4 * hf + i]);
+          s += f4sum(greg[4 * hf + i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      load_w_half(g_Wkp, wave, lane, 0, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      const float mean = s * (1.0f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float dx = greg[i].x - mean, dy = greg[i].y - mean, dz = greg[i].z - mean, dw = greg[i].w - mean;
+        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c4 = sub + 4 * i;
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = greg[i].x * inv + (be.x - mean * inv);
+        inv = rstd * g.y; y.y = greg[i].y * inv + (be.y - mean * inv);
+        inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
+        inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
+        reinterpret_cast<float4*>(g_geom_out)[(size_t)(eb + r) * 32 + c4] = y;
+        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      load_w_half(g_Wkp, wave, lane, 0, wA);
+    }
+    load_w_half(g_Wkp, wave, lane, 1, wB);
+    const float4* const q4p = reinterpret_cast<const float4*>(g_q) + (size_t)abeg * 32 + (tid & 31);
+    const int qa = tid >> 5;
+    const float4 q0 = q4p[(size_t)min(qa, natom - 1) * 32];
+    const float4 q1 = q4p[(size_t)min(qa + 8, natom - 1) * 32];
+    const float4 q2 = q4p[(size_t)min(qa + 16, natom - 1) * 32];
+    __syncthreads();  // ang complete; nobody reads the P1 rows any more
+    *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * (tid & 31)]) = q0;
+    *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * (tid & 31)]) = q1;
+    *reinterpret_cast<float4*>(&sQ[(qa + 16) * LDS_STRIDE + 4 * (tid & 31)]) = q2;
+    __builtin_amdgcn_sched_barrier(0);
+    // K = ang . Wk + bk
+    zero_acc(acc);
+    mma_half2(sA, wA, lane, 0, acc);
+    mma_half2(sA, wB, lane, 1, acc);
+    __syncthreads();  // every wave is done reading ang
+    dump_t2(sA, acc, wave, lane, sPar + 4 * D);
+    __syncthreads();
+    // logits: thread = (edge row, pair of heads)
+    {
+      const int n = tid >> 2, hh = tid & 3;
+      if (n < ne) {
+        const float* qrow = sQ + (sCtr[n] - abeg) * LDS_STRIDE + 2 * HDIM * hh;
+        const float* krow = sA + n * LDS_STRIDE + 2 * HDIM * hh;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+          float e = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 q4 = *reinterpret_cast<const float4*>(qrow + HDIM * hp + 4 * j);
+            const float4 k4 = *reinterpret_cast<const float4*>(krow + HDIM * hp + 4 * j);
+            e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
+          }
+          sE[n * NHEAD + 2 * hh + hp] = e;
+        }
+      }
+    }
+    // the next tile's inputs are requested here: they land under the softmax / LayerNorm phases
+    const int vn = vt + nwg;
+    const bool more = vn < n_tile;
+    // (every field of `t` is dead here: the tile's scalars were copied at the top of the iteration)
+    // unconditional (the last iteration re-requests its own tile): under `if (more)` the old values would stay live through
+    // the whole iteration as the other input of the merge, i.e. 44 more registers under the GEMMs and the row pass
+    LEAN_FETCH(more ? vn : vt);
+    __syncthreads();
+    // softmax + context + residual (online form)
+    {
+      const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
+      for (int la = lgp; la < natom; la += 8) {
+        const int e0 = sOff[la], e1 = sOff[la + 1];
+        float m = -INFINITY, ssum = 0.f;
+        float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = e0; n < e1; n += 2) {
+          const bool two = n + 1 < e1;
+          const int n1 = two ? n + 1 : n;
+          const float ea = sE[n * NHEAD + h];
+          const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
+          const float4 ka = *reinterpret_cast<const float4*>(&sA[n * LDS_STRIDE + 4 * c4]);
+          const float4 kb = *reinterpret_cast<const float4*>(&sA[n1 * LDS_STRIDE + 4 * c4]);
+          const float mn = fmaxf(m, fmaxf(ea, eb2));
+          const float resc = fast_exp(m - mn);
+          float pa2 = fast_exp(ea - mn), pb2 = fast_exp(eb2 - mn);
+          ssum = ssum * resc + (pa2 + pb2);
+          if (drop_p > 0.f) {
+            pa2 *= drop_scale(drop_seed, drop_tag, (size_t)(eb + n) * NHEAD + h, drop_p);
+            pb2 *= drop_scale(drop_seed, drop_tag, (size_t)(eb + n1) * NHEAD + h, drop_p);
+          }
+          cx.x = cx.x * resc + (pa2 * ka.x + pb2 * kb.x);
+          cx.y = cx.y * resc + (pa2 * ka.y + pb2 * kb.y);
+          cx.z = cx.z * resc + (pa2 * ka.z + pb2 * kb.z);
+          cx.w = cx.w * resc + (pa2 * ka.w + pb2 * kb.w);
+          m = mn;
+        }
+        if (part >= 0) {
+          float* pbuf = g_pbuf + (size_t)part * 3 * D + 4 * c4;
+          *reinterpret_cast<float4*>(pbuf) = make_float4(m, m, m, m);
+          *reinterpret_cast<float4*>(pbuf + D) = make_float4(ssum, ssum, ssum, ssum);
+          *reinterpret_cast<float4*>(pbuf + 2 * D) = cx;
+        } else {
+          const float rs2 = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+          float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
+          const float4 q4 = *qp;
+          *qp = make_float4(cx.x * rs2 + q4.x, cx.y * rs2 + q4.y, cx.z * rs2 + q4.z, cx.w * rs2 + q4.w);
+        }
+      }
+    }
+    __syncthreads();
+    // LayerNorm of the context rows: 8 threads per atom row
+    {
+      const int rr = tid >> 3, sb = tid & 7;
+      if (rr < natom && part < 0) {
+        float4 tt[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          tt[i] = *reinterpret_cast<const float4*>(&sQ[rr * LDS_STRIDE + 4 * (sb + 8 * i)]);
+          s += f4sum(tt[i]);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        const float mean = s * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dx = tt[i].x - mean, dy = tt[i].y - mean, dz = tt[i].z - mean, dw = tt[i].w - mean;
+          v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c4 = sb + 8 * i;
+          const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
+          const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
+          float4 y;
+          float inv;
+          inv = rstd * g.x; y.x = tt[i].x * inv + (be.x - mean * inv);
+          inv = rstd * g.y; y.y = tt[i].y * inv + (be.y - mean * inv);
+          inv = rstd * g.z; y.z = tt[i].z * inv + (be.z - mean * inv);
+          inv = rstd * g.w; y.w = tt[i].w * inv + (be.w - mean * inv);
+          reinterpret_cast<float4*>(g_ctx)[(size_t)(abeg + rr) * 32 + c4] = y;
+        }
+      }
+    }
+    if (!more) break;
+    __syncthreads();  // every wave is done with sQ / sE / sOff before the next tile is staged
+    vt = vn;
+  }
+}
+
 // ---- lean-LDS edge kernel on 32-edge tiles: five workgroups per CU ----------------------------------------------------
 //
 // Same phases as edge_kernel_lean on one 32 x 128 buffer (29 KB of LDS, <= 96 VGPRs): the launch time of the edge path is
@@ -1909,6 +2208,11 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.persistent_wgs > 0 && a.g_update && a.tile_rows == 64) {
     const int nwg = a.n_tile < a.persistent_wgs ? a.n_tile : a.persistent_wgs;
     hipLaunchKernelGGL(edge_kernel_persistent, dim3(nwg), dim3(P_THREADS), 0, s, a);
+    return;
+  }
+  if (a.lean && a.lean_wgs > 0 && a.g_update && a.tile_rows == 64) {
+    const int nwg = a.n_tile < a.lean_wgs ? a.n_tile : a.lean_wgs;
+    hipLaunchKernelGGL(edge_kernel_leanp, dim3(nwg), dim3(256), 0, s, a);
     return;
   }
   if (a.lean && a.g_update && a.tile_rows == 64) {

@@ -110,6 +110,7 @@ struct scann_handle {
   bool loaded = false;
   bool debug = false;
   int edge_tile = 64;  // edge rows per tile (32 or 64); env SCANN_EDGE_TILE overrides
+  int lean_persist = 0;    // env SCANN_EDGE_LEANP=1: edge_kernel_leanp (persistent form, next tile's inputs prefetched)
   bool edge_lean = true;   // edge_kernel_lean (3 workgroups per CU, tiles of <= TQ atoms) on the g_update path; env SCANN_EDGE_LEAN=0: edge_kernel_w8
   int tile_atoms = TA;     // atoms per edge tile the tile builder allows
   int n_cu = 256;      // compute units of the device
@@ -315,6 +316,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* w8 = getenv("SCANN_EDGE_W8")) h->edge_w8 = atoi(w8) != 0;
   if (const char* ln = getenv("SCANN_EDGE_LEAN")) h->edge_lean = atoi(ln) != 0;
+  if (const char* lp = getenv("SCANN_EDGE_LEANP")) h->lean_persist = atoi(lp);
   h->edge_lean = h->edge_lean && cfg->g_update;
   if (h->edge_lean) h->tile_atoms = h->edge_tile == 32 ? TQ32H : TQ;  // edge_kernel_lean32 / edge_kernel_lean
   if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
@@ -858,6 +860,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.waves8 = h->edge_w8;
     ea.lean = h->edge_lean && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ);
     ea.tile_part = db->tile_part; ea.part_buf = db->part_buf;
+    ea.lean_wgs = h->lean_persist > 0 ? (3 * h->n_cu) / 8 * 8 : 0;
     ea.xcd_remap = h->xcd_remap;
     if (h->in_train_forward && h->attn_drop_p > 0.f) {
       ea.attn_drop_p = h->attn_drop_p;
