@@ -14,7 +14,7 @@ eng = model.engine
 rng = np.random.default_rng(0)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 rb = eng.upload(bench.synth_packed_batch(rng, nb))
-for _ in range(5):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):  # argv[2]: forwards before the stamped one (sustained clocks)
     eng.forward_resident(rb, 0)
 eng.sync()
 st = eng.debug_stamps(rb).astype(np.int64)
