@@ -122,7 +122,6 @@ struct EdgeArgs {
   const EdgeTile* tiles;
   int32_t n_tile;
   int32_t tile_rows;           // 32 or 64: edge rows per tile the tile table was built for
-  int32_t persistent_wgs;      // > 0: run edge_kernel_persistent with this many workgroups (one per CU)
   int32_t xcd_remap;           // contiguous run of tiles per XCD (edge_kernel_w8)
   int32_t waves8;              // run the 8-wave (512-thread) variant edge_kernel_w8
   int32_t lean;                // run edge_kernel_lean (tiles must hold <= TQ atoms)

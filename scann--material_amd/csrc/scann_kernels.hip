@@ -1854,362 +1854,8 @@ __global__ __launch_bounds__(256, 5) void edge_kernel_lean32(EdgeArgs a) {
   }
 }
 
-#ifdef SCANN_STAMPS
-#define STAMP_DECL()                                                                                             \
-  unsigned long long acc_work[4] = {0, 0, 0, 0}, t_loop0 = 0, t_b = 0;                                           \
-  const bool stamper = a.stamps && lane == 0 && (wave == 0 || wave == 4);                                       \
-  if (stamper) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop0)::"memory")
-#define STAMP_BEGIN() \
-  if (stamper) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b)::"memory")
-#define STAMP_END(ph)                                                                  \
-  if (stamper) {                                                                       \
-    unsigned long long t_e;                                                            \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_e)::"memory");        \
-    acc_work[ph] += t_e - t_b;                                                         \
-  }
-#define STAMP_FINISH()                                                                                  \
-  if (stamper) {                                                                                        \
-    unsigned long long t_e;                                                                             \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_e)::"memory");                         \
-    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16 + (wave == 0 ? 0 : 8);                   \
-    o[0] = acc_work[0]; o[1] = acc_work[1]; o[2] = acc_work[2]; o[3] = acc_work[3];                     \
-    o[4] = t_e - t_loop0; o[5] = (unsigned long long)nsteps; o[6] = (unsigned long long)nk;             \
-  }
-#else
-#define STAMP_DECL() do {} while (0)
-#define STAMP_BEGIN() do {} while (0)
-#define STAMP_END(ph) do {} while (0)
-#define STAMP_FINISH() do {} while (0)
-#endif
-
-// ---- persistent, wave-specialised edge kernel (g_update path, many tiles per launch) ------------------------
-//
-// rocprofv3 on the saturated edge_kernel<true,2> shows SQ_WAIT_INST_ANY = 50 % of wave cycles with the MFMA pipe
-// only ~52 % busy: the two co-resident waves of a SIMD run the same program and collide in their MFMA phases.  Here a
-// workgroup is 12 waves with fixed roles -- waves 0-3 ("M") only issue the two MFMA GEMMs of a tile, waves 4-11 ("V") do
-// everything else -- and keeps TWO tiles in flight (LDS slots 0/1) in a 4-step software pipeline with one workgroup
-// barrier per step, so every SIMD always has one MFMA wave and two VALU/memory waves:
-//
-//   step 4j+0 : M  U = G.W2      of tile 2j   (slot 0) | V  attention of tile 2j-1 (slot 1), then stage G of tile 2j+1
-//   step 4j+1 : M  U = G.W2      of tile 2j+1 (slot 1) | V  row pass  of tile 2j   (slot 0)
-//   step 4j+2 : M  K = ang.Wk+bk of tile 2j   (slot 0) | V  row pass  of tile 2j+1 (slot 1)
-//   step 4j+3 : M  K = ang.Wk+bk of tile 2j+1 (slot 1) | V  attention of tile 2j   (slot 0), then stage G of tile 2j+2
-//
-// M waves keep both 128x32 weight slabs in registers for the whole launch.  The V stages are wave-local (a row, or a
-// whole atom, never leaves its wave), so the per-step barrier is the only synchronisation.  Workgroup b walks tiles
-// b, b + gridDim.x, ...  Same arithmetic as edge_kernel<true, 2>; only summation order inside the attention differs.
-struct TileMeta {
-  int eb, ne, atom_begin, natom;
-};
-
-constexpr int PV_WAVES = 8;                      // V-role waves per workgroup (M role: 4)
-constexpr int PV_THREADS = 64 * PV_WAVES;        // 512
-constexpr int P_THREADS = 256 + PV_THREADS;      // 768 = 12 waves, 3 per SIMD
-
-__global__ __launch_bounds__(P_THREADS, 3) void edge_kernel_persistent(EdgeArgs a) {
-  constexpr int TEK = 64;
-  __shared__ __attribute__((aligned(16))) float sA[2][TEK * LDS_STRIDE];  // per slot: G, then ang = c[j]*geom'
-  __shared__ __attribute__((aligned(16))) float sB[2][TEK * LDS_STRIDE];  // per slot: U = G W2, then K
-  __shared__ __attribute__((aligned(16))) float sPar[4 * D];              // layer_norm_g gamma/beta, layer_norm gamma/beta
-  __shared__ int sCol[4][TEK], sCtr[4][TEK], sOff[4][TA + 1];            // tile metadata, ring of 4 (tile k -> k & 3)
-  __shared__ TileMeta sMeta[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool is_m = __builtin_amdgcn_readfirstlane(wave) < 4;  // scalar: the role branch is wave-uniform by construction
-  const int vw = wave - 4, vtid = tid - 256;
-  const int nk = (a.n_tile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup (>= 1)
-  const int nsteps = (nk & 1) ? 4 * (nk >> 1) + 4 : 4 * (nk >> 1) + 1;
-
-  // kernel-argument fields used by the stage lambdas, hoisted so the argument struct itself is never address-taken
-  const EdgeTile* const g_tiles = a.tiles;
-  const int32_t* const g_col = a.edge_col;
-  const int32_t* const g_row = a.edge_row;
-  const int32_t* const g_eoff = a.edge_offset;
-  float* const g_geom = a.geom;
-  const float* const g_c = a.c;
-  const float* const g_P1 = a.P1;
-  const float* const g_P3 = a.P3;
-  const float* const g_q = a.q;
-  float* const g_ctx = a.ctx;
-  const float* const g_W2p = a.p.W2p;
-  const float* const g_Wkp = a.p.Wkp;
-  const int bid = blockIdx.x, nwg = gridDim.x;
-
-  if (!is_m) {  // 512 V threads stage the 4 x 128 LayerNorm parameters
-    const float* src = vtid < D ? a.p.lng_g : vtid < 2 * D ? a.p.lng_b : vtid < 3 * D ? a.p.ln_g : a.p.ln_b;
-    sPar[vtid] = src[vtid & (D - 1)];
-  }
-
-  STAMP_DECL();
-
-  // Two role-specific loops with the same number of barriers (s_barrier counts waves, not code locations; the role
-  // test is a scalar, so each wave runs exactly one of the loops).
-  if (is_m) {
-    float4 w[16];  // weight slab of the NEXT GEMM, requested right after the previous dump
-    load_w(g_W2p, wave, lane, w);
-    const int col = 32 * wave + (lane & 31);
-    const float bkv = a.p.bk[col];
-    __syncthreads();  // matches the V role's prologue barrier (tile 0 staged)
-    for (int st = 0; st < nsteps; ++st) {
-      const int j = st >> 2, ph = st & 3;
-      STAMP_BEGIN();
-      const int slot = ph & 1, k = 2 * j + slot;
-      if (k < nk) {
-        f32x16 acc[2];
-        zero_acc(acc);
-        mma128<2>(sA[slot], w, lane, acc);  // ph < 2: U = G . W2 ; else K = ang . Wk (+ bk)
-        const float badd = ph < 2 ? 0.f : bkv;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sB[slot][(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + badd;
-      }
-      load_w((((st + 1) & 3) < 2) ? g_W2p : g_Wkp, wave, lane, w);  // steps 0,1 use W2, steps 2,3 use Wk
-      STAMP_END(ph);
-      __syncthreads();
-    }
-  } else {
-    // V helpers -------------------------------------------------------------------------------------------------
-    // Global loads a V stage needs are issued at the END of the previous V step (registers stay live across the
-    // barrier), so every stage starts with its operands already in flight:
-    //   pf[0..11] : row pass  -> P1[centre], P3[neighbour], c[neighbour] chunks of this thread's edge row
-    //               attention -> the query row pieces of this wave's first atom (pf[0..3] head slice, pf[4] float4 chunk)
-    //   tnext     : descriptor of the next tile to stage;  gpre : its geometry rows while the attention stage runs
-    float4 pf[12];
-    float4 gpre[4];
-    EdgeTile tnext = g_tiles[bid];
-    auto prefetch_rp = [&](int k) {
-      const int mi = k & 3;
-      const int r = vtid >> 3, sub = vtid & 7;
-      if (r < sMeta[mi].ne) {
-        const int ctr = sCtr[mi][r], nb = sCol[mi][r];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          pf[i] = reinterpret_cast<const float4*>(g_P1)[(size_t)ctr * 32 + sub + 8 * i];
-          pf[4 + i] = reinterpret_cast<const float4*>(g_P3)[(size_t)nb * 32 + sub + 8 * i];
-          pf[8 + i] = reinterpret_cast<const float4*>(g_c)[(size_t)nb * 32 + sub + 8 * i];
-        }
-      }
-    };
-    auto prefetch_at = [&](int k) {
-      const int mi = k & 3;
-      if (vw < sMeta[mi].natom) {
-        const float4* qrow = reinterpret_cast<const float4*>(g_q) + (size_t)(sMeta[mi].atom_begin + vw) * 32;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pf[j] = qrow[4 * (lane & 7) + j];
-        pf[4] = qrow[lane & 31];
-      }
-    };
-    auto stage_issue = [&](int k) {  // metadata of tile k (= tnext) -> LDS ring; its geometry rows -> gpre; fetch next descriptor
-      const EdgeTile tile = tnext;
-      const int mi = k & 3, eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
-      if (k + 1 < nk) tnext = g_tiles[bid + (k + 1) * nwg];
-      if (vtid < TEK) {
-        sCol[mi][vtid] = vtid < ne ? g_col[eb + vtid] : 0;
-        sCtr[mi][vtid] = vtid < ne ? g_row[eb + vtid] : 0;
-      } else if (vtid - TEK <= natom) {
-        sOff[mi][vtid - TEK] = g_eoff[tile.atom_begin + (vtid - TEK)] - eb;
-      }
-      if (vtid == PV_THREADS - 1) sMeta[mi] = TileMeta{eb, ne, tile.atom_begin, natom};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = vtid + PV_THREADS * i, r = idx >> 5, c4 = idx & 31;
-        gpre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < ne) gpre[i] = reinterpret_cast<const float4*>(g_geom)[(size_t)(eb + r) * 32 + c4];
-      }
-    };
-    auto stage_commit = [&](int slot) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = vtid + PV_THREADS * i, r = idx >> 5, c4 = idx & 31;
-        *reinterpret_cast<float4*>(&sA[slot][r * LDS_STRIDE + 4 * c4]) = gpre[i];
-      }
-    };
-    auto row_pass = [&](int slot, int k) {  // attention.py:141-157 for the 64 rows of the slot, 8 threads per row
-      const int mi = k & 3;
-      const TileMeta tm = sMeta[mi];
-      const int r = vtid >> 3, sub = vtid & 7;
-      if (r >= tm.ne) return;
-      float4 t[4];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sub + 8 * i;
-        const float4 u = *reinterpret_cast<const float4*>(&sB[slot][r * LDS_STRIDE + 4 * c4]);
-        const float4 g = *reinterpret_cast<const float4*>(&sA[slot][r * LDS_STRIDE + 4 * c4]);
-        const float4 v = f4add(f4add(pf[i], u), pf[4 + i]);  // (c_i W1 + b) + g W2 + c_j W3
-        t[i] = f4add(f4swish(v), g);
-        s += f4sum(t[i]);
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sub + 8 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        reinterpret_cast<float4*>(g_geom)[(size_t)(tm.eb + r) * 32 + c4] = y;
-        *reinterpret_cast<float4*>(&sA[slot][r * LDS_STRIDE + 4 * c4]) = f4mul(pf[8 + i], y);
-      }
-    };
-    auto attention = [&](int slot, int k) {  // attention.py:180-214, one wave per atom, everything wave-local
-      const int mi = k & 3;
-      const TileMeta tm = sMeta[mi];
-      const int h = lane & 7, nl = lane >> 3;            // logits: lane = (edge within a chunk of 8, head)
-      const int c4 = lane & 31, half = lane >> 5, hc = c4 >> 2;  // context: lane = (float4 chunk, edge parity)
-      const float* kb = sB[slot];
-      for (int la = vw; la < tm.natom; la += PV_WAVES) {
-        const int at = tm.atom_begin + la;
-        const int e0 = sOff[mi][la], e1 = sOff[mi][la + 1], deg = e1 - e0;
-        float4 qh[4], qres;
-        if (la == vw) {  // prefetched at the end of the previous step
-#pragma unroll
-          for (int j = 0; j < 4; ++j) qh[j] = pf[j];
-          qres = pf[4];
-        } else {
-          const float4* qrow = reinterpret_cast<const float4*>(g_q) + (size_t)at * 32;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) qh[j] = qrow[4 * h + j];
-          qres = qrow[c4];
-        }
-        float ev[8];
-        float m = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          ev[c] = -INFINITY;
-          if (c * 8 < deg) {
-            const int n = e0 + c * 8 + nl;
-            const float* krow = kb + min(n, e1 - 1) * LDS_STRIDE + HDIM * h;
-            float e = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
-              e += (qh[j].x * 0.25f) * k4.x; e += (qh[j].y * 0.25f) * k4.y; e += (qh[j].z * 0.25f) * k4.z; e += (qh[j].w * 0.25f) * k4.w;
-            }
-            ev[c] = n < e1 ? e : -INFINITY;
-            m = fmaxf(m, ev[c]);
-          }
-        }
-        m = fmaxf(m, __shfl_xor(m, 8));
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float ssum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (c * 8 < deg) {
-            ev[c] = fast_exp(ev[c] - m);  // exp2(-inf) = 0 for the slots past the atom's last edge
-            ssum += ev[c];
-          }
-        ssum += __shfl_xor(ssum, 8);
-        ssum += __shfl_xor(ssum, 16);
-        ssum += __shfl_xor(ssum, 32);
-        const float rs = __builtin_amdgcn_rcpf(ssum);
-        float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (c * 8 < deg) {
-            const float p = ev[c] * rs;  // attention weight of (edge c*8 + nl, head h)
-#pragma unroll
-            for (int t2 = 0; t2 < 4; ++t2) {
-              const int jj = 2 * t2 + half;
-              const float at_w = __shfl(p, jj * 8 + hc);  // 0 past the last edge
-              const int n = min(e0 + c * 8 + jj, e1 - 1);
-              const float4 k4 = *reinterpret_cast<const float4*>(kb + n * LDS_STRIDE + 4 * c4);
-              cx.x += at_w * k4.x; cx.y += at_w * k4.y; cx.z += at_w * k4.z; cx.w += at_w * k4.w;
-            }
-          }
-        cx.x += __shfl_xor(cx.x, 32); cx.y += __shfl_xor(cx.y, 32); cx.z += __shfl_xor(cx.z, 32); cx.w += __shfl_xor(cx.w, 32);
-        cx = f4add(cx, qres);  // residual is the unscaled query (:212)
-        float s = f4sum(cx);
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
-        const float mean = s * (1.0f / D);
-        const float dx = cx.x - mean, dy = cx.y - mean, dz = cx.z - mean, dw = cx.w - mean;
-        float v = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
-        const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = cx.x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = cx.y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = cx.z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = cx.w * inv + (be.w - mean * inv);
-        if (half == 0) reinterpret_cast<float4*>(g_ctx)[(size_t)at * 32 + c4] = y;
-      }
-    };
-
-    // prologue: stage tile 0 into slot 0
-    stage_issue(0);
-    stage_commit(0);
-    __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-      const int j = st >> 2, ph = st & 3;
-      STAMP_BEGIN();
-      // (Issuing each stage's global loads one step early -- registers live across the barrier -- was tried and
-      // spills at the 168-VGPR budget of 3 waves/SIMD; loads are issued at the head of their own stage instead.)
-      if (ph == 0) {
-        if (j > 0) {
-          prefetch_at(2 * j - 1);
-          attention(1, 2 * j - 1);
-        }
-        if (2 * j + 1 < nk) {
-          stage_issue(2 * j + 1);
-          stage_commit(1);
-        }
-      } else if (ph == 1) {
-        if (2 * j < nk) {
-          prefetch_rp(2 * j);
-          row_pass(0, 2 * j);
-        }
-      } else if (ph == 2) {
-        if (2 * j + 1 < nk) {
-          prefetch_rp(2 * j + 1);
-          row_pass(1, 2 * j + 1);
-        }
-      } else {
-        if (2 * j < nk) {
-          prefetch_at(2 * j);
-          attention(0, 2 * j);
-        }
-        if (2 * j + 2 < nk) {
-          stage_issue(2 * j + 2);
-          stage_commit(0);
-        }
-      }
-      STAMP_END(ph);
-      __syncthreads();
-    }
-  }
-  STAMP_FINISH();
-}
-
 void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
-  if (a.persistent_wgs > 0 && a.g_update && a.tile_rows == 64) {
-    const int nwg = a.n_tile < a.persistent_wgs ? a.n_tile : a.persistent_wgs;
-    hipLaunchKernelGGL(edge_kernel_persistent, dim3(nwg), dim3(P_THREADS), 0, s, a);
-    return;
-  }
   if (a.lean && a.lean_wgs > 0 && a.g_update && a.tile_rows == 64) {
     const int nwg = a.n_tile < a.lean_wgs ? a.n_tile : a.lean_wgs;
     hipLaunchKernelGGL(edge_kernel_leanp, dim3(nwg), dim3(256), 0, s, a);

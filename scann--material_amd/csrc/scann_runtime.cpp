@@ -120,7 +120,6 @@ struct scann_handle {
   std::vector<int> time_edges;
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
   int edge_w8 = 1;     // 8-wave (512-thread) edge kernel for the g_update path; env SCANN_EDGE_W8=0 selects the 4-wave one
-  int persist_min_tiles = 1 << 30;  // launches with at least this many edge tiles use edge_kernel_persistent (env SCANN_PERSIST_MIN)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -319,7 +318,6 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* lp = getenv("SCANN_EDGE_LEANP")) h->lean_persist = atoi(lp);
   h->edge_lean = h->edge_lean && cfg->g_update;
   if (h->edge_lean) h->tile_atoms = h->edge_tile == 32 ? TQ32H : TQ;  // edge_kernel_lean32 / edge_kernel_lean
-  if (const char* pm = getenv("SCANN_PERSIST_MIN")) h->persist_min_tiles = std::max(1, atoi(pm));
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -780,8 +778,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   }
   // keep-mode (training / scann_set_debug): with edge_kernel_lean every layer writes its centres, context and geometry straight
   // into its slice of the per-layer buffers; the other edge kernels update the geometry in place and the slices are copies
-  const bool direct = h->debug && h->edge_lean && c.g_update && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ) &&
-                      (db->tile_rows == 32 || db->n_tile < h->persist_min_tiles);
+  const bool direct = h->debug && h->edge_lean && c.g_update && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ);
   const size_t nA_ = (size_t)db->n_atom * D, nE_ = (size_t)db->n_edge * D;
   auto c_of = [&](int l) { return direct ? db->dbg_c + (size_t)l * nA_ : db->c; };
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
@@ -867,7 +864,6 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       ea.attn_drop_seed = h->train_seed;
       ea.attn_drop_tag = DROP_TAG_ATTN + (unsigned)l;
     }
-    ea.persistent_wgs = (c.g_update && db->tile_rows == 64 && db->n_tile >= h->persist_min_tiles && db->n_big == 0) ? h->n_cu : 0;
 #ifdef SCANN_STAMPS
     if (!getenv("SCANN_STAMP_ATOM")) {
       if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
@@ -1207,7 +1203,7 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   w->drop_p = dropout;
   w->seed = seed;
   if (h->attn_drop_p > 0.f && !(h->cfg.g_update && ((h->edge_lean && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ)) ||
-                                                    (h->edge_w8 && db->tile_rows == 64 && db->n_tile < h->persist_min_tiles))))
+                                                    (h->edge_w8 && db->tile_rows == 64))))
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
   const bool dbg = h->debug;
   h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)

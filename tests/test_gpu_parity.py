@@ -401,9 +401,8 @@ def test_more_than_64_neighbours(hip_lib, monkeypatch):
     {"SCANN_EDGE_LEAN": "0", "SCANN_EDGE_TILE": "32"},                       # edge_kernel_w8<1>: 32-row tiles, 4-wave workgroups
     {"SCANN_EDGE_TILE": "32"},                                               # edge_kernel_lean32: 32-edge tiles, five workgroups per CU
     {"SCANN_EDGE_LEANP": "1"},                                               # edge_kernel_leanp: persistent form, next tile's inputs prefetched
-    {"SCANN_PERSIST_MIN": "1"},                                              # persistent wave-specialised kernel for every launch
     {"SCANN_XCD_REMAP": "0", "SCANN_STREAMS": "2"},                          # default edge_kernel_lean without the XCD tile order
-], ids=["w8", "w4", "w4_tile32", "w8_tile32", "lean32", "lean_persistent", "persistent", "lean_no_remap_2streams"])
+], ids=["w8", "w4", "w4_tile32", "w8_tile32", "lean32", "lean_persistent", "lean_no_remap_2streams"])
 def test_alternative_edge_kernels(hip_lib, env, monkeypatch):
     """The opt-in kernel variants (selected by environment at scann_create) stay at parity."""
     for k, v in env.items():
