@@ -136,6 +136,9 @@ struct EdgeArgs {
   const int32_t* edge_col;     // [n_edge]
   const int32_t* edge_row;     // [n_edge] centre atom of each edge
   float* geom;                 // [n_edge,128] in/out (g_update)
+  // training forward with edge_kernel_lean: per-edge tensors the backward would otherwise recompute (null in inference):
+  // V = G.W2 + P1[i] + P3[j], T = swish(V) + G (LayerNorm_g input), ang = c[j] * geom', K = ang.Wk + bk -- all [n_edge,128]
+  float *keep_V, *keep_T, *keep_ang, *keep_K;
   float* geom_out;             // edge_kernel_lean only: where geom' goes (null: in place) -- keep-mode writes each layer's geometry to its own slice
   const float* gd;             // [n_edge,20] raw distance basis (base)
   const float* edge_weight;    // [n_edge] (base)

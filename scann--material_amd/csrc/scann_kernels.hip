@@ -1063,6 +1063,10 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
       const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3r[i]);
       greg[i] = f4add(f4swish(v), greg[i]);
       s += f4sum(greg[i]);
+      if (a.keep_V) {  // training forward: the backward reads these instead of recomputing them
+        reinterpret_cast<float4*>(a.keep_V)[(size_t)(eb + r) * 32 + c4] = v;
+        reinterpret_cast<float4*>(a.keep_T)[(size_t)(eb + r) * 32 + c4] = greg[i];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     load_w_half(a.p.Wkp, wave, lane, 0, wA);  // the P3 registers are free: first half of the key weights lands over the statistics
@@ -1091,7 +1095,9 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
       inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
       inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
       reinterpret_cast<float4*>(a.geom_out ? a.geom_out : a.geom)[(size_t)(eb + r) * 32 + c4] = y;
-      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);
+      const float4 ang = f4mul(cn[i], y);
+      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = ang;
+      if (a.keep_ang) reinterpret_cast<float4*>(a.keep_ang)[(size_t)(eb + r) * 32 + c4] = ang;
     }
   } else {
 #pragma unroll
@@ -1120,6 +1126,11 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
   __syncthreads();  // every wave is done reading ang
   dump_t2(sA, acc, wave, lane, sPar + 4 * D);
   __syncthreads();
+  if (a.keep_K && r < ne) {  // training forward: K rows of the tile (coalesced copy of the finished LDS tile)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      reinterpret_cast<float4*>(a.keep_K)[(size_t)(eb + r) * 32 + sub + 4 * i] = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]);
+  }
   STAMP(a.stamps, 6);
   // logits: thread = (edge row, pair of heads)
   {

@@ -160,6 +160,8 @@ struct scann_dbatch {
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
   float *dist = nullptr, *weight = nullptr, *ring = nullptr, *cgcnn = nullptr, *c0 = nullptr;
   EdgeTile* tiles = nullptr;
+  float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128], training forward (owned by the train workspace)
+  bool kept = false;  // the last training forward filled them
   int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
   int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
@@ -799,6 +801,8 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (tm) tm->mark(0);
   }
   for (int l = 0; l <= L; ++l) {
+    // training forward through edge_kernel_lean: q, V, T, ang, K of every layer are kept for the backward
+    const bool keep = direct && h->in_train_forward && db->keep_K && db->tile_rows == 64 && h->lean_persist == 0 && l < L;
     // atom kernel at the head of layer l: ResidualNorm of layer l-1, centres, projections of layer l
     AtomArgs a{};
     a.n_atom = db->n_atom;
@@ -823,7 +827,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       const LayerParams& p = h->layers[l];
       a.mode = c.g_update ? 0 : 1;
       a.WAp = p.W1p; a.bA = p.bg; a.WBp = p.W3p; a.WCp = p.Wqp; a.bC = p.bq;
-      a.oA = db->P1; a.oB = db->P3; a.oC = db->q;
+      a.oA = db->P1; a.oB = db->P3; a.oC = keep ? db->keep_q + (size_t)l * nA_ : db->q;
     } else {
       a.mode = 2;
       a.WAp = h->head.Wap; a.bA = h->head.ba; a.WCp = h->head.Wgqp; a.bC = h->head.bgq; a.WDp = h->head.Wgkp; a.bD = h->head.bgk;
@@ -845,7 +849,12 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.tile_rows = db->tile_rows; ea.g_update = c.g_update;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = g_of(l); ea.geom_out = direct ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
-    ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = db->q; ea.ctx = ctx_of(l);
+    ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
+    if (keep) {
+      ea.keep_V = db->keep_V + (size_t)l * nE_; ea.keep_T = db->keep_T + (size_t)l * nE_;
+      ea.keep_ang = db->keep_ang + (size_t)l * nE_; ea.keep_K = db->keep_K + (size_t)l * nE_;
+      db->kept = true;
+    }
     ea.p = h->layers[l];
     const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -872,7 +881,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
 #endif
     launch_edge(ea, s);
-    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, db->q, ea.p.ln_g, ea.p.ln_b, ea.ctx, s);
+    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);
@@ -1057,6 +1066,7 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
 struct scann_train_ws {  // per resident batch, allocated on first use
   char* arena = nullptr;
   float *tA[10] = {};   // [n_atom,128] temporaries
+  float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128] or null
   float *tE[10] = {};   // [n_edge,128] temporaries
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   double* sse = nullptr;
@@ -1080,8 +1090,11 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   if (w.arena) return SCANN_OK;
   const size_t rowA = align_up((size_t)db->n_atom * D * 4), rowE = align_up((size_t)std::max(db->n_edge, 1) * D * 4);
   const size_t rowB = align_up((size_t)db->n_struct * D * 4);
+  // per-layer tensors kept by the training forward (edge_kernel_lean on 64-edge tiles): q [A,128]; V, T, ang, K [E,128]
+  const bool keepable = h->cfg.g_update && h->edge_lean && db->tile_rows == 64 && h->lean_persist == 0;
+  const size_t Lk = keepable ? (size_t)h->cfg.n_attention : 0;
   const size_t total = 10 * rowA + 10 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
-                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256;
+                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (rowA + 4 * rowE);
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   for (int i = 0; i < 10; ++i) { w.tA[i] = (float*)p; p += rowA; }
@@ -1091,7 +1104,14 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   w.dy = (float*)p; p += align_up((size_t)db->n_struct * 4);
   w.targets = (float*)p; p += align_up((size_t)db->n_struct * 4);
   w.dlut = (float*)p; p += align_up((size_t)h->cfg.n_atoms * D * 4);
-  w.sse = (double*)p;
+  w.sse = (double*)p; p += 256;
+  if (Lk) {  // slices are [rows,128] without padding between layers: size them from the un-aligned row counts
+    w.keep_q = (float*)p; p += Lk * rowA;
+    w.keep_V = (float*)p; p += Lk * rowE;
+    w.keep_T = (float*)p; p += Lk * rowE;
+    w.keep_ang = (float*)p; p += Lk * rowE;
+    w.keep_K = (float*)p; p += Lk * rowE;
+  }
   return SCANN_OK;
 }
 
@@ -1205,8 +1225,10 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   if (h->attn_drop_p > 0.f && !(h->cfg.g_update && ((h->edge_lean && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ)) ||
                                                     (h->edge_w8 && db->tile_rows == 64))))
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
+  db->keep_q = w->keep_q; db->keep_V = w->keep_V; db->keep_T = w->keep_T; db->keep_ang = w->keep_ang; db->keep_K = w->keep_K;
+  db->kept = false;
   const bool dbg = h->debug;
-  h->debug = true;  // keep centres / geometry / context of every layer (the backward recomputes the rest)
+  h->debug = true;  // keep centres / geometry / context of every layer (and, with edge_kernel_lean, q / V / T / ang / K)
   h->train_drop_p = dropout;
   h->train_seed = seed;
   h->in_train_forward = true;
@@ -1316,28 +1338,39 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
       continue;
     }
-    // forward recompute of what the fused kernels do not keep
-    {  // P1, P3, q recomputed by the forward kernel itself (one launch; its copy of the input rows goes to a scratch)
-      AtomArgs ra2{};
-      ra2.x = c_in; ra2.n_atom = A; ra2.ffn = 0; ra2.c = t4; ra2.mode = 0;
-      ra2.WAp = p.W1p; ra2.bA = p.bg; ra2.WBp = p.W3p; ra2.WCp = p.Wqp; ra2.bC = p.bq;
-      ra2.oA = db->P1; ra2.oB = db->P3; ra2.oC = db->q;
-      launch_atom(ra2, s);
+    // what the fused forward kernels did not keep is recomputed; with edge_kernel_lean the training forward kept
+    // q, V, T, ang and K of every layer (db->kept), so nothing is
+    const bool kept = db->kept;
+    const float* qL = kept ? db->keep_q + (size_t)l * nA : db->q;
+    const float* angL = kept ? db->keep_ang + (size_t)l * nE : eAng;
+    const float* KL = kept ? db->keep_K + (size_t)l * nE : eK;
+    const float* VL = kept ? db->keep_V + (size_t)l * nE : eV;
+    const float* TL = kept ? db->keep_T + (size_t)l * nE : eT;
+    if (!kept) {
+      {  // P1, P3, q recomputed by the forward kernel itself (one launch; its copy of the input rows goes to a scratch)
+        AtomArgs ra2{};
+        ra2.x = c_in; ra2.n_atom = A; ra2.ffn = 0; ra2.c = t4; ra2.mode = 0;
+        ra2.WAp = p.W1p; ra2.bA = p.bg; ra2.WBp = p.W3p; ra2.WCp = p.Wqp; ra2.bC = p.bq;
+        ra2.oA = db->P1; ra2.oB = db->P3; ra2.oC = db->q;
+        launch_atom(ra2, s);
+      }
+      launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
+      launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
     }
-    launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
-    launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
-    launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
+    launch_attn_bwd(qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-    launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
+    launch_wgrad(angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
     launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, eAng, edGt, E, s);  // per edge dang*G' (in eAng) ; dG'tot
     launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);               // dC now collects d loss / d centres_l: dC[j] = sum over the edges that point at j
     // geometry update: G' = LN_g(swish(V) + G), V = G.W2 + P1[i] + P3[j]
-    launch_linear(Gin, p.W2p, nullptr, eU, nullptr, E, 0, s);
-    launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
+    if (!kept) {
+      launch_linear(Gin, p.W2p, nullptr, eU, nullptr, E, 0, s);
+      launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
+    }
     float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
-    launch_ln_bwd(eT, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
-    launch_edge_dv(eV, dGnext, eU, E, s);                                         // dV (in eU)
+    launch_ln_bwd(TL, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
+    launch_edge_dv(VL, dGnext, eU, E, s);                                         // dV (in eU)
     launch_segment_sum(eU, db->edge_offset, dP1, A, s);                           // dP1[i] = sum over the atom's own edges
     launch_gather_sum(eU, db->in_off, db->in_edge, dP3, A, 0, s);                 // dP3[j] = sum over the edges that point at j
     float* fgk = g(la + "filter_geo/kernel");
