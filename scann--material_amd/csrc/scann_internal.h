@@ -114,6 +114,9 @@ struct AtomArgs {
   const float *WCp, *bC;   // mode 0/1: Wq,bq  | mode 2: ga query
   const float *WDp, *bD;   // mode 2: ga key
   float *oA, *oB, *oC;     // mode 0: P1,P3,q | mode 1: -, -, q | mode 2: -, gk, gq
+  // training forward: ResidualNorm intermediates the backward would otherwise recompute (null in inference), [n_atom,128]:
+  // pre1 = x W1 + b1, H1 = swish(pre1), T2 = x + drop(H1 W2 + b2) (the LayerNorm input)
+  float *keep_pre1, *keep_H1, *keep_T2;
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS, env SCANN_STAMP_ATOM=1) only: [n_tiles,16] phase clocks
 };
 void launch_atom(const AtomArgs& a, hipStream_t s);

@@ -216,8 +216,13 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int c = tcol(wave, lane, j);
       const float4 bv = *reinterpret_cast<const float4*>(&sBias[c]);
-      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) =
-          make_float4(swishf(acc[4 * j] + bv.x), swishf(acc[4 * j + 1] + bv.y), swishf(acc[4 * j + 2] + bv.z), swishf(acc[4 * j + 3] + bv.w));
+      const float4 pre = make_float4(acc[4 * j] + bv.x, acc[4 * j + 1] + bv.y, acc[4 * j + 2] + bv.z, acc[4 * j + 3] + bv.w);
+      const float4 hh = make_float4(swishf(pre.x), swishf(pre.y), swishf(pre.z), swishf(pre.w));
+      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) = hh;
+      if (a.keep_pre1 && trow < nrows) {  // training forward: kept for the backward
+        *reinterpret_cast<float4*>(a.keep_pre1 + (size_t)(row0 + trow) * D + c) = pre;
+        *reinterpret_cast<float4*>(a.keep_H1 + (size_t)(row0 + trow) * D + c) = hh;
+      }
     }
     __syncthreads();
     STAMP(a.stamps, 3);
@@ -243,7 +248,9 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
         y.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
         y.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
       }
-      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) = f4add(xv, y);
+      const float4 t2 = f4add(xv, y);
+      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) = t2;
+      if (a.keep_T2 && trow < nrows) *reinterpret_cast<float4*>(a.keep_T2 + (size_t)(row0 + trow) * D + c) = t2;
     }
     __syncthreads();
     STAMP(a.stamps, 5);

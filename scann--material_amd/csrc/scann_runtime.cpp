@@ -161,6 +161,7 @@ struct scann_dbatch {
   float *dist = nullptr, *weight = nullptr, *ring = nullptr, *cgcnn = nullptr, *c0 = nullptr;
   EdgeTile* tiles = nullptr;
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128], training forward (owned by the train workspace)
+  float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;  // ResidualNorm intermediates, [L][n_atom,128]
   bool kept = false;  // the last training forward filled them
   int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
   int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
@@ -816,6 +817,10 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       a.ffn = c.use_attn_norm ? 1 : 0;
       const LayerParams& pp = h->layers[l - 1];
       a.Wf1p = pp.Wf1p; a.bf1 = pp.bf1; a.Wf2p = pp.Wf2p; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
+      if (a.ffn && direct && h->in_train_forward && db->keep_T2 && db->tile_rows == 64 && h->lean_persist == 0) {
+        a.keep_pre1 = db->keep_pre1 + (size_t)(l - 1) * nA_; a.keep_H1 = db->keep_H1 + (size_t)(l - 1) * nA_;
+        a.keep_T2 = db->keep_T2 + (size_t)(l - 1) * nA_;
+      }
     }
     a.c = c_of(l);
     if (h->train_drop_p > 0.f) {  // training-mode Dropout(0.1) layers (scann_model.py:374, attention.py:29)
@@ -1067,6 +1072,7 @@ struct scann_train_ws {  // per resident batch, allocated on first use
   char* arena = nullptr;
   float *tA[10] = {};   // [n_atom,128] temporaries
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128] or null
+  float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;
   float *tE[10] = {};   // [n_edge,128] temporaries
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   double* sse = nullptr;
@@ -1094,7 +1100,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   const bool keepable = h->cfg.g_update && h->edge_lean && db->tile_rows == 64 && h->lean_persist == 0;
   const size_t Lk = keepable ? (size_t)h->cfg.n_attention : 0;
   const size_t total = 10 * rowA + 10 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
-                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (rowA + 4 * rowE);
+                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE);
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   for (int i = 0; i < 10; ++i) { w.tA[i] = (float*)p; p += rowA; }
@@ -1111,6 +1117,9 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
     w.keep_T = (float*)p; p += Lk * rowE;
     w.keep_ang = (float*)p; p += Lk * rowE;
     w.keep_K = (float*)p; p += Lk * rowE;
+    w.keep_pre1 = (float*)p; p += Lk * rowA;
+    w.keep_H1 = (float*)p; p += Lk * rowA;
+    w.keep_T2 = (float*)p; p += Lk * rowA;
   }
   return SCANN_OK;
 }
@@ -1226,6 +1235,7 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
                                                     (h->edge_w8 && db->tile_rows == 64))))
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
   db->keep_q = w->keep_q; db->keep_V = w->keep_V; db->keep_T = w->keep_T; db->keep_ang = w->keep_ang; db->keep_K = w->keep_K;
+  db->keep_pre1 = w->keep_pre1; db->keep_H1 = w->keep_H1; db->keep_T2 = w->keep_T2;
   db->kept = false;
   const bool dbg = h->debug;
   h->debug = true;  // keep centres / geometry / context of every layer (and, with edge_kernel_lean, q / V / T / ang / K)
@@ -1304,16 +1314,22 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
 
     // ---- ResidualNorm backward (attention.py:37-40): c_{l+1} = LN(x + drop(W2 swish(W1 x + b1) + b2)), x = ctx ----
     if (c.use_attn_norm) {
-      launch_linear(ctx, p.Wf1p, p.bf1, t1, t0, A, 2, s);   // pre1 (t0), H1 (t1)
-      launch_linear(t1, p.Wf2p, p.bf2, t2, nullptr, A, 0, s);  // Y
-      launch_dropout(t2, nA, w.seed, (unsigned)l, w.drop_p, s);
-      launch_add(t2, ctx, nA, s);                            // T2 = x + drop(Y)
-      launch_ln_bwd(t2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
+      const bool kept_rn = db->kept && db->keep_T2;  // the training forward (atom_kernel) kept pre1, H1 and T2
+      const float* pre1 = kept_rn ? db->keep_pre1 + (size_t)l * nA : t0;
+      const float* H1 = kept_rn ? db->keep_H1 + (size_t)l * nA : t1;
+      const float* T2 = kept_rn ? db->keep_T2 + (size_t)l * nA : t2;
+      if (!kept_rn) {
+        launch_linear(ctx, p.Wf1p, p.bf1, t1, t0, A, 2, s);   // pre1 (t0), H1 (t1)
+        launch_linear(t1, p.Wf2p, p.bf2, t2, nullptr, A, 0, s);  // Y
+        launch_dropout(t2, nA, w.seed, (unsigned)l, w.drop_p, s);
+        launch_add(t2, ctx, nA, s);                            // T2 = x + drop(Y)
+      }
+      launch_ln_bwd(T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
       HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
       launch_dropout(t3, nA, w.seed, (unsigned)l, w.drop_p, s);  // dY
-      launch_wgrad(t1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A, s);
+      launch_wgrad(H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A, s);
       launch_linear(t3, pt.Wf2T, nullptr, t4, nullptr, A, 0, s);  // dH1
-      launch_swish_bwd(t0, t4, t3, nA, s);                        // dpre1
+      launch_swish_bwd(pre1, t4, t3, nA, s);                        // dpre1
       launch_wgrad(ctx, t3, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A, s);
       launch_linear(t3, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
     } else {
