@@ -250,7 +250,7 @@ void launch_wgrad3(const float* X, const float* dY0, float* dW0, float* db0, con
   if (rows <= 0) return;
   // slab per workgroup: enough workgroups to fill the chip, few enough that the 64 KB of float atomics per workgroup
   // (chip-wide ~1.3 TB/s of added bytes) stays below the MFMA time
-  const int chunks = rows >= 8192 ? 2 : 1;
+  const int chunks = rows >= 65536 ? 4 : (rows >= 8192 ? 2 : 1);
   WgradSet set{};
   set.dY[0] = dY0; set.dW[0] = dW0; set.db[0] = db0;
   set.dY[1] = dY1; set.dW[1] = dW1; set.db[1] = db1;
@@ -587,6 +587,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 // Fast path when no atom of the batch has more than 16 neighbours (QM9: <= 12): the atom's key rows, logits and
 // attention gradients live in registers, so K is read once and the 8-lane dot-product reductions run once per edge.
+// Lane reductions of the attention backward through DPP (no LDS round trips): the wave-per-atom kernels are chains of such
+// sums, so their latency is the kernel time.  red8: sum over each aligned group of 8 lanes (one head), in every lane of it.
+#define SCANN_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float red8(float v) {
+  v += SCANN_DPP(v, 0xB1);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += SCANN_DPP(v, 0x4E);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += SCANN_DPP(v, 0x141);  // row_half_mirror: the other quad of the group of 8
+  return v;
+}
+__device__ __forceinline__ float red64(float v) {
+  v = red8(v);
+  v += SCANN_DPP(v, 0x128);  // row_ror:8 -- the other half of the row of 16
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict__ q, const float* __restrict__ K,
                                                          const int* __restrict__ edge_offset,
                                                          const float* __restrict__ dctx, const float* __restrict__ gamma,
@@ -615,43 +632,34 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict
     for (int n = 0; n < 16; ++n) {
       if (n >= deg) k2[n] = make_float2(0.f, 0.f);
       float e = qx * k2[n].x + qy * k2[n].y;
-      e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4);
+      e = red8(e);
       ev[n] = n < deg ? e : -INFINITY;
       m = fmaxf(m, ev[n]);
     }
     float ssum = 0.f;
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      ev[n] = n < deg ? expf(ev[n] - m) : 0.f;
+      ev[n] = n < deg ? __builtin_amdgcn_exp2f((ev[n] - m) * 1.44269504088896340736f) : 0.f;  // v_exp_f32, as in the forward
       ssum += ev[n];
     }
+    const float rsum = deg > 0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
     float px = q2.x, py = q2.y;
     float keep[16];
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      ev[n] = deg > 0 ? ev[n] / ssum : 0.f;  // attention weight
+      ev[n] = ev[n] * rsum;  // attention weight (rsum = 1/sum through v_rcp_f32, as in the forward; 0 for an atom without edges)
       keep[n] = (drop_p > 0.f && n < deg) ? drop_scale(drop_seed, drop_tag, (size_t)(e0 + n) * NHEAD + (lane >> 3), drop_p) : 1.0f;
       px += ev[n] * keep[n] * k2[n].x;
       py += ev[n] * keep[n] * k2[n].y;
     }
-    float s = px + py;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float s = red64(px + py);
     const float mean = s * (1.0f / D);
     const float cx = px - mean, cy = py - mean;
-    float v = cx * cx + cy * cy;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    const float v = red64(cx * cx + cy * cy);
     const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
     const float hx = cx * rstd, hy = cy * rstd;
     const float ax = dyv.x * g.x, ay = dyv.y * g.y;
-    float m1 = ax + ay, m2 = ax * hx + ay * hy;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      m1 += __shfl_xor(m1, o);
-      m2 += __shfl_xor(m2, o);
-    }
-    m1 *= (1.0f / D); m2 *= (1.0f / D);
+    const float m1 = red64(ax + ay) * (1.0f / D), m2 = red64(ax * hx + ay * hy) * (1.0f / D);
     const float dpx = rstd * (ax - m1 - hx * m2), dpy = rstd * (ay - m1 - hy * m2);
     dg.x = dyv.x * hx; dg.y = dyv.y * hy; dbt.x = dyv.x; dbt.y = dyv.y;
     float da[16];
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
       float d = dpx * k2[n].x + dpy * k2[n].y;
-      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+      d = red8(d);
       da[n] = d * keep[n];
       dot += ev[n] * da[n];
     }
