@@ -1328,10 +1328,9 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
       launch_dropout(t3, nA, w.seed, (unsigned)l, w.drop_p, s);  // dY
       launch_wgrad(H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A, s);
-      launch_linear(t3, pt.Wf2T, nullptr, t4, nullptr, A, 0, s);  // dH1
-      launch_swish_bwd(pre1, t4, t3, nA, s);                        // dpre1
-      launch_wgrad(ctx, t3, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A, s);
-      launch_linear(t3, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
+      launch_linear(t3, pt.Wf2T, nullptr, t4, const_cast<float*>(pre1), A, 4, s);  // dpre1 = (dY.W2^T) * swish'(pre1)
+      launch_wgrad(ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A, s);
+      launch_linear(t4, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
     } else {
       HIPCHK(h, hipMemcpyAsync(dCtx, dC, nA * 4, hipMemcpyDeviceToDevice, s));
     }

@@ -25,7 +25,8 @@ __device__ __forceinline__ float dswish_(float x) {
 __device__ __forceinline__ int acc_row_(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
 // ---- linear: Y = act(X . W + b) on 64-row tiles (same MFMA fragment scheme as the forward kernels) -----------------
-// flags: bit0 accumulate into Y, bit1 swish.  P (optional) receives the pre-activation X.W + b.
+// flags: bit0 accumulate into Y, bit1 swish, bit2 multiply by swish'(P) (P is then an INPUT: the fused swish backward).
+// Otherwise P (optional) receives the pre-activation X.W + b.
 template <int RT>  // 32-row MFMA row tiles per workgroup: 2 for large inputs, 1 otherwise (more workgroups)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                      const float* __restrict__ bias, float* __restrict__ Y,
@@ -87,6 +88,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
       for (int j = 0; j < 4; ++j)
         yold[rt][j] = *reinterpret_cast<const float4*>(Y + (size_t)(row0 + min(32 * rt + (lane & 31), nrows - 1)) * D + cb + 8 * j);
   }
+  float4 preact[RT][4];  // flags & 4: pre-activation rows (requested with the other epilogue operands)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) preact[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (flags & 4) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        preact[rt][j] = *reinterpret_cast<const float4*>(P + (size_t)(row0 + min(32 * rt + (lane & 31), nrows - 1)) * D + cb + 8 * j);
+  }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int r = 32 * rt + (lane & 31);
@@ -95,7 +108,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
       for (int j = 0; j < 4; ++j) {
         const size_t o = (size_t)(row0 + r) * D + cb + 8 * j;
         float4 v = make_float4(acc[rt][4 * j] + bv[j].x, acc[rt][4 * j + 1] + bv[j].y, acc[rt][4 * j + 2] + bv[j].z, acc[rt][4 * j + 3] + bv[j].w);
-        if (P) *reinterpret_cast<float4*>(P + o) = v;
+        if (flags & 4) {  // P is an input here: the pre-activation whose swish this product is the gradient of
+          const float4 pr = preact[rt][j];
+          v = make_float4(v.x * dswish_(pr.x), v.y * dswish_(pr.y), v.z * dswish_(pr.z), v.w * dswish_(pr.w));
+        } else if (P) {
+          *reinterpret_cast<float4*>(P + o) = v;
+        }
         if (flags & 2) v = make_float4(swish_(v.x), swish_(v.y), swish_(v.z), swish_(v.w));
         if (flags & 1) v = make_float4(v.x + yold[rt][j].x, v.y + yold[rt][j].y, v.z + yold[rt][j].z, v.w + yold[rt][j].w);
         *reinterpret_cast<float4*>(Y + o) = v;
