@@ -1,41 +1,41 @@
 #!/usr/bin/env python3
 """QM9-shaped forward throughput of the SCANN+ HIP path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W          (N > 1: this process spawns the N ranks itself)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks made by the launcher)
 
 A step = one forward of the whole graph (scann_model.py:329-453) over one batch of 128 synthetic QM9-shaped
 molecules (configs/model_qm9.yaml: 7 local-attention layers, d=128, 8 heads, g_update) whose packed inputs are
-already resident in HBM.  The engine fuses --group resident batches into one launch sequence (the packed layout has
-no per-batch padding, so a group is the concatenation of its batches; EXACTLY --steps batches are processed);
-the timed region is bracketed by barrier + device sync; value = molecules of all ranks / max-over-ranks time.
-Inference shards by structure with no data-path collective ("weak" scaling: per-GPU work fixed).
+already resident in HBM.  The packed layout has no per-batch padding, so the engine runs the K steps as
+floor(K/16) launch sequences over groups of 16..31 concatenated batches (K < 16: one group of K): EXACTLY K batches
+of 128 molecules per timed region.  The timed region is bracketed by device sync + rank barrier on both sides and is
+REPEATED until >= 1 s has been measured (after an untimed pre-warm that does not depend on --warmup: the chip needs
+a few hundred ms under load to reach its sustained clock); the reported time is the median over repeats of the
+max-over-ranks region time.  value = molecules of all ranks / that time.  Inference shards by structure with no
+data-path collective ("weak" scaling: per-GPU work fixed); ranks meet through a loopback TCP rendezvous (no torch).
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel = edge_kernel, fp32 MFMA bound; achieved =
-algorithmic FLOPs per launch / HIP-event launch duration) and `cpu_baseline` (the NumPy/C oracle timed on the
-host cores -- a reported baseline, not the product path).
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the fused edge kernel: both bounds are reported,
+`bound` names the tighter one), `one_batch_per_launch`, the host-inclusive `end_to_end` rate and `cpu_baseline`
+(the C/OpenMP oracle timed on the host cores -- a reported baseline, never the product path).
 """
 import argparse
+import importlib.util
 import json
+import math
 import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
-
-from scann import _hip  # noqa: E402  (loads libscann_hip.so; no torch / no oracle on the product path)
-from scann.models.scann_model import HipModel, normalize_config  # noqa: E402
+PKG = os.path.join(ROOT, "scann--material_amd")
 
 D = 128
-PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 = 16 x the f32 rate (1024 FLOP/clk/SIMD)
+PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 QM9_MODEL = dict(n_atoms=10, embedding_dim=48, n_attention=7, local_dim=128, num_head=8, global_dim=128,
                  dense_out=128, scale=0.5, use_attn_norm=True, use_ga_norm=True, use_ring=False, g_update=True,
                  gaussian_d=4.0)  # configs/model_qm9.yaml:1-14
-
-
 MP2018_MODEL = dict(n_atoms=95, embedding_dim=128, n_attention=9, local_dim=128, num_head=8, global_dim=128,
                     dense_out=128, scale=0.5, use_attn_norm=True, use_ga_norm=True, use_ring=False, g_update=True,
                     gaussian_d=6.0)  # configs/model_mp2018.yaml:1-14
@@ -44,6 +44,9 @@ MP2018_MODEL = dict(n_atoms=95, embedding_dim=128, n_attention=9, local_dim=128,
 def synth_packed_crystals(rng, n_struct):
     """MP2018-shaped structures: A ~ clip(LogNormal(3.0, 0.8), 2, 300), neighbours per atom U[6, 24],
     Z in [1, 94], distances U(1.5, 6.0)."""
+    import numpy as np
+    from scann import _hip
+
     atomic, mol_off, e_off, cols = [], [0], [0], []
     for _ in range(n_struct):
         A = int(np.clip(np.rint(rng.lognormal(3.0, 0.8)), 2, 300))
@@ -66,6 +69,9 @@ def synth_packed_batch(rng, n_mol, worst=False):
     """Synthetic QM9-shaped molecules straight into packed form: atoms ~ clip(round(N(18,2.9)),3,29),
     species {H .51, C .35, N .06, O .08, F .002}, neighbours per atom ~ U[3, min(12, A-1)] without replacement,
     distance ~ U(0.9, 4.0), solid angle ~ U(0.4, 3.5)."""
+    import numpy as np
+    from scann import _hip
+
     zs = np.array([1, 6, 7, 8, 9])
     ps = np.array([0.51, 0.35, 0.06, 0.08, 0.002])
     ps = ps / ps.sum()
@@ -90,9 +96,15 @@ def synth_packed_batch(rng, n_mol, worst=False):
 
 
 def edge_flops(E):
-    """Algorithmic FLOPs of one edge_kernel launch: per edge the geometry third of filter_geo (2 d^2), the key
+    """Algorithmic FLOPs of one edge-kernel launch: per edge the geometry third of filter_geo (2 d^2), the key
     projection (2 d^2) and the q.k / attn.k contractions (4 d) -- SURVEY.md 8(d) minimal form, edge part."""
     return E * (4 * D * D + 4 * D)
+
+
+def edge_bytes(A, E):
+    """Algorithmic HBM bytes of one edge-kernel launch: per edge the geometry row in and out and
+    two indices, per atom the four rows every tile needs once (c, P1, P3, q) and the context row out."""
+    return E * (2 * D * 4 + 8) + A * (5 * D * 4)
 
 
 def total_flops_min(A, E, L=7, emb=48):
@@ -120,6 +132,8 @@ def host_cores():
 
 def cpu_baseline(seconds_budget=12.0):
     """The oracle (checker) timed on this host's cores on a bounded sample of the same workload."""
+    import numpy as np
+
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import scann_oracle as so
 
@@ -155,13 +169,26 @@ def cpu_baseline(seconds_budget=12.0):
                       "padded-dense graph (BLAS threads = host cores)" % n}
 
 
-def train_bench(args, eng, rank, world):
+def group_sizes(steps, target=16):
+    """K steps -> sizes of the launch groups: floor(K / target) groups whose sizes differ by at most one (16..31 batches
+    each; K < target: one group of K).  Short runs (the driver's --steps 20) therefore run at the same launch size as long
+    ones instead of ending in a small, chip-underfilling tail group."""
+    if steps <= 0:
+        return []
+    n = max(1, steps // target)
+    base, rem = divmod(steps, n)
+    return [base + 1] * rem + [base] * (n - rem)
+
+
+def train_bench(args, eng, rdzv):
     """Weak-scaling training throughput: every rank trains on its own --batch molecules per step; the ranks exchange the
     scalar SSE/count and one flat fp32 gradient all-reduce per step over RCCL."""
+    import numpy as np
     from scann.models.trainer import Communicator
 
+    rank, world = rdzv.rank, rdzv.world
     eng.train_begin()
-    comm = Communicator(eng)  # gloo only carries the 128-byte ncclUniqueId; gradients go over RCCL
+    comm = Communicator(eng, rdzv)  # the rendezvous only carries the 128-byte ncclUniqueId; gradients go over RCCL
     rng = np.random.default_rng(2000 + rank)
     pool = [eng.upload(synth_packed_batch(rng, args.batch)) for _ in range(8)]
     targets = [rng.normal(size=args.batch).astype(np.float32) for _ in pool]
@@ -175,27 +202,18 @@ def train_bench(args, eng, rank, world):
         eng.allreduce_grads()
         eng.adam_step(5e-4 / (1.0 + 1e-5 * i))
 
-    steps, warm = min(args.steps, 400), min(args.warmup, 20)
+    steps, warm = min(args.steps, 400), max(min(args.warmup, 20), 5)
     for i in range(warm):
         step(i)
     eng.sync()
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.barrier()
+    rdzv.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         step(warm + i)
     eng.sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rdzv.barrier()
+    elapsed = rdzv.allreduce_max(elapsed)
     if rank == 0:
         print(json.dumps({
             "metric": "QM9 molecules/s training (forward + backward + Adam)", "value": world * steps * args.batch / elapsed,
@@ -203,14 +221,41 @@ def train_bench(args, eng, rank, world):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: QM9 training, configs/model_qm9.yaml, %d molecules per GPU per step, dropout 0.1, "
                                    "RCCL flat gradient all-reduce (%d floats)" % (args.batch, eng.param_count()),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world}}))
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world}}), flush=True)
     for rb in pool:
         rb.free()
-    if world > 1:
-        import torch.distributed as dist
+    rdzv.barrier()
 
-        dist.barrier()
-        dist.destroy_process_group()
+
+def end_to_end(cfg, batches, batch_size, seconds=1.5):
+    """Host-inclusive rate of the dataset path behind SCANN.evaluate / predict_model.py: a host PackedDataset (flat CSR in
+    host memory) -> native slicing -> H2D -> forward -> D2H, pipelined over 4 streams (HipModel.predict_dataset)."""
+    import numpy as np
+    from scann.models.scann_model import HipModel
+    from scann.utils import PackedDataset
+
+    mol, eoff, atomic, local, dist, wgt = [0], [0], [], [], [], []
+    for b in batches:
+        base = np.repeat(b.mol_offset[:-1], np.diff(b.mol_offset))            # first atom row of every atom's structure
+        deg = np.diff(b.edge_offset)
+        local.append(b.edge_col - np.repeat(base, deg))
+        mol.extend((b.mol_offset[1:].astype(np.int64) + mol[-1]).tolist())
+        eoff.extend((b.edge_offset[1:].astype(np.int64) + eoff[-1]).tolist())
+        atomic.append(b.atomic); dist.append(b.edge_dist); wgt.append(b.edge_weight)
+    n = len(mol) - 1
+    ds = PackedDataset.from_arrays(mol, np.concatenate(atomic), eoff, np.concatenate(local), np.concatenate(dist),
+                                   np.concatenate(wgt), np.zeros(n, np.float32), batch_size=batch_size)
+    os.environ["SCANN_STREAMS"] = "4"
+    model = HipModel(cfg, device=int(os.environ.get("LOCAL_RANK", "0")), seed=1234)
+    model.predict_dataset(ds, group=8)  # warm (allocator cache, clocks)
+    reps, t0 = 0, time.perf_counter()
+    while reps == 0 or time.perf_counter() - t0 < seconds:
+        model.predict_dataset(ds, group=8)
+        reps += 1
+    dt = time.perf_counter() - t0
+    model.engine.close()
+    return {"value": reps * n / dt, "unit": "molecules/s", "molecules": n, "passes": reps, "streams": 4, "group": 8,
+            "path": "host PackedDataset -> scann_slice_batch -> upload -> forward -> download (HipModel.predict_dataset), PCIe-inclusive"}
 
 
 def main():
@@ -219,32 +264,52 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--pool", type=int, default=128, help="distinct resident batches cycled through")
+    ap.add_argument("--pool", type=int, default=128, help="distinct resident batches the groups are built from")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SCANN_STREAMS", "1")),
                     help="HIP streams the launch sequences are spread over.  Default 1: launches do not overlap, so the "
                          "HIP-event launch durations taken inside the timed region are the kernel's own (what rocprofv3 "
-                         "--stats reports); 2 streams x --group 8 is ~6 %% faster end to end but co-schedules kernels")
+                         "--stats reports)")
     ap.add_argument("--group", type=int, default=int(os.environ.get("SCANN_BENCH_GROUP", "16")),
-                    help="resident 128-molecule batches the engine fuses into one launch sequence (packed layout: a group is "
-                         "the concatenation of its batches; 1 = one batch per launch)")
+                    help="target number of resident 128-molecule batches per launch sequence (see group_sizes; 1 = one batch per launch)")
     ap.add_argument("--worst", action="store_true", help="Swc: every molecule 29 atoms x 12 neighbours")
     ap.add_argument("--config", default="qm9", choices=["qm9", "mp2018"],
                     help="qm9 = BASELINE configs[1] (the metric); mp2018 = configs[3] shapes (crystals, L=9, batch 64), extra")
+    ap.add_argument("--min-time", type=float, default=1.0, help="seconds of timed regions to collect (median over repeats)")
+    ap.add_argument("--prewarm", type=float, default=0.6, help="seconds of untimed load before the first timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--one-batch-ref", action="store_true",
-                    help="also time single-batch launch sequences (reported as one_batch_per_launch)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip one_batch_per_launch / end_to_end / cpu_baseline (rocprofv3 runs: only the timed launch shape then "
+                         "contributes to the per-kernel averages)")
     ap.add_argument("--train", action="store_true",
                     help="extra (BASELINE configs[2]): time data-parallel TRAINING steps instead of the forward metric -- "
                          "forward(train, dropout 0.1) + SSE all-reduce + backward + flat RCCL gradient all-reduce + Adam; "
                          "--batch molecules per GPU per step")
-    ap.add_argument("--profile-reps", type=int, default=20)
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal only: allow more ranks than visible devices (rank r runs on device r %% n_devices); the line "
+                         "is then marked \"oversubscribed\" and is not a scaling measurement")
+    ap.add_argument("--profile-reps", type=int, default=12)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: THIS process becomes the launcher.  It spawns one fresh process per GPU before anything here has
+        # touched HIP (the package, ctypes binding and library are not even imported) and exits with their code.
+        spec = importlib.util.spec_from_file_location("_scann_launch", os.path.join(PKG, "scann", "parallel", "launch.py"))
+        launch = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launch)
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    sys.path.insert(0, PKG)
+    import numpy as np
+    from scann import _hip  # loads libscann_hip.so on first use; no torch / no oracle on the product path
+    from scann.models.scann_model import HipModel, normalize_config
+    from scann.parallel.rendezvous import Rendezvous
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    rdzv = Rendezvous(rank, world)
 
     os.environ["SCANN_STREAMS"] = str(max(1, args.streams))  # read by scann_create
     if args.config == "mp2018" and args.batch == 128:
@@ -254,103 +319,114 @@ def main():
     ndev = _hip.load_library().scann_device_count()
     if ndev <= 0:
         raise SystemExit("bench.py needs a GPU: libscann_hip has no CPU fallback")
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit("--gpus %d but only %d device(s) visible" % (world, ndev))
     model = HipModel(cfg, device=local % ndev, seed=1234)  # random-init weights of the QM9 architecture
     eng = model.engine
     if args.train:
-        return train_bench(args, eng, rank, world)
+        return train_bench(args, eng, rdzv)
     nstream = eng.num_streams()
-    G = max(1, args.group)
-    n_groups = max(nstream, (max(args.pool // G, 1) + nstream - 1) // nstream * nstream)
     rng = np.random.default_rng(1000 + rank)
+    n_pool = max(args.pool, 32)
     if args.config == "mp2018":
-        batches = [synth_packed_crystals(rng, args.batch) for _ in range(n_groups * G)]
+        batches = [synth_packed_crystals(rng, args.batch) for _ in range(n_pool)]
     else:
-        batches = [synth_packed_batch(rng, args.batch, args.worst) for _ in range(n_groups * G)]
-    # every step is one 128-molecule batch; the engine runs G of them per launch sequence
-    pool = [eng.upload(_hip.concat_packed(batches[i * G:(i + 1) * G]) if G > 1 else batches[i]) for i in range(n_groups)]
-    pool_n = n_groups
-    tails = {}  # remainder groups so that EXACTLY the requested number of steps is executed
-    for k in {args.steps % G, args.warmup % G} - {0}:
-        tails[k] = eng.upload(_hip.concat_packed(batches[:k]))
-    mols_per_step = args.batch
+        batches = [synth_packed_batch(rng, args.batch, args.worst) for _ in range(n_pool)]
 
-    dist = None
-    if world > 1:  # coordination only (barrier + max of the timings); never touches the GPU through torch
-        import torch
-        import torch.distributed as dist_mod
+    # resident groups: for every group size the schedules need, as many distinct groups as the pool yields (>= 1)
+    sizes_t, sizes_w = group_sizes(args.steps, args.group), group_sizes(args.warmup, args.group)
+    resident = {}
+    for g in sorted(set(sizes_t + sizes_w)):
+        n_g = max(1, min(n_pool // g, 8))
+        resident[g] = [eng.upload(_hip.concat_packed([batches[(i * g + j) % n_pool] for j in range(g)]) if g > 1 else batches[i % n_pool])
+                       for i in range(n_g)]
 
-        dist_mod.init_process_group("gloo", rank=rank, world_size=world)
-        dist = dist_mod
+    def run(sizes):
+        for i, g in enumerate(sizes):
+            eng.forward_resident(resident[g][i % len(resident[g])], i % nstream)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def run(nsteps):
-        for i in range(nsteps // G):
-            eng.forward_resident(pool[i % pool_n], i % nstream)
-        if nsteps % G:
-            eng.forward_resident(tails[nsteps % G], 0)
-
-    run(args.warmup)
+    run(sizes_w)
     eng.sync()
-    barrier()
-    if rank == 0:
-        eng.edge_timing(4)  # HIP events around the edge-kernel launches of every 4th forward, on their own streams
+    # untimed pre-warm, independent of --warmup: clocks and caches reach their loaded state (a cold process runs the first
+    # few hundred launches at ~2.15 GHz instead of ~2.4)
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < args.prewarm:
+        run(sizes_t)
+        eng.sync()
     t0 = time.perf_counter()
-    run(args.steps)
-    t_issue = time.perf_counter() - t0  # host time to enqueue every launch (diagnostic: host- vs device-bound)
+    run(sizes_t)
     eng.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
+    est = rdzv.allreduce_max(time.perf_counter() - t0)
+    repeats = int(min(4000, max(3, math.ceil(args.min_time / max(est, 1e-6))))) | 1  # odd: the median is a measured region
+    if rank == 0:  # HIP events around the edge-kernel launches of sampled forwards, on their own streams (<= ~64 forwards)
+        eng.edge_timing(max(1, repeats * len(sizes_t) // 64))
+    times, t_issue = [], 0.0
+    for _ in range(repeats):
+        eng.sync()
+        rdzv.barrier()
+        t0 = time.perf_counter()
+        run(sizes_t)
+        t1 = time.perf_counter()
+        eng.sync()
+        times.append(time.perf_counter() - t0)
+        t_issue += t1 - t0  # host time to enqueue every launch (diagnostic: host- vs device-bound)
+        rdzv.barrier()
+    all_times = rdzv.gather(times)
 
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel launch durations: (a) sampled live inside the timed region (co-scheduled with the other streams: the
-    # figure rocprofv3 --stats reports too), (b) sequential launches alone on the chip (scann_forward_profile)
-    roof = None
     if rank == 0:
+        per_repeat = np.max(np.asarray(all_times, dtype=np.float64), axis=0)  # max over ranks of every timed region
+        elapsed = float(np.median(per_repeat))
         live_us, live_n, live_edges = eng.edge_timing_read()
         eng.edge_timing(0)
-        ms_edge = n_edge = fl = 0.0
-        prof_tot = []
+        # sequential per-kernel durations of one forward (scann_forward_profile), largest timed group
+        gmax = max(sizes_t)
+        prof = []
         for i in range(args.profile_reps):
-            rb = pool[i % pool_n]
-            p = eng.profile(rb)
-            if i >= 2:  # first reps warm the caches
-                ms_edge += p["ms_edge"]
-                n_edge += p["n_edge_launch"]
-                fl += edge_flops(rb.packed.n_edge) * p["n_edge_launch"]
-                prof_tot.append(p)
-        avg_ms = ms_edge / max(n_edge, 1)
-        exclusive = fl / max(n_edge, 1) / (avg_ms * 1e-3) / 1e12
-        achieved = edge_flops(live_edges) / (live_us * 1e-6) / 1e12 if live_n else exclusive
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "edge_kernel_traffic.json")
-        if os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            if tj.get("batches_per_launch") == G and not args.worst:  # PMC passes were taken at this launch size
-                traffic = tj.get("hbm_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "%s (scann_kernels.hip), %d batches per launch" % ("edge_kernel_lean" if os.environ.get("SCANN_EDGE_LEAN", "1") != "0" else "edge_kernel_w8", G), "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                "avg_launch_us": live_us if live_n else avg_ms * 1e3, "launches_sampled": live_n,
-                "note": "achieved = HIP events around sampled edge-kernel launches inside the timed region (with 1 stream "
-                        "launches never overlap); exclusive = the same kernel in the separate profiling pass",
-                "achieved_exclusive": exclusive, "exclusive_launch_us": avg_ms * 1e3,
-                "per_forward_ms": {k: float(np.mean([p[k] for p in prof_tot])) for k in
-                                   ("ms_basis", "ms_atom", "ms_edge", "ms_readout", "ms_total")}}
-
-    if rank == 0:
+            p = eng.profile(resident[gmax][i % len(resident[gmax])])
+            if i >= 2:
+                prof.append(p)
         A = float(np.mean([b.n_atom for b in batches]))
         E = float(np.mean([b.n_edge for b in batches]))
-        value = world * args.steps * mols_per_step / elapsed
+        G_eff = args.steps / len(sizes_t)
+        if live_n:
+            e_launch, us = live_edges, live_us
+        else:
+            e_launch, us = E * gmax, 1e3 * float(np.mean([p["ms_edge"] / max(p["n_edge_launch"], 1) for p in prof]))
+        a_launch = e_launch * A / E
+        alg_flops, alg_bytes = edge_flops(e_launch), edge_bytes(a_launch, e_launch)
+        tfl = alg_flops / (us * 1e-6) / 1e12
+        tbs = alg_bytes / (us * 1e-6) / 1e12
+        kinfo = {}
+        kfile = os.path.join(ROOT, "profiles", "edge_kernel.json")  # written with the kernel: pipe, passes, traffic per workload
+        if os.path.exists(kfile):
+            kinfo = json.load(open(kfile))
+        passes = int(kinfo.get("mfma_passes", 1))      # MFMA products issued per algorithmic product (split operands)
+        pipe_peak = PEAK_F16_MFMA_TFLOPS if kinfo.get("mfma_pipe", "f32") == "f16" else PEAK_FP32_MFMA_TFLOPS
+        frac_mfma = tfl * passes / pipe_peak
+        frac_hbm = tbs / PEAK_HBM_TBS
+        wkey = "%s%s_g%d" % (args.config, "_worst" if args.worst else "", gmax)
+        traffic = (kinfo.get("traffic") or {}).get(wkey)  # PMC bytes per launch, measured at THIS workload and launch size or null
+        hbm_bound = frac_hbm >= frac_mfma
+        roof = {"bound": "hbm" if hbm_bound else "mfma",
+                "kernel": "%s (scann_kernels.hip), %d batches per launch" % (kinfo.get("name", "edge_kernel"), gmax),
+                "achieved": tbs * 1e3 if hbm_bound else tfl * passes, "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else pipe_peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": frac_hbm if hbm_bound else frac_mfma,
+                "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                "avg_launch_us": us, "launches_sampled": live_n,
+                "algorithmic": {"flops_per_launch": alg_flops, "bytes_per_launch": alg_bytes, "edges_per_launch": e_launch,
+                                "tflops": tfl, "tbytes_per_s": tbs},
+                "mfma": {"pipe": kinfo.get("mfma_pipe", "f32"), "passes": passes, "executed_tflops": tfl * passes, "peak": pipe_peak,
+                         "frac": frac_mfma, "frac_of_fp32_mfma_peak_algorithmic": tfl / PEAK_FP32_MFMA_TFLOPS},
+                "hbm": {"achieved_gbs": tbs * 1e3, "peak_gbs": PEAK_HBM_TBS * 1e3, "frac": frac_hbm},
+                "note": "avg_launch_us = HIP events around sampled edge-kernel launches inside the timed regions, on the launch "
+                        "stream (1 stream: launches never overlap); achieved = ALGORITHMIC bytes or FLOPs of a launch / that time",
+                "per_forward_ms": {k: float(np.mean([p[k] for p in prof])) for k in
+                                   ("ms_basis", "ms_atom", "ms_edge", "ms_readout", "ms_total")} if prof else None}
+        value = world * args.steps * args.batch / elapsed
         L_cfg, emb_cfg = model_cfg["n_attention"], model_cfg["embedding_dim"]
         out = {
-            "metric": "QM9 molecules/s forward" if args.config == "qm9" else "MP2018-shaped structures/s forward", "value": value, "unit": "molecules/s", "n_gpus": world,
+            "metric": "QM9 molecules/s forward" if args.config == "qm9" else "MP2018-shaped structures/s forward",
+            "value": value, "unit": "molecules/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: QM9-shaped%s, configs/model_qm9.yaml (SCANN+, L=7, d=128, H=8), "
@@ -358,35 +434,43 @@ def main():
                        if args.config == "qm9" else
                        "configs[3] shapes: MP2018-shaped crystals, configs/model_mp2018.yaml (SCANN+, L=9), batch=64 per step, forward",
                        "batch": args.batch, "atoms_per_batch": A, "edges_per_batch": E,
-                       "streams": nstream, "batches_fused_per_launch": G, "parallelism": "dp%d (independent shards, no collective)" % world},
-            "host_issue_ms_per_step": t_issue / args.steps * 1e3,
+                       "streams": nstream, "batches_fused_per_launch": G_eff, "launch_groups": sorted(set(sizes_t)),
+                       "parallelism": "dp%d (independent shards, no collective)" % world},
+            "timing": {"repeats": repeats, "timed_region_ms_median": elapsed * 1e3, "timed_region_ms_min": float(per_repeat.min()) * 1e3,
+                       "timed_region_ms_max": float(per_repeat.max()) * 1e3, "prewarm_s": args.prewarm,
+                       "rule": "each repeat = EXACTLY --steps batches between sync+barrier pairs; value from the median repeat (max over ranks)"},
+            "host_issue_ms_per_step": t_issue / repeats / args.steps * 1e3,
             "whole_path_tflops_min": world * args.steps * total_flops_min(A, E, L_cfg, emb_cfg) / elapsed / 1e12,
             "roofline": roof,
         }
-        if args.one_batch_ref and world == 1 and G > 1 and not args.worst:
-            # the same engine with exactly ONE 128-molecule batch per launch sequence (no fusing), for reference; opt-in so that
-            # the default command's rocprofv3 per-kernel averages cover the fused launches only
-            singles = [eng.upload(b) for b in batches[:min(len(batches), 4 * nstream, 32)]]
-            n1 = 400
-            for i in range(40):
+        if world > ndev:
+            out["oversubscribed"] = True
+    for g in list(resident):
+        for rb in resident.pop(g):
+            rb.free()
+    if rank == 0:
+        if not args.no_extras and world == 1 and args.config == "qm9" and not args.worst:
+            # (a) the same engine with exactly ONE 128-molecule batch per launch sequence, (b) the host-inclusive dataset path
+            singles = [eng.upload(b) for b in batches[:32]]
+            for i in range(64):
                 eng.forward_resident(singles[i % len(singles)], i % nstream)
             eng.sync()
-            t1 = time.perf_counter()
-            for i in range(n1):
-                eng.forward_resident(singles[i % len(singles)], i % nstream)
-            eng.sync()
-            out["one_batch_per_launch"] = {"value": n1 * mols_per_step / (time.perf_counter() - t1), "unit": "molecules/s",
+            n1, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < 0.5:
+                for i in range(64):
+                    eng.forward_resident(singles[i % len(singles)], i % nstream)
+                eng.sync()
+                n1 += 64
+            out["one_batch_per_launch"] = {"value": n1 * args.batch / (time.perf_counter() - t1), "unit": "molecules/s",
                                            "steps": n1, "streams": nstream}
             for rb in singles:
                 rb.free()
-        if not args.no_cpu_baseline:
+            out["end_to_end"] = end_to_end(cfg, batches, args.batch)
+        if not args.no_cpu_baseline and not args.no_extras and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    for rb in list(pool) + list(tails.values()):
-        rb.free()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    rdzv.barrier()
+    rdzv.close()
 
 
 if __name__ == "__main__":

@@ -178,6 +178,11 @@ int scann_get_grads(scann_handle_t* h, float* out);           /* [scann_param_co
 int scann_get_weights(scann_handle_t* h, float* out);         /* current master parameters, same order */
 int scann_comm_unique_id(char* out128);                       /* ncclGetUniqueId on rank 0; broadcast by the caller */
 int scann_comm_init(scann_handle_t* h, const char* id128, int rank, int world);
+/* Data-parallel start-up: every rank's master parameters become rank `root`'s (one flat ncclBroadcast) and the packed
+ * device images are regenerated from them, so that replicas created with different initialiser draws train ONE model
+ * (the reference is single-process: create_model runs once, scann_model.py:77).  No-op without a communicator.
+ * Needs scann_train_begin. */
+int scann_broadcast_weights(scann_handle_t* h, int root);
 
 /* ---- host batch packers (no GPU work) --------------------------------------------------------------
  * Replace DataIterator.__getitem__ + pad_sequence / pad_nested_sequences (datagenerator.py:69-135, general.py:14-50).

@@ -873,7 +873,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.tile_part = db->tile_part; ea.part_buf = db->part_buf;
     ea.lean_wgs = h->lean_persist > 0 ? (3 * h->n_cu) / 8 * 8 : 0;
     ea.xcd_remap = h->xcd_remap;
-    if (h->in_train_forward && h->attn_drop_p > 0.f) {
+    if (h->in_train_forward && h->attn_drop_p > 0.f) {  // validation passes run with scann_set_attention_dropout(h, 0): trainer.fit
       ea.attn_drop_p = h->attn_drop_p;
       ea.attn_drop_seed = h->train_seed;
       ea.attn_drop_tag = DROP_TAG_ATTN + (unsigned)l;
@@ -1457,6 +1457,24 @@ int scann_comm_init(scann_handle_t* h, const char* id128, int rank, int world) {
   const ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
   if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
   h->comm_world = world;
+  return SCANN_OK;
+}
+
+int scann_broadcast_weights(scann_handle_t* h, int root) {
+  if (!h || !h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_broadcast_weights: call scann_train_begin first");
+  if (!h->comm || h->comm_world == 1) return SCANN_OK;
+  if (root < 0 || root >= h->comm_world) return fail(h, SCANN_ERR_INVALID, "scann_broadcast_weights: bad root");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->streams[0];
+  const ncclResult_t r = ncclBroadcast(h->t_master, h->t_master, h->host_master.size(), ncclFloat, root, h->comm, s);
+  if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
+  launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, s);
+  if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
+    launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
+                     h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(h->host_master.data(), h->t_master, h->host_master.size() * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
   return SCANN_OK;
 }
 

@@ -88,6 +88,7 @@ SYMBOLS = [
     ("scann_get_weights", C.c_int, [_P, _P]),
     ("scann_comm_unique_id", C.c_int, [C.c_char_p]),
     ("scann_comm_init", C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
+    ("scann_broadcast_weights", C.c_int, [_P, C.c_int]),
     ("scann_pack_last_error", C.c_char_p, []),
     ("scann_pack_padded", C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 17 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("scann_slice_count", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -452,6 +453,9 @@ class Engine:
 
     def comm_init(self, unique_id, rank, world):
         self._check(self.lib.scann_comm_init(self._h, unique_id, int(rank), int(world)))
+
+    def broadcast_weights(self, root=0):
+        self._check(self.lib.scann_broadcast_weights(self._h, int(root)))
 
     def edge_timing(self, every):
         self._check(self.lib.scann_edge_timing(self._h, int(every)))

@@ -9,13 +9,14 @@ slice of structures, and the ranks exchange exactly two things per step over RCC
 from __future__ import annotations
 
 import math
-import os
+import queue
+import threading
 import time
 
 import numpy as np
 
 from .. import _hip
-from ..parallel import rank_slice
+from ..parallel import rank_slice, slice_packed
 
 
 def cosine_decay(step, initial_lr, decay_steps, alpha):
@@ -71,42 +72,67 @@ class SGDRC:
 
 
 class Communicator:
-    """RCCL communicator of the training ranks (one process per GPU, launched by torch.distributed.run).  The 128-byte
-    ncclUniqueId travels through a gloo broadcast; torch never touches the GPU."""
+    """RCCL communicator of the training ranks (one process per GPU; launched by ``torch.distributed.run`` or by
+    ``scann.parallel.spawn_ranks`` -- RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment).  The 128-byte
+    ncclUniqueId travels from rank 0 over the loopback rendezvous (``scann.parallel.Rendezvous``: plain TCP, no torch);
+    after ``scann_comm_init`` rank 0's parameters are broadcast so that every replica starts from the SAME model (the
+    reference builds one model in one process, scann_model.py:77; each rank here drew its own initialiser)."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, rendezvous=None):
+        from ..parallel import Rendezvous
+
         self.engine = engine
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rdzv = rendezvous if rendezvous is not None else Rendezvous()
+        self.rank, self.world = self.rdzv.rank, self.rdzv.world
         if self.world > 1:
-            import torch
-            import torch.distributed as dist
-
-            if not dist.is_initialized():
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            buf = torch.zeros(128, dtype=torch.uint8)
-            if self.rank == 0:
-                buf = torch.frombuffer(bytearray(_hip.comm_unique_id()), dtype=torch.uint8).clone()
-            dist.broadcast(buf, 0)
-            engine.comm_init(bytes(buf.numpy().tobytes()), self.rank, self.world)
+            uid = self.rdzv.broadcast(_hip.comm_unique_id() if self.rank == 0 else None)
+            engine.comm_init(uid, self.rank, self.world)
+            engine.broadcast_weights(0)
 
     def shard(self, packed):
         if self.world == 1:
             return packed, slice(0, packed.n_struct)
         lo, hi = rank_slice(packed.n_struct, self.rank, self.world)
-        return _slice_packed(packed, lo, hi), slice(lo, hi)
+        return slice_packed(packed, lo, hi), slice(lo, hi)
 
     def sum_pair(self, a, b):
         return self.engine.allreduce_sse(a, b) if self.world > 1 else (a, b)
 
 
-def _slice_packed(pk, lo, hi):
-    mol = pk.mol_offset.astype(np.int64)
-    eoff = pk.edge_offset.astype(np.int64)
-    a0, a1 = int(mol[lo]), int(mol[hi])
-    e0, e1 = int(eoff[a0]), int(eoff[a1])
-    return _hip.PackedBatch(pk.atomic[a0:a1], mol[lo:hi + 1] - a0, eoff[a0:a1 + 1] - e0, pk.edge_col[e0:e1] - a0,
-                            pk.edge_dist[e0:e1], pk.edge_weight[e0:e1])
+class _Prefetch:
+    """Host pipeline of ``fit``: batch k+1 is assembled (``iterator[k+1]`` + CSR packing + this rank's slice) on a worker
+    thread while the GPU runs step k.  The reference gets the same overlap from Keras' ``workers=4,
+    use_multiprocessing=True`` (scann_model.py:239-240)."""
+
+    def __init__(self, iterator, comm):
+        self.it, self.comm, self.n = iterator, comm, len(iterator)
+        self.q = queue.Queue(maxsize=2)
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _one(self, b):
+        part = getattr(self.it, "batch_part", None)
+        if part is not None and self.comm.world > 1:  # PackedDataset: only this rank's structures are ever packed
+            shard, target = part(b, self.comm.rank, self.comm.world)
+            return shard, np.asarray(target, dtype=np.float32)
+        inputs, target = self.it[b]
+        packed = inputs if isinstance(inputs, _hip.PackedBatch) else _hip.pack_inputs(inputs)
+        shard, sl = self.comm.shard(packed)
+        return shard, np.asarray(target, dtype=np.float32)[sl]
+
+    def _run(self):
+        try:
+            for b in range(self.n):
+                self.q.put(self._one(b))
+        except BaseException as e:  # surfaced in the training thread
+            self.q.put(e)
+
+    def __iter__(self):
+        for _ in range(self.n):
+            item = self.q.get()
+            if isinstance(item, BaseException):
+                raise item
+            yield item
 
 
 def fit(scann, epochs=1000, dropout=0.1, verbose=True):
@@ -116,7 +142,7 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
     model = scann.model
     eng = model.engine
     eng.train_begin()
-    eng.set_attention_dropout(0.05 if cfg["model"].get("use_drop") else 0.0)  # attention.py:115-116
+    attn_drop = 0.05 if cfg["model"].get("use_drop") else 0.0  # attention.py:115-116
     comm = Communicator(eng)
     train_it, valid_it = scann.trainIter, scann.validIter
     steps_per_epoch = len(train_it)
@@ -137,11 +163,9 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
         sse_t = sabs_t = sy = syy = 0.0
         n_t = 0
         loss_sum = 0.0
-        for b in range(len(iterator)):
-            inputs, target = iterator[b]
-            packed = inputs if isinstance(inputs, _hip.PackedBatch) else _hip.pack_inputs(inputs)
-            shard, sl = comm.shard(packed)
-            tgt = np.asarray(target, dtype=np.float32)[sl]
+        # Keras Dropout layers are the identity outside training (attention.py:115-116,191): validation runs without them
+        eng.set_attention_dropout(attn_drop if training else 0.0)
+        for shard, tgt in _Prefetch(iterator, comm):
             rb = eng.upload(shard)
             sse = eng.train_forward(rb, tgt, dropout=dropout if training else 0.0, seed=(it * 7919 + 17) & 0xFFFFFFFF)
             y, _ = eng.download(rb, want_ga=False)

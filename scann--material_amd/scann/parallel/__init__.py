@@ -1,7 +1,10 @@
-"""Data-parallel inference helpers: structures are independent units (attention.py:136 gathers inside one
+"""Data-parallel helpers: structures are independent units (attention.py:136 gathers inside one
 batch row; GlobalAttention reduces inside one row), so a batch shards across GPUs with no collective on the data
-path -- each rank runs its shard on its own handle and the host concatenates the per-structure outputs."""
+path -- each rank runs its shard on its own handle and the host concatenates the per-structure outputs.  Training adds
+the RCCL exchanges inside libscann_hip.so; the ranks find each other through ``Rendezvous`` (loopback TCP, no torch)."""
+from .launch import spawn_ranks
 from .multi_gpu import MultiGpuPredictor
-from .shard import concat_outputs, rank_slice, split_packed
+from .rendezvous import Rendezvous
+from .shard import concat_outputs, rank_slice, slice_packed, split_packed
 
-__all__ = ["split_packed", "rank_slice", "concat_outputs", "MultiGpuPredictor"]
+__all__ = ["split_packed", "slice_packed", "rank_slice", "concat_outputs", "MultiGpuPredictor", "Rendezvous", "spawn_ranks"]

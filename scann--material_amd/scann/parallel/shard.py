@@ -12,6 +12,18 @@ def rank_slice(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def slice_packed(packed, lo, hi):
+    """Structures [lo, hi) of a packed batch as a packed batch of their own (offsets and neighbour rows rebased; the
+    optional ring / cgcnn atom features travel with their atoms)."""
+    mol = packed.mol_offset.astype(np.int64)
+    eoff = packed.edge_offset.astype(np.int64)
+    a0, a1 = int(mol[lo]), int(mol[hi])
+    e0, e1 = int(eoff[a0]), int(eoff[a1])
+    cut = lambda x: x[a0:a1] if x is not None else None  # noqa: E731
+    return PackedBatch(cut(packed.atomic), mol[lo:hi + 1] - a0, eoff[a0:a1 + 1] - e0, packed.edge_col[e0:e1] - a0,
+                       packed.edge_dist[e0:e1], packed.edge_weight[e0:e1], ring=cut(packed.ring), cgcnn=cut(packed.cgcnn))
+
+
 def split_packed(packed, n_shards):
     """Cut a packed batch into ``n_shards`` contiguous runs of whole structures with balanced edge counts
     (edges carry ~3/4 of the FLOPs).  Every shard gets at least one structure when there are enough of them.
@@ -29,15 +41,7 @@ def split_packed(packed, n_shards):
         c = min(max(c, cuts[-1] + 1), B - (n_shards - s))
         cuts.append(c)
     cuts.append(B)
-    shards = []
-    for lo, hi in zip(cuts[:-1], cuts[1:]):
-        a0, a1 = int(mol[lo]), int(mol[hi])
-        e0, e1 = int(eoff[a0]), int(eoff[a1])
-        cut = lambda x: x[a0:a1] if x is not None else None  # noqa: E731
-        shards.append(PackedBatch(cut(packed.atomic), mol[lo:hi + 1] - a0, eoff[a0:a1 + 1] - e0,
-                                  packed.edge_col[e0:e1] - a0, packed.edge_dist[e0:e1], packed.edge_weight[e0:e1],
-                                  ring=cut(packed.ring), cgcnn=cut(packed.cgcnn)))
-    return shards
+    return [slice_packed(packed, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
 
 
 def concat_outputs(parts):

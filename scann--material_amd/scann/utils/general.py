@@ -61,10 +61,7 @@ def load_dataset(dataset, dataset_neighbor, target_prop, use_ref=False, use_ring
             rows.append([d["Atomic"], float(d["Properties"][target_prop]) - float(d["Properties"]["Ref_energy"])])
         else:
             rows.append([d["Atomic"], float(d["Properties"][target_prop])])
-    data_energy = np.empty(len(rows), dtype=object)
-    for i, r in enumerate(rows):
-        data_energy[i] = r
-    data_energy = np.array(rows, dtype="object") if len(rows) else data_energy
+    data_energy = np.array(rows, dtype="object")  # [n, 2 | 3] object array: SCANN.prepare_dataset indexes column 1
     data_neighbor = np.array(np.load(dataset_neighbor, allow_pickle=True), dtype="object")
     return data_energy, data_neighbor
 

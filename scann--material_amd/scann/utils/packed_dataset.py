@@ -17,7 +17,8 @@ from .._hip import slice_dataset
 
 class PackedDataset:
     def __init__(self, data_energy, data_neighbor, batch_size=32, converter=False, use_ring=False, shuffle=False,
-                 feature="atomic", g_update=False):
+                 feature="atomic", g_update=False, atomic_features=None):
+        # same keyword set as DataIterator (datagenerator.py:12-23); atomic_features only matters for feature="cgcnn"
         if feature != "atomic":
             raise NotImplementedError("PackedDataset covers feature='atomic'")
         n = len(data_energy)
@@ -38,6 +39,24 @@ class PackedDataset:
         self.ring = np.concatenate([np.asarray(d[2], dtype=np.float32).reshape(-1, 2) for d in data_energy]) if use_ring else None
         self.on_epoch_end()
 
+    @classmethod
+    def from_arrays(cls, mol_offset, atomic, edge_offset, edge_local, edge_dist, edge_weight, target, batch_size=32,
+                    shuffle=False, ring=None):
+        """A dataset that is already flat: mol_offset[n+1] (atoms), edge_offset[atoms+1], edge_local = neighbour index INSIDE
+        its structure, like the preprocessing stores it (voronoi_neighbor.py:38-47)."""
+        self = cls.__new__(cls)
+        self.batch_size, self.shuffle, self.use_ring = batch_size, shuffle, ring is not None
+        self.mol_offset = np.ascontiguousarray(mol_offset, dtype=np.int64)
+        self.edge_offset = np.ascontiguousarray(edge_offset, dtype=np.int64)
+        self.atomic = np.ascontiguousarray(atomic, dtype=np.int32)
+        self.edge_local = np.ascontiguousarray(edge_local, dtype=np.int32)
+        self.edge_dist = np.ascontiguousarray(edge_dist, dtype=np.float32)
+        self.edge_weight = np.ascontiguousarray(edge_weight, dtype=np.float32)
+        self.target = np.ascontiguousarray(target, dtype=np.float32)
+        self.ring = np.ascontiguousarray(ring, dtype=np.float32) if ring is not None else None
+        self.on_epoch_end()
+        return self
+
     def on_epoch_end(self):
         self.indexes = np.arange(len(self.target))
         if self.shuffle:
@@ -49,6 +68,17 @@ class PackedDataset:
     def batch(self, idx):
         """-> (PackedBatch, targets) of batch `idx` (the structures DataIterator.__getitem__(idx) would hold)."""
         sel = self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size]
+        pk = slice_dataset(self.mol_offset, self.edge_offset, self.atomic, self.ring, self.edge_local, self.edge_dist,
+                           self.edge_weight, sel)
+        return pk, self.target[sel]
+
+    def batch_part(self, idx, rank, world):
+        """Rank ``rank``'s contiguous share of batch ``idx`` (data-parallel training: a rank never packs the structures of
+        the other ranks).  Same split as ``scann.parallel.rank_slice`` applied to the whole batch."""
+        sel = self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size]
+        base, rem = divmod(len(sel), world)
+        lo = rank * base + min(rank, rem)
+        sel = sel[lo:lo + base + (1 if rank < rem else 0)]
         pk = slice_dataset(self.mol_offset, self.edge_offset, self.atomic, self.ring, self.edge_local, self.edge_dist,
                            self.edge_weight, sel)
         return pk, self.target[sel]

@@ -453,3 +453,62 @@ def test_multi_gpu_predictor_matches_single_handle(hip_lib):
     assert rel_err(y2, y1) <= 1e-6 and rel_err(ga2, ga1) <= 1e-6
     runs = MultiGpuPredictor._runs([5, 1, 1, 1, 5, 5], 3)
     assert runs[0][0] == 0 and runs[-1][1] == 6 and all(hi > lo for lo, hi in runs) and len(runs) == 3
+
+
+def test_s134k_sampled_batches_match_c_oracle(hip_lib):
+    """BASELINE configs[1] at FULL size, sampled: S134k = 130,831 synthetic QM9-shaped molecules in 1,023 batches of 128
+    (batch k is synth_dataset(n, seed=1000 + 128 k), tests/manual/parity_s134k.py runs all of them).  Eight batches spread
+    over the set -- the ragged last one included -- go through the dataset pipeline (predict_dataset) with the full L=7
+    model and Keras-default weights and are compared with the C/OpenMP port of the oracle at the north-star bound."""
+    import scann_oracle_c as soc
+    from scann.models.scann_model import HipModel, normalize_config
+
+    N, B = 130831, 128
+    n_batches = (N + B - 1) // B
+    assert n_batches == 1023
+    cfg = normalize_config(so.default_config("qm9"))
+    w = so.init_weights(cfg, 1234)
+    model = HipModel(cfg, w, device=0, infer=True)
+    rng = np.random.default_rng(2)
+    picks = sorted(set(rng.choice(n_batches - 1, size=7, replace=False).tolist()) | {n_batches - 1})
+    items, refs = [], []
+    for k in picks:
+        n = min(B, N - B * k)
+        de, dn = so.synth_dataset(n, seed=1000 + B * k)
+        inputs, tgt = so.pad_batch(de, dn, True)
+        items.append((inputs, tgt))
+        refs.append(soc.forward(cfg, w, inputs))
+    assert items[-1][0]["atomic"].shape[0] == N - B * (n_batches - 1) == 15
+    y, ga, t = model.predict_dataset(items, group=3, want_ga=True)
+    y_ref = np.concatenate([r[0][:, 0] for r in refs])
+    ga_ref = np.concatenate([r[1][..., 0][it[0]["atom_mask"][..., 0]] for r, it in zip(refs, items)])
+    assert y.shape == y_ref.shape == (7 * B + 15,) and np.array_equal(t, np.concatenate([it[1] for it in items]))
+    assert rel_err(y, y_ref) <= RTOL, rel_err(y, y_ref)
+    assert float(np.max(np.abs(ga - ga_ref))) <= 1e-5
+    # the MAE SCANN.evaluate() would print (scann_model.py:273-280) agrees to the same bound
+    mae_gpu, mae_ref = float(np.mean(np.abs(y - t))), float(np.mean(np.abs(y_ref - t)))
+    assert abs(mae_gpu - mae_ref) <= RTOL * mae_ref
+
+
+def test_bench_two_ranks_through_the_self_spawning_launcher(hip_lib):
+    """`python bench.py --gpus 2` with no external launcher: the parent spawns the ranks, they meet over the loopback
+    rendezvous, and rank 0 prints ONE line with n_gpus 2.  On a one-GPU box both ranks share the device (--oversubscribe:
+    a rehearsal of the multi-process path, not a scaling number)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ndev = hip_lib.scann_device_count()
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-extras",
+           "--min-time", "0.2", "--prewarm", "0.1", "--pool", "32"] + (["--oversubscribe"] if ndev < 2 else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0
+    assert out.get("oversubscribed", False) == (ndev < 2)
+    assert out["roofline"]["launches_sampled"] > 0 and 0 < out["roofline"]["frac"] < 1.5

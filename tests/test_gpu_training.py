@@ -379,3 +379,100 @@ def test_gradients_with_more_than_64_neighbours(hip_lib):
     bad = {k: v for k, v in errs.items() if not v <= 2e-3}
     assert not bad, bad
     rb.free()
+
+
+_RCCL_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle")]
+import scann_oracle as so
+from scann import _hip
+from scann.models.scann_model import HipModel, normalize_config
+from scann.models.trainer import Communicator
+from scann.parallel import rank_slice, slice_packed
+
+rank = int(os.environ["RANK"])
+cfg = normalize_config(so.default_config("qm9")); cfg["model"]["n_attention"] = 2
+model = HipModel(cfg, device=int(os.environ["LOCAL_RANK"]), seed=100 + rank)   # DIFFERENT initialiser draw per rank
+eng = model.engine
+eng.train_begin()
+comm = Communicator(eng)                                                       # ncclCommInitRank(world=2) + weight broadcast
+assert comm.world == 2
+w = eng.get_weights()
+digests = comm.rdzv.allgather(float(sum(np.abs(v).sum() for v in w.values())))
+assert digests[0] == digests[1], digests                                        # every replica now holds rank 0's parameters
+de, dn = so.synth_dataset(10, 3)
+inputs, tgt = so.pad_batch(de, dn, True)
+pk = _hip.pack_inputs(inputs)
+lo, hi = rank_slice(pk.n_struct, rank, 2)
+rb = eng.upload(slice_packed(pk, lo, hi))
+sse = eng.train_forward(rb, np.asarray(tgt, np.float32)[lo:hi])
+sse_g, cnt_g = comm.sum_pair(sse, hi - lo)                                      # global RMSE (losses.py:5-6)
+eng.zero_grads(); eng.train_backward(rb, sse_g, cnt_g); eng.allreduce_grads()
+g = eng.get_grads()
+if rank == 0:                                                                   # the same step on ONE rank with the whole batch
+    ref = HipModel(cfg, w, device=0).engine
+    ref.train_begin()
+    rb2 = ref.upload(pk)
+    sse1 = ref.train_forward(rb2, np.asarray(tgt, np.float32))
+    ref.zero_grads(); ref.train_backward(rb2, sse1, pk.n_struct)
+    g1 = ref.get_grads()
+    assert cnt_g == pk.n_struct and abs(sse_g - sse1) <= 1e-5 * sse1, (sse_g, sse1)
+    for k in g1:
+        scale = max(float(np.sqrt(np.mean(g1[k].astype(np.float64) ** 2))), 1e-12)
+        assert float(np.max(np.abs(g[k] - g1[k]))) <= 1e-3 * scale + 1e-9, k
+    print("RCCL2_OK")
+comm.rdzv.barrier()
+'''
+
+
+def test_two_rank_rccl_gradients_match_single_rank(hip_lib, tmp_path):
+    """configs[2] with a REAL world-size-2 RCCL communicator: two processes, one device each; the ranks start from different
+    initialiser draws (the broadcast makes them one model), all-reduced gradients and the global RMSE equal the single-rank
+    full-batch step.  Needs two GPUs: skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
+    import os
+
+    if hip_lib.scann_device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    from scann.parallel import spawn_ranks
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text("ROOT = %r\n" % root + _RCCL_WORKER)
+    assert spawn_ranks([str(script)], 2, timeout=600) == 0
+
+
+def test_validation_forward_has_no_attention_dropout(hip_lib, tmp_path):
+    """use_drop: Dropout(0.05) on the attention weights is a TRAINING-mode layer (attention.py:115-116,191).  fit() must run
+    its validation passes without it: val_mae drives ModelCheckpoint / EarlyStopping / SGDR."""
+    from scann.models import trainer
+
+    cfg, w, pk, targets, model = setup(n=6)
+    eng = model.engine
+    eng.train_begin()
+    calls = []
+    orig = eng.set_attention_dropout
+    eng.set_attention_dropout = lambda p: (calls.append(p), orig(p))[1]
+
+    class It:
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return pk, targets
+
+    class S:
+        pass
+
+    s = S()
+    cfg["model"]["use_drop"] = True
+    cfg["hyper"].update(save_path=str(tmp_path / "run"), target="homo", lr=1e-4, min_lr=1e-5, scheduler="cosine")
+    s.config, s.model, s.trainIter, s.validIter = cfg, model, It(), It()
+    hist = trainer.fit(s, epochs=1, verbose=False)
+    assert calls == [0.05, 0.0], calls  # training epoch with the rate, validation epoch without
+    rb = eng.upload(pk)
+    sse_val = eng.train_forward(rb, targets, dropout=0.0, seed=9)   # what the validation pass computed ...
+    y_inf, _ = model.engine.forward(pk, want_ga=False)              # ... equals the inference forward
+    assert abs(sse_val - float(np.sum((y_inf - targets) ** 2))) <= 1e-4 * max(sse_val, 1e-6)
+    assert np.isfinite(hist["val_mae"][0])
+    rb.free()

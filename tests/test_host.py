@@ -215,8 +215,7 @@ sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "o
 import torch, torch.distributed as dist
 import scann_oracle as so
 from scann import _hip
-from scann.models.trainer import _slice_packed
-from scann.parallel import rank_slice
+from scann.parallel import rank_slice, slice_packed
 import torch_ref
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -226,7 +225,7 @@ de, dn = so.synth_dataset(7, 12)
 inputs, targets = so.pad_batch(de, dn, True)
 pk = _hip.pack_inputs(inputs)
 lo, hi = rank_slice(pk.n_struct, rank, world)
-shard, t = _slice_packed(pk, lo, hi), targets[lo:hi]
+shard, t = slice_packed(pk, lo, hi), targets[lo:hi]
 # what scann_train_forward / scann_allreduce_sse / scann_train_backward / scann_allreduce_grads do, on the CPU stand-in:
 W = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
 y, _ = torch_ref.forward_packed(cfg, W, shard, "float64", as_tensor=True)
@@ -505,3 +504,117 @@ def test_data_iterator_cgcnn_features(tmp_path, monkeypatch):
         it = DataIterator(de, dn, batch_size=6, feature="cgcnn", atomic_features={int(k): v for k, v in bad.items()})
         for i in range(len(it)):
             it[i]
+
+
+# ---- round 2: torch-free rendezvous, self-spawning launcher, slicing helpers ----------------------------------------
+
+_RDZV_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+from scann.parallel.rendezvous import Rendezvous
+r = Rendezvous()
+assert r.world == 3
+uid = r.broadcast(bytes(range(128)) if r.rank == 0 else None)     # what Communicator does with the ncclUniqueId
+assert uid == bytes(range(128))
+assert r.allreduce_max(0.1 * (r.rank + 1)) == 0.1 * 3               # bench.py's max-over-ranks region time
+assert r.allreduce_sum(r.rank + 1) == 6
+g = r.gather([r.rank, r.rank * 2])
+assert (g == [[0, 0], [1, 2], [2, 4]]) if r.rank == 0 else g is None
+for _ in range(50):
+    r.barrier()
+r.close()
+assert "torch" not in sys.modules
+print("RDZV_OK %d" % r.rank)
+'''
+
+
+def test_rendezvous_three_ranks_without_torch(tmp_path):
+    """The ranks' host-side exchanges (ncclUniqueId broadcast, barrier, max of a time) over loopback TCP, started by the
+    package's own launcher: no torch anywhere."""
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.parallel.launch import spawn_ranks
+
+    script = tmp_path / "rdzv_worker.py"
+    script.write_text("ROOT = %r\n" % ROOT + _RDZV_WORKER)
+    assert spawn_ranks([str(script)], 3, timeout=120) == 0
+
+
+def test_bench_gpus_n_spawns_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher: the parent spawns two ranks (before touching HIP) and returns their
+    status.  Without a GPU every rank stops at the device check -- loudly, and the parent reports the failure."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU box: covered by the -m gpu tests")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-2000:]
+
+
+def test_bench_group_sizes_cover_exactly_the_steps():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for k in (1, 5, 15, 16, 20, 31, 32, 47, 100, 2000):
+        sizes = bench.group_sizes(k)
+        assert sum(sizes) == k and max(sizes) - min(sizes) <= 1
+        assert (len(sizes) == 1 and sizes[0] == k) if k < 32 else all(16 <= s <= 31 for s in sizes)
+    assert bench.group_sizes(0) == []
+    assert bench.group_sizes(7, 1) == [1] * 7
+
+
+def test_slice_packed_carries_ring_and_cgcnn():
+    from scann import _hip
+    from scann.parallel import rank_slice, slice_packed
+
+    de, dn = so.synth_dataset(9, 3)
+    inputs, _ = so.pad_batch(de, dn, True)
+    pk = _hip.pack_inputs(inputs)
+    rng = np.random.default_rng(0)
+    pk.ring = rng.random((pk.n_atom, 2)).astype(np.float32)
+    pk.cgcnn = rng.random((pk.n_atom, 92)).astype(np.float32)
+    parts = [slice_packed(pk, *rank_slice(pk.n_struct, r, 2)) for r in range(2)]
+    assert sum(p.n_struct for p in parts) == 9
+    assert np.array_equal(np.concatenate([p.ring for p in parts]), pk.ring)
+    assert np.array_equal(np.concatenate([p.cgcnn for p in parts]), pk.cgcnn)
+    back = _hip.concat_packed(parts)
+    for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight", "ring", "cgcnn"):
+        assert np.array_equal(getattr(back, f), getattr(pk, f)), f
+
+
+def test_packed_dataset_signature_and_rank_parts():
+    """PackedDataset takes DataIterator's keyword set (SCANN.prepare_dataset(packed=True) passes atomic_features) and a
+    rank's part of a batch equals that rank's slice of the whole batch."""
+    from scann import _hip
+    from scann.parallel import rank_slice, slice_packed
+    from scann.utils import PackedDataset
+
+    de, dn = so.synth_dataset(23, 8)
+    ds = PackedDataset(data_energy=de, data_neighbor=dn, batch_size=10, use_ring=False, feature="atomic", g_update=True,
+                       atomic_features=None, shuffle=False)
+    assert len(ds) == 3
+    for b in range(len(ds)):
+        whole, tgt = ds[b]
+        for world in (2, 3):
+            got = [ds.batch_part(b, r, world) for r in range(world)]
+            assert np.array_equal(np.concatenate([t for _, t in got]), tgt)
+            for r, (p, _) in enumerate(got):
+                ref = slice_packed(whole, *rank_slice(whole.n_struct, r, world))
+                for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+                    assert np.array_equal(getattr(p, f), getattr(ref, f)), (b, world, r, f)
+    flat = PackedDataset.from_arrays(ds.mol_offset, ds.atomic, ds.edge_offset, ds.edge_local, ds.edge_dist, ds.edge_weight,
+                                     ds.target, batch_size=10)
+    a, b = flat[1], ds[1]
+    assert np.array_equal(a[0].edge_col, b[0].edge_col) and np.array_equal(a[1], b[1])
+
+
+def test_package_does_not_import_torch():
+    """north_star: Python host code + ctypes, no PyTorch on the product path."""
+    code = ("import sys; sys.path.insert(0, %r); import scann, scann.models, scann.parallel, scann.utils, "
+            "scann.models.trainer; assert 'torch' not in sys.modules and 'tensorflow' not in sys.modules; print('CLEAN')"
+            % os.path.join(ROOT, "scann--material_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "CLEAN" in r.stdout, r.stderr[-2000:]
+    pkg = os.path.join(ROOT, "scann--material_amd")
+    hits = subprocess.run(["grep", "-rnE", r"^\s*(import|from)\s+torch", pkg, "--include=*.py"], capture_output=True, text=True)
+    assert hits.stdout.strip() == "", hits.stdout
