@@ -143,7 +143,9 @@ int scann_edge_timing_read(scann_handle_t* h, double* avg_us, int64_t* n_launche
 /* Test hook: copy an intermediate of the last forward of `db` to host.
  * what: 0 = centers after layer `layer` (0 = after dense_embed) [n_atom,128];
  *       1 = geometry features after layer `layer` [n_edge,128];
- *       2 = context (LocalAttention output incl. layer_norm) of layer `layer`>=1 [n_atom,128].
+ *       2 = context (LocalAttention output incl. layer_norm) of layer `layer`>=1 [n_atom,128];
+ *       3..7 (g_update, after scann_train_forward only) = K, ang, V, T [n_edge,128] and q [n_atom,128] kept for the backward
+ *       by LocalAttention `layer`>=1.
  * Only valid when the forward was run with scann_set_debug(h, 1) (keeps per-layer copies). */
 int scann_set_debug(scann_handle_t* h, int on);
 int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer, float* out);

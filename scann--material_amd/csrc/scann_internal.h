@@ -14,12 +14,13 @@ constexpr int NHEAD = 8;         // num_head
 constexpr int HDIM = D / NHEAD;  // 16
 constexpr int NG = 20;           // Gaussian basis size (scann_model.py:378)
 constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict-free b128 A-fragment reads)
-constexpr int TE_MAX = 64;       // edge rows per edge tile: 32 or 64 (one or two 32-row MFMA row tiles)
+constexpr int TE_MAX = 64;       // edge rows per edge tile (two 32-row MFMA row tiles)
 constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row tile)
-constexpr int TQ = 24;           // atoms per EDGE tile when edge_kernel_lean runs (its query-row buffer)
-constexpr int TQ32H = 16;        // the same for edge_kernel_lean32 (32-edge tiles)
+constexpr int TQ = 24;           // atoms per EDGE tile (the query-row buffer of edge_kernel)
 constexpr int TB = 16;           // edges per basis-kernel workgroup (64 measured slower: 0.095 vs 0.088 ms per 16-batch forward)
-constexpr int WPACK = D * D;     // floats in one packed 128x128 weight
+constexpr int WPACK = D * D;     // floats in one packed 128x128 weight (fp32 fragment order, or its split-fp16 image: same bytes)
+constexpr float WSCALE = 256.f;  // split-fp16 weights are stored times 2^8 (their lo parts stay normal fp16 numbers); exact inverse in the epilogues
+constexpr float WMAX = 65504.f / WSCALE;  // largest weight magnitude the fp16 hi part can hold
 
 // Inverted dropout keyed by (seed, tag, element index): the backward pass regenerates the identical mask.
 // Returns 0 (dropped) or 1/(1-p).
@@ -47,8 +48,10 @@ struct LayerParams {
   const float *W1p, *W3p, *bg;  // filter_geo rows [0,128) (centre) and [256,384) (neighbour) + bias
   const float *Wqp, *bq;        // query
   // edge-tile kernel
-  const float *W2p;             // filter_geo rows [128,256) (geometry)
+  const float *W2p;             // filter_geo rows [128,256) (geometry), fp32 fragment order (training kernels)
   const float *Wkp, *bk;        // key
+  const _Float16 *W2h, *Wkh;    // the same two kernels as split-fp16 images (pack_weight_f16): what edge_kernel multiplies with
+  const _Float16 *Wfh;          // base branch: filter_geo [20,128] zero-padded to K = 32, split-fp16 image
   const float *lng_g, *lng_b;   // layer_norm_g
   const float *ln_g, *ln_b;     // layer_norm
   const float *Wfg, *bfg;       // base branch (g_update False): filter_geo [20,128] raw + bias
@@ -122,16 +125,12 @@ struct AtomArgs {
 void launch_atom(const AtomArgs& a, hipStream_t s);
 
 struct EdgeArgs {
-  const EdgeTile* tiles;
+  const EdgeTile* tiles;       // whole atoms per tile: <= TE_MAX edges and <= TQ atoms
   int32_t n_tile;
-  int32_t tile_rows;           // 32 or 64: edge rows per tile the tile table was built for
-  int32_t xcd_remap;           // contiguous run of tiles per XCD (edge_kernel_w8)
-  int32_t waves8;              // run the 8-wave (512-thread) variant edge_kernel_w8
-  int32_t lean;                // run edge_kernel_lean (tiles must hold <= TQ atoms)
-  int32_t lean_wgs;            // > 0: edge_kernel_leanp, the persistent form, with this many workgroups (a multiple of 8)
-  // atoms with more than 64 neighbours (edge_kernel_lean only): their edges are cut into chunk tiles of one atom each;
-  // tile_part[tile] = partial slot of a chunk tile, -1 for ordinary tiles (null: no such atom in the batch); a chunk tile
-  // leaves (running max, sum, unnormalised context) per column in part_buf[slot][3][128] for edge_merge_kernel
+  int32_t xcd_remap;           // contiguous run of tiles per XCD
+  // atoms with more than 64 neighbours: their edges are cut into chunk tiles of one atom each; tile_part[tile] = partial slot
+  // of a chunk tile, -1 for ordinary tiles (null: no such atom in the batch); a chunk tile leaves (running max, sum,
+  // unnormalised context) per column in part_buf[slot][3][128] for edge_merge_kernel
   const int32_t* tile_part;
   float* part_buf;
   int32_t g_update;
@@ -139,10 +138,10 @@ struct EdgeArgs {
   const int32_t* edge_col;     // [n_edge]
   const int32_t* edge_row;     // [n_edge] centre atom of each edge
   float* geom;                 // [n_edge,128] in/out (g_update)
-  // training forward with edge_kernel_lean: per-edge tensors the backward would otherwise recompute (null in inference):
+  // training forward: per-edge tensors the backward would otherwise recompute (null in inference):
   // V = G.W2 + P1[i] + P3[j], T = swish(V) + G (LayerNorm_g input), ang = c[j] * geom', K = ang.Wk + bk -- all [n_edge,128]
   float *keep_V, *keep_T, *keep_ang, *keep_K;
-  float* geom_out;             // edge_kernel_lean only: where geom' goes (null: in place) -- keep-mode writes each layer's geometry to its own slice
+  float* geom_out;             // where geom' goes (null: in place) -- keep-mode writes each layer's geometry to its own slice
   const float* gd;             // [n_edge,20] raw distance basis (base)
   const float* edge_weight;    // [n_edge] (base)
   const float *c, *P1, *P3, *q;  // [n_atom,128]
@@ -181,5 +180,9 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
 
 // Host-side permutation of a row-major [128,128] (in,out) kernel into MFMA fragment order.
 void pack_weight(const float* W, int ld, float* Wp);
+// Split-fp16 image of rows [0, k_real) of a row-major [*,128] kernel for v_mfma_f32_32x32x16_f16 (edge_kernel: mma_split):
+// [wave 4][k-step ks][plane hi|lo][lane 64][8 halfs], element j of lane l = fp16 part of WSCALE * W[16 s + 8 (l >> 5) + j][32 w + (l & 31)]
+// (zero for k >= k_real).  4 * ks * 2 * 64 * 8 halfs = ks * 2048 floats' worth of bytes.
+void pack_weight_f16(const float* W, int ld, int k_real, int ks, uint16_t* out);
 
 }  // namespace scann

@@ -396,293 +396,32 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 }
 
 // ---- edge-tile kernel ------------------------------------------------------------------------------
-
-#ifndef EDGE_OCC32
-#define EDGE_OCC32 3  // waves per SIMD requested for the 32-row tile variant
-#endif
-// RT = 32-row MFMA row tiles per edge tile (tile holds <= 32*RT edges of whole atoms, <= TA atoms).
-template <bool GUPD, int RT>
-__global__ __launch_bounds__(256, RT == 1 ? EDGE_OCC32 : 2) void edge_kernel(EdgeArgs a) {
-  constexpr int TEK = 32 * RT;     // edge rows per tile
-  constexpr int TPR = 256 / TEK;   // threads per edge row in the row pass (4 or 8)
-  constexpr int NCH = 32 / TPR;    // float4 chunks per thread
-  constexpr int SA_ROWS = TEK > TA ? TEK : TA;
-  __shared__ __attribute__((aligned(16))) float sA[SA_ROWS * LDS_STRIDE];  // G, then ang = c[j]*geom', then query rows
-  __shared__ __attribute__((aligned(16))) float sB[TEK * LDS_STRIDE];      // U = G W2, then K
-  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];           // logits
-  __shared__ __attribute__((aligned(16))) float sPar[4 * D];               // layer_norm_g gamma/beta, layer_norm gamma/beta
-  __shared__ int sCol[TEK], sCtr[TEK], sOff[TA + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const EdgeTile tile = a.tiles[blockIdx.x];
-  const int eb = tile.edge_begin;
-  const int ne = tile.edge_end - eb;
-  const int natom = tile.atom_end - tile.atom_begin;
-  const int col = 32 * wave + (lane & 31);
-  float* const sQ = sA;  // [<=TA][LDS_STRIDE] query rows of the tile's atoms (attention phase)
-
-  STAMP(a.stamps, 0);
-  float4 w[16];
-  if (GUPD) load_w(a.p.W2p, wave, lane, w);  // in flight while the geometry tile is staged
-  else load_w(a.p.Wkp, wave, lane, w);
-  if (tid < TEK) {
-    sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
-    sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
-  } else if (tid - TEK <= natom) {
-    sOff[tid - TEK] = a.edge_offset[tile.atom_begin + (tid - TEK)] - eb;  // tile-local CSR row pointers
-  }
-  if (tid < D) {
-    if (GUPD) {
-      sPar[tid] = a.p.lng_g[tid];
-      sPar[D + tid] = a.p.lng_b[tid];
-    }
-  } else {
-    sPar[2 * D + (tid - D)] = a.p.ln_g[tid - D];
-    sPar[3 * D + (tid - D)] = a.p.ln_b[tid - D];
-  }
-  f32x16 acc[RT];
-  if (GUPD) {
-    for (int i = tid; i < TEK * 32; i += 256) {
-      const int r = i >> 5, c4 = i & 31;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < ne) v = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
-      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = v;
-    }
-    __syncthreads();
-    STAMP(a.stamps, 1);
-    // U = G . W2  (geometry third of the concat GEMM, attention.py:142-151)
-    zero_acc(acc);
-    mma128<RT>(sA, w, lane, acc);
-    STAMP(a.stamps, 2);
-    load_w(a.p.Wkp, wave, lane, w);  // key weights arrive during the row pass
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i];
-  }
-  __syncthreads();
-  STAMP(a.stamps, 3);
-
-  // Row pass, TPR threads per edge row: geometry update + LayerNorm_g, gate with the gathered neighbour row.
-  {
-    const int r = tid / TPR, sub = tid % TPR;
-    if (r < ne) {
-      const int ctr = sCtr[r], nb = sCol[r];
-      const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
-      if (GUPD) {
-        const float4* p1 = reinterpret_cast<const float4*>(a.P1) + (size_t)ctr * 32;
-        const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
-        float4 t[NCH], cn[NCH];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) cn[i] = crow[sub + TPR * i];  // neighbour centre row (attention.py:136), used below
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const int c4 = sub + TPR * i;
-          const float4 u = *reinterpret_cast<const float4*>(&sB[r * LDS_STRIDE + 4 * c4]);
-          const float4 g = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
-          // concat order [centre, geometry, neighbour] (attention.py:143-149): (c_i W1 + b) + g W2 + c_j W3
-          const float4 v = f4add(f4add(p1[c4], u), p3[c4]);
-          t[i] = f4add(f4swish(v), g);  // geometry_update + neighbor_geometry (:153)
-          s += f4sum(t[i]);
-        }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
-        const float mean = s * (1.0f / D);
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-          v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o);
-        const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const int c4 = sub + TPR * i;
-          const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
-          const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
-          float4 y;
-          float inv;
-          inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-          inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-          inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-          inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-          reinterpret_cast<float4*>(a.geom)[(size_t)(eb + r) * 32 + c4] = y;  // threaded to the next layer (scann_model.py:415)
-          *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);  // attention.py:157
-        }
-      } else {
-        // base SCANN: geomL = swish(gd Wf + bf) * weight (attention.py:155), gd = raw Gaussian basis
-        float gd[NG];
-#pragma unroll
-        for (int k = 0; k < NG; ++k) gd[k] = a.gd[(size_t)(eb + r) * NG + k];
-        const float wgt = a.edge_weight[eb + r];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const int c4 = sub + TPR * i;
-          float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int k = 0; k < NG; ++k) {
-            const float4 wv = reinterpret_cast<const float4*>(a.p.Wfg)[k * 32 + c4];
-            acc4.x += gd[k] * wv.x; acc4.y += gd[k] * wv.y; acc4.z += gd[k] * wv.z; acc4.w += gd[k] * wv.w;
-          }
-          const float4 bv = reinterpret_cast<const float4*>(a.p.bfg)[c4];
-          float4 y = f4swish(f4add(acc4, bv));
-          y.x *= wgt; y.y *= wgt; y.z *= wgt; y.w *= wgt;
-          *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(crow[c4], y);
-        }
-      }
-    } else if (!GUPD && r < TEK) {
-      // ragged tail rows must be defined for the MFMA (GUPD staged zeros already)
-#pragma unroll
-      for (int i = 0; i < NCH; ++i)
-        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + TPR * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  // query rows of this tile's atoms: fetched now, parked in registers across the key GEMM
-  float4 qreg[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
-    qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (la < natom) qreg[i] = reinterpret_cast<const float4*>(a.q)[(size_t)(tile.atom_begin + la) * 32 + c4];
-  }
-  __syncthreads();
-  STAMP(a.stamps, 4);
-
-  // K = ang . Wk + bk  (attention.py:163)
-  zero_acc(acc);
-  mma128<RT>(sA, w, lane, acc);
-  STAMP(a.stamps, 5);
-  {
-    const float b = a.p.bk[col];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[rt][i] + b;
-  }
-  __syncthreads();  // K complete, sA no longer read by any MFMA
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i, la = idx >> 5, c4 = idx & 31;
-    *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
-  }
-  __syncthreads();
-  STAMP(a.stamps, 6);
-
-  // Attention.  Packed edges are all unmasked, so the additive -1e9 mask and the multiplicative mask
-  // (attention.py:186,206) are the identity; an atom without edges reduces to ctx = LN(q), exactly what the
-  // reference's fully-masked row yields (uniform softmax zeroed by the mask).
-  // (1) logits: thread = (edge row, 8/TPR heads); e[b,h,c,n] = sum_d (q*dk)[c,h,d] k[c,n,h,d]  (:180-183)
-  {
-    constexpr int HPT = NHEAD / TPR;  // heads per thread
-    const int n = tid / TPR, hh = tid % TPR;
-    if (n < ne) {
-      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + HDIM * HPT * hh;
-      const float* krow = sB + n * LDS_STRIDE + HDIM * HPT * hh;
-#pragma unroll
-      for (int hp = 0; hp < HPT; ++hp) {
-        float e = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 q4 = *reinterpret_cast<const float4*>(qrow + HDIM * hp + 4 * j);
-          const float4 k4 = *reinterpret_cast<const float4*>(krow + HDIM * hp + 4 * j);
-          e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
-        }
-        sE[n * NHEAD + HPT * hh + hp] = e;
-      }
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 8);
-  // (2) softmax (tf.nn.softmax, :189) + context + residual: thread = (atom group, float4 chunk); the 4 lanes of
-  // a head recompute that head's softmax rather than exchanging it.  exp via v_exp_f32, 1/sum via v_rcp_f32.
-  {
-    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
-    for (int la = lgp; la < natom; la += 8) {
-      const int e0 = sOff[la], e1 = sOff[la + 1];
-      float m = -INFINITY;
-      for (int n = e0; n < e1; ++n) m = fmaxf(m, sE[n * NHEAD + h]);
-      float ssum = 0.f;
-      for (int n = e0; n < e1; ++n) ssum += fast_exp(sE[n * NHEAD + h] - m);
-      const float rs = __builtin_amdgcn_rcpf(ssum);
-      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int n = e0; n < e1; ++n) {
-        const float attn = fast_exp(sE[n * NHEAD + h] - m) * rs;
-        const float4 k4 = *reinterpret_cast<const float4*>(&sB[n * LDS_STRIDE + 4 * c4]);
-        cx.x += attn * k4.x; cx.y += attn * k4.y; cx.z += attn * k4.z; cx.w += attn * k4.w;  // v = key (:198-206)
-      }
-      float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
-      *qp = f4add(cx, *qp);  // residual is the unscaled query (:212)
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 9);
-  // (3) LayerNorm of the context rows (:214): 8 threads per atom row
-  {
-    const int r = tid >> 3, sub = tid & 7;
-    if (r < natom) {
-      float4 t[4];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        t[i] = *reinterpret_cast<const float4*>(&sQ[r * LDS_STRIDE + 4 * (sub + 8 * i)]);
-        s += f4sum(t[i]);
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sub + 8 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + r) * 32 + c4] = y;
-      }
-    }
-  }
-  STAMP(a.stamps, 7);
-}
-
-// ---- 8-wave edge kernel: same 64-row tile, one 32x32 MFMA tile per wave ----------------------------------------
 //
-// Occupancy variant of edge_kernel<true, 2>: 512 threads, wave (rt, cb) = (wave >> 2, wave & 3) owns rows [32 rt, 32 rt+32)
-// x columns [32 cb, 32 cb+32).  Every VALU/LDS phase has twice the threads per tile (8 threads per edge row, one head per
-// thread in the logits, 16 atom groups), and the weight slab is streamed in two halves so the kernel fits 128 VGPRs:
-// 4 waves per SIMD, two workgroups per CU.
-__device__ __forceinline__ void load_w_half(const float* __restrict__ Wp, int cb, int lane, int half, float4 (&w)[8]) {
-  const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + cb * (16 * 64) + half * (8 * 64) + lane;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) w[t] = wsrc[t * 64];
-}
-__device__ __forceinline__ void mma_half(const float* __restrict__ sXrt, const float4 (&w)[8], int lane, int half, f32x16& acc) {
-  const float* xrow = sXrt + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5) + 64 * half;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * t);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc, 0, 0, 0);
-  }
-}
+// One workgroup (4 waves) per tile of <= 64 edges of <= TQ whole atoms; three workgroups per CU (<= 53.3 KB of LDS,
+// <= 168 VGPRs).  LocalAttention.call for those edges (attention.py:136-216), fused:
+//
+//   GEMM 1   U = G . W2 (g_update; base branch: gd . Wf, K = 20 padded to 32)                    split-fp16 MFMA
+//   epilogue IN THE ACCUMULATOR LAYOUT (lane = edge row, 16 columns): V = U + P1[i] + P3[j], T = swish(V) + G,
+//            LayerNorm_g statistics (lane pair -> LDS -> the row's four waves), geom' -> HBM, ang = c[j] * geom' -> LDS
+//   GEMM 2   K = ang . Wk + bk                                                                    split-fp16 MFMA
+//   epilogue logits q[i].K per (edge, head) straight from the accumulators, K -> LDS
+//   softmax over each atom's edges (online), context + unscaled-query residual, LayerNorm -> HBM
+//
+// Split-fp16 projections: every fp32 operand x is carried as two fp16 numbers, hi = fp16(x) and lo = fp16(x - hi)
+// (22 significant bits; fp16 subnormals are honoured by the matrix pipe, tools/mfma_f16_probe.hip), and a product of two
+// such operands is three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator: lo.hi + hi.lo + hi.hi (the lo.lo term is below
+// fp32 resolution).  Measured against fp64 the result is as close as the exact-fp32 MFMA chain (1.5e-7 of sum |a b| for
+// K = 128; profiles/r02_notes.md) at 3/16 of its matrix-pipe time: f16 MFMA runs at 16x the f32 rate.  Weights are split
+// once at load time (pack_weight_f16: pre-scaled by 2^8 so that their lo parts stay normal numbers; the exact inverse is
+// applied to the accumulators), activations when a tile is written to LDS -- the tile buffer holds a hi plane and a lo plane
+// of 64 x 128 fp16 instead of 64 x 128 fp32: same bytes, same b128 fragment reads.
+// Range: |activation| and |weight * 256| must stay below 65504 (scann_load_weights refuses larger weights; activations here
+// are LayerNorm / swish outputs of O(1..10)).
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PLANE_STRIDE = 136;  // halfs per staged row: 128 + 8 pad = 272 B (conflict-free b128 fragment reads)
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Consecutive tiles hold neighbouring
 // atoms of the same structures and gather the same centre rows, so give every XCD a CONTIGUOUS run of tiles
@@ -692,475 +431,371 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
   return x * q + min(x, r) + i;
 }
 
-// RTW = 32-row MFMA row tiles per workgroup: 2 -> 64-edge tiles, 512 threads (default); 1 -> 32-edge tiles, 256 threads.
-template <int RTW>
-__global__ __launch_bounds__(256 * RTW, 4) void edge_kernel_w8(EdgeArgs a) {
-  constexpr int TEK = 32 * RTW;
-  constexpr int NT = 256 * RTW;  // threads
-  __shared__ __attribute__((aligned(16))) float sA[(TEK > TA ? TEK : TA) * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sB[TEK * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
-  __shared__ __attribute__((aligned(16))) float sPar[4 * D];
-  __shared__ int sCol[TEK], sCtr[TEK], sOff[TA + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rt = wave >> 2, cb = wave & 3;
-  const EdgeTile tile = a.tiles[a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x];
-  const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
-  const int col = 32 * cb + (lane & 31);
-  float* const sQ = sA;
-
-  STAMP(a.stamps, 0);
-  float4 w[8];
-  load_w_half(a.p.W2p, cb, lane, 0, w);
-  if (tid < TEK) {
-    sCol[tid] = tid < ne ? a.edge_col[eb + tid] : 0;
-    sCtr[tid] = tid < ne ? a.edge_row[eb + tid] : 0;
-  } else if (tid - TEK <= natom) {
-    sOff[tid - TEK] = a.edge_offset[tile.atom_begin + (tid - TEK)] - eb;
-  }
-  for (int i = tid; i < 4 * D; i += NT) {
-    const float* src = i < D ? a.p.lng_g : i < 2 * D ? a.p.lng_b : i < 3 * D ? a.p.ln_g : a.p.ln_b;
-    sPar[i] = src[i & (D - 1)];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + NT * i, r = idx >> 5, c4 = idx & 31;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < ne) v = reinterpret_cast<const float4*>(a.geom)[(size_t)(eb + r) * 32 + c4];
-    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = v;
-  }
-  __syncthreads();
-  STAMP(a.stamps, 1);
-  // U = G . W2
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 0, acc);
-  load_w_half(a.p.W2p, cb, lane, 1, w);
-  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 1, acc);
-  STAMP(a.stamps, 2);
-  load_w_half(a.p.Wkp, cb, lane, 0, w);  // first half of the key weights arrives during the row pass
-#pragma unroll
-  for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[i];
-  __syncthreads();
-  STAMP(a.stamps, 3);
-
-  // row pass, 8 threads per edge row (attention.py:141-157)
-  {
-    const int r = tid >> 3, sub = tid & 7;
-    if (r < ne) {
-      const int ctr = sCtr[r], nb = sCol[r];
-      const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
-      const float4* p1 = reinterpret_cast<const float4*>(a.P1) + (size_t)ctr * 32;
-      const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
-      float4 t[4];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sub + 8 * i;
-        const float4 u = *reinterpret_cast<const float4*>(&sB[r * LDS_STRIDE + 4 * c4]);
-        const float4 g = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
-        const float4 v = f4add(f4add(p1[c4], u), p3[c4]);
-        t[i] = f4add(f4swish(v), g);
-        s += f4sum(t[i]);
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sub + 8 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        reinterpret_cast<float4*>(a.geom)[(size_t)(eb + r) * 32 + c4] = y;
-        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(crow[c4], y);
-      }
-    }
-  }
-  constexpr int NQ = 1024 / NT;
-  float4 qreg[NQ];
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const int idx = tid + NT * i, la = idx >> 5, c4 = idx & 31;
-    qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (la < natom) qreg[i] = reinterpret_cast<const float4*>(a.q)[(size_t)(tile.atom_begin + la) * 32 + c4];
-  }
-  __syncthreads();
-  STAMP(a.stamps, 4);
-  // K = ang . Wk + bk
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 0, acc);
-  load_w_half(a.p.Wkp, cb, lane, 1, w);
-  mma_half(sA + rt * 32 * LDS_STRIDE, w, lane, 1, acc);
-  STAMP(a.stamps, 5);
-  {
-    const float b = a.p.bk[col];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sB[(32 * rt + acc_row(i, lane)) * LDS_STRIDE + col] = acc[i] + b;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const int idx = tid + NT * i, la = idx >> 5, c4 = idx & 31;
-    *reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]) = qreg[i];
-  }
-  __syncthreads();
-  STAMP(a.stamps, 6);
-  // logits: thread = (edge row, head)
-  {
-    const int n = tid >> 3, hh = tid & 7;
-    if (n < ne) {
-      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + HDIM * hh;
-      const float* krow = sB + n * LDS_STRIDE + HDIM * hh;
-      float e = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
-        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
-        e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
-      }
-      sE[n * NHEAD + hh] = e;
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 8);
-  // softmax + context + residual: thread = (atom group of 16, float4 chunk).  One pass over the atom's edges with a
-  // running maximum (online softmax: exp(e - max) / sum, the max-subtracted form of tf.nn.softmax, attention.py:189,
-  // evaluated with rescaling instead of three passes); two edges per iteration so their LDS reads overlap.
-  {
-    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
-    for (int la = lgp; la < natom; la += NT / 32) {
-      const int e0 = sOff[la], e1 = sOff[la + 1];
-      float m = -INFINITY, ssum = 0.f;
-      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int n = e0; n < e1; n += 2) {
-        const bool two = n + 1 < e1;
-        const int n1 = two ? n + 1 : n;
-        const float ea = sE[n * NHEAD + h];
-        const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
-        const float4 ka = *reinterpret_cast<const float4*>(&sB[n * LDS_STRIDE + 4 * c4]);
-        const float4 kb = *reinterpret_cast<const float4*>(&sB[n1 * LDS_STRIDE + 4 * c4]);
-        const float mn = fmaxf(m, fmaxf(ea, eb2));
-        const float resc = fast_exp(m - mn);  // exp2(-inf) = 0 on the first iteration
-        float pa = fast_exp(ea - mn), pb = fast_exp(eb2 - mn);
-        ssum = ssum * resc + (pa + pb);
-        if (a.attn_drop_p > 0.f) {  // training only: dropout on the (normalised) attention weights, not on the sum
-          pa *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
-          pb *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
-        }
-        cx.x = cx.x * resc + (pa * ka.x + pb * kb.x);
-        cx.y = cx.y * resc + (pa * ka.y + pb * kb.y);
-        cx.z = cx.z * resc + (pa * ka.z + pb * kb.z);
-        cx.w = cx.w * resc + (pa * ka.w + pb * kb.w);
-        m = mn;
-      }
-      const float rs = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
-      float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
-      const float4 q4 = *qp;
-      *qp = make_float4(cx.x * rs + q4.x, cx.y * rs + q4.y, cx.z * rs + q4.z, cx.w * rs + q4.w);  // + unscaled query (:212)
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 9);
-  // LayerNorm of the context rows: 16 threads per atom row
-  for (int r = tid >> 4; r < TA; r += NT / 16) {
-    const int sub = tid & 15;
-    if (r < natom) {
-      float4 t[2];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        t[i] = *reinterpret_cast<const float4*>(&sQ[r * LDS_STRIDE + 4 * (sub + 16 * i)]);
-        s += f4sum(t[i]);
-      }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int c4 = sub + 16 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + r) * 32 + c4] = y;
-      }
-    }
-  }
-  STAMP(a.stamps, 7);
+// hi / lo fp16 parts of four consecutive fp32 values
+__device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+  l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+}
+__device__ __forceinline__ float4 join4(const f16x4 h, const f16x4 l) {
+  return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
 }
 
-// ---- lean-LDS edge kernel: three workgroups per CU ---------------------------------------------------------------
-//
-// Phase clocks of edge_kernel_w8 show the two GEMM phases saturating the MFMA pipe (8.2 k cycles each per tile) and the
-// other phases being latency chains (35 k cycles per tile), so MFMA utilisation is set by how many tiles a CU keeps in
-// flight: 2 x 16.4 k / 51.6 k = 62 %.  This variant keeps ONE 64 x 128 LDS buffer per workgroup -- G, U, ang and K
-// take turns in it; the thread that stages a piece of G keeps it in registers for the residual -- plus the query
-// rows of <= TQ atoms: 51 KB, so three workgroups (of 4 waves, <= 168 VGPRs) fit a CU.
-__device__ __forceinline__ void mma_half2(const float* __restrict__ sX, const float4 (&w)[8], int lane, int half,
-                                          f32x16 (&acc)[2]) {
-  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5) + 64 * half;
+// One wave's slab of a split weight (pack_weight_f16): [wave][k-step][plane hi|lo][lane][8 halfs] -- per k-step and plane
+// one coalesced 1-KiB read.  KS = K / 16 k-steps.
+template <int KS, int KT = KS>
+__device__ __forceinline__ void load_wsplit(const _Float16* __restrict__ Wp, int wave, int lane, f16x8 (&wh)[KS], f16x8 (&wl)[KS], int s0 = 0) {
+  const f16x8* __restrict__ src = reinterpret_cast<const f16x8*>(Wp) + (size_t)wave * (KT * 2 * 64) + lane;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int s = 0; s < KS; ++s) {
+    wh[s] = src[(2 * (s0 + s)) * 64];
+    wl[s] = src[(2 * (s0 + s) + 1) * 64];
+  }
+}
+
+// acc[rt] (transposed: lane = row 32 rt + (lane & 31), registers = 16 of the wave's 32 columns, see mma128T) +=
+// X[rows][0 .. 16 KS) . W[0 .. 16 KS)[32 wave .. +32), X given as hi / lo planes in LDS.  Operand map of
+// v_mfma_f32_32x32x16_f16 (checked with exact integers by tools/mfma_f16_probe.hip): lane l supplies A[i = l & 31][k = 8 (l >> 5) + j]
+// and B[k = 8 (l >> 5) + j][j' = l & 31], j = 0..7; weights are the A operand, so the product comes out transposed.
+template <int KS>
+__device__ __forceinline__ void mma_split(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, const f16x8 (&wh)[KS],
+                                          const f16x8 (&wl)[KS], int lane, f32x16 (&acc)[2]) {
+  const int off = (lane & 31) * PLANE_STRIDE + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
-      // operands swapped (weights as A, rows as B): the product comes out transposed, i.e. lane l holds ROW l & 31 and the
-      // sixteen columns (i & 3) + 8 (i >> 2) + 4 (l >> 5) of the wave's 32 -- four runs of four consecutive columns, so the
-      // tile is written back with ds_write_b128 instead of sixteen ds_write_b32
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, a.x, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, a.y, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, a.z, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, a.w, acc[rt], 0, 0, 0);
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(sH + off + rt * 32 * PLANE_STRIDE + 16 * s);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(sL + off + rt * 32 * PLANE_STRIDE + 16 * s);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, acc[rt], 0, 0, 0);
     }
   }
 }
-// write the transposed accumulators of mma_half2 (+ a per-column bias row, or null) to a [64][LDS_STRIDE] tile
-__device__ __forceinline__ void dump_t2(float* __restrict__ sT, const f32x16 (&acc)[2], int wave, int lane, const float* __restrict__ sBias) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = 32 * wave + 8 * j + 4 * (lane >> 5);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sBias) bv = *reinterpret_cast<const float4*>(sBias + c);
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-      *reinterpret_cast<float4*>(&sT[(32 * rt + (lane & 31)) * LDS_STRIDE + c]) =
-          make_float4(acc[rt][4 * j] + bv.x, acc[rt][4 * j + 1] + bv.y, acc[rt][4 * j + 2] + bv.z, acc[rt][4 * j + 3] + bv.w);
-  }
+
+__device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32); }
+
+// Global access as (uniform base pointer) + (32-bit per-lane BYTE offset): compiles to the saddr form of global_load / global_store
+// -- one offset VGPR per row instead of a 64-bit address pair per tensor (the tensors here are < 4 GiB each: scann_batch_upload
+// checks n_edge * 512 < 2^32).
+__device__ __forceinline__ float4 ld4(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off, const float4 v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-__global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
+template <bool GUPD>
+__global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
+#pragma clang fp contract(off)  // fusions are written out (fmaf): both unrolled row-tile copies of a formula must round alike,
+                                // so that a row's result does not depend on where in a tile it lands (batch-composition invariance)
   constexpr int TEK = 64;
-  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];  // G -> U -> ang = c[j]*geom' -> K
-  __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];   // P1 rows, then query rows of the tile's atoms, then context
-  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
-  __shared__ __attribute__((aligned(16))) float sPar[5 * D];  // layer_norm_g gamma/beta, layer_norm gamma/beta, key bias
-  __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ + 1];
+  // hi / lo planes of the A operand (G or the basis, then ang): 2 x 64 x 272 B; afterwards K as fp32 [64][LDS_STRIDE]
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TEK * PLANE_STRIDE * 2];
+  __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];  // P1 rows, then query rows of the tile's atoms, then context
+  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];      // LayerNorm_g partial statistics [row][wave][2], then logits
+  __shared__ __attribute__((aligned(16))) float sPar[5 * D];          // layer_norm_g gamma/beta (base: filter bias), layer_norm gamma/beta, key bias
+  __shared__ int sOff[TQ + 1];
+  static_assert(sizeof(sTile) >= TEK * LDS_STRIDE * sizeof(float), "K tile must fit the plane buffer");
+  _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
+  _Float16* const sL = sH + TEK * PLANE_STRIDE;
+  float* const sK = reinterpret_cast<float*>(sTile);
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tix = a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
   const EdgeTile tile = a.tiles[tix];
   const int part = a.tile_part ? a.tile_part[tix] : -1;  // >= 0: one <= 64-edge chunk of an atom with more than 64 neighbours
   const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
-  const int r = tid >> 2, sub = tid & 3;  // row-pass mapping: 4 threads per edge row, float4 chunks sub, sub+4, ...
+  const int nem1 = ne > 0 ? ne - 1 : 0;
+  const int lrow = lane & 31, lh = lane >> 5;  // accumulator layout: this lane's rows lrow, lrow + 32; column runs 32 wave + 8 j + 4 lh
+  const int cbase = 32 * wave + 4 * lh;
 
   STAMP(a.stamps, 0);
   STAMP_REAL(a.stamps, 12);  // 100 MHz reference clock at entry and exit: shader clock = cycles / ticks * 100 MHz
-  // Every load of the prologue is issued UNCONDITIONALLY (rows clamped into the tile, values selected afterwards): a load
-  // under a per-thread guard is compiled as branch + load + s_waitcnt vmcnt(0) + store, i.e. one full memory round trip
-  // per guard (16 in a row here before: 22 k cycles per tile).
-  const int nem1 = ne > 0 ? ne - 1 : 0;
-  const int rs = r < ne ? r : nem1;
-  float4 wA[8], wB[8];
-  load_w_half(a.p.W2p, wave, lane, 0, wA);
-  load_w_half(a.p.W2p, wave, lane, 1, wB);
-  const int32_t* pa = tid < TEK ? (ne > 0 ? a.edge_col + eb + min(tid, nem1) : a.edge_offset)
-                                : a.edge_offset + tile.atom_begin + min(tid - TEK, natom);
-  const int32_t* pb = ne > 0 ? a.edge_row + eb + min(tid & (TEK - 1), nem1) : a.edge_offset;
-  const int va = *pa, vb = *pb;
-  const float bkc = a.p.bk[tid & (D - 1)];  // key bias row (-> sPar): fetched with the prologue so that its wait never queues behind the geometry stores
-  const float par0 = (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)];
+  // ---- prologue: every load is issued UNCONDITIONALLY from clamped rows and selected afterwards (a load under a per-thread
+  // guard compiles to branch + load + s_waitcnt vmcnt(0): one full memory round trip per guard) -------------------------------
+  // one weight slab at a time, in two halves of 4 k-steps (A: k < 64, B: k >= 64): W2 (base branch: Wf, 2 k-steps in A), later Wk
+  f16x8 whA[4], wlA[4], whB[4], wlB[4];
+  if (GUPD) {
+    load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
+    load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+  } else {
+    f16x8 th[2], tl[2];
+    load_wsplit<2>(a.p.Wfh, wave, lane, th, tl);
+    whA[0] = th[0]; whA[1] = th[1]; wlA[0] = tl[0]; wlA[1] = tl[1];
+  }
+  unsigned nboff[2];  // byte offset of (neighbour atom row, this lane's first column) in an [n_atom,128] tensor
+  int ctr[2];         // tile-local centre atom of this lane's two edge rows
+  float ewgt[2] = {0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int e = ne > 0 ? eb + min(lrow + 32 * rt, nem1) : 0;
+    nboff[rt] = ((unsigned)(ne > 0 ? a.edge_col[e] : 0) * D + cbase) * 4;
+    ctr[rt] = ne > 0 ? a.edge_row[e] - tile.atom_begin : 0;
+    if (!GUPD) ewgt[rt] = ne > 0 ? a.edge_weight[e] : 0.f;
+  }
+  const int voff = a.edge_offset[tile.atom_begin + min(tid, natom)];
+  const float bkc = a.p.bk[tid & (D - 1)];
+  const float par0 = GUPD ? (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)] : a.p.bfg[tid & (D - 1)];
   const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
-  float4 p1reg[3];  // centre thirds P1 = c_i W1 + bg of the tile's atoms (an atom's edges share the row)
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = tid + 256 * i, la = min(idx >> 5, natom - 1), c4 = idx & 31;
-    p1reg[i] = reinterpret_cast<const float4*>(a.P1)[(size_t)(tile.atom_begin + la) * 32 + c4];
-  }
-  float4 greg[8];  // this thread's pieces of G stay in registers for the residual (attention.py:153)
   {
-    const float4* grow = reinterpret_cast<const float4*>(ne > 0 ? a.geom + (size_t)(eb + rs) * D : a.P1);
+    const int r = tid >> 2, sub = tid & 3;  // staging map: 4 threads per edge row
+    const int rs = r < ne ? r : nem1;
+    if (GUPD) {
+      float4 p1reg[3];  // centre thirds P1 = c_i W1 + bg of the tile's atoms
 #pragma unroll
-    for (int i = 0; i < 8; ++i) greg[i] = grow[sub + 4 * i];
-  }
-  if (tid < TEK) {
-    sCol[tid] = tid < ne ? va : 0;
-    sCtr[tid] = tid < ne ? vb : 0;
-  } else if (tid - TEK <= natom) {
-    sOff[tid - TEK] = part >= 0 ? (tid == TEK ? 0 : ne) : va - eb;  // a chunk tile holds edges [0, ne) of its single atom
-  }
-  sPar[tid] = par0;
-  sPar[2 * D + tid] = par1;
-  if (tid < D) sPar[4 * D + tid] = bkc;
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i, la = min(idx >> 5, natom - 1), c4 = idx & 31;
+        p1reg[i] = ld4(a.P1, ((unsigned)(tile.atom_begin + la) * 32 + c4) * 16);
+      }
+      float4 greg[8];
+      const float* gsrc = ne > 0 ? a.geom : a.P1;  // a tile without edges reads (and ignores) a valid row
+      const unsigned goff = (ne > 0 ? (unsigned)(eb + rs) * D : (unsigned)tile.atom_begin * D) * 4 + sub * 16;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = tid + 256 * i;
-    *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
-  }
+      for (int i = 0; i < 8; ++i) greg[i] = ld4(gsrc, goff + 64 * i);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (r >= ne) greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = greg[i];
-  }
-  __syncthreads();
-  STAMP(a.stamps, 1);
-  // U = G . W2
-  f32x16 acc[2];
-  zero_acc(acc);
-  mma_half2(sA, wA, lane, 0, acc);
-  mma_half2(sA, wB, lane, 1, acc);
-  STAMP(a.stamps, 2);
-  __syncthreads();  // every wave is done reading G
-  dump_t2(sA, acc, wave, lane, nullptr);
-  __syncthreads();
-  STAMP(a.stamps, 3);
-
-#ifdef SCANN_DIAG_GEMMONLY
-  // diagnostic (wrong results): prologue + the two GEMMs + their write-backs only -- the rate the matrix work alone reaches
-  load_w_half(a.p.Wkp, wave, lane, 0, wA);
-  load_w_half(a.p.Wkp, wave, lane, 1, wB);
-  __syncthreads();
-  zero_acc(acc);
-  mma_half2(sA, wA, lane, 0, acc);
-  mma_half2(sA, wB, lane, 1, acc);
-  __syncthreads();
-  dump_t2(sA, acc, wave, lane, sPar + 4 * D);
-  __syncthreads();
-  if (r < ne) reinterpret_cast<float4*>(a.geom_out ? a.geom_out : a.geom)[(size_t)(eb + r) * 32 + sub] = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * sub]);
-  return;
-#endif
-  // row pass (attention.py:141-157): u read and ang written at the thread's own positions of sA
-  if (r < ne) {
-    const int ctr = sCtr[r], nb = sCol[r];
-    const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
-    const float* p1 = sQ + (ctr - tile.atom_begin) * LDS_STRIDE;
-    const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
-    // all sixteen gathered pieces (P3 and centre row of the neighbour, attention.py:136) are requested at once: one memory
-    // round trip for the row pass (the key weights are fetched after it, so the registers are free here)
-    float4 p3r[8], cn[8];
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i;
+        *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
+      }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p3r[i] = p3[sub + 4 * i];
+      for (int i = 0; i < 8; ++i) {
+        if (r >= ne) greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        f16x4 h, l;
+        split4(greg[i], h, l);
+        *reinterpret_cast<f16x4*>(sH + r * PLANE_STRIDE + 4 * (sub + 4 * i)) = h;
+        *reinterpret_cast<f16x4*>(sL + r * PLANE_STRIDE + 4 * (sub + 4 * i)) = l;
+      }
+    } else {
+      // base SCANN (attention.py:155): the raw distance basis gd[e][0..20) of the tile's edges, zero-padded to K = 32
+      float4 gv[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) cn[i] = crow[sub + 4 * i];
-    float s = 0.f;
+      for (int i = 0; i < 2; ++i) {
+        const int c4 = sub + 4 * i;  // float4 piece 0..7 of the 32-wide row; pieces 5..7 are padding
+        gv[i] = ne > 0 ? ld4(a.gd, (unsigned)(eb + rs) * (NG * 4) + min(c4, 4) * 16) : ld4(a.q, (unsigned)tile.atom_begin * (D * 4));
+      }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c4 = sub + 4 * i;
-      const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
-      const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3r[i]);
-      greg[i] = f4add(f4swish(v), greg[i]);
-      s += f4sum(greg[i]);
-      if (a.keep_V) {  // training forward: the backward reads these instead of recomputing them
-        reinterpret_cast<float4*>(a.keep_V)[(size_t)(eb + r) * 32 + c4] = v;
-        reinterpret_cast<float4*>(a.keep_T)[(size_t)(eb + r) * 32 + c4] = greg[i];
+      for (int i = 0; i < 2; ++i) {
+        const int c4 = sub + 4 * i;
+        if (r >= ne || c4 > 4) gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        f16x4 h, l;
+        split4(gv[i], h, l);
+        *reinterpret_cast<f16x4*>(sH + r * PLANE_STRIDE + 4 * c4) = h;
+        *reinterpret_cast<f16x4*>(sL + r * PLANE_STRIDE + 4 * c4) = l;
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    load_w_half(a.p.Wkp, wave, lane, 0, wA);  // the P3 registers are free: first half of the key weights lands over the statistics
-    __builtin_amdgcn_sched_barrier(0);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    const float mean = s * (1.0f / D);
-    float v = 0.f;
+  }
+  if (tid <= natom) sOff[tid] = part >= 0 ? (tid == 0 ? 0 : ne) : voff - eb;  // a chunk tile holds edges [0, ne) of its single atom
+  sPar[tid] = par0;            // g_update: gamma | beta of layer_norm_g; base: filter bias (both halves)
+  sPar[2 * D + tid] = par1;    // gamma | beta of layer_norm
+  if (tid < D) sPar[4 * D + tid] = bkc;
+  __syncthreads();
+  STAMP(a.stamps, 1);
+
+  // gathered neighbour thirds P3[j] = c_j W3: requested before the GEMM, consumed after it
+  float4 p3r[2][4];
+  if (GUPD) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float dx = greg[i].x - mean, dy = greg[i].y - mean, dz = greg[i].z - mean, dw = greg[i].w - mean;
-      v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p3r[rt][j] = ld4(a.P3, nboff[rt] + 32 * j);
+  }
+  f32x16 acc[2];
+  zero_acc(acc);
+  if (GUPD) {
+    mma_split<4>(sH, sL, whA, wlA, lane, acc);
+    mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
+  } else {
+    f16x8 th[2] = {whA[0], whA[1]}, tl[2] = {wlA[0], wlA[1]};
+    mma_split<2>(sH, sL, th, tl, lane, acc);
+  }
+  STAMP(a.stamps, 2);
+  __builtin_amdgcn_sched_barrier(0);
+
+  constexpr float WINV = 1.0f / WSCALE;
+  const int qa = tid >> 5;  // query rows qa, qa + 8, qa + 16 of the tile go through this thread
+  const unsigned qoff = (unsigned)tile.atom_begin * (D * 4) + (tid & 31) * 16;
+  float4 q0, q1, q2;
+  float4 cn[2][4];
+  const unsigned eoff[2] = {((unsigned)(eb + lrow) * D + cbase) * 4, ((unsigned)(eb + lrow + 32) * D + cbase) * 4};  // (edge row, first column) bytes
+  float* const gout = a.geom_out ? a.geom_out : a.geom;
+  if (GUPD) {
+    // geometry update (attention.py:141-153) on the accumulators: T = swish(U + P1[i] + P3[j]) + G
+    float mean32[2], m2[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = lrow + 32 * rt;
+      const float* p1 = sQ + ctr[rt] * LDS_STRIDE + cbase;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 p1v = *reinterpret_cast<const float4*>(p1 + 8 * j);
+        const float4 g = join4(*reinterpret_cast<const f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j),
+                               *reinterpret_cast<const f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j));
+        float4 v;
+        v.x = fmaf(acc[rt][4 * j], WINV, p1v.x) + p3r[rt][j].x;
+        v.y = fmaf(acc[rt][4 * j + 1], WINV, p1v.y) + p3r[rt][j].y;
+        v.z = fmaf(acc[rt][4 * j + 2], WINV, p1v.z) + p3r[rt][j].z;
+        v.w = fmaf(acc[rt][4 * j + 3], WINV, p1v.w) + p3r[rt][j].w;
+        const float4 t = f4add(f4swish(v), g);
+        acc[rt][4 * j] = t.x; acc[rt][4 * j + 1] = t.y; acc[rt][4 * j + 2] = t.z; acc[rt][4 * j + 3] = t.w;
+        s += f4sum(t);
+        if (a.keep_V && row < ne) {  // training forward: the backward reads these instead of recomputing them
+          st4(a.keep_V, eoff[rt] + 32 * j, v);
+          st4(a.keep_T, eoff[rt] + 32 * j, t);
+        }
+      }
+      // LayerNorm_g statistics of the row: its 128 columns sit in 2 lanes x 4 waves.  Pairwise (Chan) combination of
+      // (mean, sum of squared deviations) of the eight 16-column pieces: as accurate as the two-pass form.
+      mean32[rt] = xor32(s) * (1.0f / 32.0f);
+      float v2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float d = acc[rt][i] - mean32[rt];
+        v2 = fmaf(d, d, v2);
+      }
+      m2[rt] = xor32(v2);
+      __builtin_amdgcn_sched_barrier(0);  // one row tile at a time: hoisting both tiles' LDS reads costs 40 VGPRs (spills)
     }
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+    if (lh == 0) {
+      *reinterpret_cast<float2*>(&sE[((lrow) * 4 + wave) * 2]) = make_float2(mean32[0], m2[0]);
+      *reinterpret_cast<float2*>(&sE[((lrow + 32) * 4 + wave) * 2]) = make_float2(mean32[1], m2[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the P3 registers are free: neighbour centre rows c[j] (attention.py:136) and the key weights land over the barrier
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c4 = sub + 4 * i;
-      const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
-      const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
-      float4 y;
-      float inv;
-      inv = rstd * g.x; y.x = greg[i].x * inv + (be.x - mean * inv);
-      inv = rstd * g.y; y.y = greg[i].y * inv + (be.y - mean * inv);
-      inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
-      inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
-      reinterpret_cast<float4*>(a.geom_out ? a.geom_out : a.geom)[(size_t)(eb + r) * 32 + c4] = y;
-      const float4 ang = f4mul(cn[i], y);
-      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = ang;
-      if (a.keep_ang) reinterpret_cast<float4*>(a.keep_ang)[(size_t)(eb + r) * 32 + c4] = ang;
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
+    load_wsplit<4, 8>(a.p.Wkh, wave, lane, whA, wlA, 0);  // first half of the key weights; the second half is requested at the GEMM
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // statistics complete; every wave is done with the G planes and the P1 rows
+    STAMP(a.stamps, 3);
+    // query rows of the tile's atoms: requested now, parked in sQ (the P1 rows are dead) before the key GEMM
+    q0 = ld4(a.q, qoff + min(qa, natom - 1) * (D * 4));
+    q1 = ld4(a.q, qoff + min(qa + 8, natom - 1) * (D * 4));
+    q2 = ld4(a.q, qoff + min(qa + 16, natom - 1) * (D * 4));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = lrow + 32 * rt;
+      const float4 sa = *reinterpret_cast<const float4*>(&sE[row * 8]), sb = *reinterpret_cast<const float4*>(&sE[row * 8 + 4]);
+      const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * 0.25f;
+      const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
+      const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
+      const float rstd = 1.0f / sqrtf(var + 1e-6f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[D + cbase + 8 * j]);
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = fmaf(acc[rt][4 * j], inv, be.x - mean * inv);
+        inv = rstd * g.y; y.y = fmaf(acc[rt][4 * j + 1], inv, be.y - mean * inv);
+        inv = rstd * g.z; y.z = fmaf(acc[rt][4 * j + 2], inv, be.z - mean * inv);
+        inv = rstd * g.w; y.w = fmaf(acc[rt][4 * j + 3], inv, be.w - mean * inv);
+        float4 ang = f4mul(cn[rt][j], y);  // attention.py:157
+        if (row < ne) {
+          st4(gout, eoff[rt] + 32 * j, y);  // threaded to the next layer (scann_model.py:415)
+          if (a.keep_ang) st4(a.keep_ang, eoff[rt] + 32 * j, ang);
+        } else {
+          ang = make_float4(0.f, 0.f, 0.f, 0.f);  // ragged tail rows stay defined (and zero) for the MFMA
+        }
+        f16x4 h, l;
+        split4(ang, h, l);
+        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one row tile at a time (register pressure)
     }
   } else {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)  // ragged tail rows: U of the zero rows is 0 already, keep ang = 0 explicit
-      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
-    load_w_half(a.p.Wkp, wave, lane, 0, wA);
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
+    load_wsplit<4, 8>(a.p.Wkh, wave, lane, whA, wlA, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave is done reading the basis planes
+    STAMP(a.stamps, 3);
+    // query rows of the tile's atoms: requested now, parked in sQ (the P1 rows are dead) before the key GEMM
+    q0 = ld4(a.q, qoff + min(qa, natom - 1) * (D * 4));
+    q1 = ld4(a.q, qoff + min(qa + 8, natom - 1) * (D * 4));
+    q2 = ld4(a.q, qoff + min(qa + 16, natom - 1) * (D * 4));
+    __builtin_amdgcn_sched_barrier(0);
+    // base SCANN: geomL = swish(gd Wf + bf) * weight (attention.py:155); ang = c[j] * geomL
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = lrow + 32 * rt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bf = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
+        float4 y = f4swish(make_float4(fmaf(acc[rt][4 * j], WINV, bf.x), fmaf(acc[rt][4 * j + 1], WINV, bf.y),
+                                       fmaf(acc[rt][4 * j + 2], WINV, bf.z), fmaf(acc[rt][4 * j + 3], WINV, bf.w)));
+        y.x *= ewgt[rt]; y.y *= ewgt[rt]; y.z *= ewgt[rt]; y.w *= ewgt[rt];
+        float4 ang = f4mul(cn[rt][j], y);
+        if (row >= ne) ang = make_float4(0.f, 0.f, 0.f, 0.f);
+        f16x4 h, l;
+        split4(ang, h, l);
+        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+      }
+    }
   }
-  load_w_half(a.p.Wkp, wave, lane, 1, wB);
-  // query rows: fetched here, parked in sQ as soon as the P1 rows are dead (rows clamped, never guarded: see the prologue)
-  const float4* const q4p = reinterpret_cast<const float4*>(a.q) + (size_t)tile.atom_begin * 32 + (tid & 31);
-  const int qa = tid >> 5;  // atom rows qa, qa + 8, qa + 16
-  const float4 q0 = q4p[(size_t)min(qa, natom - 1) * 32];
-  const float4 q1 = q4p[(size_t)min(qa + 8, natom - 1) * 32];
-  const float4 q2 = q4p[(size_t)min(qa + 16, natom - 1) * 32];
-  __syncthreads();  // ang complete; nobody reads the P1 rows any more
+  // query rows: the P1 rows are dead (barrier above)
   *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * (tid & 31)]) = q0;
   *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * (tid & 31)]) = q1;
   *reinterpret_cast<float4*>(&sQ[(qa + 16) * LDS_STRIDE + 4 * (tid & 31)]) = q2;
-  __builtin_amdgcn_sched_barrier(0);  // keep the stores here: sunk below the GEMM the rows get parked in scratch
+  __syncthreads();  // ang planes and query rows complete
   STAMP(a.stamps, 4);
-  // K = ang . Wk + bk
+
+  // K = ang . Wk + bk (attention.py:163); the second half of Wk arrives under the first half's MFMAs
+  load_wsplit<4, 8>(a.p.Wkh, wave, lane, whB, wlB, 4);
+  __builtin_amdgcn_sched_barrier(0);
   zero_acc(acc);
-  mma_half2(sA, wA, lane, 0, acc);
-  mma_half2(sA, wB, lane, 1, acc);
+  mma_split<4>(sH, sL, whA, wlA, lane, acc);
+  mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
   STAMP(a.stamps, 5);
-  __syncthreads();  // every wave is done reading ang
-  dump_t2(sA, acc, wave, lane, sPar + 4 * D);
-  __syncthreads();
-  if (a.keep_K && r < ne) {  // training forward: K rows of the tile (coalesced copy of the finished LDS tile)
+  // logits e[n, h] = (q[i, h, :] * 16^-0.5) . K[n, h, :] (attention.py:180-183) from the accumulators: this lane holds 8 of the
+  // 16 columns of heads 2 wave (j = 0, 1) and 2 wave + 1 (j = 2, 3) of its rows; its partner lane (^32) holds the other 8
+  float lg[2][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      reinterpret_cast<float4*>(a.keep_K)[(size_t)(eb + r) * 32 + sub + 4 * i] = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]);
-  }
-  STAMP(a.stamps, 6);
-  // logits: thread = (edge row, pair of heads)
-  {
-    const int n = tid >> 2, hh = tid & 3;
-    if (n < ne) {
-      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + 2 * HDIM * hh;
-      const float* krow = sA + n * LDS_STRIDE + 2 * HDIM * hh;
+  for (int rt = 0; rt < 2; ++rt) {
+    const float* qrow = sQ + ctr[rt] * LDS_STRIDE + cbase;
 #pragma unroll
-      for (int hp = 0; hp < 2; ++hp) {
-        float e = 0.f;
+    for (int hp = 0; hp < 2; ++hp) {
+      float e = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 q4 = *reinterpret_cast<const float4*>(qrow + HDIM * hp + 4 * j);
-          const float4 k4 = *reinterpret_cast<const float4*>(krow + HDIM * hp + 4 * j);
-          e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
-        }
-        sE[n * NHEAD + 2 * hh + hp] = e;
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * hp + jj;
+        const float4 bk = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * j);
+        const float k0 = fmaf(acc[rt][4 * j], WINV, bk.x), k1 = fmaf(acc[rt][4 * j + 1], WINV, bk.y);
+        const float k2 = fmaf(acc[rt][4 * j + 2], WINV, bk.z), k3 = fmaf(acc[rt][4 * j + 3], WINV, bk.w);
+        acc[rt][4 * j] = k0; acc[rt][4 * j + 1] = k1; acc[rt][4 * j + 2] = k2; acc[rt][4 * j + 3] = k3;
+        e = fmaf(q4.x * 0.25f, k0, e); e = fmaf(q4.y * 0.25f, k1, e); e = fmaf(q4.z * 0.25f, k2, e); e = fmaf(q4.w * 0.25f, k3, e);
       }
+      lg[rt][hp] = xor32(e);
+    }
+  }
+  __syncthreads();  // every wave is done reading the ang planes: K may overwrite them
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = lrow + 32 * rt;
+    sE[row * NHEAD + 2 * wave + lh] = lh ? lg[rt][1] : lg[rt][0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 k4 = make_float4(acc[rt][4 * j], acc[rt][4 * j + 1], acc[rt][4 * j + 2], acc[rt][4 * j + 3]);
+      *reinterpret_cast<float4*>(&sK[row * LDS_STRIDE + cbase + 8 * j]) = k4;
+      if (a.keep_K && row < ne) st4(a.keep_K, eoff[rt] + 32 * j, k4);
     }
   }
   __syncthreads();
   STAMP(a.stamps, 8);
-  // softmax + context + residual, one pass with a running maximum (see edge_kernel_w8)
+  // softmax over each atom's edges + context + unscaled-query residual (attention.py:186-212), one pass with a running maximum.
+  // Packed edges are all unmasked: the additive -1e9 and the multiplicative mask are the identity; an atom without edges
+  // yields q (then LayerNorm), which is what the reference's fully-masked row gives.
   {
     const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
     for (int la = lgp; la < natom; la += 8) {
@@ -1172,20 +807,20 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
         const int n1 = two ? n + 1 : n;
         const float ea = sE[n * NHEAD + h];
         const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
-        const float4 ka = *reinterpret_cast<const float4*>(&sA[n * LDS_STRIDE + 4 * c4]);
-        const float4 kb = *reinterpret_cast<const float4*>(&sA[n1 * LDS_STRIDE + 4 * c4]);
+        const float4 ka = *reinterpret_cast<const float4*>(&sK[n * LDS_STRIDE + 4 * c4]);
+        const float4 kb = *reinterpret_cast<const float4*>(&sK[n1 * LDS_STRIDE + 4 * c4]);
         const float mn = fmaxf(m, fmaxf(ea, eb2));
         const float resc = fast_exp(m - mn);
         float pa = fast_exp(ea - mn), pb = fast_exp(eb2 - mn);
-        ssum = ssum * resc + (pa + pb);
-        if (a.attn_drop_p > 0.f) {
+        ssum = fmaf(ssum, resc, pa + pb);
+        if (a.attn_drop_p > 0.f) {  // training with use_drop: Dropout(0.05) on the attention weights (attention.py:116,191)
           pa *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
           pb *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
         }
-        cx.x = cx.x * resc + (pa * ka.x + pb * kb.x);
-        cx.y = cx.y * resc + (pa * ka.y + pb * kb.y);
-        cx.z = cx.z * resc + (pa * ka.z + pb * kb.z);
-        cx.w = cx.w * resc + (pa * ka.w + pb * kb.w);
+        cx.x = fmaf(cx.x, resc, fmaf(pa, ka.x, pb * kb.x));
+        cx.y = fmaf(cx.y, resc, fmaf(pa, ka.y, pb * kb.y));
+        cx.z = fmaf(cx.z, resc, fmaf(pa, ka.z, pb * kb.z));
+        cx.w = fmaf(cx.w, resc, fmaf(pa, ka.w, pb * kb.w));
         m = mn;
       }
       if (part >= 0) {  // chunk tile: leave the softmax state of this chunk for edge_merge_kernel
@@ -1197,13 +832,13 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
         const float rs = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
         float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
         const float4 q4 = *qp;
-        *qp = make_float4(cx.x * rs + q4.x, cx.y * rs + q4.y, cx.z * rs + q4.z, cx.w * rs + q4.w);
+        *qp = make_float4(fmaf(cx.x, rs, q4.x), fmaf(cx.y, rs, q4.y), fmaf(cx.z, rs, q4.z), fmaf(cx.w, rs, q4.w));
       }
     }
   }
   __syncthreads();
   STAMP(a.stamps, 9);
-  // LayerNorm of the context rows: 8 threads per atom row
+  // LayerNorm of the context rows (attention.py:214): 8 threads per atom row
   {
     const int rr = tid >> 3, sb = tid & 7;
     if (rr < natom && part < 0) {
@@ -1239,7 +874,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel_lean(EdgeArgs a) {
         inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
         inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
         inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + rr) * 32 + c4] = y;
+        st4(a.ctx, ((unsigned)(tile.atom_begin + rr) * 32 + c4) * 16, y);
       }
     }
   }
@@ -1287,622 +922,11 @@ void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf,
   if (n_big > 0) hipLaunchKernelGGL(edge_merge_kernel, dim3(n_big), dim3(128), 0, s, big_tab, part_buf, q, ln_g, ln_b, ctx);
 }
 
-// ---- persistent form of edge_kernel_lean: the next tile's inputs are requested before the attention phases ------------
-//
-// Occupancy bound of the tile structure: N T_mfma / (T_other + T_mfma) with N = 3 tiles per CU; the prologue (13.5 k of the
-// 52 k cycles of T_other) is pure waiting for the tile's geometry rows, P1 rows, indices and first weight slab.  Here a
-// workgroup walks tiles blockIdx.x, + gridDim.x, ... and issues tile k+1's prologue loads into registers right after tile
-// k's logits, so they land under the softmax / LayerNorm phases; LayerNorm parameters and the key bias are staged once.
-// One tile's inputs, requested into plain locals of the kernel (a struct passed by reference stays a stack object here:
-// every fetched value went through scratch).  VT = virtual block index of the tile.
-#define LEAN_FETCH(VT)                                                                                                  \
-  do {                                                                                                                  \
-    const int tix_ = xr ? xcd_tile((VT), n_tile) : (VT);                                                                \
-    const EdgeTile tile_ = g_tiles[tix_];                                                                               \
-    t_part = g_part ? g_part[tix_] : -1;                                                                                \
-    t_eb = tile_.edge_begin; t_ne = tile_.edge_end - tile_.edge_begin; t_natom = tile_.atom_end - tile_.atom_begin;      \
-    t_abeg = tile_.atom_begin;                                                                                          \
-    const int nem1_ = t_ne > 0 ? t_ne - 1 : 0;                                                                          \
-    const int rs_ = r < t_ne ? r : nem1_;                                                                               \
-    const int32_t* pa_ = tid < 64 ? (t_ne > 0 ? g_col + t_eb + min(tid, nem1_) : g_eoff)                                \
-                                  : g_eoff + t_abeg + min(tid - 64, t_natom);                                           \
-    const int32_t* pb_ = t_ne > 0 ? g_row + t_eb + min(tid & 63, nem1_) : g_eoff;                                       \
-    t_va = *pa_; t_vb = *pb_;                                                                                           \
-    {                                                                                                                   \
-      const float4* p14_ = reinterpret_cast<const float4*>(g_P1) + (size_t)t_abeg * 32 + (tid & 31);                    \
-      const int qa_ = tid >> 5;                                                                                         \
-      t_p1a = p14_[(size_t)min(qa_, t_natom - 1) * 32];                                                                 \
-      t_p1b = p14_[(size_t)min(qa_ + 8, t_natom - 1) * 32];                                                             \
-      t_p1c = p14_[(size_t)min(qa_ + 16, t_natom - 1) * 32];                                                            \
-    }                                                                                                                   \
-    const float4* grow_ = reinterpret_cast<const float4*>(t_ne > 0 ? g_geom + (size_t)(t_eb + rs_) * D : g_P1);          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) t_g[i_] = grow_[sub + 4 * i_];                                     \
-  } while (0)
-
-__global__ __launch_bounds__(256, 3) void edge_kernel_leanp(EdgeArgs a) {
-  constexpr int TEK = 64;
-  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
-  __shared__ __attribute__((aligned(16))) float sPar[5 * D];
-  __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ + 1];
-  const int tid0 = threadIdx.x;
-  // kernel-argument fields used inside the loop, hoisted (the argument struct itself is never address-taken)
-  const EdgeTile* const g_tiles = a.tiles;
-  const int32_t* const g_part = a.tile_part;
-  const int32_t* const g_col = a.edge_col;
-  const int32_t* const g_row = a.edge_row;
-  const int32_t* const g_eoff = a.edge_offset;
-  float* const g_geom = a.geom;
-  float* const g_geom_out = a.geom_out ? a.geom_out : a.geom;
-  const float* const g_c = a.c;
-  const float* const g_P1 = a.P1;
-  const float* const g_P3 = a.P3;
-  const float* const g_q = a.q;
-  float* const g_ctx = a.ctx;
-  float* const g_pbuf = a.part_buf;
-  const float* const g_W2p = a.p.W2p;
-  const float* const g_Wkp = a.p.Wkp;
-  const int n_tile = a.n_tile, xr = a.xcd_remap, nwg = gridDim.x;
-  const float drop_p = a.attn_drop_p;
-  const unsigned drop_tag = a.attn_drop_tag;
-  const unsigned long long drop_seed = a.attn_drop_seed;
-
-  sPar[tid0] = (tid0 < D ? a.p.lng_g : a.p.lng_b)[tid0 & (D - 1)];
-  sPar[2 * D + tid0] = (tid0 < D ? a.p.ln_g : a.p.ln_b)[tid0 & (D - 1)];
-  if (tid0 < D) sPar[4 * D + tid0] = a.p.bk[tid0];
-
-  float4 t_g[8], t_p1a, t_p1b, t_p1c;
-  int t_va, t_vb, t_eb, t_ne, t_natom, t_abeg, t_part;
-  {
-    const int tid = tid0, r = tid >> 2, sub = tid & 3;
-    LEAN_FETCH((int)blockIdx.x);
-  }
-  for (int vt = blockIdx.x;;) {
-    // the thread index is re-materialised per iteration behind an opaque barrier: otherwise every per-thread address of the
-    // body (LDS rows, weight fragments, staging slots) is hoisted out of the loop and kept in registers across it (156 spills)
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6, r = tid >> 2, sub = tid & 3;
-    const int eb = t_eb, ne = t_ne, natom = t_natom, abeg = t_abeg, part = t_part;
-    float4 wA[8], wB[8];  // the weight slabs are L2-resident: requested here, they land while the tile is staged
-    load_w_half(g_W2p, wave, lane, 0, wA);
-    load_w_half(g_W2p, wave, lane, 1, wB);
-    if (tid < TEK) {
-      sCol[tid] = tid < ne ? t_va : 0;
-      sCtr[tid] = tid < ne ? t_vb : 0;
-    } else if (tid - TEK <= natom) {
-      sOff[tid - TEK] = part >= 0 ? (tid == TEK ? 0 : ne) : t_va - eb;
-    }
-    *reinterpret_cast<float4*>(&sQ[(tid >> 5) * LDS_STRIDE + 4 * (tid & 31)]) = t_p1a;
-    *reinterpret_cast<float4*>(&sQ[((tid >> 5) + 8) * LDS_STRIDE + 4 * (tid & 31)]) = t_p1b;
-    *reinterpret_cast<float4*>(&sQ[((tid >> 5) + 16) * LDS_STRIDE + 4 * (tid & 31)]) = t_p1c;
-    float4 greg[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      greg[i] = r < ne ? t_g[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = greg[i];
-    }
-    __syncthreads();
-    // U = G . W2
-    f32x16 acc[2];
-    zero_acc(acc);
-    mma_half2(sA, wA, lane, 0, acc);
-    mma_half2(sA, wB, lane, 1, acc);
-    __syncthreads();  // every wave is done reading G
-    dump_t2(sA, acc, wave, lane, nullptr);
-    __syncthreads();
-    // row pass (attention.py:141-157)
-    if (r < ne) {
-      const int ctr = sCtr[r], nb = sCol[r];
-      const float4* crow = reinterpret_cast<const float4*>(g_c) + (size_t)nb * 32;
-      const float* p1 = sQ + (ctr - abeg) * LDS_STRIDE;
-      const float4* p3 = reinterpret_cast<const float4*>(g_P3) + (size_t)nb * 32;
-      float4 cn[8];
-      float s = 0.f;
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {  // P3 pieces in two groups of four (register budget of the persistent form)
-        float4 p3r[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) p3r[i] = p3[sub + 4 * (4 * hf + i)];
-        if (hf == 1) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) cn[i] = crow[sub + 4 * i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c4 = sub + 4 * (4 * hf + i);
-          const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
-          const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3r[i]);
-          greg[4 * hf + i] = f4add(f4swish(v), greg[4 * hf + i]);
-          s += f4sum(greg[4 * hf + i]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      load_w_half(g_Wkp, wave, lane, 0, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float dx = greg[i].x - mean, dy = greg[i].y - mean, dz = greg[i].z - mean, dw = greg[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c4 = sub + 4 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = greg[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = greg[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
-        reinterpret_cast<float4*>(g_geom_out)[(size_t)(eb + r) * 32 + c4] = y;
-        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 4 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
-      load_w_half(g_Wkp, wave, lane, 0, wA);
-    }
-    load_w_half(g_Wkp, wave, lane, 1, wB);
-    const float4* const q4p = reinterpret_cast<const float4*>(g_q) + (size_t)abeg * 32 + (tid & 31);
-    const int qa = tid >> 5;
-    const float4 q0 = q4p[(size_t)min(qa, natom - 1) * 32];
-    const float4 q1 = q4p[(size_t)min(qa + 8, natom - 1) * 32];
-    const float4 q2 = q4p[(size_t)min(qa + 16, natom - 1) * 32];
-    __syncthreads();  // ang complete; nobody reads the P1 rows any more
-    *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * (tid & 31)]) = q0;
-    *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * (tid & 31)]) = q1;
-    *reinterpret_cast<float4*>(&sQ[(qa + 16) * LDS_STRIDE + 4 * (tid & 31)]) = q2;
-    __builtin_amdgcn_sched_barrier(0);
-    // K = ang . Wk + bk
-    zero_acc(acc);
-    mma_half2(sA, wA, lane, 0, acc);
-    mma_half2(sA, wB, lane, 1, acc);
-    __syncthreads();  // every wave is done reading ang
-    dump_t2(sA, acc, wave, lane, sPar + 4 * D);
-    __syncthreads();
-    // logits: thread = (edge row, pair of heads)
-    {
-      const int n = tid >> 2, hh = tid & 3;
-      if (n < ne) {
-        const float* qrow = sQ + (sCtr[n] - abeg) * LDS_STRIDE + 2 * HDIM * hh;
-        const float* krow = sA + n * LDS_STRIDE + 2 * HDIM * hh;
-#pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-          float e = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 q4 = *reinterpret_cast<const float4*>(qrow + HDIM * hp + 4 * j);
-            const float4 k4 = *reinterpret_cast<const float4*>(krow + HDIM * hp + 4 * j);
-            e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
-          }
-          sE[n * NHEAD + 2 * hh + hp] = e;
-        }
-      }
-    }
-    // the next tile's inputs are requested here: they land under the softmax / LayerNorm phases
-    const int vn = vt + nwg;
-    const bool more = vn < n_tile;
-    // (every field of `t` is dead here: the tile's scalars were copied at the top of the iteration)
-    // unconditional (the last iteration re-requests its own tile): under `if (more)` the old values would stay live through
-    // the whole iteration as the other input of the merge, i.e. 44 more registers under the GEMMs and the row pass
-    LEAN_FETCH(more ? vn : vt);
-    __syncthreads();
-    // softmax + context + residual (online form)
-    {
-      const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
-      for (int la = lgp; la < natom; la += 8) {
-        const int e0 = sOff[la], e1 = sOff[la + 1];
-        float m = -INFINITY, ssum = 0.f;
-        float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int n = e0; n < e1; n += 2) {
-          const bool two = n + 1 < e1;
-          const int n1 = two ? n + 1 : n;
-          const float ea = sE[n * NHEAD + h];
-          const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
-          const float4 ka = *reinterpret_cast<const float4*>(&sA[n * LDS_STRIDE + 4 * c4]);
-          const float4 kb = *reinterpret_cast<const float4*>(&sA[n1 * LDS_STRIDE + 4 * c4]);
-          const float mn = fmaxf(m, fmaxf(ea, eb2));
-          const float resc = fast_exp(m - mn);
-          float pa2 = fast_exp(ea - mn), pb2 = fast_exp(eb2 - mn);
-          ssum = ssum * resc + (pa2 + pb2);
-          if (drop_p > 0.f) {
-            pa2 *= drop_scale(drop_seed, drop_tag, (size_t)(eb + n) * NHEAD + h, drop_p);
-            pb2 *= drop_scale(drop_seed, drop_tag, (size_t)(eb + n1) * NHEAD + h, drop_p);
-          }
-          cx.x = cx.x * resc + (pa2 * ka.x + pb2 * kb.x);
-          cx.y = cx.y * resc + (pa2 * ka.y + pb2 * kb.y);
-          cx.z = cx.z * resc + (pa2 * ka.z + pb2 * kb.z);
-          cx.w = cx.w * resc + (pa2 * ka.w + pb2 * kb.w);
-          m = mn;
-        }
-        if (part >= 0) {
-          float* pbuf = g_pbuf + (size_t)part * 3 * D + 4 * c4;
-          *reinterpret_cast<float4*>(pbuf) = make_float4(m, m, m, m);
-          *reinterpret_cast<float4*>(pbuf + D) = make_float4(ssum, ssum, ssum, ssum);
-          *reinterpret_cast<float4*>(pbuf + 2 * D) = cx;
-        } else {
-          const float rs2 = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
-          float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
-          const float4 q4 = *qp;
-          *qp = make_float4(cx.x * rs2 + q4.x, cx.y * rs2 + q4.y, cx.z * rs2 + q4.z, cx.w * rs2 + q4.w);
-        }
-      }
-    }
-    __syncthreads();
-    // LayerNorm of the context rows: 8 threads per atom row
-    {
-      const int rr = tid >> 3, sb = tid & 7;
-      if (rr < natom && part < 0) {
-        float4 tt[4];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          tt[i] = *reinterpret_cast<const float4*>(&sQ[rr * LDS_STRIDE + 4 * (sb + 8 * i)]);
-          s += f4sum(tt[i]);
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        const float mean = s * (1.0f / D);
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float dx = tt[i].x - mean, dy = tt[i].y - mean, dz = tt[i].z - mean, dw = tt[i].w - mean;
-          v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        }
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c4 = sb + 8 * i;
-          const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
-          const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
-          float4 y;
-          float inv;
-          inv = rstd * g.x; y.x = tt[i].x * inv + (be.x - mean * inv);
-          inv = rstd * g.y; y.y = tt[i].y * inv + (be.y - mean * inv);
-          inv = rstd * g.z; y.z = tt[i].z * inv + (be.z - mean * inv);
-          inv = rstd * g.w; y.w = tt[i].w * inv + (be.w - mean * inv);
-          reinterpret_cast<float4*>(g_ctx)[(size_t)(abeg + rr) * 32 + c4] = y;
-        }
-      }
-    }
-    if (!more) break;
-    __syncthreads();  // every wave is done with sQ / sE / sOff before the next tile is staged
-    vt = vn;
-  }
-}
-
-// ---- lean-LDS edge kernel on 32-edge tiles: five workgroups per CU ----------------------------------------------------
-//
-// Same phases as edge_kernel_lean on one 32 x 128 buffer (29 KB of LDS, <= 96 VGPRs): the launch time of the edge path is
-// (rounds of tiles) x (tile latency) and the latency is a dependency chain, not matrix work, so more, smaller tiles in
-// flight per CU trade weight traffic (the kernels are re-read per tile) for matrix-pipe occupancy.  Weights stream in
-// quarter slabs through two 4 x float4 buffers.
-constexpr int TQ32 = 16;  // atoms per 32-edge tile
-__device__ __forceinline__ void load_w_quarter(const float* __restrict__ Wp, int cb, int lane, int qt, float4 (&w)[4]) {
-  const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + cb * (16 * 64) + qt * (4 * 64) + lane;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) w[t] = wsrc[t * 64];
-}
-__device__ __forceinline__ void mma_quarter1(const float* __restrict__ sX, const float4 (&w)[4], int lane, int qt, f32x16& acc) {
-  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5) + 32 * qt;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * t);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, a.x, acc, 0, 0, 0);  // transposed product (see mma_half2)
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, a.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, a.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, a.w, acc, 0, 0, 0);
-  }
-}
-// acc (+)= X[32 x 128] . W[:, 32 wave .. +32]; wa / wb hold quarters 0 / 1 on entry; `next` (or null): the kernel whose
-// quarters 0 / 1 are requested as soon as the buffers free up
-__device__ __forceinline__ void gemm32(const float* __restrict__ sX, const float* __restrict__ Wp, const float* __restrict__ next,
-                                       int wave, int lane, float4 (&wa)[4], float4 (&wb)[4], f32x16& acc) {
-  mma_quarter1(sX, wa, lane, 0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  load_w_quarter(Wp, wave, lane, 2, wa);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_quarter1(sX, wb, lane, 1, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  load_w_quarter(Wp, wave, lane, 3, wb);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_quarter1(sX, wa, lane, 2, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  if (next) load_w_quarter(next, wave, lane, 0, wa);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_quarter1(sX, wb, lane, 3, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  if (next) load_w_quarter(next, wave, lane, 1, wb);
-  __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void dump_t1(float* __restrict__ sT, const f32x16& acc, int wave, int lane, const float* __restrict__ sBias) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = 32 * wave + 8 * j + 4 * (lane >> 5);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sBias) bv = *reinterpret_cast<const float4*>(sBias + c);
-    *reinterpret_cast<float4*>(&sT[(lane & 31) * LDS_STRIDE + c]) =
-        make_float4(acc[4 * j] + bv.x, acc[4 * j + 1] + bv.y, acc[4 * j + 2] + bv.z, acc[4 * j + 3] + bv.w);
-  }
-}
-
-__global__ __launch_bounds__(256, 5) void edge_kernel_lean32(EdgeArgs a) {
-  constexpr int TEK = 32;
-  __shared__ __attribute__((aligned(16))) float sA[TEK * LDS_STRIDE];   // G -> U -> ang = c[j]*geom' -> K
-  __shared__ __attribute__((aligned(16))) float sQ[TQ32 * LDS_STRIDE];  // P1 rows, then query rows of the tile's atoms, then context
-  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];
-  __shared__ __attribute__((aligned(16))) float sPar[5 * D];
-  __shared__ int sCol[TEK], sCtr[TEK], sOff[TQ32 + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tix = a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
-  const EdgeTile tile = a.tiles[tix];
-  const int part = a.tile_part ? a.tile_part[tix] : -1;
-  const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
-  const int r = tid >> 3, sub = tid & 7;  // row-pass mapping: 8 threads per edge row, float4 chunks sub, sub+8, sub+16, sub+24
-
-  // prologue: every load unguarded from clamped rows (see edge_kernel_lean)
-  const int nem1 = ne > 0 ? ne - 1 : 0;
-  const int rs = r < ne ? r : nem1;
-  float4 wa[4], wb[4];
-  load_w_quarter(a.p.W2p, wave, lane, 0, wa);
-  load_w_quarter(a.p.W2p, wave, lane, 1, wb);
-  const int32_t* pa = tid < TEK ? (ne > 0 ? a.edge_col + eb + min(tid, nem1) : a.edge_offset)
-                                : a.edge_offset + tile.atom_begin + min(tid - TEK, natom);
-  const int32_t* pb = ne > 0 ? a.edge_row + eb + min(tid & (TEK - 1), nem1) : a.edge_offset;
-  const int va = *pa, vb = *pb;
-  const float bkc = a.p.bk[tid & (D - 1)];
-  const float par0 = (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)];
-  const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
-  const int qa = tid >> 5, qc = tid & 31;  // atom rows qa, qa + 8 of the P1 / query staging
-  const float4* const p14 = reinterpret_cast<const float4*>(a.P1) + (size_t)tile.atom_begin * 32 + qc;
-  const float4 p1a = p14[(size_t)min(qa, natom - 1) * 32], p1b = p14[(size_t)min(qa + 8, natom - 1) * 32];
-  float4 greg[4];
-  {
-    const float4* grow = reinterpret_cast<const float4*>(ne > 0 ? a.geom + (size_t)(eb + rs) * D : a.P1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) greg[i] = grow[sub + 8 * i];
-  }
-  if (tid < TEK) {
-    sCol[tid] = tid < ne ? va : 0;
-    sCtr[tid] = tid < ne ? vb : 0;
-  } else if (tid - TEK <= natom) {
-    sOff[tid - TEK] = part >= 0 ? (tid == TEK ? 0 : ne) : va - eb;
-  }
-  sPar[tid] = par0;
-  sPar[2 * D + tid] = par1;
-  if (tid < D) sPar[4 * D + tid] = bkc;
-  *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * qc]) = p1a;
-  *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * qc]) = p1b;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (r >= ne) greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 8 * i)]) = greg[i];
-  }
-  __syncthreads();
-  // U = G . W2
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  gemm32(sA, a.p.W2p, nullptr, wave, lane, wa, wb, acc);
-  __syncthreads();  // every wave is done reading G
-  dump_t1(sA, acc, wave, lane, nullptr);
-  __syncthreads();
-
-  // row pass (attention.py:141-157)
-  if (r < ne) {
-    const int ctr = sCtr[r], nb = sCol[r];
-    const float4* crow = reinterpret_cast<const float4*>(a.c) + (size_t)nb * 32;
-    const float* p1 = sQ + (ctr - tile.atom_begin) * LDS_STRIDE;
-    const float4* p3 = reinterpret_cast<const float4*>(a.P3) + (size_t)nb * 32;
-    float4 p3r[4], cn[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p3r[i] = p3[sub + 8 * i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cn[i] = crow[sub + 8 * i];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c4 = sub + 8 * i;
-      const float4 u = *reinterpret_cast<const float4*>(&sA[r * LDS_STRIDE + 4 * c4]);
-      const float4 v = f4add(f4add(*reinterpret_cast<const float4*>(p1 + 4 * c4), u), p3r[i]);
-      greg[i] = f4add(f4swish(v), greg[i]);
-      s += f4sum(greg[i]);
-    }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    const float mean = s * (1.0f / D);
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float dx = greg[i].x - mean, dy = greg[i].y - mean, dz = greg[i].z - mean, dw = greg[i].w - mean;
-      v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c4 = sub + 8 * i;
-      const float4 g = *reinterpret_cast<const float4*>(&sPar[4 * c4]);
-      const float4 be = *reinterpret_cast<const float4*>(&sPar[D + 4 * c4]);
-      float4 y;
-      float inv;
-      inv = rstd * g.x; y.x = greg[i].x * inv + (be.x - mean * inv);
-      inv = rstd * g.y; y.y = greg[i].y * inv + (be.y - mean * inv);
-      inv = rstd * g.z; y.z = greg[i].z * inv + (be.z - mean * inv);
-      inv = rstd * g.w; y.w = greg[i].w * inv + (be.w - mean * inv);
-      reinterpret_cast<float4*>(a.geom_out ? a.geom_out : a.geom)[(size_t)(eb + r) * 32 + c4] = y;
-      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * c4]) = f4mul(cn[i], y);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(&sA[r * LDS_STRIDE + 4 * (sub + 8 * i)]) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  load_w_quarter(a.p.Wkp, wave, lane, 0, wa);
-  load_w_quarter(a.p.Wkp, wave, lane, 1, wb);
-  const float4* const q4p = reinterpret_cast<const float4*>(a.q) + (size_t)tile.atom_begin * 32 + qc;
-  const float4 q0 = q4p[(size_t)min(qa, natom - 1) * 32], q1 = q4p[(size_t)min(qa + 8, natom - 1) * 32];
-  __syncthreads();  // ang complete; nobody reads the P1 rows any more
-  *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * qc]) = q0;
-  *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * qc]) = q1;
-  __builtin_amdgcn_sched_barrier(0);
-  // K = ang . Wk + bk
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  gemm32(sA, a.p.Wkp, nullptr, wave, lane, wa, wb, acc);
-  __syncthreads();  // every wave is done reading ang
-  dump_t1(sA, acc, wave, lane, sPar + 4 * D);
-  __syncthreads();
-  // logits: thread = (edge row, head)
-  {
-    const int n = tid >> 3, hh = tid & 7;
-    if (n < ne) {
-      const float* qrow = sQ + (sCtr[n] - tile.atom_begin) * LDS_STRIDE + HDIM * hh;
-      const float* krow = sA + n * LDS_STRIDE + HDIM * hh;
-      float e = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 4 * j);
-        const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
-        e += (q4.x * 0.25f) * k4.x; e += (q4.y * 0.25f) * k4.y; e += (q4.z * 0.25f) * k4.z; e += (q4.w * 0.25f) * k4.w;
-      }
-      sE[n * NHEAD + hh] = e;
-    }
-  }
-  __syncthreads();
-  // softmax + context + residual (online form, see edge_kernel_w8)
-  {
-    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
-    for (int la = lgp; la < natom; la += 8) {
-      const int e0 = sOff[la], e1 = sOff[la + 1];
-      float m = -INFINITY, ssum = 0.f;
-      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int n = e0; n < e1; n += 2) {
-        const bool two = n + 1 < e1;
-        const int n1 = two ? n + 1 : n;
-        const float ea = sE[n * NHEAD + h];
-        const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
-        const float4 ka = *reinterpret_cast<const float4*>(&sA[n * LDS_STRIDE + 4 * c4]);
-        const float4 kb = *reinterpret_cast<const float4*>(&sA[n1 * LDS_STRIDE + 4 * c4]);
-        const float mn = fmaxf(m, fmaxf(ea, eb2));
-        const float resc = fast_exp(m - mn);
-        float pa2 = fast_exp(ea - mn), pb2 = fast_exp(eb2 - mn);
-        ssum = ssum * resc + (pa2 + pb2);
-        if (a.attn_drop_p > 0.f) {
-          pa2 *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
-          pb2 *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
-        }
-        cx.x = cx.x * resc + (pa2 * ka.x + pb2 * kb.x);
-        cx.y = cx.y * resc + (pa2 * ka.y + pb2 * kb.y);
-        cx.z = cx.z * resc + (pa2 * ka.z + pb2 * kb.z);
-        cx.w = cx.w * resc + (pa2 * ka.w + pb2 * kb.w);
-        m = mn;
-      }
-      if (part >= 0) {
-        float* pbuf = a.part_buf + (size_t)part * 3 * D + 4 * c4;
-        *reinterpret_cast<float4*>(pbuf) = make_float4(m, m, m, m);
-        *reinterpret_cast<float4*>(pbuf + D) = make_float4(ssum, ssum, ssum, ssum);
-        *reinterpret_cast<float4*>(pbuf + 2 * D) = cx;
-      } else {
-        const float rs2 = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
-        float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
-        const float4 q4 = *qp;
-        *qp = make_float4(cx.x * rs2 + q4.x, cx.y * rs2 + q4.y, cx.z * rs2 + q4.z, cx.w * rs2 + q4.w);
-      }
-    }
-  }
-  __syncthreads();
-  // LayerNorm of the context rows: 8 threads per atom row
-  {
-    const int rr = tid >> 3, sb = tid & 7;
-    if (rr < natom && part < 0) {
-      float4 t[4];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        t[i] = *reinterpret_cast<const float4*>(&sQ[rr * LDS_STRIDE + 4 * (sb + 8 * i)]);
-        s += f4sum(t[i]);
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sb + 8 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        reinterpret_cast<float4*>(a.ctx)[(size_t)(tile.atom_begin + rr) * 32 + c4] = y;
-      }
-    }
-  }
-}
-
 void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
-  if (a.lean && a.lean_wgs > 0 && a.g_update && a.tile_rows == 64) {
-    const int nwg = a.n_tile < a.lean_wgs ? a.n_tile : a.lean_wgs;
-    hipLaunchKernelGGL(edge_kernel_leanp, dim3(nwg), dim3(256), 0, s, a);
-    return;
-  }
-  if (a.lean && a.g_update && a.tile_rows == 64) {
-    hipLaunchKernelGGL(edge_kernel_lean, dim3(a.n_tile), dim3(256), 0, s, a);
-    return;
-  }
-  if (a.lean && a.g_update && a.tile_rows == 32) {
-    hipLaunchKernelGGL(edge_kernel_lean32, dim3(a.n_tile), dim3(256), 0, s, a);
-    return;
-  }
-  if (a.waves8 && a.g_update && a.tile_rows == 32) {
-    hipLaunchKernelGGL(edge_kernel_w8<1>, dim3(a.n_tile), dim3(256), 0, s, a);
-    return;
-  }
-  if (a.waves8 && a.g_update && a.tile_rows == 64) {
-    hipLaunchKernelGGL(edge_kernel_w8<2>, dim3(a.n_tile), dim3(512), 0, s, a);
-    return;
-  }
   const dim3 grid(a.n_tile), block(256);
-  if (a.tile_rows == 32) {
-    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((edge_kernel<false, 1>), grid, block, 0, s, a);
-  } else {
-    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((edge_kernel<false, 2>), grid, block, 0, s, a);
-  }
+  if (a.g_update) hipLaunchKernelGGL((edge_kernel<true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((edge_kernel<false>), grid, block, 0, s, a);
 }
 
 // ---- basis kernel ----------------------------------------------------------------------------------
@@ -2178,3 +1202,4 @@ void launch_readout(const ReadoutArgs& a, hipStream_t s) {
 }
 
 }  // namespace scann
+

@@ -109,17 +109,13 @@ struct scann_handle {
   std::vector<WeightSpec> specs;
   bool loaded = false;
   bool debug = false;
-  int edge_tile = 64;  // edge rows per tile (32 or 64); env SCANN_EDGE_TILE overrides
-  int lean_persist = 0;    // env SCANN_EDGE_LEANP=1: edge_kernel_leanp (persistent form, next tile's inputs prefetched)
-  bool edge_lean = true;   // edge_kernel_lean (3 workgroups per CU, tiles of <= TQ atoms) on the g_update path; env SCANN_EDGE_LEAN=0: edge_kernel_w8
-  int tile_atoms = TA;     // atoms per edge tile the tile builder allows
+  int tile_atoms = TQ;     // atoms per edge tile the tile builder allows (edge_kernel's query-row buffer)
   int n_cu = 256;      // compute units of the device
   int time_every = 0;  // > 0: sample edge-kernel launch durations on every n-th forward (scann_edge_timing)
   int64_t time_count = 0;
   std::vector<hipEvent_t> time_ev;  // pairs (start, stop)
   std::vector<int> time_edges;
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
-  int edge_w8 = 1;     // 8-wave (512-thread) edge kernel for the g_update path; env SCANN_EDGE_W8=0 selects the 4-wave one
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -281,6 +277,63 @@ void pack_weight(const float* W, int ld, float* Wp) {
         for (int i = 0; i < 4; ++i)
           Wp[((size_t)(w * 16 + t) * 64 + lane) * 4 + i] = W[(size_t)(8 * t + 4 * (lane >> 5) + i) * ld + 32 * w + (lane & 31)];
 }
+
+// fp32 -> fp16 bits, round to nearest even, subnormals kept (host twin of the device's v_cvt_f16_f32)
+static uint16_t f32_to_f16_bits(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7FFFFFFFu;
+  if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (x > 0x7F800000u ? 0x200u : 0));  // inf / nan
+  if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                    // rounds to >= 65520: inf
+  if (x < 0x33000001u) return (uint16_t)sign;                                                  // <= 2^-25: zero
+  const int e = (int)(x >> 23) - 127;
+  uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+  int shift = 13;
+  uint32_t base;
+  if (e < -14) {  // subnormal result
+    shift += -14 - e;
+    base = 0;
+  } else {
+    base = (uint32_t)(e + 15) << 10;
+    m &= 0x7FFFFFu;
+  }
+  const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+  uint32_t r = base + q;  // a mantissa carry runs into the exponent field, which is the right result
+  if (rem > halfway || (rem == halfway && (q & 1))) ++r;
+  return (uint16_t)(sign | r);
+}
+static float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 0x3FFu;
+  float out;
+  if (e == 0) {
+    out = std::ldexp((float)m, -24);
+  } else if (e == 31) {
+    uint32_t x = 0x7F800000u | (m << 13);
+    memcpy(&out, &x, 4);
+  } else {
+    out = std::ldexp((float)(m | 0x400u), (int)e - 25);
+  }
+  uint32_t x;
+  memcpy(&x, &out, 4);
+  x |= sign;
+  memcpy(&out, &x, 4);
+  return out;
+}
+void pack_weight_f16(const float* W, int ld, int k_real, int ks, uint16_t* out) {
+  for (int w = 0; w < 4; ++w)
+    for (int s = 0; s < ks; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int k = 16 * s + 8 * (lane >> 5) + j;
+          const float x = k < k_real ? WSCALE * W[(size_t)k * ld + 32 * w + (lane & 31)] : 0.f;
+          const uint16_t hi = f32_to_f16_bits(x);
+          const uint16_t lo = f32_to_f16_bits(x - f16_bits_to_f32(hi));
+          const size_t base = ((size_t)(w * ks + s) * 2) * 64 * 8 + (size_t)lane * 8 + j;
+          out[base] = hi;
+          out[base + 64 * 8] = lo;
+        }
+}
 }  // namespace scann
 
 extern "C" {
@@ -314,13 +367,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->cfg = *cfg;
   h->device = device_id;
   h->specs = build_specs(*cfg);
-  if (const char* et = getenv("SCANN_EDGE_TILE")) h->edge_tile = atoi(et) == 32 ? 32 : 64;
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
-  if (const char* w8 = getenv("SCANN_EDGE_W8")) h->edge_w8 = atoi(w8) != 0;
-  if (const char* ln = getenv("SCANN_EDGE_LEAN")) h->edge_lean = atoi(ln) != 0;
-  if (const char* lp = getenv("SCANN_EDGE_LEANP")) h->lean_persist = atoi(lp);
-  h->edge_lean = h->edge_lean && cfg->g_update;
-  if (h->edge_lean) h->tile_atoms = h->edge_tile == 32 ? TQ32H : TQ;  // edge_kernel_lean32 / edge_kernel_lean
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -437,22 +484,40 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 1, 0});
     return off;
   };
+  auto put_f16 = [&](const float* W, int k_real, int ks) {  // split-fp16 image (edge_kernel); ks * 2048 floats' worth of bytes
+    const size_t off = img.size();
+    img.resize(off + (size_t)ks * 2048);
+    pack_weight_f16(W, D, k_real, ks, reinterpret_cast<uint16_t*>(img.data() + off));
+    h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 0, ks == 8 ? -1 : -2});
+    return off;
+  };
+  for (const WeightSpec& sp : h->specs)  // the fp16 hi part of a split weight holds |w| * 2^8 < 65504
+    if (sp.cols) {
+      const float* wp = src[sp.name];
+      for (int64_t i = 0; i < sp.numel(); ++i)
+        if (!(std::fabs(wp[i]) < WMAX))
+          return fail(h, SCANN_ERR_UNSUPPORTED, "scann_load_weights: |" + sp.name + "| reaches " + std::to_string(std::fabs(wp[i])) +
+                                                    "; the split-fp16 projections need |w| < 255.9 (or the value is not finite)");
+    }
   struct LTOff { size_t W1T, W2T, W3T, WqT, WkT, Wf1T, Wf2T; };
   std::vector<LTOff> lto(L);
   struct LOff {
     size_t W1p, W3p, bg, Wqp, bq, W2p, Wkp, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, Wf1p, bf1, Wf2p, bf2, lnr_g, lnr_b;
+    size_t W2h, Wkh, Wfh;
   };
   std::vector<LOff> lo(L);
   const size_t NONE = (size_t)-1;
   for (int i = 0; i < L; ++i) {
     const std::string p = "local_attention_" + std::to_string(i) + "/";
     LOff& o = lo[i];
-    o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
+    o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE,
+             NONE, NONE, NONE};
     const float* fg = src[p + "filter_geo/kernel"];
     lto[i] = LTOff{(size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
     if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
       o.W1p = put_packed(fg);
       o.W2p = put_packed(fg + (size_t)D * D);
+      o.W2h = put_f16(fg + (size_t)D * D, D, 8);
       o.W3p = put_packed(fg + (size_t)2 * D * D);
       lto[i].W1T = put_packedT(fg);
       lto[i].W2T = put_packedT(fg + (size_t)D * D);
@@ -462,6 +527,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       o.lng_b = put_raw(src[p + "layer_norm_g/beta"], D);
     } else {
       o.Wfg = put_raw(fg, (size_t)NG * D);
+      o.Wfh = put_f16(fg, NG, 2);
       o.bfg = put_raw(src[p + "filter_geo/bias"], D);
     }
     o.Wqp = put_packed(src[p + "query/kernel"]);
@@ -469,6 +535,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lto[i].WkT = put_packedT(src[p + "key/kernel"]);
     o.bq = put_raw(src[p + "query/bias"], D);
     o.Wkp = put_packed(src[p + "key/kernel"]);
+    o.Wkh = put_f16(src[p + "key/kernel"], D, 8);
     o.bk = put_raw(src[p + "key/bias"], D);
     o.ln_g = put_raw(src[p + "layer_norm/gamma"], D);
     o.ln_b = put_raw(src[p + "layer_norm/beta"], D);
@@ -539,6 +606,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lp.W2p = P(o.W2p); lp.Wkp = P(o.Wkp); lp.bk = P(o.bk);
     lp.lng_g = P(o.lng_g); lp.lng_b = P(o.lng_b); lp.ln_g = P(o.ln_g); lp.ln_b = P(o.ln_b);
     lp.Wfg = P(o.Wfg); lp.bfg = P(o.bfg);
+    lp.W2h = reinterpret_cast<const _Float16*>(P(o.W2h)); lp.Wkh = reinterpret_cast<const _Float16*>(P(o.Wkh));
+    lp.Wfh = reinterpret_cast<const _Float16*>(P(o.Wfh));
     lp.Wf1p = P(o.Wf1p); lp.bf1 = P(o.bf1); lp.Wf2p = P(o.Wf2p); lp.bf2 = P(o.bf2);
     lp.lnr_g = P(o.lnr_g); lp.lnr_b = P(o.lnr_b);
   }
@@ -602,6 +671,8 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     max_atoms = std::max(max_atoms, n);
   }
   if ((size_t)max_atoms * 5 * sizeof(float) > 60000) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: structure too large");
+  if ((uint64_t)std::max(A, E) * D * 4 >= (1ull << 32))  // edge_kernel addresses a tensor row as base + 32-bit byte offset
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: more than 8,388,607 atoms or edges in one batch; split it");
   if (!h->cfg.feature_cgcnn) {
     for (int a = 0; a < A; ++a)
       if (b->atomic[a] < 0 || b->atomic[a] >= h->cfg.n_atoms)
@@ -614,10 +685,10 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   std::vector<EdgeTile> tiles;
   std::vector<int32_t> tile_part, big_tab;  // atoms with more than TE_MAX neighbours (edge_kernel_lean only)
   int32_t n_slot = 0, max_degree = 0;
-  int tile_rows = h->edge_tile;
+  int tile_rows = TE_MAX;
   {
     std::string err;
-    const int r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, h->edge_tile, h->tile_atoms, h->edge_lean, tiles,
+    const int r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles,
                              tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err);
     if (r) return fail(h, r, "scann_batch_upload: " + err);
   }
@@ -779,9 +850,9 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     const int r = ensure_debug(h, db);
     if (r) return r;
   }
-  // keep-mode (training / scann_set_debug): with edge_kernel_lean every layer writes its centres, context and geometry straight
-  // into its slice of the per-layer buffers; the other edge kernels update the geometry in place and the slices are copies
-  const bool direct = h->debug && h->edge_lean && c.g_update && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ);
+  // keep-mode (training / scann_set_debug): every layer writes its centres, context and geometry straight into its slice of
+  // the per-layer buffers (base branch: no geometry to thread; the slices are filled by copies)
+  const bool direct = h->debug && c.g_update;
   const size_t nA_ = (size_t)db->n_atom * D, nE_ = (size_t)db->n_edge * D;
   auto c_of = [&](int l) { return direct ? db->dbg_c + (size_t)l * nA_ : db->c; };
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
@@ -803,7 +874,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   }
   for (int l = 0; l <= L; ++l) {
     // training forward through edge_kernel_lean: q, V, T, ang, K of every layer are kept for the backward
-    const bool keep = direct && h->in_train_forward && db->keep_K && db->tile_rows == 64 && h->lean_persist == 0 && l < L;
+    const bool keep = direct && h->in_train_forward && db->keep_K && l < L;
     // atom kernel at the head of layer l: ResidualNorm of layer l-1, centres, projections of layer l
     AtomArgs a{};
     a.n_atom = db->n_atom;
@@ -817,7 +888,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       a.ffn = c.use_attn_norm ? 1 : 0;
       const LayerParams& pp = h->layers[l - 1];
       a.Wf1p = pp.Wf1p; a.bf1 = pp.bf1; a.Wf2p = pp.Wf2p; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
-      if (a.ffn && direct && h->in_train_forward && db->keep_T2 && db->tile_rows == 64 && h->lean_persist == 0) {
+      if (a.ffn && direct && h->in_train_forward && db->keep_T2) {
         a.keep_pre1 = db->keep_pre1 + (size_t)(l - 1) * nA_; a.keep_H1 = db->keep_H1 + (size_t)(l - 1) * nA_;
         a.keep_T2 = db->keep_T2 + (size_t)(l - 1) * nA_;
       }
@@ -851,7 +922,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (h->debug && !direct) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
     if (l == L) break;
     EdgeArgs ea{};
-    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.tile_rows = db->tile_rows; ea.g_update = c.g_update;
+    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = g_of(l); ea.geom_out = direct ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
     ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
@@ -868,10 +939,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       (void)hipEventCreate(&ev1);
       (void)hipEventRecord(ev0, s);
     }
-    ea.waves8 = h->edge_w8;
-    ea.lean = h->edge_lean && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ);
     ea.tile_part = db->tile_part; ea.part_buf = db->part_buf;
-    ea.lean_wgs = h->lean_persist > 0 ? (3 * h->n_cu) / 8 * 8 : 0;
     ea.xcd_remap = h->xcd_remap;
     if (h->in_train_forward && h->attn_drop_p > 0.f) {  // validation passes run with scann_set_attention_dropout(h, 0): trainer.fit
       ea.attn_drop_p = h->attn_drop_p;
@@ -1057,6 +1125,12 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
   if (what == 0 && layer >= 0 && layer <= L) { src = db->dbg_c + layer * rowA; n = rowA; }
   else if (what == 1 && h->cfg.g_update && layer >= 0 && layer <= L) { src = db->dbg_g + layer * rowE; n = rowE; }
   else if (what == 2 && layer >= 1 && layer <= L) { src = db->dbg_ctx + (layer - 1) * rowA; n = rowA; }
+  else if (what >= 3 && what <= 7 && db->kept && layer >= 1 && layer <= L) {
+    // per-layer tensors kept by the last TRAINING forward (scann_train_forward): 3 = K, 4 = ang, 5 = V, 6 = T [n_edge,128]; 7 = q [n_atom,128]
+    const float* base = what == 3 ? db->keep_K : what == 4 ? db->keep_ang : what == 5 ? db->keep_V : what == 6 ? db->keep_T : db->keep_q;
+    n = what == 7 ? rowA : rowE;
+    src = base + (size_t)(layer - 1) * n;
+  }
   else return fail(h, SCANN_ERR_INVALID, "scann_debug_read: bad selector");
   if (n) HIPCHK(h, hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
   return SCANN_OK;
@@ -1097,7 +1171,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   const size_t rowA = align_up((size_t)db->n_atom * D * 4), rowE = align_up((size_t)std::max(db->n_edge, 1) * D * 4);
   const size_t rowB = align_up((size_t)db->n_struct * D * 4);
   // per-layer tensors kept by the training forward (edge_kernel_lean on 64-edge tiles): q [A,128]; V, T, ang, K [E,128]
-  const bool keepable = h->cfg.g_update && h->edge_lean && db->tile_rows == 64 && h->lean_persist == 0;
+  const bool keepable = h->cfg.g_update;
   const size_t Lk = keepable ? (size_t)h->cfg.n_attention : 0;
   const size_t total = 10 * rowA + 10 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
                        align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE);
@@ -1231,9 +1305,6 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   db->last_slot = 0;
   w->drop_p = dropout;
   w->seed = seed;
-  if (h->attn_drop_p > 0.f && !(h->cfg.g_update && ((h->edge_lean && db->tile_atoms <= (db->tile_rows == 32 ? TQ32H : TQ)) ||
-                                                    (h->edge_w8 && db->tile_rows == 64))))
-    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_forward: attention dropout is implemented in edge_kernel_lean / edge_kernel_w8 only");
   db->keep_q = w->keep_q; db->keep_V = w->keep_V; db->keep_T = w->keep_T; db->keep_ang = w->keep_ang; db->keep_K = w->keep_K;
   db->keep_pre1 = w->keep_pre1; db->keep_H1 = w->keep_H1; db->keep_T2 = w->keep_T2;
   db->kept = false;
@@ -1343,7 +1414,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
       launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
       launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
-                    c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
+                    w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
       launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
       launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
       launch_edge_dang(c_in, db->edge_col, eV, edAng, nullptr, eAng, edGt, E, s);  // per edge dang*geomL (in eAng) ; dgeomL = dang*c[j]
@@ -1373,7 +1444,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
     }
     launch_attn_bwd(qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
-                    c.g_update ? w.attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
+                    w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
     launch_wgrad(angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
     launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, eAng, edGt, E, s);  // per edge dang*G' (in eAng) ; dG'tot

@@ -20,7 +20,8 @@ struct RepackDesc {
   int64_t src;        // element offset into the master (canonical) parameter vector
   int64_t dst;        // element offset into the weight arena
   int32_t transpose;  // packed image of W^T instead of W (backward dX GEMMs)
-  int32_t raw;        // > 0: plain copy of this many elements (<= 16384); 0: 128x128 fragment-order pack
+  int32_t raw;        // > 0: plain copy of this many elements (<= 16384); 0: 128x128 fp32 fragment-order pack;
+                      // -1: split-fp16 image of a [128,128] kernel, -2: of a [20,128] kernel padded to K = 32 (pack_weight_f16)
 };
 
 void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags, hipStream_t s);

@@ -1122,8 +1122,24 @@ __global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float*
   const RepackDesc d = descs[blockIdx.y];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 16383
   if (idx >= D * D) return;
-  if (d.raw) {
+  if (d.raw > 0) {
     if (idx < d.raw) arena[d.dst + idx] = master[d.src + idx];
+    return;
+  }
+  if (d.raw < 0) {  // split-fp16 image (pack_weight_f16): this thread writes one 4-byte slot = halfs j, j + 1 of one lane
+    const int ks = d.raw == -1 ? 8 : 2, k_real = d.raw == -1 ? D : NG;
+    if (idx >= ks * 2048) return;
+    const int jp = idx & 3, lane = (idx >> 2) & 63, plane = (idx >> 8) & 1, sw = idx >> 9, st = sw % ks, w = sw / ks;
+    _Float16 out[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = 16 * st + 8 * (lane >> 5) + 2 * jp + u;
+      const float x = k < k_real ? WSCALE * master[d.src + (size_t)k * D + 32 * w + (lane & 31)] : 0.f;
+      const _Float16 hi = (_Float16)x;
+      out[u] = plane ? (_Float16)(x - (float)hi) : hi;
+    }
+    reinterpret_cast<_Float16*>(arena + d.dst)[2 * idx] = out[0];
+    reinterpret_cast<_Float16*>(arena + d.dst)[2 * idx + 1] = out[1];
     return;
   }
   const int i = idx & 3, lane = (idx >> 2) & 63, t = (idx >> 8) & 15, w = idx >> 12;

@@ -476,7 +476,7 @@ class Engine:
         return out[:n]
 
     def debug_read(self, rb, what, layer):
-        n = rb.packed.n_edge if what == 1 else rb.packed.n_atom
+        n = rb.packed.n_edge if what in (1, 3, 4, 5, 6) else rb.packed.n_atom
         out = np.empty((n, 128), dtype=np.float32)
         self._check(self.lib.scann_debug_read(self._h, rb._h, int(what), int(layer), _ptr(out)))
         return out
