@@ -15,7 +15,7 @@ constexpr int HDIM = D / NHEAD;  // 16
 constexpr int NG = 20;           // Gaussian basis size (scann_model.py:378)
 constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict-free b128 A-fragment reads)
 constexpr int TE_MAX = 64;       // edge rows per edge tile (two 32-row MFMA row tiles)
-constexpr int TA = 32;           // atom rows per atom tile (one 32-row MFMA row tile)
+constexpr int TA = 64;           // atom rows per atom tile (two 32-row MFMA row tiles)
 constexpr int TQ = 24;           // atoms per EDGE tile (the query-row buffer of edge_kernel)
 constexpr int TB = 16;           // edges per basis-kernel workgroup (64 measured slower: 0.095 vs 0.088 ms per 16-batch forward)
 constexpr int WPACK = D * D;     // floats in one packed 128x128 weight (fp32 fragment order, or its split-fp16 image: same bytes)
@@ -45,8 +45,9 @@ struct EdgeTile {
 // the MFMA fragment order produced by pack_weight() (see scann_kernels.hip: gemm128).
 struct LayerParams {
   // atom-tile kernel
-  const float *W1p, *W3p, *bg;  // filter_geo rows [0,128) (centre) and [256,384) (neighbour) + bias
+  const float *W1p, *W3p, *bg;  // filter_geo rows [0,128) (centre) and [256,384) (neighbour) + bias (fp32 fragment order: training kernels)
   const float *Wqp, *bq;        // query
+  const _Float16 *W1h, *W3h, *Wqh, *Wf1h, *Wf2h;  // split-fp16 images of the same kernels (atom_kernel)
   // edge-tile kernel
   const float *W2p;             // filter_geo rows [128,256) (geometry), fp32 fragment order (training kernels)
   const float *Wkp, *bk;        // key
@@ -62,6 +63,7 @@ struct LayerParams {
 struct HeadParams {
   const float *Wap, *ba;                // after_Lc
   const float *Wgqp, *bgq, *Wgkp, *bgk; // global_attention query / key
+  const _Float16 *Wah, *Wgqh, *Wgkh;    // split-fp16 images (atom_kernel mode 2)
   const float *Wb, *bb;                 // bf_property (row-major [128,128])
   const float *wo, *bo;                 // predict_property [128], [1]
 };
@@ -103,7 +105,8 @@ struct AtomArgs {
   int32_t n_atom;
   // ResidualNorm (ffn != 0): c = LN(x + W2 swish(W1 x + b1) + b2)
   int32_t ffn;
-  const float *Wf1p, *bf1, *Wf2p, *bf2, *lnr_g, *lnr_b;
+  const _Float16 *Wf1h, *Wf2h;   // split-fp16 images (pack_weight_f16)
+  const float *bf1, *bf2, *lnr_g, *lnr_b;
   float* c;                // [n_atom,128] centres out (always written)
   // training only: Dropout(0.1) on the staged rows (layer 0, scann_model.py:374) or on the ResidualNorm branch
   // (attention.py:29); drop_p == 0 in inference
@@ -112,10 +115,10 @@ struct AtomArgs {
   unsigned long long drop_seed;
   // projections
   int32_t mode;            // 0: P1,P3,q (g_update)  1: q only (base)  2: readout (after_Lc -> gq, gk)
-  const float *WAp, *bA;   // mode 0: W1p,bg   | mode 2: after_Lc
-  const float *WBp;        // mode 0: W3p
-  const float *WCp, *bC;   // mode 0/1: Wq,bq  | mode 2: ga query
-  const float *WDp, *bD;   // mode 2: ga key
+  const _Float16 *WAh, *WBh, *WCh, *WDh;  // split-fp16 images: mode 0: W1, W3, Wq | mode 1: -, -, Wq | mode 2: after_Lc, -, ga query, ga key
+  const float *bA;         // mode 0: bg        | mode 2: after_Lc bias
+  const float *bC;         // mode 0/1: bq      | mode 2: ga query bias
+  const float *bD;         // mode 2: ga key bias
   float *oA, *oB, *oC;     // mode 0: P1,P3,q | mode 1: -, -, q | mode 2: -, gk, gq
   // training forward: ResidualNorm intermediates the backward would otherwise recompute (null in inference), [n_atom,128]:
   // pre1 = x W1 + b1, H1 = swish(pre1), T2 = x + drop(H1 W2 + b2) (the LayerNorm input)

@@ -132,291 +132,7 @@ __device__ __forceinline__ int tcol(int wave, int lane, int j) { return 32 * wav
 // C/D map of the 32x32 MFMA: register i of lane l holds row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31.
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
-// ---- atom-tile kernel ------------------------------------------------------------------------------
-
-// One weight slab (64 VGPRs) is live at a time: each slab is requested right after the previous GEMM's MFMAs and pinned
-// there with sched_barrier (hipcc otherwise hoists it above them and keeps two slabs live: 202 VGPRs, 2 waves/SIMD).
-// 158 VGPRs -> 3 waves per SIMD = 3 workgroups per CU; +1.7 % end to end.  (4 waves/SIMD spills.)
-template <bool FFN, int MODE>
-__global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
-  __shared__ __attribute__((aligned(16))) float sX[TA * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sH[TA * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sLN[2 * D];  // ResidualNorm LayerNorm gamma, beta
-  __shared__ __attribute__((aligned(16))) float sBias[5 * D];  // rows: bf1, bf2, bA, bC, bD
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * TA;
-  const int nrows = min(TA, a.n_atom - row0);
-  const int trow = lane & 31;  // this lane's row in the transposed accumulator layout (mma128T)
-  // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
-  const float* const firstW = MODE == 1 ? a.WCp : a.WAp;
-
-  STAMP(a.stamps, 0);
-  // vmcnt retires in issue order: a bias or LayerNorm parameter requested after a weight slab waits for the whole slab,
-  // and one requested after output stores waits for their acknowledgements.  So every small operand is fetched here, first.
-  {
-    const int j = tid & (D - 1);
-    const bool lo = tid < D;
-    const float v0 = FFN ? (lo ? a.bf1 : a.bf2)[j] : 0.f;
-    const float v1 = MODE == 1 ? a.bC[j] : (lo ? a.bA : a.bC)[j];
-    const float v2 = MODE == 2 ? a.bD[j] : 0.f;
-    const float v3 = FFN ? (lo ? a.lnr_g : a.lnr_b)[j] : 0.f;
-    sBias[tid] = v0;                              // bf1 | bf2
-    sBias[2 * D + tid] = v1;                      // bA | bC   (mode 1: bC in both halves)
-    if (lo) sBias[4 * D + j] = v2;                // bD
-    sLN[tid] = v3;
-  }
-  float4 wA[16];
-  if (FFN) load_w(a.Wf1p, wave, lane, wA);
-  else load_w(firstW, wave, lane, wA);
-
-  // stage x rows (zero-fill the ragged tail so the MFMAs see defined data).  The four row loads of a thread are issued
-  // together from clamped rows and masked afterwards: a load under a per-thread guard costs a full memory round trip each.
-  {
-    const int c4 = tid & 31, r0 = tid >> 5;  // rows r0, r0 + 8, r0 + 16, r0 + 24
-    int src[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rc = min(r0 + 8 * k, nrows - 1);
-      src[k] = a.x_index ? a.x_index[row0 + rc] : (row0 + rc);
-    }
-    float4 xv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xv[k] = reinterpret_cast<const float4*>(a.x)[(size_t)src[k] * 32 + c4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r = r0 + 8 * k;
-      float4 v = r < nrows ? xv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nrows) {
-        if (!FFN && a.drop_p > 0.f) {  // training: Dropout after dense_embed (scann_model.py:374)
-          const size_t e = (size_t)(row0 + r) * D + 4 * c4;
-          v.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
-          v.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
-          v.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
-          v.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
-        }
-        if (!FFN) reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] = v;  // centres = staged rows (layer 0 / no ResidualNorm)
-      }
-      *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = v;
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 1);
-
-  f32x16 acc;
-  if (FFN) {
-    // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    mma128T(sX, wA, lane, acc);
-    STAMP(a.stamps, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(a.Wf2p, wave, lane, wA);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tcol(wave, lane, j);
-      const float4 bv = *reinterpret_cast<const float4*>(&sBias[c]);
-      const float4 pre = make_float4(acc[4 * j] + bv.x, acc[4 * j + 1] + bv.y, acc[4 * j + 2] + bv.z, acc[4 * j + 3] + bv.w);
-      const float4 hh = make_float4(swishf(pre.x), swishf(pre.y), swishf(pre.z), swishf(pre.w));
-      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) = hh;
-      if (a.keep_pre1 && trow < nrows) {  // training forward: kept for the backward
-        *reinterpret_cast<float4*>(a.keep_pre1 + (size_t)(row0 + trow) * D + c) = pre;
-        *reinterpret_cast<float4*>(a.keep_H1 + (size_t)(row0 + trow) * D + c) = hh;
-      }
-    }
-    __syncthreads();
-    STAMP(a.stamps, 3);
-    // y = h W2 + b2 ; t = x + y
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    mma128T(sH, wA, lane, acc);
-    STAMP(a.stamps, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(firstW, wave, lane, wA);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // every wave is done reading sH
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tcol(wave, lane, j);
-      const float4 bv = *reinterpret_cast<const float4*>(&sBias[D + c]);
-      const float4 xv = *reinterpret_cast<const float4*>(&sX[trow * LDS_STRIDE + c]);
-      float4 y = make_float4(acc[4 * j] + bv.x, acc[4 * j + 1] + bv.y, acc[4 * j + 2] + bv.z, acc[4 * j + 3] + bv.w);
-      if (a.drop_p > 0.f) {  // attention.py:29 (training)
-        const size_t e = (size_t)(row0 + trow) * D + c;
-        y.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
-        y.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
-        y.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
-        y.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
-      }
-      const float4 t2 = f4add(xv, y);
-      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) = t2;
-      if (a.keep_T2 && trow < nrows) *reinterpret_cast<float4*>(a.keep_T2 + (size_t)(row0 + trow) * D + c) = t2;
-    }
-    __syncthreads();
-    STAMP(a.stamps, 5);
-    // c = LayerNorm(t): 8 threads per row, 4 float4 each
-    {
-      const int r = tid >> 3, sub = tid & 7;
-      float4 t[4];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        t[i] = *reinterpret_cast<const float4*>(&sH[r * LDS_STRIDE + 4 * (sub + 8 * i)]);
-        s += f4sum(t[i]);
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sub + 8 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sLN[4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sLN[D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = y;
-        if (r < nrows) reinterpret_cast<float4*>(a.c)[(size_t)(row0 + r) * 32 + c4] = y;
-      }
-    }
-    __syncthreads();
-    STAMP(a.stamps, 6);
-  }
-
-  // The projections stay in registers until the last weight slab has been requested; their stores go out together at
-  // the end (16-byte pieces) so that no load of this workgroup ever queues behind a store acknowledgement.
-  f32x16 accP1, accP3;
-  if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accP1[i] = 0.f;
-    mma128T(sX, wA, lane, accP1);
-    STAMP(a.stamps, 7);
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(a.WBp, wave, lane, wA);
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(a.stamps, 8);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accP3[i] = 0.f;
-    mma128T(sX, wA, lane, accP3);
-    STAMP(a.stamps, 9);
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(a.WCp, wave, lane, wA);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
-    STAMP(a.stamps, 10);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    mma128T(sX, wA, lane, acc);
-    STAMP(a.stamps, 11);
-    __builtin_amdgcn_sched_barrier(0);
-    if (trow < nrows) {
-      const size_t o = (size_t)(row0 + trow) * D;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = tcol(wave, lane, j);
-        const float4 bq = *reinterpret_cast<const float4*>(&sBias[(MODE == 0 ? 3 : 2) * D + c]);
-        if (MODE == 0) {
-          const float4 bg = *reinterpret_cast<const float4*>(&sBias[2 * D + c]);
-          *reinterpret_cast<float4*>(a.oA + o + c) = make_float4(accP1[4 * j] + bg.x, accP1[4 * j + 1] + bg.y, accP1[4 * j + 2] + bg.z, accP1[4 * j + 3] + bg.w);
-          *reinterpret_cast<float4*>(a.oB + o + c) = make_float4(accP3[4 * j], accP3[4 * j + 1], accP3[4 * j + 2], accP3[4 * j + 3]);
-        }
-        *reinterpret_cast<float4*>(a.oC + o + c) = make_float4(acc[4 * j] + bq.x, acc[4 * j + 1] + bq.y, acc[4 * j + 2] + bq.z, acc[4 * j + 3] + bq.w);
-      }
-    }
-    STAMP(a.stamps, 12);
-  }
-  if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    mma128T(sX, wA, lane, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(a.WCp, wave, lane, wA);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = tcol(wave, lane, j);
-      const float4 bv = *reinterpret_cast<const float4*>(&sBias[2 * D + c]);
-      *reinterpret_cast<float4*>(&sH[trow * LDS_STRIDE + c]) =
-          make_float4(swishf(acc[4 * j] + bv.x), swishf(acc[4 * j + 1] + bv.y), swishf(acc[4 * j + 2] + bv.z), swishf(acc[4 * j + 3] + bv.w));
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accP1[i] = 0.f;
-    mma128T(sH, wA, lane, accP1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_w(a.WDp, wave, lane, wA);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    mma128T(sH, wA, lane, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (trow < nrows) {
-      const size_t o = (size_t)(row0 + trow) * D;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = tcol(wave, lane, j);
-        const float4 bq = *reinterpret_cast<const float4*>(&sBias[3 * D + c]);
-        const float4 bk = *reinterpret_cast<const float4*>(&sBias[4 * D + c]);
-        *reinterpret_cast<float4*>(a.oC + o + c) = make_float4(accP1[4 * j] + bq.x, accP1[4 * j + 1] + bq.y, accP1[4 * j + 2] + bq.z, accP1[4 * j + 3] + bq.w);
-        *reinterpret_cast<float4*>(a.oB + o + c) = make_float4(acc[4 * j] + bk.x, acc[4 * j + 1] + bk.y, acc[4 * j + 2] + bk.z, acc[4 * j + 3] + bk.w);
-      }
-    }
-  }
-}
-
-void launch_atom(const AtomArgs& a, hipStream_t s) {
-  if (a.n_atom <= 0) return;
-  const dim3 grid((a.n_atom + TA - 1) / TA), block(256);
-#define SCANN_ATOM_CASE(F, M) hipLaunchKernelGGL((atom_kernel<F, M>), grid, block, 0, s, a)
-  if (a.ffn) {
-    if (a.mode == 0) SCANN_ATOM_CASE(true, 0);
-    else if (a.mode == 1) SCANN_ATOM_CASE(true, 1);
-    else SCANN_ATOM_CASE(true, 2);
-  } else {
-    if (a.mode == 0) SCANN_ATOM_CASE(false, 0);
-    else if (a.mode == 1) SCANN_ATOM_CASE(false, 1);
-    else SCANN_ATOM_CASE(false, 2);
-  }
-#undef SCANN_ATOM_CASE
-}
-
-// ---- edge-tile kernel ------------------------------------------------------------------------------
-//
-// One workgroup (4 waves) per tile of <= 64 edges of <= TQ whole atoms; three workgroups per CU (<= 53.3 KB of LDS,
-// <= 168 VGPRs).  LocalAttention.call for those edges (attention.py:136-216), fused:
-//
-//   GEMM 1   U = G . W2 (g_update; base branch: gd . Wf, K = 20 padded to 32)                    split-fp16 MFMA
-//   epilogue IN THE ACCUMULATOR LAYOUT (lane = edge row, 16 columns): V = U + P1[i] + P3[j], T = swish(V) + G,
-//            LayerNorm_g statistics (lane pair -> LDS -> the row's four waves), geom' -> HBM, ang = c[j] * geom' -> LDS
-//   GEMM 2   K = ang . Wk + bk                                                                    split-fp16 MFMA
-//   epilogue logits q[i].K per (edge, head) straight from the accumulators, K -> LDS
-//   softmax over each atom's edges (online), context + unscaled-query residual, LayerNorm -> HBM
-//
-// Split-fp16 projections: every fp32 operand x is carried as two fp16 numbers, hi = fp16(x) and lo = fp16(x - hi)
-// (22 significant bits; fp16 subnormals are honoured by the matrix pipe, tools/mfma_f16_probe.hip), and a product of two
-// such operands is three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator: lo.hi + hi.lo + hi.hi (the lo.lo term is below
-// fp32 resolution).  Measured against fp64 the result is as close as the exact-fp32 MFMA chain (1.5e-7 of sum |a b| for
-// K = 128; profiles/r02_notes.md) at 3/16 of its matrix-pipe time: f16 MFMA runs at 16x the f32 rate.  Weights are split
-// once at load time (pack_weight_f16: pre-scaled by 2^8 so that their lo parts stay normal numbers; the exact inverse is
-// applied to the accumulators), activations when a tile is written to LDS -- the tile buffer holds a hi plane and a lo plane
-// of 64 x 128 fp16 instead of 64 x 128 fp32: same bytes, same b128 fragment reads.
-// Range: |activation| and |weight * 256| must stay below 65504 (scann_load_weights refuses larger weights; activations here
-// are LayerNorm / swish outputs of O(1..10)).
+// ---- split-fp16 projection helpers (shared by the atom and edge kernels; scheme: see the edge-tile section) ------------
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -485,6 +201,317 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ base, unsigned b
 __device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off, const float4 v) {
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+
+// ---- atom-tile kernel ------------------------------------------------------------------------------
+//
+// One workgroup (4 waves) per tile of TA = 64 atom rows, three workgroups per CU; every projection is a split-fp16 MFMA GEMM
+// of the tile (hi / lo planes in ONE LDS buffer in which x, the ResidualNorm hidden row, the centres and -- readout --
+// swish(after_Lc) take turns) against a 128x128 weight streamed from L2 in two halves of 32 VGPRs, the next half always
+// requested while the current one multiplies.  Everything between the GEMMs happens in the accumulator layout (lane = row,
+// 16 columns): bias, swish, dropout, the residual (x stays in registers, exact fp32), LayerNorm statistics (lane pair ->
+// LDS -> the row's four waves), and the output stores (16-byte pieces).
+//   FFN  : c = LN(x + drop(W2 swish(W1 x + b1) + b2))                       ResidualNorm of the previous layer, attention.py:37-40
+//   MODE 0: P1 = c W1 + bg, P3 = c W3, q = c Wq + bq                        centre / neighbour thirds of filter_geo :142-151, query :160
+//   MODE 1: q only (base branch)           MODE 2: z = swish(c Wa + ba); gq = z Wgq + b, gk = z Wgk + b   (scann_model.py:424, attention.py:269-272)
+
+// acc = X . W for the tile staged in (sH, sL), W's halves already in (whA, wlA) / (whB, wlB); when NEXT, the halves of the
+// following weight are requested into the same registers as soon as the MFMAs that read them have been issued.
+template <bool NEXT>
+__device__ __forceinline__ void gemm_tile(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, f16x8 (&whA)[4], f16x8 (&wlA)[4],
+                                          f16x8 (&whB)[4], f16x8 (&wlB)[4], const _Float16* __restrict__ next, int wave, int lane,
+                                          f32x16 (&acc)[2]) {
+  zero_acc(acc);
+  mma_split<4>(sH, sL, whA, wlA, lane, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if (NEXT) load_wsplit<4, 8>(next, wave, lane, whA, wlA, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if (NEXT) load_wsplit<4, 8>(next, wave, lane, whB, wlB, 4);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool FFN, int MODE>
+__global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
+#pragma clang fp contract(off)  // fusions are written out: both row-tile copies of a formula round alike (see edge_kernel)
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TA * PLANE_STRIDE * 2];  // hi / lo planes of the current GEMM input
+  __shared__ __attribute__((aligned(16))) float sRed[TA * 8];  // LayerNorm partial statistics [row][wave][mean, m2]
+  __shared__ __attribute__((aligned(16))) float sPar[7 * D];   // bf1 | bf2 | lnr_g | lnr_b | bA | bC | bD
+  _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
+  _Float16* const sL = sH + TA * PLANE_STRIDE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
+  const int row0 = blockIdx.x * TA;
+  const int nrows = min(TA, a.n_atom - row0);
+  constexpr float WINV = 1.0f / WSCALE;
+  // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
+  const _Float16* const firstW = MODE == 1 ? a.WCh : a.WAh;
+
+  STAMP(a.stamps, 0);
+  f16x8 whA[4], wlA[4], whB[4], wlB[4];
+  load_wsplit<4, 8>(FFN ? a.Wf1h : firstW, wave, lane, whA, wlA, 0);
+  load_wsplit<4, 8>(FFN ? a.Wf1h : firstW, wave, lane, whB, wlB, 4);
+  {  // bias / LayerNorm rows -> sPar (absent ones read a valid dummy row and are never used)
+    const float* const tab[7] = {FFN ? a.bf1 : a.bC, FFN ? a.bf2 : a.bC, FFN ? a.lnr_g : a.bC, FFN ? a.lnr_b : a.bC,
+                                 MODE != 1 ? a.bA : a.bC, a.bC, MODE == 2 ? a.bD : a.bC};
+    float pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pv[i] = (tid < D ? tab[2 * i] : tab[2 * i + 1 < 7 ? 2 * i + 1 : 6])[tid & (D - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (256 * i + tid < 7 * D) sPar[256 * i + tid] = pv[i];
+  }
+  // x rows of the tile in the accumulator layout, straight into registers (they stay there for the residual); rows clamped,
+  // never guarded, and zero-filled afterwards so that the MFMAs see defined data
+  float4 xr[2][4];
+  unsigned ooff[2];  // byte offset of (output row, this lane's first column) in an [n_atom,128] tensor
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int rc = row0 + min(lrow + 32 * rt, nrows - 1);
+    const int src = a.x_index ? a.x_index[rc] : rc;
+    ooff[rt] = ((unsigned)(row0 + lrow + 32 * rt) * D + cbase) * 4;
+    const unsigned soff = ((unsigned)src * D + cbase) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xr[rt][j] = ld4(a.x, soff + 32 * j);
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = lrow + 32 * rt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = row < nrows ? xr[rt][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!FFN && row < nrows) {
+        if (a.drop_p > 0.f) {  // training: Dropout after dense_embed (scann_model.py:374)
+          const size_t e = (size_t)(row0 + row) * D + cbase + 8 * j;
+          v.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
+          v.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
+          v.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
+          v.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
+        }
+        st4(a.c, ooff[rt] + 32 * j, v);  // centres = staged rows (layer 0 / no ResidualNorm)
+      }
+      xr[rt][j] = v;
+      f16x4 h, l;
+      split4(v, h, l);
+      *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+      *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+    }
+  }
+  __syncthreads();
+  STAMP(a.stamps, 1);
+
+  f32x16 acc[2];
+  if (FFN) {
+    // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
+    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.Wf2h, wave, lane, acc);
+    STAMP(a.stamps, 2);
+    __syncthreads();  // every wave is done reading the x planes
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = lrow + 32 * rt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bv = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
+        const float4 pre = make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
+                                       fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
+        const float4 hh = f4swish(pre);
+        if (a.keep_pre1 && row < nrows) {  // training forward: kept for the backward
+          st4(a.keep_pre1, ooff[rt] + 32 * j, pre);
+          st4(a.keep_H1, ooff[rt] + 32 * j, hh);
+        }
+        f16x4 h, l;
+        split4(hh, h, l);
+        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+      }
+    }
+    __syncthreads();
+    STAMP(a.stamps, 3);
+    // y = h W2 + b2 ; t = x + drop(y)
+    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, firstW, wave, lane, acc);
+    STAMP(a.stamps, 4);
+    float mean32[2], m2[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = lrow + 32 * rt;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bv = *reinterpret_cast<const float4*>(&sPar[D + cbase + 8 * j]);
+        float4 y = make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
+                               fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
+        if (a.drop_p > 0.f) {  // attention.py:29 (training)
+          const size_t e = (size_t)(row0 + row) * D + cbase + 8 * j;
+          y.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
+          y.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
+          y.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
+          y.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
+        }
+        const float4 t2 = f4add(xr[rt][j], y);
+        acc[rt][4 * j] = t2.x; acc[rt][4 * j + 1] = t2.y; acc[rt][4 * j + 2] = t2.z; acc[rt][4 * j + 3] = t2.w;
+        s += f4sum(t2);
+        if (a.keep_T2 && row < nrows) st4(a.keep_T2, ooff[rt] + 32 * j, t2);
+      }
+      // LayerNorm statistics: pairwise combination of the eight 16-column pieces of the row (see edge_kernel)
+      mean32[rt] = xor32(s) * (1.0f / 32.0f);
+      float v2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float d = acc[rt][i] - mean32[rt];
+        v2 = fmaf(d, d, v2);
+      }
+      m2[rt] = xor32(v2);
+    }
+    if (lh == 0) {
+      *reinterpret_cast<float2*>(&sRed[(lrow * 4 + wave) * 2]) = make_float2(mean32[0], m2[0]);
+      *reinterpret_cast<float2*>(&sRed[((lrow + 32) * 4 + wave) * 2]) = make_float2(mean32[1], m2[1]);
+    }
+    __syncthreads();  // statistics complete; every wave is done reading the hidden planes
+    STAMP(a.stamps, 5);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = lrow + 32 * rt;
+      const float4 sa = *reinterpret_cast<const float4*>(&sRed[row * 8]), sb = *reinterpret_cast<const float4*>(&sRed[row * 8 + 4]);
+      const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * 0.25f;
+      const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
+      const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
+      const float rstd = 1.0f / sqrtf(var + 1e-6f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + cbase + 8 * j]);
+        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + cbase + 8 * j]);
+        float4 y;
+        float inv;
+        inv = rstd * g.x; y.x = fmaf(acc[rt][4 * j], inv, be.x - mean * inv);
+        inv = rstd * g.y; y.y = fmaf(acc[rt][4 * j + 1], inv, be.y - mean * inv);
+        inv = rstd * g.z; y.z = fmaf(acc[rt][4 * j + 2], inv, be.z - mean * inv);
+        inv = rstd * g.w; y.w = fmaf(acc[rt][4 * j + 3], inv, be.w - mean * inv);
+        if (row < nrows) st4(a.c, ooff[rt] + 32 * j, y);
+        f16x4 h, l;
+        split4(y, h, l);
+        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+      }
+    }
+    __syncthreads();
+    STAMP(a.stamps, 6);
+  }
+
+  if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
+    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WBh, wave, lane, acc);
+    STAMP(a.stamps, 7);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bg = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
+        if (lrow + 32 * rt < nrows)
+          st4(a.oA, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bg.x), fmaf(acc[rt][4 * j + 1], WINV, bg.y),
+                                                   fmaf(acc[rt][4 * j + 2], WINV, bg.z), fmaf(acc[rt][4 * j + 3], WINV, bg.w)));
+      }
+    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
+    STAMP(a.stamps, 9);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lrow + 32 * rt < nrows)
+          st4(a.oB, ooff[rt] + 32 * j, make_float4(acc[rt][4 * j] * WINV, acc[rt][4 * j + 1] * WINV, acc[rt][4 * j + 2] * WINV, acc[rt][4 * j + 3] * WINV));
+  }
+  if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
+    STAMP(a.stamps, 10);
+    gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
+    STAMP(a.stamps, 11);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bq = *reinterpret_cast<const float4*>(&sPar[5 * D + cbase + 8 * j]);
+        if (lrow + 32 * rt < nrows)
+          st4(a.oC, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bq.x), fmaf(acc[rt][4 * j + 1], WINV, bq.y),
+                                                   fmaf(acc[rt][4 * j + 2], WINV, bq.z), fmaf(acc[rt][4 * j + 3], WINV, bq.w)));
+      }
+    STAMP(a.stamps, 12);
+  }
+  if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
+    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
+    __syncthreads();  // every wave is done reading the centre planes
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = lrow + 32 * rt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bv = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
+        const float4 z = f4swish(make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
+                                             fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w)));
+        f16x4 h, l;
+        split4(z, h, l);
+        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+      }
+    }
+    __syncthreads();
+    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WDh, wave, lane, acc);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bq = *reinterpret_cast<const float4*>(&sPar[5 * D + cbase + 8 * j]);
+        if (lrow + 32 * rt < nrows)
+          st4(a.oC, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bq.x), fmaf(acc[rt][4 * j + 1], WINV, bq.y),
+                                                   fmaf(acc[rt][4 * j + 2], WINV, bq.z), fmaf(acc[rt][4 * j + 3], WINV, bq.w)));
+      }
+    gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bk = *reinterpret_cast<const float4*>(&sPar[6 * D + cbase + 8 * j]);
+        if (lrow + 32 * rt < nrows)
+          st4(a.oB, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bk.x), fmaf(acc[rt][4 * j + 1], WINV, bk.y),
+                                                   fmaf(acc[rt][4 * j + 2], WINV, bk.z), fmaf(acc[rt][4 * j + 3], WINV, bk.w)));
+      }
+  }
+}
+
+void launch_atom(const AtomArgs& a, hipStream_t s) {
+  if (a.n_atom <= 0) return;
+  const dim3 grid((a.n_atom + TA - 1) / TA), block(256);
+#define SCANN_ATOM_CASE(F, M) hipLaunchKernelGGL((atom_kernel<F, M>), grid, block, 0, s, a)
+  if (a.ffn) {
+    if (a.mode == 0) SCANN_ATOM_CASE(true, 0);
+    else if (a.mode == 1) SCANN_ATOM_CASE(true, 1);
+    else SCANN_ATOM_CASE(true, 2);
+  } else {
+    if (a.mode == 0) SCANN_ATOM_CASE(false, 0);
+    else if (a.mode == 1) SCANN_ATOM_CASE(false, 1);
+    else SCANN_ATOM_CASE(false, 2);
+  }
+#undef SCANN_ATOM_CASE
+}
+
+// ---- edge-tile kernel ------------------------------------------------------------------------------
+//
+// One workgroup (4 waves) per tile of <= 64 edges of <= TQ whole atoms; three workgroups per CU (<= 53.3 KB of LDS,
+// <= 168 VGPRs).  LocalAttention.call for those edges (attention.py:136-216), fused:
+//
+//   GEMM 1   U = G . W2 (g_update; base branch: gd . Wf, K = 20 padded to 32)                    split-fp16 MFMA
+//   epilogue IN THE ACCUMULATOR LAYOUT (lane = edge row, 16 columns): V = U + P1[i] + P3[j], T = swish(V) + G,
+//            LayerNorm_g statistics (lane pair -> LDS -> the row's four waves), geom' -> HBM, ang = c[j] * geom' -> LDS
+//   GEMM 2   K = ang . Wk + bk                                                                    split-fp16 MFMA
+//   epilogue logits q[i].K per (edge, head) straight from the accumulators, K -> LDS
+//   softmax over each atom's edges (online), context + unscaled-query residual, LayerNorm -> HBM
+//
+// Split-fp16 projections: every fp32 operand x is carried as two fp16 numbers, hi = fp16(x) and lo = fp16(x - hi)
+// (22 significant bits; fp16 subnormals are honoured by the matrix pipe, tools/mfma_f16_probe.hip), and a product of two
+// such operands is three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator: lo.hi + hi.lo + hi.hi (the lo.lo term is below
+// fp32 resolution).  Measured against fp64 the result is as close as the exact-fp32 MFMA chain (1.5e-7 of sum |a b| for
+// K = 128; profiles/r02_notes.md) at 3/16 of its matrix-pipe time: f16 MFMA runs at 16x the f32 rate.  Weights are split
+// once at load time (pack_weight_f16: pre-scaled by 2^8 so that their lo parts stay normal numbers; the exact inverse is
+// applied to the accumulators), activations when a tile is written to LDS -- the tile buffer holds a hi plane and a lo plane
+// of 64 x 128 fp16 instead of 64 x 128 fp32: same bytes, same b128 fragment reads.
+// Range: |activation| and |weight * 256| must stay below 65504 (scann_load_weights refuses larger weights; activations here
+// are LayerNorm / swish outputs of O(1..10)).
 
 template <bool GUPD>
 __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {

@@ -210,7 +210,7 @@ int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offse
 int scann_plan_tiles(const scann_batch_t* b, int32_t tile_rows, int32_t tile_atoms, int32_t allow_chunks, int32_t cap,
                      int32_t* tiles_out, int32_t* part_out, int32_t* n_tiles, int32_t* n_slots) {
   if (!b || !n_tiles || !n_slots || !b->mol_offset || !b->edge_offset || (b->n_edge > 0 && !b->edge_col) || b->n_struct <= 0 ||
-      b->n_atom <= 0 || b->n_edge < 0 || (tile_rows != 32 && tile_rows != 64) || tile_atoms <= 0 || tile_atoms > scann::TA)
+      b->n_atom <= 0 || b->n_edge < 0 || (tile_rows != 32 && tile_rows != 64) || tile_atoms <= 0 || tile_atoms > 32)
     return pack_fail("scann_plan_tiles: bad argument");
   if (b->mol_offset[0] != 0 || b->mol_offset[b->n_struct] != b->n_atom || b->edge_offset[0] != 0 || b->edge_offset[b->n_atom] != b->n_edge)
     return pack_fail("scann_plan_tiles: offsets do not cover the batch");

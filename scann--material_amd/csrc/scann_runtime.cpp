@@ -150,7 +150,7 @@ struct scann_handle {
 };
 
 struct scann_dbatch {
-  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0, tile_rows = 64, max_degree = 0, tile_atoms = TA;
+  int32_t n_struct = 0, n_atom = 0, n_edge = 0, n_tile = 0, max_atoms = 0, tile_rows = 64, max_degree = 0, tile_atoms = TQ;
   char* arena = nullptr;  // inputs + workspace, one allocation
   // inputs
   int32_t *atomic = nullptr, *mol_offset = nullptr, *edge_offset = nullptr, *edge_col = nullptr, *edge_row = nullptr;
@@ -503,7 +503,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   std::vector<LTOff> lto(L);
   struct LOff {
     size_t W1p, W3p, bg, Wqp, bq, W2p, Wkp, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, Wf1p, bf1, Wf2p, bf2, lnr_g, lnr_b;
-    size_t W2h, Wkh, Wfh;
+    size_t W2h, Wkh, Wfh, W1h, W3h, Wqh, Wf1h, Wf2h;
   };
   std::vector<LOff> lo(L);
   const size_t NONE = (size_t)-1;
@@ -511,11 +511,13 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     const std::string p = "local_attention_" + std::to_string(i) + "/";
     LOff& o = lo[i];
     o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE,
-             NONE, NONE, NONE};
+             NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     const float* fg = src[p + "filter_geo/kernel"];
     lto[i] = LTOff{(size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
     if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
       o.W1p = put_packed(fg);
+      o.W1h = put_f16(fg, D, 8);
+      o.W3h = put_f16(fg + (size_t)2 * D * D, D, 8);
       o.W2p = put_packed(fg + (size_t)D * D);
       o.W2h = put_f16(fg + (size_t)D * D, D, 8);
       o.W3p = put_packed(fg + (size_t)2 * D * D);
@@ -531,6 +533,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       o.bfg = put_raw(src[p + "filter_geo/bias"], D);
     }
     o.Wqp = put_packed(src[p + "query/kernel"]);
+    o.Wqh = put_f16(src[p + "query/kernel"], D, 8);
     lto[i].WqT = put_packedT(src[p + "query/kernel"]);
     lto[i].WkT = put_packedT(src[p + "key/kernel"]);
     o.bq = put_raw(src[p + "query/bias"], D);
@@ -544,6 +547,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       lto[i].Wf1T = put_packedT(src[r + "dense_1/kernel"]);
       lto[i].Wf2T = put_packedT(src[r + "dense_2/kernel"]);
       o.Wf1p = put_packed(src[r + "dense_1/kernel"]);
+      o.Wf1h = put_f16(src[r + "dense_1/kernel"], D, 8);
+      o.Wf2h = put_f16(src[r + "dense_2/kernel"], D, 8);
       o.bf1 = put_raw(src[r + "dense_1/bias"], D);
       o.Wf2p = put_packed(src[r + "dense_2/kernel"]);
       o.bf2 = put_raw(src[r + "dense_2/bias"], D);
@@ -553,6 +558,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   }
   const size_t oWaT = put_packedT(src["after_Lc/kernel"]), oWgqT = put_packedT(src["global_attention/query/kernel"]),
                oWgkT = put_packedT(src["global_attention/key/kernel"]);
+  const size_t oWah = put_f16(src["after_Lc/kernel"], D, 8), oWgqh = put_f16(src["global_attention/query/kernel"], D, 8),
+               oWgkh = put_f16(src["global_attention/key/kernel"], D, 8);
   const size_t oWa = put_packed(src["after_Lc/kernel"]), oba = put_raw(src["after_Lc/bias"], D);
   const size_t oWgq = put_packed(src["global_attention/query/kernel"]), obgq = put_raw(src["global_attention/query/bias"], D);
   const size_t oWgk = put_packed(src["global_attention/key/kernel"]), obgk = put_raw(src["global_attention/key/bias"], D);
@@ -608,6 +615,9 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lp.Wfg = P(o.Wfg); lp.bfg = P(o.bfg);
     lp.W2h = reinterpret_cast<const _Float16*>(P(o.W2h)); lp.Wkh = reinterpret_cast<const _Float16*>(P(o.Wkh));
     lp.Wfh = reinterpret_cast<const _Float16*>(P(o.Wfh));
+    lp.W1h = reinterpret_cast<const _Float16*>(P(o.W1h)); lp.W3h = reinterpret_cast<const _Float16*>(P(o.W3h));
+    lp.Wqh = reinterpret_cast<const _Float16*>(P(o.Wqh)); lp.Wf1h = reinterpret_cast<const _Float16*>(P(o.Wf1h));
+    lp.Wf2h = reinterpret_cast<const _Float16*>(P(o.Wf2h));
     lp.Wf1p = P(o.Wf1p); lp.bf1 = P(o.bf1); lp.Wf2p = P(o.Wf2p); lp.bf2 = P(o.bf2);
     lp.lnr_g = P(o.lnr_g); lp.lnr_b = P(o.lnr_b);
   }
@@ -616,7 +626,9 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     h->layersT[i] = scann_handle::LayerT{P(lto[i].W1T), P(lto[i].W2T), P(lto[i].W3T), P(lto[i].WqT), P(lto[i].WkT), P(lto[i].Wf1T), P(lto[i].Wf2T)};
   h->WaT = P(oWaT); h->WgqT = P(oWgqT); h->WgkT = P(oWgkT);
   h->arena_floats = img.size(); h->o_lut = olut; h->o_emb = oemb; h->o_Wde = oWe; h->o_bde = obe;
-  h->head = HeadParams{P(oWa), P(oba), P(oWgq), P(obgq), P(oWgk), P(obgk), P(oWb), P(obb), P(owo), P(obo)};
+  h->head = HeadParams{P(oWa), P(oba), P(oWgq), P(obgq), P(oWgk), P(obgk),
+                       reinterpret_cast<const _Float16*>(P(oWah)), reinterpret_cast<const _Float16*>(P(oWgqh)),
+                       reinterpret_cast<const _Float16*>(P(oWgkh)), P(oWb), P(obb), P(owo), P(obo)};
   h->basis = BasisParams{P(oWd), P(obd), P(oWw), P(obw), P(ocd), P(ocw)};
   h->cd = P(ocd);
   h->lut = P(olut);
@@ -887,7 +899,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       a.x_index = nullptr;
       a.ffn = c.use_attn_norm ? 1 : 0;
       const LayerParams& pp = h->layers[l - 1];
-      a.Wf1p = pp.Wf1p; a.bf1 = pp.bf1; a.Wf2p = pp.Wf2p; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
+      a.Wf1h = pp.Wf1h; a.bf1 = pp.bf1; a.Wf2h = pp.Wf2h; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
       if (a.ffn && direct && h->in_train_forward && db->keep_T2) {
         a.keep_pre1 = db->keep_pre1 + (size_t)(l - 1) * nA_; a.keep_H1 = db->keep_H1 + (size_t)(l - 1) * nA_;
         a.keep_T2 = db->keep_T2 + (size_t)(l - 1) * nA_;
@@ -902,11 +914,11 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (l < L) {
       const LayerParams& p = h->layers[l];
       a.mode = c.g_update ? 0 : 1;
-      a.WAp = p.W1p; a.bA = p.bg; a.WBp = p.W3p; a.WCp = p.Wqp; a.bC = p.bq;
+      a.WAh = p.W1h; a.bA = p.bg; a.WBh = p.W3h; a.WCh = p.Wqh; a.bC = p.bq;
       a.oA = db->P1; a.oB = db->P3; a.oC = keep ? db->keep_q + (size_t)l * nA_ : db->q;
     } else {
       a.mode = 2;
-      a.WAp = h->head.Wap; a.bA = h->head.ba; a.WCp = h->head.Wgqp; a.bC = h->head.bgq; a.WDp = h->head.Wgkp; a.bD = h->head.bgk;
+      a.WAh = h->head.Wah; a.bA = h->head.ba; a.WCh = h->head.Wgqh; a.bC = h->head.bgq; a.WDh = h->head.Wgkh; a.bD = h->head.bgk;
       a.oB = db->gk; a.oC = db->gq;
     }
 #ifdef SCANN_STAMPS
@@ -1436,7 +1448,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       {  // P1, P3, q recomputed by the forward kernel itself (one launch; its copy of the input rows goes to a scratch)
         AtomArgs ra2{};
         ra2.x = c_in; ra2.n_atom = A; ra2.ffn = 0; ra2.c = t4; ra2.mode = 0;
-        ra2.WAp = p.W1p; ra2.bA = p.bg; ra2.WBp = p.W3p; ra2.WCp = p.Wqp; ra2.bC = p.bq;
+        ra2.WAh = p.W1h; ra2.bA = p.bg; ra2.WBh = p.W3h; ra2.WCh = p.Wqh; ra2.bC = p.bq;
         ra2.oA = db->P1; ra2.oB = db->P3; ra2.oC = db->q;
         launch_atom(ra2, s);
       }
