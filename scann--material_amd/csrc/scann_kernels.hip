@@ -173,17 +173,19 @@ __device__ __forceinline__ void load_wsplit(const _Float16* __restrict__ Wp, int
 // X[rows][0 .. 16 KS) . W[0 .. 16 KS)[32 wave .. +32), X given as hi / lo planes in LDS.  Operand map of
 // v_mfma_f32_32x32x16_f16 (checked with exact integers by tools/mfma_f16_probe.hip): lane l supplies A[i = l & 31][k = 8 (l >> 5) + j]
 // and B[k = 8 (l >> 5) + j][j' = l & 31], j = 0..7; weights are the A operand, so the product comes out transposed.
-template <int KS>
+template <int KS, bool FIRST = false>
 __device__ __forceinline__ void mma_split(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, const f16x8 (&wh)[KS],
                                           const f16x8 (&wl)[KS], int lane, f32x16 (&acc)[2]) {
   const int off = (lane & 31) * PLANE_STRIDE + 8 * (lane >> 5);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const f16x8 xh = *reinterpret_cast<const f16x8*>(sH + off + rt * 32 * PLANE_STRIDE + 16 * s);
       const f16x8 xl = *reinterpret_cast<const f16x8*>(sL + off + rt * 32 * PLANE_STRIDE + 16 * s);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, acc[rt], 0, 0, 0);
+      // FIRST: the chain starts from the inline constant 0 (no zero-fill of the 16 accumulator registers)
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, FIRST && s == 0 ? zero : acc[rt], 0, 0, 0);
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, acc[rt], 0, 0, 0);
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, acc[rt], 0, 0, 0);
     }
@@ -220,8 +222,7 @@ template <bool NEXT>
 __device__ __forceinline__ void gemm_tile(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, f16x8 (&whA)[4], f16x8 (&wlA)[4],
                                           f16x8 (&whB)[4], f16x8 (&wlB)[4], const _Float16* __restrict__ next, int wave, int lane,
                                           f32x16 (&acc)[2]) {
-  zero_acc(acc);
-  mma_split<4>(sH, sL, whA, wlA, lane, acc);
+  mma_split<4, true>(sH, sL, whA, wlA, lane, acc);
   __builtin_amdgcn_sched_barrier(0);
   if (NEXT) load_wsplit<4, 8>(next, wave, lane, whA, wlA, 0);
   __builtin_amdgcn_sched_barrier(0);
@@ -566,8 +567,9 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   const float bkc = a.p.bk[tid & (D - 1)];
   const float par0 = GUPD ? (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)] : a.p.bfg[tid & (D - 1)];
   const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
+  float4 greg[2][4];
   {
-    const int r = tid >> 2, sub = tid & 3;  // staging map: 4 threads per edge row
+    const int r = tid >> 2, sub = tid & 3;  // staging map of the base branch: 4 threads per edge row
     const int rs = r < ne ? r : nem1;
     if (GUPD) {
       float4 p1reg[3];  // centre thirds P1 = c_i W1 + bg of the tile's atoms
@@ -576,23 +578,31 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
         const int idx = tid + 256 * i, la = min(idx >> 5, natom - 1), c4 = idx & 31;
         p1reg[i] = ld4(a.P1, ((unsigned)(tile.atom_begin + la) * 32 + c4) * 16);
       }
-      float4 greg[8];
-      const float* gsrc = ne > 0 ? a.geom : a.P1;  // a tile without edges reads (and ignores) a valid row
-      const unsigned goff = (ne > 0 ? (unsigned)(eb + rs) * D : (unsigned)tile.atom_begin * D) * 4 + sub * 16;
+      // geometry rows G of the tile's edges in the ACCUMULATOR layout, straight into registers: they stay there, exact fp32,
+      // for the residual (attention.py:153); a tile without edges reads (and ignores) a valid row
+      const float* gsrc = ne > 0 ? a.geom : a.P1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) greg[i] = ld4(gsrc, goff + 64 * i);
+      for (int rt = 0; rt < 2; ++rt) {
+        const unsigned goff = ((ne > 0 ? (unsigned)(eb + min(lrow + 32 * rt, nem1)) : (unsigned)tile.atom_begin) * D + cbase) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) greg[rt][j] = ld4(gsrc, goff + 32 * j);
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int idx = tid + 256 * i;
         *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (r >= ne) greg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        f16x4 h, l;
-        split4(greg[i], h, l);
-        *reinterpret_cast<f16x4*>(sH + r * PLANE_STRIDE + 4 * (sub + 4 * i)) = h;
-        *reinterpret_cast<f16x4*>(sL + r * PLANE_STRIDE + 4 * (sub + 4 * i)) = l;
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = lrow + 32 * rt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (row >= ne) greg[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          f16x4 h, l;
+          split4(greg[rt][j], h, l);
+          *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+          *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+        }
       }
     } else {
       // base SCANN (attention.py:155): the raw distance basis gd[e][0..20) of the tile's edges, zero-padded to K = 32
@@ -620,22 +630,21 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   __syncthreads();
   STAMP(a.stamps, 1);
 
-  // gathered neighbour thirds P3[j] = c_j W3: requested before the GEMM, consumed after it
   float4 p3r[2][4];
+  f32x16 acc[2];
   if (GUPD) {
+    mma_split<4, true>(sH, sL, whA, wlA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    // gathered neighbour thirds P3[j] = c_j W3 (into the registers the first weight half leaves): in flight over the second half
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) p3r[rt][j] = ld4(a.P3, nboff[rt] + 32 * j);
-  }
-  f32x16 acc[2];
-  zero_acc(acc);
-  if (GUPD) {
-    mma_split<4>(sH, sL, whA, wlA, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);
     mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
   } else {
     f16x8 th[2] = {whA[0], whA[1]}, tl[2] = {wlA[0], wlA[1]};
-    mma_split<2>(sH, sL, th, tl, lane, acc);
+    mma_split<2, true>(sH, sL, th, tl, lane, acc);
   }
   STAMP(a.stamps, 2);
   __builtin_amdgcn_sched_barrier(0);
@@ -658,8 +667,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 p1v = *reinterpret_cast<const float4*>(p1 + 8 * j);
-        const float4 g = join4(*reinterpret_cast<const f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j),
-                               *reinterpret_cast<const f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j));
+        const float4 g = greg[rt][j];
         float4 v;
         v.x = fmaf(acc[rt][4 * j], WINV, p1v.x) + p3r[rt][j].x;
         v.y = fmaf(acc[rt][4 * j + 1], WINV, p1v.y) + p3r[rt][j].y;
@@ -780,8 +788,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   // K = ang . Wk + bk (attention.py:163); the second half of Wk arrives under the first half's MFMAs
   load_wsplit<4, 8>(a.p.Wkh, wave, lane, whB, wlB, 4);
   __builtin_amdgcn_sched_barrier(0);
-  zero_acc(acc);
-  mma_split<4>(sH, sL, whA, wlA, lane, acc);
+  mma_split<4, true>(sH, sL, whA, wlA, lane, acc);
   mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
   STAMP(a.stamps, 5);
   // logits e[n, h] = (q[i, h, :] * 16^-0.5) . K[n, h, :] (attention.py:180-183) from the accumulators: this lane holds 8 of the
@@ -820,35 +827,37 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   }
   __syncthreads();
   STAMP(a.stamps, 8);
-  // softmax over each atom's edges + context + unscaled-query residual (attention.py:186-212), one pass with a running maximum.
+  // softmax over each atom's edges + context + unscaled-query residual (attention.py:186-212).
   // Packed edges are all unmasked: the additive -1e9 and the multiplicative mask are the identity; an atom without edges
   // yields q (then LayerNorm), which is what the reference's fully-masked row gives.
   {
     const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
     for (int la = lgp; la < natom; la += 8) {
       const int e0 = sOff[la], e1 = sOff[la + 1];
-      float m = -INFINITY, ssum = 0.f;
+      // row maximum first (logits only), then one exp per edge: no running-maximum rescaling in the accumulation loop
+      float m = -INFINITY;
+      for (int n = e0; n < e1; n += 4) {
+        const float v0 = sE[n * NHEAD + h], v1 = sE[min(n + 1, e1 - 1) * NHEAD + h];
+        const float v2 = sE[min(n + 2, e1 - 1) * NHEAD + h], v3 = sE[min(n + 3, e1 - 1) * NHEAD + h];
+        m = fmaxf(fmaxf(m, fmaxf(v0, v1)), fmaxf(v2, v3));
+      }
+      float ssum = 0.f;
       float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int n = e0; n < e1; n += 2) {
         const bool two = n + 1 < e1;
         const int n1 = two ? n + 1 : n;
-        const float ea = sE[n * NHEAD + h];
-        const float eb2 = two ? sE[n1 * NHEAD + h] : -INFINITY;
         const float4 ka = *reinterpret_cast<const float4*>(&sK[n * LDS_STRIDE + 4 * c4]);
         const float4 kb = *reinterpret_cast<const float4*>(&sK[n1 * LDS_STRIDE + 4 * c4]);
-        const float mn = fmaxf(m, fmaxf(ea, eb2));
-        const float resc = fast_exp(m - mn);
-        float pa = fast_exp(ea - mn), pb = fast_exp(eb2 - mn);
-        ssum = fmaf(ssum, resc, pa + pb);
+        float pa = fast_exp(sE[n * NHEAD + h] - m), pb = two ? fast_exp(sE[n1 * NHEAD + h] - m) : 0.f;
+        ssum += pa + pb;
         if (a.attn_drop_p > 0.f) {  // training with use_drop: Dropout(0.05) on the attention weights (attention.py:116,191)
           pa *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
           pb *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
         }
-        cx.x = fmaf(cx.x, resc, fmaf(pa, ka.x, pb * kb.x));
-        cx.y = fmaf(cx.y, resc, fmaf(pa, ka.y, pb * kb.y));
-        cx.z = fmaf(cx.z, resc, fmaf(pa, ka.z, pb * kb.z));
-        cx.w = fmaf(cx.w, resc, fmaf(pa, ka.w, pb * kb.w));
-        m = mn;
+        cx.x = fmaf(pa, ka.x, fmaf(pb, kb.x, cx.x));
+        cx.y = fmaf(pa, ka.y, fmaf(pb, kb.y, cx.y));
+        cx.z = fmaf(pa, ka.z, fmaf(pb, kb.z, cx.z));
+        cx.w = fmaf(pa, ka.w, fmaf(pb, kb.w, cx.w));
       }
       if (part >= 0) {  // chunk tile: leave the softmax state of this chunk for edge_merge_kernel
         float* pb = a.part_buf + (size_t)part * 3 * D + 4 * c4;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase clocks of atom_kernel<true, 0> (ResidualNorm + P1/P3/q projections of a 32-atom tile).
+"""Diagnostic: phase clocks of atom_kernel<true, 0> (ResidualNorm + P1/P3/q projections of a 64-atom tile).
 Run with SCANN_HIP_LIB=.../libscann_hip_stamps.so SCANN_STAMP_ATOM=1 (make -C scann--material_amd/csrc stamps)."""
 import os, sys
 import numpy as np
@@ -18,9 +18,10 @@ for _ in range(5):
     eng.forward_resident(rb, 0)
 eng.sync()
 st = eng.debug_stamps(rb).astype(np.int64)
-names = ["stage x", "GEMM ffn1", "dump+barrier", "GEMM ffn2", "residual+barrier", "LayerNorm+barrier", "GEMM W1", "store P1 (+W3 wait)",
-         "GEMM W3", "store P3 (+Wq wait)", "GEMM Wq", "store q"]
+order = [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12]
+names = ["stage x (loads -> planes) + barrier", "GEMM ffn1", "barrier + swish -> planes + barrier", "GEMM ffn2", "residual + statistics + barrier",
+         "LayerNorm -> c store + planes + barrier", "GEMM W1", "store P1 + GEMM W3", "store P3", "GEMM Wq", "store q"]
 print("tiles", st.shape[0], "total cycles/tile mean", (st[:, 12] - st[:, 0]).mean())
-for i, n in enumerate(names):
-    col = st[:, i + 1] - st[:, i]
+for n, (i, j) in zip(names, zip(order[:-1], order[1:])):
+    col = st[:, j] - st[:, i]
     print("%-22s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))

@@ -18,12 +18,13 @@ for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):  # argv[2]: forwar
     eng.forward_resident(rb, 0)
 eng.sync()
 st = eng.debug_stamps(rb).astype(np.int64)
-order = [0, 1, 2, 3, 4, 5, 6, 8, 9, 7]  # stamp slots in program order
-names = ["load G", "GEMM1", "dump U", "row pass", "GEMM2", "dump K+q", "logits", "softmax+ctx", "LN+store"]
+order = [0, 1, 2, 3, 4, 5, 8, 9, 7]  # stamp slots in program order
+names = ["prologue (loads -> planes) + barrier", "GEMM1", "epilogue 1a: V, T, LN_g statistics + barrier", "epilogue 1b: normalise, geom' store, ang planes, q rows + barrier",
+         "GEMM2", "logits from accumulators, K dump + 2 barriers", "softmax + context + barrier", "LayerNorm + ctx store"]
 print("tiles", st.shape[0], "total cycles/tile mean", (st[:, 7] - st[:, 0]).mean())
 for n, (i, j) in zip(names, zip(order[:-1], order[1:])):
     col = st[:, j] - st[:, i]
-    print("%-10s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))
+    print("%-70s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))
 print("kernel span (first start -> last end) cycles:", st[:, 7].max() - st[:, 0].min(), "(s_memtime ticks at 100MHz? see guide: tick = shader cycle)")
 if st[:, 12].any() and st[:, 13].any():
     ticks = (st[:, 13] - st[:, 12]).astype(np.float64)
