@@ -140,6 +140,8 @@ struct scann_handle {
   bool in_train_forward = false;
   unsigned long long train_seed = 0;
   ncclComm_t comm = nullptr;
+  hipStream_t train_aux = nullptr;       // side stream of the backward pass: weight-gradient GEMMs run beside the data-gradient chain
+  std::vector<hipEvent_t> train_ev;      // ring of fork / join events between the two streams
   // reusable scratch of the synchronous scann_forward path (grow-only device arena + pinned host staging)
   char* sc_arena = nullptr;
   size_t sc_cap = 0;
@@ -397,6 +399,8 @@ void scann_destroy(scann_handle_t* h) {
   for (void* q : {(void*)h->t_master, (void*)h->t_grad, (void*)h->t_m, (void*)h->t_v, (void*)h->t_l2, (void*)h->t_descs})
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
+  if (h->train_aux) (void)hipStreamDestroy(h->train_aux);
+  for (hipEvent_t e : h->train_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->time_ev) (void)hipEventDestroy(e);
   if (h->sc_db) {
     cached_free(h->sc_db->dbg_c);
@@ -1161,6 +1165,10 @@ struct scann_train_ws {  // per resident batch, allocated on first use
   float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;
   float *tE[10] = {};   // [n_edge,128] temporaries
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
+  float* wpart = nullptr;  // per-slab partial sums of every weight gradient of a step (WgradCtx::arena)
+  size_t wpart_floats = 0;
+  WgradReduceEntry* wtable = nullptr;  // device table of (destination, slots), one entry per gradient tensor
+  int wtable_cap = 0;
   double* sse = nullptr;
   float drop_p = 0.f, attn_p = 0.f;
   unsigned long long seed = 0;
@@ -1185,8 +1193,18 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   // per-layer tensors kept by the training forward (edge_kernel_lean on 64-edge tiles): q [A,128]; V, T, ang, K [E,128]
   const bool keepable = h->cfg.g_update;
   const size_t Lk = keepable ? (size_t)h->cfg.n_attention : 0;
+  // weight-gradient partial slots: per layer <= 2 gradients over the edge rows (key, filter_geo geometry third; base: key) and
+  // <= 5 over the atom rows (filter_geo centre / neighbour thirds, query, ResidualNorm dense_1 / dense_2), readout 3 over atoms
+  // and 1 over structures; each with a bias row per slab
+  const size_t Lc = (size_t)h->cfg.n_attention;
+  w.wpart_floats = (size_t)(D * D + D) * (Lc * (2 * (size_t)wgrad_slabs(std::max(db->n_edge, 1)) + 5 * (size_t)wgrad_slabs(db->n_atom)) +
+                                           3 * (size_t)wgrad_slabs(db->n_atom) + (size_t)wgrad_slabs(db->n_struct)) +
+                   // LayerNorm gamma / beta partials: per layer ln_bwd over edges and atoms, attention backward over atoms
+                   (size_t)2 * D * Lc * ((size_t)ln_bwd_slots(std::max(db->n_edge, 1)) + (size_t)ln_bwd_slots(db->n_atom) +
+                                         (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
   const size_t total = 10 * rowA + 10 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
-                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE);
+                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4) +
+                       align_up((size_t)(w.wtable_cap = 32 * (int)Lc + 64) * sizeof(WgradReduceEntry));
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   for (int i = 0; i < 10; ++i) { w.tA[i] = (float*)p; p += rowA; }
@@ -1197,6 +1215,8 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   w.targets = (float*)p; p += align_up((size_t)db->n_struct * 4);
   w.dlut = (float*)p; p += align_up((size_t)h->cfg.n_atoms * D * 4);
   w.sse = (double*)p; p += 256;
+  w.wpart = (float*)p; p += align_up(w.wpart_floats * 4);
+  w.wtable = (WgradReduceEntry*)p; p += align_up((size_t)w.wtable_cap * sizeof(WgradReduceEntry));
   if (Lk) {  // slices are [rows,128] without padding between layers: size them from the un-aligned row counts
     w.keep_q = (float*)p; p += Lk * rowA;
     w.keep_V = (float*)p; p += Lk * rowE;
@@ -1268,6 +1288,11 @@ int scann_train_begin(scann_handle_t* h) {
     if (reg) std::fill(l2.begin() + h->spec_off[i], l2.begin() + h->spec_off[i] + h->specs[i].numel(), 1.0f);
   }
   HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
+  if (!h->train_aux && !getenv("SCANN_TRAIN_ONE_STREAM")) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
+    h->train_ev.resize(128);
+    for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   h->t_step = 0;
   return SCANN_OK;
 }
@@ -1359,6 +1384,30 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   const double rmse = std::sqrt(sse_global / (double)count_global);
   const float scale = rmse > 0 ? (float)(1.0 / ((double)count_global * rmse)) : 0.f;
   launch_dy(db->y, w.targets, B, scale, w.dy, s);
+  // Weight-gradient GEMMs are off the critical path (only the final reduce needs them): with the kept-activation forward
+  // their operands are never overwritten inside a layer, so they run on a side stream beside the data-gradient chain, which
+  // alone does not fill the chip at batch 128.  fork(): side stream waits for everything enqueued so far; join(): main waits
+  // for the side stream (start of every layer: the previous layer's temporaries are about to be overwritten).
+  hipStream_t aux = h->train_aux;
+  const bool side = db->kept && aux != nullptr;
+  size_t ev_i = 0;
+  auto fork = [&]() -> hipStream_t {
+    if (!side) return s;
+    hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
+    (void)hipEventRecord(e, s);
+    (void)hipStreamWaitEvent(aux, e, 0);
+    return aux;
+  };
+  auto join = [&]() {
+    if (!side) return;
+    hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
+    (void)hipEventRecord(e, aux);
+    (void)hipStreamWaitEvent(s, e, 0);
+  };
+  WgradCtx wg;
+  wg.arena = w.wpart;
+  wg.d_table = w.wtable;
+  wg.table_cap = w.wtable_cap;
 
   // named temporaries
   float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4], *t3 = w.tA[5], *dQ = w.tA[6],
@@ -1377,16 +1426,20 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   ra.dgq = t2; ra.dgk = t3; ra.rep_out = w.rep; ra.dpre_out = w.dpre;
   ra.dwo = g("predict_property/kernel"); ra.dbo = g("predict_property/bias");
   launch_readout_bwd(ra, s);
-  launch_wgrad(w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B, s);
-  launch_wgrad3(t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), t3, g("global_attention/key/kernel"),
-                g("global_attention/key/bias"), nullptr, nullptr, nullptr, A, s);
+  {
+    hipStream_t ws = fork();
+    launch_wgrad(wg, w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B, ws);
+    launch_wgrad3(wg, t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), t3, g("global_attention/key/kernel"),
+                  g("global_attention/key/bias"), nullptr, nullptr, nullptr, A, ws);
+  }
   launch_linear_sum(t2, h->WgqT, t3, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
-  launch_swish_bwd(t0, t4, t2, nA, s);                        // dpreA
-  launch_wgrad(cL, t2, g("after_Lc/kernel"), g("after_Lc/bias"), A, s);
-  launch_linear(t2, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
+  launch_swish_bwd(t0, t4, dQ, nA, s);                        // dpreA (dQ is free until the first layer: t2 is still being read beside us)
+  launch_wgrad(wg, cL, dQ, g("after_Lc/kernel"), g("after_Lc/bias"), A, fork());
+  launch_linear(dQ, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
   for (int l = L - 1; l >= 0; --l) {
+    join();  // the weight-gradient GEMMs of the previous layer have read their operands
     const LayerParams& p = h->layers[l];
     const scann_handle::LayerT& pt = h->layersT[l];
     const std::string la = "local_attention_" + std::to_string(l) + "/", rn = "residual_norm_" + std::to_string(l) + "/";
@@ -1407,12 +1460,12 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
         launch_dropout(t2, nA, w.seed, (unsigned)l, w.drop_p, s);
         launch_add(t2, ctx, nA, s);                            // T2 = x + drop(Y)
       }
-      launch_ln_bwd(T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
+      launch_ln_bwd(wg, T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
       HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
       launch_dropout(t3, nA, w.seed, (unsigned)l, w.drop_p, s);  // dY
-      launch_wgrad(H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A, s);
+      launch_wgrad(wg, H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A, fork());
       launch_linear(t3, pt.Wf2T, nullptr, t4, const_cast<float*>(pre1), A, 4, s);  // dpre1 = (dY.W2^T) * swish'(pre1)
-      launch_wgrad(ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A, s);
+      launch_wgrad(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A, fork());
       launch_linear(t4, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
     } else {
       HIPCHK(h, hipMemcpyAsync(dCtx, dC, nA * 4, hipMemcpyDeviceToDevice, s));
@@ -1425,14 +1478,14 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_base_geom(db->gd, p.Wfg, p.bfg, db->weight, eV, E, s);            // geomL (eV)
       launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
       launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
-      launch_attn_bwd(db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
+      launch_attn_bwd(wg, db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-      launch_wgrad(eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
+      launch_wgrad(wg, eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
       launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
       launch_edge_dang(c_in, db->edge_col, eV, edAng, nullptr, eAng, edGt, E, s);  // per edge dang*geomL (in eAng) ; dgeomL = dang*c[j]
       launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);              // dC[j] = sum over the edges that point at j
       launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, edGt, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), s);
-      launch_wgrad(c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A, s);
+      launch_wgrad(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A, s);
       launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
       continue;
     }
@@ -1455,9 +1508,9 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
       launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
     }
-    launch_attn_bwd(qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
+    launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-    launch_wgrad(angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
+    launch_wgrad(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E, kept ? fork() : s);  // recomputed ang is overwritten below: main stream then
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
     launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, eAng, edGt, E, s);  // per edge dang*G' (in eAng) ; dG'tot
     launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);               // dC now collects d loss / d centres_l: dC[j] = sum over the edges that point at j
@@ -1467,16 +1520,16 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
     }
     float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
-    launch_ln_bwd(TL, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
+    launch_ln_bwd(wg, TL, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
     launch_edge_dv(VL, dGnext, eU, E, s);                                         // dV (in eU)
     launch_segment_sum(eU, db->edge_offset, dP1, A, s);                           // dP1[i] = sum over the atom's own edges
     launch_gather_sum(eU, db->in_off, db->in_edge, dP3, A, 0, s);                 // dP3[j] = sum over the edges that point at j
     float* fgk = g(la + "filter_geo/kernel");
-    launch_wgrad(Gin, eU, fgk + (size_t)D * D, nullptr, E, s);                   // dW2
+    launch_wgrad(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E, fork());              // dW2
     launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                // dG += dV.W2^T
     // per-atom projections
-    launch_wgrad3(c_in, dP1, fgk, g(la + "filter_geo/bias"), dP3, fgk + (size_t)2 * D * D, nullptr, dQ, g(la + "query/kernel"),
-                  g(la + "query/bias"), A, s);
+    launch_wgrad3(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), dP3, fgk + (size_t)2 * D * D, nullptr, dQ, g(la + "query/kernel"),
+                  g(la + "query/bias"), A, fork());
     launch_linear_sum(dP1, pt.W1T, dP3, pt.W3T, dQ, pt.WqT, dC, A, 1, s);  // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T
     dG_in = dGnext;
   }
@@ -1499,6 +1552,10 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
                      c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), s);
   }
+  if (wg.off > w.wpart_floats || (int)wg.entries.size() > wg.table_cap)
+    return fail(h, SCANN_ERR_HIP, "scann_train_backward: weight-gradient partial arena overrun");
+  join();
+  wgrad_flush(wg, s);  // ONE launch adds the per-slab partials of every weight gradient, in slab order
   HIPCHK(h, hipGetLastError());
   return SCANN_OK;
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include "scann_internal.h"
 
+#include <vector>
+
 namespace scann {
 
 struct ReadoutBwdArgs {
@@ -24,18 +26,39 @@ struct RepackDesc {
                       // -1: split-fp16 image of a [128,128] kernel, -2: of a [20,128] kernel padded to K = 32 (pack_weight_f16)
 };
 
-void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags, hipStream_t s);
-void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s);
+// Weight gradients are bit-reproducible: every launch_wgrad* stores per-slab partial sums into slots of `ctx.arena` (bump
+// allocated, never reused within a step) and records (destination, slots); wgrad_flush adds them in slab order with ONE
+// launch at the end of the backward pass.  wgrad_slabs(rows) slots of 128*128 (+128 with a bias) floats per gradient.
+struct WgradReduceEntry {
+  float* dst;
+  const float* part;
+  int32_t n_slab, numel;
+};
+struct WgradCtx {
+  float* arena = nullptr;                 // partial slots (device)
+  size_t off = 0;                         // floats used
+  WgradReduceEntry* d_table = nullptr;    // device copy of `entries` (capacity table_cap), filled by wgrad_flush
+  int table_cap = 0;
+  std::vector<WgradReduceEntry> entries;  // one per gradient tensor of the step
+};
+int wgrad_slabs(int rows);
+void wgrad_flush(WgradCtx& ctx, hipStream_t s);
+void launch_wgrad(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s);
 // up to three weight gradients that share the left operand X in one launch (null dY1 / dY2: fewer)
-void launch_wgrad3(const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
+void launch_wgrad3(WgradCtx& ctx, const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
                    const float* dY2, float* dW2, float* db2, int rows, hipStream_t s);
+
+void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags, hipStream_t s);
+
 // Y (+)= X0.W0 + X1.W1 + X2.W2 (packed [128,128] kernels; null X1 / X2: fewer terms)
 void launch_linear_sum(const float* X0, const float* W0, const float* X1, const float* W1, const float* X2, const float* W2, float* Y,
                        int rows, int accumulate, hipStream_t s);
 void launch_swish_bwd(const float* pre, const float* dout, float* dpre, size_t n, hipStream_t s);
 void launch_add(float* dst, const float* src, size_t n, hipStream_t s);
 void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s);
-void launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
+int ln_bwd_slots(int rows);
+int attn_bwd_slots(int n_atom, int max_degree);
+void launch_ln_bwd(WgradCtx& ctx, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
                    int accumulate, hipStream_t s);
 void launch_edge_ang(const float* c, const int* nb, const float* g, float* ang, int n_edge, hipStream_t s);
 // dcn[e] = dang[e] * g[e] (per edge; summed per neighbour atom with launch_gather_sum), dg_tot = dang * c[nb] (+ dg_in)
@@ -47,7 +70,7 @@ void launch_edge_v(const float* U, const float* P1, const float* P3, const int* 
                    float* T, int n_edge, hipStream_t s);
 void launch_edge_dv(const float* V, const float* dT, float* dV, int n_edge, hipStream_t s);
 void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s);
-void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
+void launch_attn_bwd(WgradCtx& ctx, const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
                      float* dK, float* dgamma, float* dbeta, int n_atom, int max_degree, float drop_p, unsigned drop_tag,
                      unsigned long long drop_seed, hipStream_t s);
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);

@@ -197,18 +197,19 @@ void launch_linear_sum(const float* X0, const float* W0, const float* X1, const 
 }
 
 // ---- weight gradient: dW[i][j] += sum_rows X[row][i] dY[row][j];  db[j] += sum_rows dY[row][j] ---------------------
-// A workgroup reduces a 256-row slab with MFMA (A = X^T read column-wise from LDS) and adds its 128x128 partial with
-// float atomics (order of the adds is not fixed: gradients are reproducible to rounding only).
+// Two stages, no atomics, bit-reproducible: a workgroup reduces one slab of rows with MFMA (A = X^T read column-wise from
+// LDS) and STORES its 128x128 partial (and its bias partial) to a slot of its own; wgrad_reduce_kernel, launched once at the
+// end of the backward pass for ALL the weight gradients of the step, adds the slots of every gradient in slab order.
 struct WgradSet {
   const float* dY[3];
-  float* dW[3];
-  float* db[3];
+  float* part[3];   // [n_slab][128*128] partial sums of this call
+  float* bpart[3];  // [n_slab][128] bias partials or null
 };
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, WgradSet set, int rows, int chunks) {
   // blockIdx.y selects one of up to three gradients that share the left operand X (c^T.[dP1 | dP3 | dq], attention.py:142-160)
   const float* __restrict__ dY = set.dY[blockIdx.y];
-  float* __restrict__ dW = set.dW[blockIdx.y];
-  float* __restrict__ db = set.db[blockIdx.y];
+  float* __restrict__ part = set.part[blockIdx.y] + (size_t)blockIdx.x * D * D;
+  float* __restrict__ bpart = set.bpart[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float sX[64 * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float sD[64 * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
       }
     }
     __syncthreads();
-    if (db && tid < D)
+    if (bpart && tid < D)
       for (int r = 0; r < 64; ++r) bsum += sD[r * LDS_STRIDE + tid];
     // k runs over the 64 rows of the chunk: MFMA step s uses rows 2s + (lane>>5)
     const int h = lane >> 5, f = lane & 31;
@@ -261,25 +262,72 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) atomicAdd(&dW[(size_t)(32 * m + acc_row_(i, lane)) * D + col], acc[m][i]);
-  if (db && tid < D) atomicAdd(&db[tid], bsum);
+    for (int i = 0; i < 16; ++i) part[(size_t)(32 * m + acc_row_(i, lane)) * D + col] = acc[m][i];
+  if (bpart && tid < D) bpart[(size_t)blockIdx.x * D + tid] = bsum;
 }
 
-void launch_wgrad3(const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
+// dst[i] += part[0][i] + part[1][i] + ... in slab order, for every gradient tensor of the step (blockIdx.y)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceEntry* __restrict__ table) {
+  const WgradReduceEntry e = table[blockIdx.y];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= e.numel) return;
+  const float* __restrict__ p = e.part + idx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved chains (fixed association), independent loads in flight
+  int k = 0;
+  for (; k + 4 <= e.n_slab; k += 4) {
+    s0 += p[(size_t)k * e.numel];
+    s1 += p[(size_t)(k + 1) * e.numel];
+    s2 += p[(size_t)(k + 2) * e.numel];
+    s3 += p[(size_t)(k + 3) * e.numel];
+  }
+  for (; k < e.n_slab; ++k) s0 += p[(size_t)k * e.numel];
+  e.dst[idx] += (s0 + s1) + (s2 + s3);
+}
+
+int wgrad_chunks(int rows) {
+  // slab per workgroup: about one wave of workgroups over the chip (<= 256 slabs), so that the partial slots stay bounded
+  // (<= 256 x 64 KB per gradient) whatever the batch size
+  const int tiles = (rows + 63) / 64;
+  return std::max(1, (tiles + 191) / 192);
+}
+int wgrad_slabs(int rows) {
+  const int chunks = wgrad_chunks(rows);
+  return (rows + 64 * chunks - 1) / (64 * chunks);
+}
+
+void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
+  const int n = (int)std::min<size_t>(ctx.entries.size(), (size_t)ctx.table_cap);
+  if (n > 0) {
+    (void)hipMemcpyAsync(ctx.d_table, ctx.entries.data(), (size_t)n * sizeof(WgradReduceEntry), hipMemcpyHostToDevice, s);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(D * D / 256, n), dim3(256), 0, s, ctx.d_table);
+  }
+  ctx.entries.clear();
+}
+
+void launch_wgrad3(WgradCtx& ctx, const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
                    const float* dY2, float* dW2, float* db2, int rows, hipStream_t s) {
   if (rows <= 0) return;
-  // slab per workgroup: enough workgroups to fill the chip, few enough that the 64 KB of float atomics per workgroup
-  // (chip-wide ~1.3 TB/s of added bytes) stays below the MFMA time
-  const int chunks = rows >= 65536 ? 4 : (rows >= 8192 ? 2 : 1);
-  WgradSet set{};
-  set.dY[0] = dY0; set.dW[0] = dW0; set.db[0] = db0;
-  set.dY[1] = dY1; set.dW[1] = dW1; set.db[1] = db1;
-  set.dY[2] = dY2; set.dW[2] = dW2; set.db[2] = db2;
+  const int chunks = wgrad_chunks(rows), n_slab = wgrad_slabs(rows);
+  const float* dYs[3] = {dY0, dY1, dY2};
+  float* dWs[3] = {dW0, dW1, dW2};
+  float* dbs[3] = {db0, db1, db2};
   const int ny = dY2 ? 3 : (dY1 ? 2 : 1);
-  hipLaunchKernelGGL(wgrad_kernel, dim3((rows + 64 * chunks - 1) / (64 * chunks), ny), dim3(256), 0, s, X, set, rows, chunks);
+  WgradSet set{};
+  for (int i = 0; i < ny; ++i) {
+    set.dY[i] = dYs[i];
+    set.part[i] = ctx.arena + ctx.off;
+    ctx.entries.push_back(WgradReduceEntry{dWs[i], set.part[i], n_slab, D * D});
+    ctx.off += (size_t)n_slab * D * D;
+    if (dbs[i]) {
+      set.bpart[i] = ctx.arena + ctx.off;
+      ctx.entries.push_back(WgradReduceEntry{dbs[i], set.bpart[i], n_slab, D});
+      ctx.off += (size_t)n_slab * D;
+    }
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(n_slab, ny), dim3(256), 0, s, X, set, rows, chunks);
 }
-void launch_wgrad(const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
-  launch_wgrad3(X, dY, dW, db, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, s);
+void launch_wgrad(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
+  launch_wgrad3(ctx, X, dY, dW, db, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, s);
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------
@@ -391,15 +439,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   float tot = 0.f;
 #pragma unroll 8
   for (int rr = 0; rr < 32; ++rr) tot += sred[which][rr][col];
-  atomicAdd((which ? dbeta : dgamma) + col, tot);
+  (which ? dbeta : dgamma)[(size_t)blockIdx.x * D + col] = tot;  // this workgroup's slot (summed in slot order by wgrad_reduce_kernel)
 }
-void launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
+void wgrad_flush(WgradCtx& ctx, hipStream_t s);
+static int ln_bwd_groups(int rows) { return std::min(32, std::max(1, (rows + 32 * 160 - 1) / (32 * 160))); }
+int ln_bwd_slots(int rows) {
+  const int groups = ln_bwd_groups(rows);
+  return (rows + 32 * groups - 1) / (32 * groups);
+}
+// records (dst, slots) of one parameter-gradient vector whose per-workgroup partial sums a kernel is about to store
+static float* reserve_vec(WgradCtx& ctx, float* dst, int n_slot, hipStream_t) {
+  float* part = ctx.arena + ctx.off;
+  ctx.entries.push_back(WgradReduceEntry{dst, part, n_slot, D});
+  ctx.off += (size_t)n_slot * D;
+  return part;
+}
+void launch_ln_bwd(WgradCtx& ctx, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
                    int accumulate, hipStream_t s) {
   if (rows <= 0) return;
-  // every workgroup ends in 256 atomics on the same 256 addresses (dgamma, dbeta): keep the launch at <= ~160 workgroups
-  const int groups = std::min(32, std::max(1, (rows + 32 * 160 - 1) / (32 * 160)));
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 32 * groups - 1) / (32 * groups)), dim3(256), 0, s, x, gamma, dy, dx, dgamma,
-                     dbeta, rows, groups, accumulate);
+  const int groups = ln_bwd_groups(rows), n_wg = ln_bwd_slots(rows);
+  float* gp = reserve_vec(ctx, dgamma, n_wg, s);
+  float* bp = reserve_vec(ctx, dbeta, n_wg, s);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_wg), dim3(256), 0, s, x, gamma, dy, dx, gp, bp, rows, groups, accumulate);
 }
 
 // ---- edge elementwise kernels (thread = float4 chunk of an edge row) -------------------------------------------------
@@ -601,10 +662,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     reinterpret_cast<float2*>(dq)[(size_t)at * 64 + lane] = make_float2(dqx, dqy);
   }
-  atomicAdd(&dgamma[2 * lane], dg.x);
-  atomicAdd(&dgamma[2 * lane + 1], dg.y);
-  atomicAdd(&dbeta[2 * lane], dbt.x);
-  atomicAdd(&dbeta[2 * lane + 1], dbt.y);
+  const size_t slot = (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * D;  // one slot per wave
+  reinterpret_cast<float2*>(dgamma + slot)[lane] = dg;
+  reinterpret_cast<float2*>(dbeta + slot)[lane] = dbt;
 }
 // Fast path when no atom of the batch has more than 16 neighbours (QM9: <= 12): the atom's key rows, logits and
 // attention gradients live in registers, so K is read once and the 8-lane dot-product reductions run once per edge.
@@ -713,22 +773,32 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict
   const int t = threadIdx.x;
   const float tot = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
   const int ln = t & 63, which = t >> 6;
-  atomicAdd((which < 2 ? dgamma : dbeta) + 2 * ln + (which & 1), tot);
+  (which < 2 ? dgamma : dbeta)[(size_t)blockIdx.x * D + 2 * ln + (which & 1)] = tot;  // this workgroup's slot
 }
 
-void launch_attn_bwd(const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
+int attn_bwd_slots(int n_atom, int max_degree) {
+  if (max_degree <= 16) {
+    const int apw16 = n_atom >= 16384 ? 8 : 4;
+    return (n_atom + 4 * apw16 - 1) / (4 * apw16);  // one slot per workgroup
+  }
+  return 4 * ((n_atom + 4 * 2 - 1) / (4 * 2));      // one slot per wave
+}
+void launch_attn_bwd(WgradCtx& ctx, const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
                      float* dK, float* dgamma, float* dbeta, int n_atom, int max_degree, float drop_p, unsigned drop_tag,
                      unsigned long long drop_seed, hipStream_t s) {
   if (n_atom <= 0) return;
+  const int n_slot = attn_bwd_slots(n_atom, max_degree);
+  float* gp = reserve_vec(ctx, dgamma, n_slot, s);
+  float* bp = reserve_vec(ctx, dbeta, n_slot, s);
   if (max_degree <= 16) {
     const int apw16 = n_atom >= 16384 ? 8 : 4;
     hipLaunchKernelGGL(attn_bwd16_kernel, dim3((n_atom + 4 * apw16 - 1) / (4 * apw16)), dim3(256), 0, s, q, K, edge_offset, dctx,
-                       gamma, dq, dK, dgamma, dbeta, n_atom, apw16, drop_p, drop_tag, drop_seed);
+                       gamma, dq, dK, gp, bp, n_atom, apw16, drop_p, drop_tag, drop_seed);
     return;
   }
   const int apw = 2;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((n_atom + 4 * apw - 1) / (4 * apw)), dim3(256), 0, s, q, K, edge_offset, dctx,
-                     gamma, dq, dK, dgamma, dbeta, n_atom, apw, drop_p, drop_tag, drop_seed);
+                     gamma, dq, dK, gp, bp, n_atom, apw, drop_p, drop_tag, drop_seed);
 }
 
 // ---- readout backward: one workgroup per structure ------------------------------------------------------------------
