@@ -161,23 +161,25 @@ class HipModel:
             self.count_params(), self.config["model"]["n_attention"], self.config["model"]["g_update"]))
 
 
-def _read_container(path):
+def _read_container(path, config=None):
     with open(path, "rb") as f:
         magic = f.read(8)
-    if magic.startswith(b"\x89HDF"):
-        raise NotImplementedError(
-            "%s is a Keras HDF5 checkpoint; importing the reference's .h5 files needs h5py and is not "
-            "implemented yet (SURVEY.md section 8f-3).  Use a container written by HipModel.save()." % path)
+    if magic.startswith(b"\x89HDF"):  # a Keras full-model HDF5 checkpoint of the reference (scann_model.py:166-177)
+        from .keras_import import load_keras_h5
+
+        return load_keras_h5(path, config)
     z = np.load(path, allow_pickle=False)
     cfg = json.loads(str(z["__config__"]))
     return cfg, {k: z[k] for k in z.files if k != "__config__"}
 
 
 def load_model(path, custom_objects=None, infer=False, config=None):
-    """``tf.keras.models.load_model`` counterpart (scann_model.py:79,87,323)."""
-    cfg, weights = _read_container(path)
-    if config is not None:  # the caller's yaml wins for everything but the architecture
-        cfg["hyper"].update({k: v for k, v in config.get("hyper", {}).items()})
+    """``tf.keras.models.load_model`` counterpart (scann_model.py:79,87,323): this package's weight container, or a Keras
+    HDF5 checkpoint written by the reference (imported by ``keras_import``; pass the run's ``config`` for the keys the file
+    does not determine)."""
+    cfg, weights = _read_container(path, config)
+    if config is not None:  # the caller's yaml wins for everything but the architecture (hyper.target selects the mrelu head)
+        cfg["hyper"].update({k: v for k, v in config.get("hyper", {}).items() if k != "target" or "target" not in cfg["hyper"]})
     return HipModel(cfg, weights, infer=infer)
 
 
@@ -212,7 +214,7 @@ class SCANN:
             else:
                 self.model = create_model(self.config)
         else:
-            self.model = load_model(pretrained, infer=True)
+            self.model = load_model(pretrained, infer=True, config=self.config)
 
     @classmethod
     def load_model_infer(cls, path):

@@ -524,3 +524,29 @@ def test_bench_two_ranks_through_the_self_spawning_launcher(hip_lib):
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0
     assert out.get("oversubscribed", False) == (ndev < 2)
     assert out["roofline"]["launches_sampled"] > 0 and 0 < out["roofline"]["frac"] < 1.5
+
+
+def test_keras_h5_checkpoint_loads_and_predicts(hip_lib, tmp_path):
+    """SCANN(config, pretrained=<Keras .h5>, mode="infer") -- the reference's way of loading a trained model
+    (scann_model.py:79-83) -- through the pure-Python HDF5 reader and the Keras-name map; the file is written in Keras' layout
+    by h5py (not by TensorFlow: unavailable here).  Same predictions as the same weights loaded from the native container."""
+    import json
+    import os
+    import subprocess
+
+    from scann.models import SCANN
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import h5py"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with h5py to write the Keras-layout file")
+    cfg, w, inputs, model = make(n=10, seed=3)
+    npz, h5 = tmp_path / "model.npz", tmp_path / "model_homo.h5"
+    np.savez(npz, __config__=np.array(json.dumps(model.config)), **w)
+    subprocess.run([py, os.path.join(root, "tools", "make_keras_h5_fixture.py"), str(npz), str(h5)], check=True)
+    yaml_cfg = {"model": {k: v for k, v in cfg["model"].items() if k in ("n_atoms", "scale")}, "hyper": {"target": "homo"}}
+    scann = SCANN(yaml_cfg, pretrained=str(h5), mode="infer")
+    y1, ga1 = scann.model.predict(inputs)
+    y0, ga0 = model.predict(inputs)
+    assert np.array_equal(y1, y0) and np.array_equal(ga1, ga0)
+    assert scann.model.config["model"]["n_attention"] == cfg["model"]["n_attention"]

@@ -326,15 +326,18 @@ def test_prepare_input_from_neighbors_matches_batch_of_one():
         assert _hip.pack_inputs(got).n_edge == int(ref["neighbor_mask"].sum())
 
 
-def test_keras_hdf5_checkpoint_is_refused_with_a_clear_message(tmp_path):
-    """Keras .h5 import is not available; the loader must say so instead of mis-parsing."""
+def test_hdf5_files_go_to_the_keras_importer_and_bad_ones_fail_loudly(tmp_path):
+    """A path with the HDF5 magic is a Keras checkpoint of the reference: it is routed to keras_import; a
+    file that is not a complete HDF5 / Keras file raises instead of being mis-parsed (tests/test_keras_import.py has the
+    working cases)."""
     from scann.models.scann_model import _read_container
+    from scann.utils.hdf5_lite import Hdf5Error
 
     p = tmp_path / "model_homo.h5"
-    p.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(NotImplementedError) as e:
+    p.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\x07" + b"\0" * 64)  # superblock version 7 does not exist
+    with pytest.raises(Hdf5Error) as e:
         _read_container(str(p))
-    assert "HDF5" in str(e.value)
+    assert "superblock version" in str(e.value)
 
 
 def test_native_packers_ring_cgcnn_masks_and_errors():

@@ -1,0 +1,163 @@
+"""importing the reference's Keras HDF5 checkpoints without h5py / TensorFlow.
+
+Pins: (1) the pure-Python HDF5 reader against a committed file written by h5py / libhdf5 1.10.6; (2) the Keras-name ->
+container-name mapping on a nested dict shaped like Keras' ``model_weights`` group; (3) when an interpreter with h5py is
+around (this image: /opt/conda/bin/python3.9), a full container -> Keras-layout .h5 -> importer round trip for every
+architecture switch.  None of this is a file written by TensorFlow itself (unavailable offline): see keras_import.py."""
+import importlib.util
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import scann_oracle as so
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H5PY_PYTHON = next((p for p in ("/opt/conda/bin/python3.9", shutil.which("python3.9") or "") if p and os.path.exists(p) and
+                    subprocess.run([p, "-c", "import h5py"], capture_output=True).returncode == 0), None)
+
+
+def test_hdf5_lite_reads_a_file_written_by_libhdf5():
+    from scann.utils.hdf5_lite import Dataset, File, Group
+
+    spec = importlib.util.spec_from_file_location("make_h5_fixture", os.path.join(ROOT, "tests", "golden", "make_h5_fixture.py"))
+    # the generator imports h5py at module level: take only its contents() (numpy + json) by executing it with h5py stubbed
+    import sys
+    import types
+    had = sys.modules.get("h5py")
+    sys.modules["h5py"] = types.ModuleType("h5py")
+    try:
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if had is None:
+            del sys.modules["h5py"]
+        else:
+            sys.modules["h5py"] = had
+    c = mod.contents()
+    f = File(os.path.join(ROOT, "tests", "golden", "hdf5_lite_fixture.h5"))
+    assert f.attrs["keras_version"] == "2.10.0" and f.attrs["model_config"] == c["config"] and f.attrs["backend"] == b"tensorflow"
+    g = f["model_weights"]
+    assert isinstance(g, Group) and [n.decode() for n in g.attrs["layer_names"]] == c["names"] and sorted(g.keys()) == sorted(c["names"])
+    for n in c["names"]:
+        d = g[n]["%s/sub/kernel:0" % n]
+        assert isinstance(d, Dataset) and d.shape == (6, 5) and np.array_equal(d.read(), c["kernels"][n])
+        assert [w.decode() for w in g[n].attrs["weight_names"]] == ["%s/sub/kernel:0" % n]
+    assert np.array_equal(f["vec64"].read(), c["vec64"]) and f["vec64"].read().dtype == np.float64
+    assert np.array_equal(f["ints"].read(), c["ints"]) and np.array_equal(f["be"].read(), np.asarray(c["be"], dtype="<f4"))
+    assert f["scalar"].read() == 3.5
+    assert len(f["empty_attr_holder"].attrs["weight_names"]) == 0
+    assert len(list(g.visit_datasets())) == len(c["names"])
+    with pytest.raises(KeyError):
+        f["model_weights/nope"]
+
+
+def _keras_nested(cfg, w):
+    """The container `w` as the nested structure Keras' model_weights group has (layer -> [(weight name, array)]), with the
+    auto-generated names a create_model build produces: global LayerNormalization / Dense counters, weightless layers."""
+    m = cfg["model"]
+    sfx = lambda stem, k: stem if k == 0 else "%s_%d" % (stem, k)  # noqa: E731
+    layers = [("atomic", []), ("neighbors", [])]
+    if "embed_atom/embeddings" in w:
+        layers.append(("embed_atom", [("embed_atom/embeddings:0", w["embed_atom/embeddings"])]))
+    else:
+        layers.append(("embed_atom", [("embed_atom/kernel:0", w["embed_atom/kernel"]), ("embed_atom/bias:0", w["embed_atom/bias"])]))
+    plain = lambda n: (n, [("%s/kernel:0" % n, w[n + "/kernel"]), ("%s/bias:0" % n, w[n + "/bias"])])  # noqa: E731
+    if m["use_ring"]:
+        layers.append(plain("extra_embed"))
+    layers += [plain("dense_embed"), ("dropout", []), ("gaussian_expansion", [])]
+    if m["g_update"]:
+        layers += [plain("neighbor_d"), plain("neighbor_w"), ("geometry_features", [])]
+    ln, dn = 3, 5  # counters need not start at 0: other models built earlier in the same process shift them
+    for k in range(m["n_attention"]):
+        name, p = sfx("local_attention", k), "local_attention_%d/" % k
+        ws = []
+        for sub in ("query", "key", "filter_geo"):
+            ws += [("%s/%s/kernel:0" % (name, sub), w[p + sub + "/kernel"]), ("%s/%s/bias:0" % (name, sub), w[p + sub + "/bias"])]
+        for part in (["layer_norm", "layer_norm_g"] if m["g_update"] else ["layer_norm"]):
+            ws += [("%s/%s/gamma:0" % (name, sfx("layer_normalization", ln)), w[p + part + "/gamma"]),
+                   ("%s/%s/beta:0" % (name, sfx("layer_normalization", ln)), w[p + part + "/beta"])]
+            ln += 1
+        layers.append((name, ws))
+        if m["use_attn_norm"]:
+            name, p = sfx("residual_norm", k), "residual_norm_%d/" % k
+            ws = []
+            for j in (1, 2):
+                ws += [("%s/sequential/%s/kernel:0" % (name, sfx("dense", dn)), w[p + "dense_%d/kernel" % j]),
+                       ("%s/sequential/%s/bias:0" % (name, sfx("dense", dn)), w[p + "dense_%d/bias" % j])]
+                dn += 1
+            ws += [("%s/%s/gamma:0" % (name, sfx("layer_normalization", ln)), w[p + "layer_norm/gamma"]),
+                   ("%s/%s/beta:0" % (name, sfx("layer_normalization", ln)), w[p + "layer_norm/beta"])]
+            ln += 1
+            layers.append((name, ws))
+    layers.append(plain("after_Lc"))
+    layers.append(("global_attention", [("global_attention/%s/%s:0" % (s_, l_), w["global_attention/%s/%s" % (s_, l_)])
+                                        for s_ in ("query", "key") for l_ in ("kernel", "bias")]))
+    layers += [plain("bf_property"), plain("predict_property")]
+    from collections import OrderedDict
+    return OrderedDict(layers)
+
+
+CASES = {
+    "qm9_plus": dict(),
+    "base": dict(g_update=False),
+    "no_attn_norm": dict(use_attn_norm=False, use_ga_norm=False),
+    "ring_cgcnn": dict(use_ring=True, feature="cgcnn"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_keras_name_map_on_a_model_weights_shaped_dict(name):
+    from scann.models.keras_import import infer_model_config, map_keras_weights
+
+    cfg = so.default_config("qm9")
+    cfg["model"].update(CASES[name], n_attention=3)
+    w = so.init_weights(cfg, 11, perturb=True)
+    got = map_keras_weights(_keras_nested(cfg, w))
+    assert set(got) == set(w), set(got) ^ set(w)
+    for k in w:
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], w[k]), k
+    m, _ = infer_model_config(got)
+    for key in ("n_attention", "g_update", "use_attn_norm", "use_ring", "local_dim", "global_dim", "dense_out", "embedding_dim"):
+        assert m[key] == cfg["model"][key], key
+    assert m["feature"] == cfg["model"].get("feature", "atomic")
+
+
+def test_keras_name_map_rejects_foreign_layers():
+    from scann.models.keras_import import map_keras_weights
+
+    cfg = so.default_config("qm9")
+    cfg["model"]["n_attention"] = 1
+    layers = _keras_nested(cfg, so.init_weights(cfg, 1))
+    layers["conv1d"] = [("conv1d/kernel:0", np.zeros((3, 3), np.float32))]
+    with pytest.raises(ValueError, match="not part of the SCANN graph"):
+        map_keras_weights(layers)
+
+
+@pytest.mark.skipif(H5PY_PYTHON is None, reason="no interpreter with h5py to write the Keras-layout file")
+@pytest.mark.parametrize("name", sorted(CASES) + ["e_b"])
+def test_container_to_keras_h5_and_back(tmp_path, name):
+    """container (.npz) -> Keras-layout HDF5 written by h5py (tools/make_keras_h5_fixture.py) -> load_keras_h5: the same
+    bits, and the architecture the file determines."""
+    from scann.models.keras_import import load_keras_h5
+    from scann.models.scann_model import normalize_config
+
+    cfg = normalize_config(so.default_config("qm9"))
+    cfg["model"].update(CASES.get(name, {}), n_attention=2, gaussian_d=5.0)
+    if name == "e_b":
+        cfg["hyper"]["target"] = "e_b"
+    w = so.init_weights(cfg, 7, perturb=True)
+    npz, h5 = tmp_path / "model.npz", tmp_path / "model_keras.h5"
+    np.savez(npz, __config__=np.array(json.dumps(cfg)), **w)
+    subprocess.run([H5PY_PYTHON, os.path.join(ROOT, "tools", "make_keras_h5_fixture.py"), str(npz), str(h5)], check=True)
+    yaml_like = {"model": {"n_atoms": 10, "scale": 0.5}, "hyper": {"target": "homo", "batch_size": 128}}
+    got_cfg, got = load_keras_h5(str(h5), yaml_like)
+    assert set(got) == set(w)
+    for k in w:
+        assert np.array_equal(got[k], w[k]), k
+    for key in ("n_attention", "g_update", "use_attn_norm", "use_ga_norm", "use_ring", "feature", "gaussian_d", "embedding_dim", "num_head"):
+        assert got_cfg["model"][key] == cfg["model"][key], (key, got_cfg["model"][key], cfg["model"][key])
+    assert got_cfg["hyper"]["target"] == ("e_b" if name == "e_b" else "homo") and got_cfg["hyper"]["batch_size"] == 128
