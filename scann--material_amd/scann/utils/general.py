@@ -89,15 +89,12 @@ def prepare_input_from_neighbors(atomic_numbers, neighbors, angle=True):
 
 
 def prepare_input_pmt(struct, d_t=4.0, w_t=0.4, angle=True):
-    """README entry point (general.py:206-246).  The Voronoi neighbour search itself (pymatgen ``VoronoiNN``,
-    voronoi_neighbor.py:11-61) is outside the accelerated path and not re-implemented: with pymatgen installed this
-    delegates to it, otherwise it says so."""
-    try:
-        from pymatgen.analysis.local_env import VoronoiNN  # noqa: F401
-    except ImportError as e:  # pragma: no cover - pymatgen is absent in this image
-        raise ImportError("prepare_input_pmt needs pymatgen for the Voronoi neighbour search; build the neighbour lists "
-                          "elsewhere and call prepare_input_from_neighbors(atomic_numbers, neighbors, angle)") from e
-    from .voronoi import compute_voronoi_neighbor  # pragma: no cover
+    """README entry point (general.py:206-246): model inputs of ONE structure -- Voronoi neighbour lists (solid-angle weights,
+    filtered by ``w_t`` / ``d_t``) padded into the Keras input dict.  ``struct``: a periodic ``Structure`` of
+    ``scann.utils.voronoi_neighbor`` (box a ``Molecule`` first: ``boxed(mol)``), or a pymatgen ``Structure`` (anything with
+    ``.lattice.matrix``, ``.cart_coords``, ``.species``, ``.atomic_numbers``).  The tessellation itself is
+    ``voronoi_neighbor.compute_voronoi_neighbor`` (scipy / qhull; no pymatgen needed)."""
+    from .voronoi_neighbor import compute_voronoi_neighbor
 
-    neighbors = compute_voronoi_neighbor(struct, d_thresh=d_t, w_thresh=w_t)  # pragma: no cover
-    return prepare_input_from_neighbors(struct.atomic_numbers, neighbors, angle)  # pragma: no cover
+    neighbors = compute_voronoi_neighbor(struct, d_thresh=d_t, w_thresh=w_t)
+    return prepare_input_from_neighbors(struct.atomic_numbers, neighbors, angle)
