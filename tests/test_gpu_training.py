@@ -25,6 +25,29 @@ def setup(n=6, L=2, seed=1, **model_over):
     return cfg, w, pk, targets, model
 
 
+GRAD_FLOOR, GRAD_SLACK, GRAD_CAP = 2e-5, 4.0, 2e-4
+
+
+def check_grads(got, cfg, w, pk, targets, attn_scale=None):
+    """Gradient parity rule.  Reference: fp64 autograd of the independent torch graph.  A single-precision step cannot be closer
+    to it than the SAME graph run by torch in fp32 is, so every tensor is held to max(GRAD_FLOOR, GRAD_SLACK x that fp32
+    error), and to GRAD_CAP overall.  (Measured, tests/manual/grad_floor.py: HIP errors 4e-7 ... 1.5e-5 of the tensor scale,
+    1 - 2.2 x the torch-fp32 floor; the 2e-3 bound of round 1 was three orders looser than the implementation needs.)
+    Returns (rmse of the fp64 graph, errors)."""
+    import torch_ref
+
+    _, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=attn_scale)
+    _, _, g32, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=attn_scale, dtype="float32")
+    for k in ref:  # the autograd loss includes the l2 term; the library adds 2*l2*W inside the optimiser step -> remove it here
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+            g32[k] = g32[k] - 2e-4 * w[k].astype(np.float64)
+    e_gpu, e_32 = grad_errors(got, ref), grad_errors(g32, ref)
+    bad = {k: (e_gpu[k], e_32[k]) for k in ref if not e_gpu[k] <= min(GRAD_CAP, max(GRAD_FLOOR, GRAD_SLACK * e_32[k]))}
+    assert not bad, bad
+    return rmse, e_gpu
+
+
 def grad_errors(got, ref):
     out = {}
     for k, r in ref.items():
@@ -46,15 +69,8 @@ def test_gradients_match_autograd(hip_lib, over):
     eng.zero_grads()
     eng.train_backward(rb, sse, pk.n_struct)
     got = eng.get_grads()
-    loss, rmse, ref, y_ref = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    rmse, _ = check_grads(got, cfg, w, pk, targets)
     assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 1e-5 * max(rmse, 1e-6)
-    # the autograd loss includes the l2 term; the library adds 2*l2*W inside the optimiser step -> remove it here
-    for k in ref:
-        if k.endswith(torch_ref.REGULARIZED):
-            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
-    errs = grad_errors(got, ref)
-    bad = {k: v for k, v in errs.items() if not v <= 2e-3}
-    assert not bad, bad
     rb.free()
 
 
@@ -72,14 +88,9 @@ def test_seven_layer_gradients_and_accumulation(hip_lib):
     g1 = eng.get_grads()
     eng.train_backward(rb, sse, pk.n_struct)
     g2 = eng.get_grads()
-    _, _, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets)
-    for k in ref:
-        if k.endswith(torch_ref.REGULARIZED):
-            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
-    errs = grad_errors(g1, ref)
-    assert max(errs.values()) <= 5e-3, {k: v for k, v in errs.items() if v > 5e-3}
+    check_grads(g1, cfg, w, pk, targets)
     for k in g1:
-        assert np.allclose(g2[k], 2 * g1[k], rtol=2e-3, atol=1e-7 + 2e-3 * np.abs(g1[k]).max())
+        assert np.allclose(g2[k], 2 * g1[k], rtol=1e-5, atol=1e-9 + 1e-6 * np.abs(g1[k]).max())  # the reduce adds a second, identical sum
     rb.free()
 
 
@@ -246,11 +257,13 @@ def drop_scale_np(seed, tag, idx, p):
     return np.where(u < np.float32(p), 0.0, 1.0 / (1.0 - float(np.float32(p))))
 
 
-def test_attention_dropout_gradients(hip_lib):
-    """use_drop: the GPU's counter-based attention mask, rebuilt on the host, is fed to the torch graph; gradients match."""
+@pytest.mark.parametrize("g_update", [True, False], ids=["scann_plus", "base"])
+def test_attention_dropout_gradients(hip_lib, g_update):
+    """use_drop: the GPU's counter-based attention mask, rebuilt on the host, is fed to the torch graph; gradients match
+    (both LocalAttention branches run the same softmax code)."""
     import torch_ref
 
-    cfg, w, pk, targets, model = setup(n=6, L=2, seed=2)
+    cfg, w, pk, targets, model = setup(n=6, L=2, seed=2, g_update=g_update)
     eng = model.engine
     eng.train_begin()
     eng.set_attention_dropout(0.3)  # large rate so that many weights are actually dropped
@@ -263,13 +276,8 @@ def test_attention_dropout_gradients(hip_lib):
     idx = np.arange(pk.n_edge * 8, dtype=np.uint64)
     scales = [drop_scale_np(seed, 2000 + l, idx, 0.3).reshape(pk.n_edge, 8) for l in range(2)]
     assert 0.2 < np.mean(scales[0] == 0) < 0.4
-    loss, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=scales)
+    rmse, _ = check_grads(got, cfg, w, pk, targets, attn_scale=scales)
     assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6)
-    for k in ref:
-        if k.endswith(torch_ref.REGULARIZED):
-            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
-    errs = grad_errors(got, ref)
-    assert max(errs.values()) <= 3e-3, {k: v for k, v in errs.items() if v > 3e-3}
     eng.set_attention_dropout(0.0)
     rb.free()
 
@@ -298,13 +306,8 @@ def test_ring_cgcnn_embedding_gradients(hip_lib, ring, cgcnn):
     eng.zero_grads()
     eng.train_backward(rb, sse, pk.n_struct)
     got = eng.get_grads()
-    _, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    rmse, _ = check_grads(got, cfg, w, pk, targets)
     assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6)
-    for k in ref:
-        if k.endswith(torch_ref.REGULARIZED):
-            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
-    errs = grad_errors(got, ref)
-    assert max(errs.values()) <= 2e-3, {k: v for k, v in errs.items() if v > 2e-3}
     eng.adam_step(1e-3)  # also exercises the re-pack without the species LUT
     s2 = eng.train_forward(rb, targets)
     assert np.isfinite(s2)
@@ -332,12 +335,7 @@ def test_gradients_mp2018_shapes(hip_lib):
     eng.zero_grads()
     eng.train_backward(rb, sse, pk.n_struct)
     got = eng.get_grads()
-    _, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets)
-    for k in ref:
-        if k.endswith(torch_ref.REGULARIZED):
-            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
-    errs = grad_errors(got, ref)
-    assert max(errs.values()) <= 3e-3, {k: v for k, v in errs.items() if v > 3e-3}
+    rmse, _ = check_grads(got, cfg, w, pk, targets)
     rb.free()
 
 
@@ -370,14 +368,8 @@ def test_gradients_with_more_than_64_neighbours(hip_lib):
     eng.zero_grads()
     eng.train_backward(rb, sse, pk.n_struct)
     got = eng.get_grads()
-    loss, rmse, ref, y_ref = torch_ref.loss_and_grads(cfg, w, pk, targets)
+    rmse, _ = check_grads(got, cfg, w, pk, targets)
     assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 1e-5 * max(rmse, 1e-6)
-    for k in ref:
-        if k.endswith(torch_ref.REGULARIZED):
-            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
-    errs = grad_errors(got, ref)
-    bad = {k: v for k, v in errs.items() if not v <= 2e-3}
-    assert not bad, bad
     rb.free()
 
 
@@ -420,7 +412,7 @@ if rank == 0:                                                                   
     assert cnt_g == pk.n_struct and abs(sse_g - sse1) <= 1e-5 * sse1, (sse_g, sse1)
     for k in g1:
         scale = max(float(np.sqrt(np.mean(g1[k].astype(np.float64) ** 2))), 1e-12)
-        assert float(np.max(np.abs(g[k] - g1[k]))) <= 1e-3 * scale + 1e-9, k
+        assert float(np.max(np.abs(g[k] - g1[k]))) <= 2e-5 * scale + 1e-9, k  # same sums, different association: rounding only
     print("RCCL2_OK")
 comm.rdzv.barrier()
 '''

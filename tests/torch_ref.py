@@ -10,19 +10,21 @@ REGULARIZED = ("query/kernel", "key/kernel", "filter_geo/kernel", "dense_1/kerne
                "after_Lc/kernel", "bf_property/kernel")  # kernel_regularizer=l2(1e-4): attention.py:27-28,95-109,260-265; scann_model.py:428,441
 
 
-def loss_and_grads(config, weights, pk, targets, attn_scale=None):
+def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64"):
     """Training loss of the reference (scann_model.py:210-214: RMSE + sum of l2(1e-4) kernel regularisers) and its
-    gradient w.r.t. every tensor, by torch autograd in fp64.  Dropout layers are inactive (rate 0)."""
+    gradient w.r.t. every tensor, by torch autograd in fp64 (``dtype="float32"``: the same graph in single precision --
+    the rounding floor any fp32 implementation of the step sits on).  Dropout layers are inactive (rate 0)."""
     import torch
 
-    W = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in weights.items()}
-    y, _ = forward_packed(config, W, pk, "float64", as_tensor=True, attn_scale=attn_scale)
-    t = torch.tensor(np.asarray(targets), dtype=torch.float64).reshape(-1, 1)
+    dt = getattr(torch, dtype)
+    W = {k: torch.tensor(np.asarray(v), dtype=dt, requires_grad=True) for k, v in weights.items()}
+    y, _ = forward_packed(config, W, pk, dtype, as_tensor=True, attn_scale=attn_scale)
+    t = torch.tensor(np.asarray(targets), dtype=dt).reshape(-1, 1)
     rmse = torch.sqrt(torch.mean((y - t) ** 2))  # losses.py:5-6
     reg = sum((W[k] ** 2).sum() for k in W if k.endswith(REGULARIZED)) * 1e-4
     loss = rmse + reg
     loss.backward()
-    return float(loss), float(rmse), {k: v.grad.numpy() for k, v in W.items()}, y.detach().numpy()
+    return float(loss.detach()), float(rmse.detach()), {k: v.grad.numpy().astype(np.float64) for k, v in W.items()}, y.detach().numpy()
 
 
 def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_scale=None):
