@@ -142,15 +142,21 @@ class HipModel:
             pending.clear()
 
         n = len(dataset)
+        grouped = getattr(dataset, "batches", None)  # PackedDataset: a whole group with one native slice call
         for g0 in range(0, n, group):
-            parts = []
-            for i in range(g0, min(n, g0 + group)):
-                item, tgt = dataset[i]
-                parts.append(item if isinstance(item, _hip.PackedBatch) else _hip.pack_inputs(item))
+            if grouped is not None:
+                pk, tgt = grouped(g0, min(n, g0 + group))
                 ts.append(np.asarray(tgt, dtype=np.float32))
-            rb = eng.upload(_hip.concat_packed(parts) if len(parts) > 1 else parts[0])
+            else:
+                parts = []
+                for i in range(g0, min(n, g0 + group)):
+                    item, tgt = dataset[i]
+                    parts.append(item if isinstance(item, _hip.PackedBatch) else _hip.pack_inputs(item))
+                    ts.append(np.asarray(tgt, dtype=np.float32))
+                pk = _hip.concat_packed(parts) if len(parts) > 1 else parts[0]
+            rb = eng.upload(pk)
             eng.forward_resident(rb, len(pending))
-            pending.append((rb, [p.n_struct for p in parts]))
+            pending.append((rb, None))
             if len(pending) >= ns:
                 drain()
         drain()

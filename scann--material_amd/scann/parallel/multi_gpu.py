@@ -11,6 +11,22 @@ import numpy as np
 from .. import _hip
 
 
+class _Run:
+    """Batches [lo, hi) of a PackedDataset, sliced lazily by whoever iterates (a device thread)."""
+
+    def __init__(self, ds, lo, hi):
+        self.ds, self.lo, self.hi = ds, lo, hi
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def __getitem__(self, i):
+        return self.ds[self.lo + i]
+
+    def batches(self, i0, i1):
+        return self.ds.batches(self.lo + i0, self.lo + i1)
+
+
 class MultiGpuPredictor:
     """``MultiGpuPredictor(config, weights).predict_dataset(dataset)``: the batches of ``dataset`` are dealt to the devices
     in contiguous runs (one run per device, sized by edge count) and every device runs ``HipModel.predict_dataset`` on its
@@ -52,14 +68,24 @@ class MultiGpuPredictor:
         n = len(dataset)
         if n == 0:
             return np.zeros(0, np.float32), (np.zeros(0, np.float32) if want_ga else None), np.zeros(0, np.float32)
-        items = [dataset[i] for i in range(n)]
-        costs = [(it.n_edge + 8 * it.n_atom) if isinstance(it, _hip.PackedBatch) else 1 for it, _ in items]
+        if hasattr(dataset, "batches") and hasattr(dataset, "edge_offset"):
+            # PackedDataset: batch costs from its offsets; every device thread slices ITS run of batches itself (the host work
+            # scales with the devices instead of being done up front by the caller)
+            mol, eoff = dataset.mol_offset, dataset.edge_offset
+            per_struct = (eoff[mol[1:]] - eoff[mol[:-1]]) + 8 * np.diff(mol)
+            sel_cost = per_struct[dataset.indexes].astype(np.float64)
+            costs = np.add.reduceat(sel_cost, np.arange(0, len(sel_cost), dataset.batch_size))
+            items = None
+        else:
+            items = [dataset[i] for i in range(n)]
+            costs = [(it.n_edge + 8 * it.n_atom) if isinstance(it, _hip.PackedBatch) else 1 for it, _ in items]
         runs = self._runs(costs, len(self.models))
         out, err = [None] * len(runs), []
 
         def work(k, lo, hi):
             try:
-                out[k] = self.models[k].predict_dataset(items[lo:hi], group=group, want_ga=want_ga)
+                part = _Run(dataset, lo, hi) if items is None else items[lo:hi]
+                out[k] = self.models[k].predict_dataset(part, group=group, want_ga=want_ga)
             except BaseException as e:  # surfaced in the caller's thread
                 err.append(e)
 

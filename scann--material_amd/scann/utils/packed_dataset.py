@@ -72,6 +72,15 @@ class PackedDataset:
                            self.edge_weight, sel)
         return pk, self.target[sel]
 
+    def batches(self, i0, i1):
+        """Batches i0 .. i1-1 as ONE PackedBatch (their structures in order) with ONE native slice call, plus the targets --
+        what ``concat_packed([self[i][0] for i in range(i0, i1)])`` builds, without the per-batch Python work.  Structures
+        are independent and the packed layout has no per-batch padding, so a group of batches is just a longer batch."""
+        sel = self.indexes[i0 * self.batch_size:i1 * self.batch_size]
+        pk = slice_dataset(self.mol_offset, self.edge_offset, self.atomic, self.ring, self.edge_local, self.edge_dist,
+                           self.edge_weight, sel)
+        return pk, self.target[sel]
+
     def batch_part(self, idx, rank, world):
         """Rank ``rank``'s contiguous share of batch ``idx`` (data-parallel training: a rank never packs the structures of
         the other ranks).  Same split as ``scann.parallel.rank_slice`` applied to the whole batch."""
