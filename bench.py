@@ -7,7 +7,7 @@
 A step = one forward of the whole graph (scann_model.py:329-453) over one batch of 128 synthetic QM9-shaped
 molecules (configs/model_qm9.yaml: 7 local-attention layers, d=128, 8 heads, g_update) whose packed inputs are
 already resident in HBM.  The packed layout has no per-batch padding, so the engine runs the K steps as
-floor(K/16) launch sequences over groups of 16..31 concatenated batches (K < 16: one group of K): EXACTLY K batches
+ceil(K/16) launch sequences over groups of at most 16 concatenated batches (equal sizes +-1): EXACTLY K batches
 of 128 molecules per timed region.  The timed region is bracketed by device sync + rank barrier on both sides and is
 REPEATED until >= 1 s has been measured (after an untimed pre-warm that does not depend on --warmup: the chip needs
 a few hundred ms under load to reach its sustained clock); the reported time is the median over repeats of the
@@ -170,12 +170,13 @@ def cpu_baseline(seconds_budget=12.0):
 
 
 def group_sizes(steps, target=16):
-    """K steps -> sizes of the launch groups: floor(K / target) groups whose sizes differ by at most one (16..31 batches
-    each; K < target: one group of K).  Short runs (the driver's --steps 20) therefore run at the same launch size as long
-    ones instead of ending in a small, chip-underfilling tail group."""
+    """K steps -> sizes of the launch groups: ceil(K / target) groups whose sizes differ by at most one, so no group exceeds
+    `target` batches (a 16-batch group is what the on-die caches hold of one layer's working set: 141 MB of geometry + 95 MB
+    of atom rows against the 256 MB Infinity Cache; 20 batches already fall off that edge) and a short run (the driver's
+    --steps 20 -> 10 + 10) does not end in a small, chip-underfilling tail group."""
     if steps <= 0:
         return []
-    n = max(1, steps // target)
+    n = (steps + target - 1) // target
     base, rem = divmod(steps, n)
     return [base + 1] * rem + [base] * (n - rem)
 

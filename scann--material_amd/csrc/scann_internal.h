@@ -17,7 +17,6 @@ constexpr int LDS_STRIDE = 132;  // floats per staged row: 128 + 4 pad (conflict
 constexpr int TE_MAX = 64;       // edge rows per edge tile (two 32-row MFMA row tiles)
 constexpr int TA = 64;           // atom rows per atom tile (two 32-row MFMA row tiles)
 constexpr int TQ = 24;           // atoms per EDGE tile (the query-row buffer of edge_kernel)
-constexpr int TB = 16;           // edges per basis-kernel workgroup (64 measured slower: 0.095 vs 0.088 ms per 16-batch forward)
 constexpr int WPACK = D * D;     // floats in one packed 128x128 weight (fp32 fragment order, or its split-fp16 image: same bytes)
 constexpr float WSCALE = 256.f;  // split-fp16 weights are stored times 2^8 (their lo parts stay normal fp16 numbers); exact inverse in the epilogues
 constexpr float WMAX = 65504.f / WSCALE;  // largest weight magnitude the fp16 hi part can hold
@@ -71,6 +70,7 @@ struct HeadParams {
 struct BasisParams {
   const float *Wd, *bd, *Ww, *bw;  // neighbor_d / neighbor_w [20,128]
   const float *cd, *cw;            // Gaussian centres (20 each)
+  const _Float16 *Wdh, *Wwh;       // split-fp16 images of the two kernels, K padded to 32 (basis_kernel)
 };
 
 // ---- launch wrappers (defined in scann_kernels.hip) -------------------------------------------

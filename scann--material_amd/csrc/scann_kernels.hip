@@ -173,17 +173,17 @@ __device__ __forceinline__ void load_wsplit(const _Float16* __restrict__ Wp, int
 // X[rows][0 .. 16 KS) . W[0 .. 16 KS)[32 wave .. +32), X given as hi / lo planes in LDS.  Operand map of
 // v_mfma_f32_32x32x16_f16 (checked with exact integers by tools/mfma_f16_probe.hip): lane l supplies A[i = l & 31][k = 8 (l >> 5) + j]
 // and B[k = 8 (l >> 5) + j][j' = l & 31], j = 0..7; weights are the A operand, so the product comes out transposed.
-template <int KS, bool FIRST = false>
+template <int KS, bool FIRST = false, int STRIDE = PLANE_STRIDE>
 __device__ __forceinline__ void mma_split(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, const f16x8 (&wh)[KS],
                                           const f16x8 (&wl)[KS], int lane, f32x16 (&acc)[2]) {
-  const int off = (lane & 31) * PLANE_STRIDE + 8 * (lane >> 5);
+  const int off = (lane & 31) * STRIDE + 8 * (lane >> 5);
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const f16x8 xh = *reinterpret_cast<const f16x8*>(sH + off + rt * 32 * PLANE_STRIDE + 16 * s);
-      const f16x8 xl = *reinterpret_cast<const f16x8*>(sL + off + rt * 32 * PLANE_STRIDE + 16 * s);
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(sH + off + rt * 32 * STRIDE + 16 * s);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(sL + off + rt * 32 * STRIDE + 16 * s);
       // FIRST: the chain starts from the inline constant 0 (no zero-fill of the 16 accumulator registers)
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, FIRST && s == 0 ? zero : acc[rt], 0, 0, 0);
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, acc[rt], 0, 0, 0);
@@ -978,47 +978,66 @@ __device__ __forceinline__ float gauss_fast(float x, float c) {
   return fast_exp(-(d * d) * 4.0f);
 }
 
+// geom0 = swish(G(dist) Wd + bd) * swish(G(weight) Ww + bw) for a tile of 64 edges: the two K = 20 products run on the matrix
+// pipe (split-fp16, K padded to 32; the VALU form of round 1 issued 2,600 instructions per wave and was VALU-bound at 92 us
+// per 16-batch launch), bias / swish / product in the accumulator layout, rows stored in 16-byte pieces.
+constexpr int BASIS_STRIDE = 72;  // halfs per staged row: 64 + 8 pad = 144 B (conflict-free b128 fragment reads)
 __global__ __launch_bounds__(256) void basis_kernel(BasisParams p, const float* __restrict__ dist,
                                                     const float* __restrict__ weight, int n_edge,
                                                     float* __restrict__ geom) {
-  __shared__ float sG[TB][2 * NG];
-  const int tid = threadIdx.x;
-  const int e0 = blockIdx.x * TB;
-  const int ne = min(TB, n_edge - e0);
-  const int col = tid & (D - 1), half = tid >> 7;
-  float wd[NG], ww[NG];
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) _Float16 sH[64 * BASIS_STRIDE];  // per row: distance basis [0,32) | angle basis [32,64), hi parts
+  __shared__ __attribute__((aligned(16))) _Float16 sL[64 * BASIS_STRIDE];  // lo parts
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
+  const int e0 = blockIdx.x * 64;
+  const int ne = min(64, n_edge - e0);
+  f16x8 bdh[2], bdl[2], bwh[2], bwl[2];
+  load_wsplit<2>(p.Wdh, wave, lane, bdh, bdl);
+  load_wsplit<2>(p.Wwh, wave, lane, bwh, bwl);
+  float4 bd[4], bw[4];
 #pragma unroll
-  for (int k = 0; k < NG; ++k) {  // this thread's column of both [20,128] kernels, in flight during the basis phase
-    wd[k] = p.Wd[k * D + col];
-    ww[k] = p.Ww[k * D + col];
+  for (int j = 0; j < 4; ++j) {
+    bd[j] = *reinterpret_cast<const float4*>(p.bd + cbase + 8 * j);
+    bw[j] = *reinterpret_cast<const float4*>(p.bw + cbase + 8 * j);
   }
-  const float bd = p.bd[col], bw = p.bw[col];
-  {  // Gaussian expansions of the tile's edges; operands requested together from clamped rows, values masked afterwards
-    constexpr int NV = (TB * 2 * NG + 255) / 256;
-    float x[NV], cc[NV];
+  {
+    const int r = tid >> 2, sub = tid & 3;  // 4 threads per edge row, 8 basis columns each
+    const int rs = min(r, ne - 1);
+    const float xd = dist[e0 + rs], xw = weight[e0 + rs];
+    f16x8 gh[2], gl[2];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = min(tid + 256 * j, TB * 2 * NG - 1), e = min(i / (2 * NG), ne - 1), k = i % (2 * NG);
-      x[j] = (k < NG ? dist : weight)[e0 + e];
-      cc[j] = k < NG ? p.cd[k] : p.cw[k - NG];
+    for (int i = 0; i < 8; ++i) {
+      const int k = 8 * sub + i;
+      const float cdk = p.cd[min(k, NG - 1)], cwk = p.cw[min(k, NG - 1)];
+      const float vd = (k < NG && r < ne) ? gauss_fast(xd, cdk) : 0.f, vw = (k < NG && r < ne) ? gauss_fast(xw, cwk) : 0.f;
+      gh[0][i] = (_Float16)vd; gl[0][i] = (_Float16)(vd - (float)gh[0][i]);
+      gh[1][i] = (_Float16)vw; gl[1][i] = (_Float16)(vw - (float)gh[1][i]);
     }
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = tid + 256 * j;
-      if (i < TB * 2 * NG) sG[i / (2 * NG)][i % (2 * NG)] = i / (2 * NG) < ne ? gauss_fast(x[j], cc[j]) : 0.f;
-    }
+    *reinterpret_cast<f16x8*>(sH + r * BASIS_STRIDE + 8 * sub) = gh[0];
+    *reinterpret_cast<f16x8*>(sL + r * BASIS_STRIDE + 8 * sub) = gl[0];
+    *reinterpret_cast<f16x8*>(sH + r * BASIS_STRIDE + 32 + 8 * sub) = gh[1];
+    *reinterpret_cast<f16x8*>(sL + r * BASIS_STRIDE + 32 + 8 * sub) = gl[1];
   }
   __syncthreads();
-#pragma unroll 2
-  for (int e = half; e < ne; e += 2) {
-    float ad = 0.f, aw = 0.f;
+  f32x16 accd[2], accw[2];
+  mma_split<2, true, BASIS_STRIDE>(sH, sL, bdh, bdl, lane, accd);
+  mma_split<2, true, BASIS_STRIDE>(sH + 32, sL + 32, bwh, bwl, lane, accw);
+  constexpr float WINV = 1.0f / WSCALE;
 #pragma unroll
-    for (int k = 0; k < NG; ++k) {
-      ad += sG[e][k] * wd[k];
-      aw += sG[e][NG + k] * ww[k];
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = lrow + 32 * rt;
+    if (row < ne) {
+      const unsigned off = ((unsigned)(e0 + row) * D + cbase) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 sd = f4swish(make_float4(fmaf(accd[rt][4 * j], WINV, bd[j].x), fmaf(accd[rt][4 * j + 1], WINV, bd[j].y),
+                                              fmaf(accd[rt][4 * j + 2], WINV, bd[j].z), fmaf(accd[rt][4 * j + 3], WINV, bd[j].w)));
+        const float4 sw = f4swish(make_float4(fmaf(accw[rt][4 * j], WINV, bw[j].x), fmaf(accw[rt][4 * j + 1], WINV, bw[j].y),
+                                              fmaf(accw[rt][4 * j + 2], WINV, bw[j].z), fmaf(accw[rt][4 * j + 3], WINV, bw[j].w)));
+        st4(geom, off + 32 * j, f4mul(sd, sw));  // neighbor_d * neighbor_w (scann_model.py:381-389)
+      }
     }
-    // neighbor_d * neighbor_w (scann_model.py:381-389)
-    geom[(size_t)(e0 + e) * D + col] = swishf(ad + bd) * swishf(aw + bw);
   }
 }
 
@@ -1031,7 +1050,7 @@ __global__ void basis_raw_kernel(const float* __restrict__ cd, const float* __re
 void launch_basis(const BasisParams& p, const float* dist, const float* weight, int n_edge, float* geom,
                   hipStream_t s) {
   if (n_edge <= 0) return;
-  hipLaunchKernelGGL(basis_kernel, dim3((n_edge + TB - 1) / TB), dim3(256), 0, s, p, dist, weight, n_edge, geom);
+  hipLaunchKernelGGL(basis_kernel, dim3((n_edge + 63) / 64), dim3(256), 0, s, p, dist, weight, n_edge, geom);
 }
 
 void launch_basis_raw(const float* cd, const float* dist, int n_edge, float* gd, hipStream_t s) {

@@ -569,8 +569,10 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   const size_t oWgk = put_packed(src["global_attention/key/kernel"]), obgk = put_raw(src["global_attention/key/bias"], D);
   const size_t oWb = put_raw(src["bf_property/kernel"], (size_t)D * D), obb = put_raw(src["bf_property/bias"], D);
   const size_t owo = put_raw(src["predict_property/kernel"], D), obo = put_raw(src["predict_property/bias"], 1);
-  size_t oWd = NONE, obd = NONE, oWw = NONE, obw = NONE;
+  size_t oWd = NONE, obd = NONE, oWw = NONE, obw = NONE, oWdh = NONE, oWwh = NONE;
   if (c.g_update) {
+    oWdh = put_f16(src["neighbor_d/kernel"], NG, 2);
+    oWwh = put_f16(src["neighbor_w/kernel"], NG, 2);
     oWd = put_raw(src["neighbor_d/kernel"], (size_t)NG * D);
     obd = put_raw(src["neighbor_d/bias"], D);
     oWw = put_raw(src["neighbor_w/kernel"], (size_t)NG * D);
@@ -633,7 +635,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   h->head = HeadParams{P(oWa), P(oba), P(oWgq), P(obgq), P(oWgk), P(obgk),
                        reinterpret_cast<const _Float16*>(P(oWah)), reinterpret_cast<const _Float16*>(P(oWgqh)),
                        reinterpret_cast<const _Float16*>(P(oWgkh)), P(oWb), P(obb), P(owo), P(obo)};
-  h->basis = BasisParams{P(oWd), P(obd), P(oWw), P(obw), P(ocd), P(ocw)};
+  h->basis = BasisParams{P(oWd), P(obd), P(oWw), P(obw), P(ocd), P(ocw), reinterpret_cast<const _Float16*>(P(oWdh)),
+                         reinterpret_cast<const _Float16*>(P(oWwh))};
   h->cd = P(ocd);
   h->lut = P(olut);
   h->embed = EmbedArgs{};

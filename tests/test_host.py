@@ -560,8 +560,9 @@ def test_bench_group_sizes_cover_exactly_the_steps():
 
     for k in (1, 5, 15, 16, 20, 31, 32, 47, 100, 2000):
         sizes = bench.group_sizes(k)
-        assert sum(sizes) == k and max(sizes) - min(sizes) <= 1
-        assert (len(sizes) == 1 and sizes[0] == k) if k < 32 else all(16 <= s <= 31 for s in sizes)
+        assert sum(sizes) == k and max(sizes) - min(sizes) <= 1 and max(sizes) <= 16
+        assert len(sizes) == -(-k // 16)
+    assert bench.group_sizes(20) == [10, 10] and bench.group_sizes(2000) == [16] * 125
     assert bench.group_sizes(0) == []
     assert bench.group_sizes(7, 1) == [1] * 7
 
