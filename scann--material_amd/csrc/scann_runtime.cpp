@@ -1163,10 +1163,10 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
 
 struct scann_train_ws {  // per resident batch, allocated on first use
   char* arena = nullptr;
-  float *tA[10] = {};   // [n_atom,128] temporaries
+  float *tA[15] = {};   // [n_atom,128] temporaries (5 of them the second set of the per-layer gradients, see scann_train_backward)
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128] or null
   float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;
-  float *tE[10] = {};   // [n_edge,128] temporaries
+  float *tE[12] = {};   // [n_edge,128] temporaries
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   float* wpart = nullptr;  // per-slab partial sums of every weight gradient of a step (WgradCtx::arena)
   size_t wpart_floats = 0;
@@ -1205,13 +1205,13 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
                    // LayerNorm gamma / beta partials: per layer ln_bwd over edges and atoms, attention backward over atoms
                    (size_t)2 * D * Lc * ((size_t)ln_bwd_slots(std::max(db->n_edge, 1)) + (size_t)ln_bwd_slots(db->n_atom) +
                                          (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
-  const size_t total = 10 * rowA + 10 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
+  const size_t total = 15 * rowA + 12 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
                        align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4) +
                        align_up((size_t)(w.wtable_cap = 32 * (int)Lc + 64) * sizeof(WgradReduceEntry));
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
-  for (int i = 0; i < 10; ++i) { w.tA[i] = (float*)p; p += rowA; }
-  for (int i = 0; i < 10; ++i) { w.tE[i] = (float*)p; p += rowE; }
+  for (int i = 0; i < 15; ++i) { w.tA[i] = (float*)p; p += rowA; }
+  for (int i = 0; i < 12; ++i) { w.tE[i] = (float*)p; p += rowE; }
   w.rep = (float*)p; p += rowB;
   w.dpre = (float*)p; p += rowB;
   w.dy = (float*)p; p += align_up((size_t)db->n_struct * 4);
@@ -1407,6 +1407,15 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     (void)hipEventRecord(e, aux);
     (void)hipStreamWaitEvent(s, e, 0);
   };
+  std::vector<hipEvent_t> ev_layer((size_t)L + 1, nullptr);  // recorded on the side stream after layer l's gradient launch (L = readout)
+  auto mark_layer = [&](int l) {
+    if (!side) return;
+    ev_layer[l] = h->train_ev[ev_i++ % h->train_ev.size()];
+    (void)hipEventRecord(ev_layer[l], aux);
+  };
+  auto wait_layer = [&](int l) {  // the main stream may not overwrite operand set l & 1 before layer l's gradients have read it
+    if (side && l <= L && ev_layer[l]) (void)hipStreamWaitEvent(s, ev_layer[l], 0);
+  };
   WgradCtx wg;
   wg.arena = w.wpart;
   wg.d_table = w.wtable;
@@ -1417,32 +1426,45 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
         *dP1 = w.tA[7], *dP3 = w.tA[8], *t4 = w.tA[9];
   float *eAng = w.tE[0], *eK = w.tE[1], *edK = w.tE[2], *edAng = w.tE[3], *eU = w.tE[4], *eV = w.tE[5], *eT = w.tE[6],
         *edGt = w.tE[7], *edGa = w.tE[8], *edGb = w.tE[9];
+  // The operands of a layer's weight gradients (t3, t4, dQ, dP1, dP3, edK, eU) exist twice: layer l uses set l & 1, so its
+  // gradient launch may run beside the whole data-gradient chain of layer l - 1 and is only waited for when layer l - 2 is
+  // about to overwrite the set.
+  float* const setA[2][5] = {{t3, t4, dQ, dP1, dP3}, {w.tA[10], w.tA[11], w.tA[12], w.tA[13], w.tA[14]}};
+  float* const setE[2][2] = {{edK, eU}, {w.tE[10], w.tE[11]}};
   const float* cL = db->dbg_c + (size_t)L * nA;  // centres entering after_Lc
 
   // ---- readout (scann_model.py:424-447, attention.py:267-318) ----
+  float* const rdgk = setA[L & 1][0];  // the readout counts as "layer L" of the operand-set scheme: its gradients read set L & 1
   // forward recompute: preA = cL.Wa + ba (t0), z = swish(preA) (t1); gq, gk, ga, y are still in the batch workspace
   launch_linear(cL, h->head.Wap, h->head.ba, t1, t0, A, 2, s);
   ReadoutBwdArgs ra{};
   ra.mol_offset = db->mol_offset; ra.n_struct = B; ra.max_atoms = db->max_atoms; ra.use_ga_norm = c.use_ga_norm;
   ra.gq = db->gq; ra.gk = db->gk; ra.ga = db->ga; ra.dy = w.dy;
   ra.Wb = h->head.Wb; ra.bb = h->head.bb; ra.wo = h->head.wo;
-  ra.dgq = t2; ra.dgk = t3; ra.rep_out = w.rep; ra.dpre_out = w.dpre;
+  ra.dgq = t2; ra.dgk = rdgk; ra.rep_out = w.rep; ra.dpre_out = w.dpre;
   ra.dwo = g("predict_property/kernel"); ra.dbo = g("predict_property/bias");
   launch_readout_bwd(ra, s);
   {
     hipStream_t ws = fork();
     launch_wgrad(wg, w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B, ws);
-    launch_wgrad3(wg, t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), t3, g("global_attention/key/kernel"),
+    launch_wgrad3(wg, t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), rdgk, g("global_attention/key/kernel"),
                   g("global_attention/key/bias"), nullptr, nullptr, nullptr, A, ws);
   }
-  launch_linear_sum(t2, h->WgqT, t3, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
-  launch_swish_bwd(t0, t4, dQ, nA, s);                        // dpreA (dQ is free until the first layer: t2 is still being read beside us)
-  launch_wgrad(wg, cL, dQ, g("after_Lc/kernel"), g("after_Lc/bias"), A, fork());
-  launch_linear(dQ, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
+  launch_linear_sum(t2, h->WgqT, rdgk, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
+  float* const dpreA = setA[L & 1][2];                        // the readout counts as "layer L" of the operand-set scheme
+  launch_swish_bwd(t0, t4, dpreA, nA, s);                     // dpreA (t2 is still being read beside us)
+  launch_wgrad(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A, fork());
+  mark_layer(L);
+  launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
   for (int l = L - 1; l >= 0; --l) {
-    join();  // the weight-gradient GEMMs of the previous layer have read their operands
+    wait_layer(l + 2);  // operand set l & 1 was last used by layer l + 2: its weight-gradient launch must have read it
+    if (side) {
+      float* const* a5 = setA[l & 1];
+      t3 = a5[0]; t4 = a5[1]; dQ = a5[2]; dP1 = a5[3]; dP3 = a5[4];
+      edK = setE[l & 1][0]; eU = setE[l & 1][1];
+    }
     const LayerParams& p = h->layers[l];
     const scann_handle::LayerT& pt = h->layersT[l];
     const std::string la = "local_attention_" + std::to_string(l) + "/", rn = "residual_norm_" + std::to_string(l) + "/";
@@ -1464,11 +1486,14 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
         launch_add(t2, ctx, nA, s);                            // T2 = x + drop(Y)
       }
       launch_ln_bwd(wg, T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
-      HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
-      launch_dropout(t3, nA, w.seed, (unsigned)l, w.drop_p, s);  // dY
-      launch_wgrad(wg, H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A, fork());
+      // gradient of the Dense_2 output = dT2 through the Dropout mask, in a buffer of its own: dT2 (dCtx) is the residual path and
+      // is accumulated into below, while the queued weight gradient reads its operand at the end of the layer
+      if (w.drop_p > 0.f) launch_dropout_copy(t3, dCtx, nA, w.seed, (unsigned)l, w.drop_p, s);
+      else HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
+      wgrad_add(wg, H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A);
       launch_linear(t3, pt.Wf2T, nullptr, t4, const_cast<float*>(pre1), A, 4, s);  // dpre1 = (dY.W2^T) * swish'(pre1)
-      launch_wgrad(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A, fork());
+      wgrad_add(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A);
+      if (!side) wgrad_launch(wg, s);  // without the kept-activation forward the operands do not survive the layer
       launch_linear(t4, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
     } else {
       HIPCHK(h, hipMemcpyAsync(dCtx, dC, nA * 4, hipMemcpyDeviceToDevice, s));
@@ -1483,7 +1508,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
       launch_attn_bwd(wg, db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-      launch_wgrad(wg, eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);
+      launch_wgrad(wg, eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);  // also launches the queued ResidualNorm gradients
       launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
       launch_edge_dang(c_in, db->edge_col, eV, edAng, nullptr, eAng, edGt, E, s);  // per edge dang*geomL (in eAng) ; dgeomL = dang*c[j]
       launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);              // dC[j] = sum over the edges that point at j
@@ -1513,26 +1538,31 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     }
     launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-    launch_wgrad(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E, kept ? fork() : s);  // recomputed ang is overwritten below: main stream then
+    wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
+    if (!side) wgrad_launch(wg, s);  // the recomputed ang / temporaries do not survive the layer: launch now
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
-    launch_edge_dang(c_in, db->edge_col, Gout, edAng, dG_in, eAng, edGt, E, s);  // per edge dang*G' (in eAng) ; dG'tot
-    launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);               // dC now collects d loss / d centres_l: dC[j] = sum over the edges that point at j
+    // dC now collects d loss / d centres_l: dC[j] = sum over the edges that point at j of dang * G' (backward of the gate ang = c[j] * G')
+    launch_gather_prod_sum(edAng, Gout, db->in_off, db->in_edge, dC, A, 0, s);
     // geometry update: G' = LN_g(swish(V) + G), V = G.W2 + P1[i] + P3[j]
     if (!kept) {
       launch_linear(Gin, p.W2p, nullptr, eU, nullptr, E, 0, s);
       launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
     }
     float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
-    launch_ln_bwd(wg, TL, p.lng_g, edGt, dGnext, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), E, 0, s);  // dT (residual path)
-    launch_edge_dv(VL, dGnext, eU, E, s);                                         // dV (in eU)
-    launch_segment_sum(eU, db->edge_offset, dP1, A, s);                           // dP1[i] = sum over the atom's own edges
-    launch_gather_sum(eU, db->in_off, db->in_edge, dP3, A, 0, s);                 // dP3[j] = sum over the edges that point at j
+    // LayerNorm_g backward with its neighbours fused: in  dG'tot = dang * c[j] + dG'(next layer), out  dT (residual path, -> dGnext)
+    // and dV = dT * swish'(V) (-> eU)
+    launch_ln_bwd_edge(wg, TL, p.lng_g, edAng, c_in, db->edge_col, dG_in, VL, dGnext, eU, g(la + "layer_norm_g/gamma"),
+                       g(la + "layer_norm_g/beta"), E, s);
+    launch_atom_sums(eU, db->edge_offset, db->in_off, db->in_edge, dP1, dP3, A, s);  // dP1[i]: the atom's own edges; dP3[j]: the edges that point at j
     float* fgk = g(la + "filter_geo/kernel");
-    launch_wgrad(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E, fork());              // dW2
+    wgrad_add(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E);                     // dW2
     launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                // dG += dV.W2^T
     // per-atom projections
-    launch_wgrad3(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), dP3, fgk + (size_t)2 * D * D, nullptr, dQ, g(la + "query/kernel"),
-                  g(la + "query/bias"), A, fork());
+    wgrad_add(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), A);
+    wgrad_add(wg, c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A);
+    wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
+    wgrad_launch(wg, fork());  // every weight gradient of this layer (ResidualNorm 2, key, filter_geo 3, query) in ONE launch
+    mark_layer(l);
     launch_linear_sum(dP1, pt.W1T, dP3, pt.W3T, dQ, pt.WqT, dC, A, 1, s);  // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T
     dG_in = dGnext;
   }

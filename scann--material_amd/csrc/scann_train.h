@@ -34,7 +34,14 @@ struct WgradReduceEntry {
   const float* part;
   int32_t n_slab, numel;
 };
+constexpr int WGRAD_MAX_JOBS = 8;
 struct WgradCtx {
+  struct Job {
+    const float *X, *dY;
+    float *part, *bpart;
+    int32_t rows, chunks;
+  };
+  std::vector<Job> jobs;                  // queued by wgrad_add, launched together by wgrad_launch
   float* arena = nullptr;                 // partial slots (device)
   size_t off = 0;                         // floats used
   WgradReduceEntry* d_table = nullptr;    // device copy of `entries` (capacity table_cap), filled by wgrad_flush
@@ -42,6 +49,8 @@ struct WgradCtx {
   std::vector<WgradReduceEntry> entries;  // one per gradient tensor of the step
 };
 int wgrad_slabs(int rows);
+void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows);
+void wgrad_launch(WgradCtx& ctx, hipStream_t s);
 void wgrad_flush(WgradCtx& ctx, hipStream_t s);
 void launch_wgrad(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s);
 // up to three weight gradients that share the left operand X in one launch (null dY1 / dY2: fewer)
@@ -70,6 +79,13 @@ void launch_edge_v(const float* U, const float* P1, const float* P3, const int* 
                    float* T, int n_edge, hipStream_t s);
 void launch_edge_dv(const float* V, const float* dT, float* dV, int n_edge, hipStream_t s);
 void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s);
+void launch_ln_bwd_edge(WgradCtx& ctx, const float* T, const float* gamma, const float* dang, const float* c, const int* nb,
+                        const float* dg_in, const float* V, float* dT, float* dV, float* dgamma, float* dbeta, int rows, hipStream_t s);
+void launch_gather_prod_sum(const float* x, const float* y, const int* in_off, const int* in_edge, float* out, int n_atom, int accumulate,
+                            hipStream_t s);
+void launch_atom_sums(const float* dV, const int* edge_offset, const int* in_off, const int* in_edge, float* own, float* in, int n_atom,
+                      hipStream_t s);
+void launch_dropout_copy(float* dst, const float* src, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s);
 void launch_attn_bwd(WgradCtx& ctx, const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
                      float* dK, float* dgamma, float* dbeta, int n_atom, int max_degree, float drop_p, unsigned drop_tag,
                      unsigned long long drop_seed, hipStream_t s);

@@ -200,13 +200,18 @@ void launch_linear_sum(const float* X0, const float* W0, const float* X1, const 
 // Two stages, no atomics, bit-reproducible: a workgroup reduces one slab of rows with MFMA (A = X^T read column-wise from
 // LDS) and STORES its 128x128 partial (and its bias partial) to a slot of its own; wgrad_reduce_kernel, launched once at the
 // end of the backward pass for ALL the weight gradients of the step, adds the slots of every gradient in slab order.
-struct WgradSet {
-  const float* dY[3];
-  float* part[3];   // [n_slab][128*128] partial sums of this call
-  float* bpart[3];  // [n_slab][128] bias partials or null
+struct WgradSet {  // up to WGRAD_MAX_JOBS independent gradients in one launch (blockIdx.y)
+  const float* X[WGRAD_MAX_JOBS];
+  const float* dY[WGRAD_MAX_JOBS];
+  float* part[WGRAD_MAX_JOBS];   // [n_slab][128*128] partial sums of the job
+  float* bpart[WGRAD_MAX_JOBS];  // [n_slab][128] bias partials or null
+  int32_t rows[WGRAD_MAX_JOBS], chunks[WGRAD_MAX_JOBS];
 };
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, WgradSet set, int rows, int chunks) {
-  // blockIdx.y selects one of up to three gradients that share the left operand X (c^T.[dP1 | dP3 | dq], attention.py:142-160)
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradSet set) {
+  // blockIdx.y selects the job: all weight gradients of one LocalAttention / ResidualNorm layer go out in ONE launch
+  const int rows = set.rows[blockIdx.y], chunks = set.chunks[blockIdx.y];
+  if (blockIdx.x * 64 * chunks >= rows) return;  // jobs over fewer rows than the largest one
+  const float* __restrict__ X = set.X[blockIdx.y];
   const float* __restrict__ dY = set.dY[blockIdx.y];
   float* __restrict__ part = set.part[blockIdx.y] + (size_t)blockIdx.x * D * D;
   float* __restrict__ bpart = set.bpart[blockIdx.y];
@@ -304,30 +309,47 @@ void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
   ctx.entries.clear();
 }
 
+// queue one gradient dW += X^T dY (db += column sums of dY when db) for the next wgrad_launch
+void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows) {
+  if (rows <= 0) return;
+  WgradCtx::Job j{};
+  j.X = X; j.dY = dY; j.rows = rows; j.chunks = wgrad_chunks(rows);
+  const int n_slab = wgrad_slabs(rows);
+  j.part = ctx.arena + ctx.off;
+  ctx.entries.push_back(WgradReduceEntry{dW, j.part, n_slab, D * D});
+  ctx.off += (size_t)n_slab * D * D;
+  if (db) {
+    j.bpart = ctx.arena + ctx.off;
+    ctx.entries.push_back(WgradReduceEntry{db, j.bpart, n_slab, D});
+    ctx.off += (size_t)n_slab * D;
+  }
+  ctx.jobs.push_back(j);
+}
+// one launch (per WGRAD_MAX_JOBS) for everything queued
+void wgrad_launch(WgradCtx& ctx, hipStream_t s) {
+  for (size_t j0 = 0; j0 < ctx.jobs.size(); j0 += WGRAD_MAX_JOBS) {
+    const int n = (int)std::min<size_t>(WGRAD_MAX_JOBS, ctx.jobs.size() - j0);
+    WgradSet set{};
+    int max_slab = 0;
+    for (int k = 0; k < n; ++k) {
+      const WgradCtx::Job& j = ctx.jobs[j0 + k];
+      set.X[k] = j.X; set.dY[k] = j.dY; set.part[k] = j.part; set.bpart[k] = j.bpart; set.rows[k] = j.rows; set.chunks[k] = j.chunks;
+      max_slab = std::max(max_slab, wgrad_slabs(j.rows));
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(max_slab, n), dim3(256), 0, s, set);
+  }
+  ctx.jobs.clear();
+}
 void launch_wgrad3(WgradCtx& ctx, const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
                    const float* dY2, float* dW2, float* db2, int rows, hipStream_t s) {
-  if (rows <= 0) return;
-  const int chunks = wgrad_chunks(rows), n_slab = wgrad_slabs(rows);
-  const float* dYs[3] = {dY0, dY1, dY2};
-  float* dWs[3] = {dW0, dW1, dW2};
-  float* dbs[3] = {db0, db1, db2};
-  const int ny = dY2 ? 3 : (dY1 ? 2 : 1);
-  WgradSet set{};
-  for (int i = 0; i < ny; ++i) {
-    set.dY[i] = dYs[i];
-    set.part[i] = ctx.arena + ctx.off;
-    ctx.entries.push_back(WgradReduceEntry{dWs[i], set.part[i], n_slab, D * D});
-    ctx.off += (size_t)n_slab * D * D;
-    if (dbs[i]) {
-      set.bpart[i] = ctx.arena + ctx.off;
-      ctx.entries.push_back(WgradReduceEntry{dbs[i], set.bpart[i], n_slab, D});
-      ctx.off += (size_t)n_slab * D;
-    }
-  }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(n_slab, ny), dim3(256), 0, s, X, set, rows, chunks);
+  wgrad_add(ctx, X, dY0, dW0, db0, rows);
+  if (dY1) wgrad_add(ctx, X, dY1, dW1, db1, rows);
+  if (dY2) wgrad_add(ctx, X, dY2, dW2, db2, rows);
+  wgrad_launch(ctx, s);
 }
 void launch_wgrad(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
-  launch_wgrad3(ctx, X, dY, dW, db, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, s);
+  wgrad_add(ctx, X, dY, dW, db, rows);
+  wgrad_launch(ctx, s);
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------
@@ -353,6 +375,15 @@ __global__ void dropout_kernel(float* __restrict__ x, size_t n, unsigned long lo
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= drop_scale(seed, tag, i, p);
 }
+// dst = src * mask: the Dropout backward into a buffer of its own (the un-dropped gradient is still needed)
+__global__ void dropout_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n, unsigned long long seed, unsigned tag,
+                                    float p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] * drop_scale(seed, tag, i, p);
+}
+void launch_dropout_copy(float* dst, const float* src, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(dropout_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n, seed, tag, p);
+}
 void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s) {
   if (n && p > 0.f) hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, seed, tag, p);
 }
@@ -360,10 +391,21 @@ void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, f
 // ---- LayerNorm backward (rows of 128; 8 threads per row) ---------------------------------------------------------------
 // y = xhat*gamma + beta, xhat = (x - mean) * rstd  (attention.py:35,111,113; eps 1e-6)
 // dxhat = dy*gamma ; dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)) ; dgamma += dy*xhat ; dbeta += dy
+// Optional fusions of the LocalAttention backward (null when unused): the incoming gradient is formed on the fly as
+// dy = dang * c[nb] + dg_in (the gate ang = c[j] * G', attention.py:157, plus the geometry gradient of the next layer), and
+// dV = dx * swish'(V) (attention.py:151) leaves with dx.
+struct LnBwdFuse {
+  const float* dang;   // [rows,128] or null: dy is read as is
+  const float* c;      // [n_atom,128]
+  const int* nb;       // [rows]
+  const float* dg_in;  // [rows,128] or null
+  const float* V;      // [rows,128] or null
+  float* dV;           // [rows,128]
+};
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     int groups, int accumulate) {
+                                                     int groups, int accumulate, LnBwdFuse f) {
   // 8 threads per row (float4 chunks sub, sub+8, sub+16, sub+24 like the forward LayerNorm), 32 rows per pass, `groups`
   // passes per workgroup; all loads of a pass are requested together from clamped rows.
   const int tid = threadIdx.x, r_in = tid >> 3, sub = tid & 7;
@@ -383,8 +425,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       xv[i] = reinterpret_cast<const float4*>(x)[(size_t)rc * 32 + sub + 8 * i];
-      dv[i] = reinterpret_cast<const float4*>(dy)[(size_t)rc * 32 + sub + 8 * i];
+      dv[i] = reinterpret_cast<const float4*>(f.dang ? f.dang : dy)[(size_t)rc * 32 + sub + 8 * i];
       old[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (f.dang) {
+      const int j = f.nb[rc];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 cn = reinterpret_cast<const float4*>(f.c)[(size_t)j * 32 + sub + 8 * i];
+        dv[i] = make_float4(dv[i].x * cn.x, dv[i].y * cn.y, dv[i].z * cn.z, dv[i].w * cn.w);
+        if (f.dg_in) {
+          const float4 o = reinterpret_cast<const float4*>(f.dg_in)[(size_t)rc * 32 + sub + 8 * i];
+          dv[i].x += o.x; dv[i].y += o.y; dv[i].z += o.z; dv[i].w += o.w;
+        }
+      }
     }
     if (accumulate) {
 #pragma unroll
@@ -419,9 +473,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     if (r < rows) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        reinterpret_cast<float4*>(dx)[(size_t)r * 32 + sub + 8 * i] =
-            make_float4(rstd * (ax[i].x - m1 - xv[i].x * m2) + old[i].x, rstd * (ax[i].y - m1 - xv[i].y * m2) + old[i].y,
-                        rstd * (ax[i].z - m1 - xv[i].z * m2) + old[i].z, rstd * (ax[i].w - m1 - xv[i].w * m2) + old[i].w);
+        const float4 dxv = make_float4(rstd * (ax[i].x - m1 - xv[i].x * m2) + old[i].x, rstd * (ax[i].y - m1 - xv[i].y * m2) + old[i].y,
+                                       rstd * (ax[i].z - m1 - xv[i].z * m2) + old[i].z, rstd * (ax[i].w - m1 - xv[i].w * m2) + old[i].w);
+        reinterpret_cast<float4*>(dx)[(size_t)r * 32 + sub + 8 * i] = dxv;
+        if (f.V) {
+          const float4 vv = reinterpret_cast<const float4*>(f.V)[(size_t)r * 32 + sub + 8 * i];
+          reinterpret_cast<float4*>(f.dV)[(size_t)r * 32 + sub + 8 * i] =
+              make_float4(dxv.x * dswish_(vv.x), dxv.y * dswish_(vv.y), dxv.z * dswish_(vv.z), dxv.w * dswish_(vv.w));
+        }
         dg[i].x += dv[i].x * xv[i].x; dg[i].y += dv[i].y * xv[i].y; dg[i].z += dv[i].z * xv[i].z; dg[i].w += dv[i].w * xv[i].w;
         dbt[i].x += dv[i].x; dbt[i].y += dv[i].y; dbt[i].z += dv[i].z; dbt[i].w += dv[i].w;
       }
@@ -442,7 +501,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   (which ? dbeta : dgamma)[(size_t)blockIdx.x * D + col] = tot;  // this workgroup's slot (summed in slot order by wgrad_reduce_kernel)
 }
 void wgrad_flush(WgradCtx& ctx, hipStream_t s);
-static int ln_bwd_groups(int rows) { return std::min(32, std::max(1, (rows + 32 * 160 - 1) / (32 * 160))); }
+// row groups of 32 per workgroup: with per-workgroup partial slots instead of atomics the launch no longer has to stay small
+// (round 1 capped it at ~160 workgroups); about 1,500 workgroups fill the chip several times over
+static int ln_bwd_groups(int rows) { return std::min(32, std::max(1, (rows + 32 * 1536 - 1) / (32 * 1536))); }
 int ln_bwd_slots(int rows) {
   const int groups = ln_bwd_groups(rows);
   return (rows + 32 * groups - 1) / (32 * groups);
@@ -460,7 +521,17 @@ void launch_ln_bwd(WgradCtx& ctx, const float* x, const float* gamma, const floa
   const int groups = ln_bwd_groups(rows), n_wg = ln_bwd_slots(rows);
   float* gp = reserve_vec(ctx, dgamma, n_wg, s);
   float* bp = reserve_vec(ctx, dbeta, n_wg, s);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_wg), dim3(256), 0, s, x, gamma, dy, dx, gp, bp, rows, groups, accumulate);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_wg), dim3(256), 0, s, x, gamma, dy, dx, gp, bp, rows, groups, accumulate, LnBwdFuse{});
+}
+// LayerNorm_g backward of LocalAttention with its neighbours fused: dy = dang * c[nb] (+ dg_in) in, dx = dT and dV = dT * swish'(V) out
+void launch_ln_bwd_edge(WgradCtx& ctx, const float* T, const float* gamma, const float* dang, const float* c, const int* nb,
+                        const float* dg_in, const float* V, float* dT, float* dV, float* dgamma, float* dbeta, int rows, hipStream_t s) {
+  if (rows <= 0) return;
+  const int groups = ln_bwd_groups(rows), n_wg = ln_bwd_slots(rows);
+  float* gp = reserve_vec(ctx, dgamma, n_wg, s);
+  float* bp = reserve_vec(ctx, dbeta, n_wg, s);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_wg), dim3(256), 0, s, T, gamma, (const float*)nullptr, dT, gp, bp, rows, groups, 0,
+                     LnBwdFuse{dang, c, nb, dg_in, V, dV});
 }
 
 // ---- edge elementwise kernels (thread = float4 chunk of an edge row) -------------------------------------------------
@@ -506,6 +577,52 @@ __global__ void gather_sum_kernel(const float4* __restrict__ val, const int* __r
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   out[i] = s;
+}
+// out[a] (+)= sum over the edges e that point AT atom a of x[e] * y[e]: the neighbour-centre gradient dC[j] = sum dang * G' without
+// materialising the per-edge product
+__global__ void gather_prod_sum_kernel(const float4* __restrict__ x, const float4* __restrict__ y, const int* __restrict__ in_off,
+                                       const int* __restrict__ in_edge, float4* __restrict__ out, int n_atom, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_atom * 32) return;
+  const int a = (int)(i >> 5), c4 = (int)(i & 31);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (accumulate) s = out[i];
+  for (int k = in_off[a]; k < in_off[a + 1]; ++k) {
+    const size_t o = (size_t)in_edge[k] * 32 + c4;
+    const float4 u = x[o], v = y[o];
+    s.x += u.x * v.x; s.y += u.y * v.y; s.z += u.z * v.z; s.w += u.w * v.w;
+  }
+  out[i] = s;
+}
+void launch_gather_prod_sum(const float* x, const float* y, const int* in_off, const int* in_edge, float* out, int n_atom, int accumulate,
+                            hipStream_t s) {
+  if (n_atom > 0)
+    hipLaunchKernelGGL(gather_prod_sum_kernel, dim3((unsigned)(((size_t)n_atom * 32 + 255) / 256)), dim3(256), 0, s, (const float4*)x,
+                       (const float4*)y, in_off, in_edge, (float4*)out, n_atom, accumulate);
+}
+// both atom-indexed sums of dV in one launch: own[a] = sum over atom a's CSR row (dP1), in[a] = sum over the edges that point at a (dP3)
+__global__ void atom_sums_kernel(const float4* __restrict__ dV, const int* __restrict__ edge_offset, const int* __restrict__ in_off,
+                                 const int* __restrict__ in_edge, float4* __restrict__ own, float4* __restrict__ in, int n_atom) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_atom * 32) return;
+  const int a = (int)(i >> 5), c4 = (int)(i & 31);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = s;
+  for (int e = edge_offset[a]; e < edge_offset[a + 1]; ++e) {
+    const float4 v = dV[(size_t)e * 32 + c4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  for (int k = in_off[a]; k < in_off[a + 1]; ++k) {
+    const float4 v = dV[(size_t)in_edge[k] * 32 + c4];
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  own[i] = s;
+  in[i] = t;
+}
+void launch_atom_sums(const float* dV, const int* edge_offset, const int* in_off, const int* in_edge, float* own, float* in, int n_atom,
+                      hipStream_t s) {
+  if (n_atom > 0)
+    hipLaunchKernelGGL(atom_sums_kernel, dim3((unsigned)(((size_t)n_atom * 32 + 255) / 256)), dim3(256), 0, s, (const float4*)dV,
+                       edge_offset, in_off, in_edge, (float4*)own, (float4*)in, n_atom);
 }
 void launch_gather_sum(const float* val, const int* in_off, const int* in_edge, float* out, int n_atom, int accumulate, hipStream_t s) {
   if (n_atom > 0)
