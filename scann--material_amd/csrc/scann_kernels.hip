@@ -2,19 +2,20 @@
 //
 // Layout: structures are packed -- atoms [n_atom,128] and CSR edges [n_edge,128] -- so
 // the reference's padded [B,M,N,d] tensors (attention.py:136-212) are never materialised.  Every
-// dense projection is an fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32, one k-ordered fma chain)
-// of a row tile staged in LDS against a 128x128 weight that each wave streams straight from
-// L2/HBM into registers in fragment order (no LDS staging of weights: a wave owns 32 output columns,
-// so every weight element is read by exactly one wave of the workgroup).
+// dense projection is a split-fp16 MFMA product with fp32 accumulation (v_mfma_f32_32x32x16_f16, three
+// products per operand pair: fp32 accuracy at 3/16 of the fp32-MFMA time; scheme and evidence in the
+// edge-tile section) of a row tile staged in LDS as hi / lo planes against a 128x128 weight that each
+// wave streams straight from L2 into registers in fragment order (no LDS staging of weights: a wave
+// owns 32 output columns, so every weight element is read by exactly one wave of the workgroup).
 //
 // Kernels (one launch each per LocalAttention iteration, see scann_runtime.cpp: run_forward):
 //   atom_kernel   : [ResidualNorm of previous layer] -> centres c; P1 = c W1 + bg, P3 = c W3, q = c Wq + bq
 //                   (attention.py:37-40, :160, and the centre/neighbour thirds of filter_geo :142-151)
-//   edge_kernel   : per tile of <=64 edges (whole atoms): U = G W2 (MFMA); geom' = LN_g(swish(U+P1[i]+P3[j])+G)
-//                   (:141-153); ang = c[j]*geom' (:136,:157); K = ang Wk + bk (MFMA, :163);
+//   edge_kernel   : per tile of <=64 edges (whole atoms): U = G W2; geom' = LN_g(swish(U+P1[i]+P3[j])+G)
+//                   (:141-153); ang = c[j]*geom' (:136,:157); K = ang Wk + bk (:163);
 //                   per (atom, head) softmax over its edges and ctx = LN(sum attn K + q) (:180-214)
 //   readout_kernel: GlobalAttention + bf_property + predict_property (attention.py:267-318,
-//                   scann_model.py:437-447), one workgroup per structure
+//                   scann_model.py:437-447), one workgroup per structure (pair energies: exact-fp32 MFMA)
 //   basis_kernel  : Gaussian expansion + neighbor_d/neighbor_w MLP (custom_layers.py:63-65,
 //                   scann_model.py:378-389)
 #include "scann_internal.h"
@@ -71,64 +72,6 @@ __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4swish(float4 a) { return make_float4(swishf(a.x), swishf(a.y), swishf(a.z), swishf(a.w)); }
 __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-// ---- MFMA GEMM of a staged row tile against one packed 128x128 weight ---------------------------
-//
-// acc[rt] (32 rows x 32 cols per wave) += X[32*rt .. 32*rt+31][0..127] . W[0..127][32*wave .. +31]
-//
-// v_mfma_f32_32x32x2_f32 operand map: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
-// The k order is ours to choose as long as A and B agree: k-step (t, i), lane half h <-> k = 8t + 4h + i,
-// so a lane's A operands for four consecutive steps are one 16-byte LDS read and its B operands one
-// 16-byte global read.  Packed weight element ((w*16 + t)*64 + lane)*4 + i = W[8t + 4(lane>>5) + i][32w + (lane&31)].
-// load_w: one wave's 128x32 slab of a packed weight, 16 coalesced 1-KiB reads, issued early so the
-// L2/HBM latency hides under whatever precedes the MFMAs.
-__device__ __forceinline__ void load_w(const float* __restrict__ Wp, int wave, int lane, float4 (&w)[16]) {
-  const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(Wp) + wave * (16 * 64) + lane;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) w[t] = wsrc[t * 64];
-}
-
-template <int RT>
-__device__ __forceinline__ void mma128(const float* __restrict__ sX, const float4 (&w)[16], int lane,
-                                       f32x16 (&acc)[RT]) {
-  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const float4 a = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[rt], 0, 0, 0);
-    }
-  }
-}
-
-template <int RT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT]) {
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[rt][i] = 0.0f;
-}
-
-// Operands swapped (weights as A, rows as B): the product comes out transposed -- lane l holds ROW l & 31 and the sixteen
-// columns (i & 3) + 8 (i >> 2) + 4 (l >> 5) of the wave's 32, four runs of four consecutive columns -- so every epilogue
-// moves 16-byte pieces (ds_write_b128 / global_store_dwordx4) instead of sixteen 4-byte ones.  Same k order, same sums.
-__device__ __forceinline__ void mma128T(const float* __restrict__ sX, const float4 (&w)[16], int lane, f32x16& acc) {
-  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const float4 a = *reinterpret_cast<const float4*>(xrow + 8 * t);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, a.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, a.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, a.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, a.w, acc, 0, 0, 0);
-  }
-}
-// column of the j-th run of a lane in the transposed layout
-__device__ __forceinline__ int tcol(int wave, int lane, int j) { return 32 * wave + 8 * j + 4 * (lane >> 5); }
-
 // C/D map of the 32x32 MFMA: register i of lane l holds row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31.
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
@@ -152,9 +95,6 @@ __device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
   h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
   l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
   l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-}
-__device__ __forceinline__ float4 join4(const f16x4 h, const f16x4 l) {
-  return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
 }
 
 // One wave's slab of a split weight (pack_weight_f16): [wave][k-step][plane hi|lo][lane][8 halfs] -- per k-step and plane
@@ -525,6 +465,10 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];      // LayerNorm_g partial statistics [row][wave][2], then logits
   __shared__ __attribute__((aligned(16))) float sPar[5 * D];          // layer_norm_g gamma/beta (base: filter bias), layer_norm gamma/beta, key bias
   __shared__ int sOff[TQ + 1];
+#ifdef SCANN_DIAG_OCC2  // diagnostic: two workgroups per CU instead of three (how much of the time is latency hidden by occupancy?)
+  __shared__ float sDummy[7 * 1024];
+  if (a.n_tile < 0) sDummy[threadIdx.x] = 1.f;
+#endif
   static_assert(sizeof(sTile) >= TEK * LDS_STRIDE * sizeof(float), "K tile must fit the plane buffer");
   _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
   _Float16* const sL = sH + TEK * PLANE_STRIDE;

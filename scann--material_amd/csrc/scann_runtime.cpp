@@ -1200,6 +1200,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   // <= 5 over the atom rows (filter_geo centre / neighbour thirds, query, ResidualNorm dense_1 / dense_2), readout 3 over atoms
   // and 1 over structures; each with a bias row per slab
   const size_t Lc = (size_t)h->cfg.n_attention;
+  w.wtable_cap = 32 * (int)Lc + 64;  // entries of the reduce table: <= 20 gradient tensors per layer
   w.wpart_floats = (size_t)(D * D + D) * (Lc * (2 * (size_t)wgrad_slabs(std::max(db->n_edge, 1)) + 5 * (size_t)wgrad_slabs(db->n_atom)) +
                                            3 * (size_t)wgrad_slabs(db->n_atom) + (size_t)wgrad_slabs(db->n_struct)) +
                    // LayerNorm gamma / beta partials: per layer ln_bwd over edges and atoms, attention backward over atoms
@@ -1207,7 +1208,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
                                          (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
   const size_t total = 15 * rowA + 12 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
                        align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4) +
-                       align_up((size_t)(w.wtable_cap = 32 * (int)Lc + 64) * sizeof(WgradReduceEntry));
+                       align_up((size_t)w.wtable_cap * sizeof(WgradReduceEntry));
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   for (int i = 0; i < 15; ++i) { w.tA[i] = (float*)p; p += rowA; }
