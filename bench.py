@@ -36,6 +36,7 @@ PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s
 QM9_MODEL = dict(n_atoms=10, embedding_dim=48, n_attention=7, local_dim=128, num_head=8, global_dim=128,
                  dense_out=128, scale=0.5, use_attn_norm=True, use_ga_norm=True, use_ring=False, g_update=True,
                  gaussian_d=4.0)  # configs/model_qm9.yaml:1-14
+QM9_STD_MODEL = dict(QM9_MODEL, n_attention=8)  # configs/model_qm9_std.yaml:1-14 (BASELINE configs[4]: SCANN+ on QM9 Gap)
 MP2018_MODEL = dict(n_atoms=95, embedding_dim=128, n_attention=9, local_dim=128, num_head=8, global_dim=128,
                     dense_out=128, scale=0.5, use_attn_norm=True, use_ga_norm=True, use_ring=False, g_update=True,
                     gaussian_d=6.0)  # configs/model_mp2018.yaml:1-14
@@ -273,8 +274,9 @@ def main():
     ap.add_argument("--group", type=int, default=int(os.environ.get("SCANN_BENCH_GROUP", "16")),
                     help="target number of resident 128-molecule batches per launch sequence (see group_sizes; 1 = one batch per launch)")
     ap.add_argument("--worst", action="store_true", help="Swc: every molecule 29 atoms x 12 neighbours")
-    ap.add_argument("--config", default="qm9", choices=["qm9", "mp2018"],
-                    help="qm9 = BASELINE configs[1] (the metric); mp2018 = configs[3] shapes (crystals, L=9, batch 64), extra")
+    ap.add_argument("--config", default="qm9", choices=["qm9", "qm9_std", "mp2018"],
+                    help="qm9 = BASELINE configs[1] (the metric); qm9_std = configs[4] (SCANN+ L=8, QM9 shapes), mp2018 = configs[3] "
+                         "shapes (crystals, L=9, batch 64): extras")
     ap.add_argument("--min-time", type=float, default=1.0, help="seconds of timed regions to collect (median over repeats)")
     ap.add_argument("--prewarm", type=float, default=0.6, help="seconds of untimed load before the first timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -315,7 +317,7 @@ def main():
     os.environ["SCANN_STREAMS"] = str(max(1, args.streams))  # read by scann_create
     if args.config == "mp2018" and args.batch == 128:
         args.batch = 64  # configs/model_mp2018.yaml:16
-    model_cfg = dict(QM9_MODEL) if args.config == "qm9" else dict(MP2018_MODEL)
+    model_cfg = dict({"qm9": QM9_MODEL, "qm9_std": QM9_STD_MODEL, "mp2018": MP2018_MODEL}[args.config])
     cfg = normalize_config({"model": model_cfg, "hyper": {"target": "homo", "batch_size": args.batch}})
     ndev = _hip.load_library().scann_device_count()
     if ndev <= 0:
@@ -426,13 +428,15 @@ def main():
         value = world * args.steps * args.batch / elapsed
         L_cfg, emb_cfg = model_cfg["n_attention"], model_cfg["embedding_dim"]
         out = {
-            "metric": "QM9 molecules/s forward" if args.config == "qm9" else "MP2018-shaped structures/s forward",
+            "metric": "QM9 molecules/s forward" if args.config != "mp2018" else "MP2018-shaped structures/s forward",
             "value": value, "unit": "molecules/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: QM9-shaped%s, configs/model_qm9.yaml (SCANN+, L=7, d=128, H=8), "
                                     "batch=128 per step, forward" % (" worst-case 29x12" if args.worst else ""))
                        if args.config == "qm9" else
+                       "configs[4]: QM9-shaped, configs/model_qm9_std.yaml (SCANN+, L=8, d=128, H=8), batch=128 per step, forward"
+                       if args.config == "qm9_std" else
                        "configs[3] shapes: MP2018-shaped crystals, configs/model_mp2018.yaml (SCANN+, L=9), batch=64 per step, forward",
                        "batch": args.batch, "atoms_per_batch": A, "edges_per_batch": E,
                        "streams": nstream, "batches_fused_per_launch": G_eff, "launch_groups": sorted(set(sizes_t)),

@@ -18,9 +18,15 @@ from .._hip import slice_dataset
 class PackedDataset:
     def __init__(self, data_energy, data_neighbor, batch_size=32, converter=False, use_ring=False, shuffle=False,
                  feature="atomic", g_update=False, atomic_features=None):
-        # same keyword set as DataIterator (datagenerator.py:12-23); atomic_features only matters for feature="cgcnn"
-        if feature != "atomic":
-            raise NotImplementedError("PackedDataset covers feature='atomic'")
+        # same keyword set as DataIterator (datagenerator.py:12-23); feature="cgcnn": the batches carry the 92-d element
+        # descriptors of their atoms (datagenerator.py:109-110) looked up in the table DataIterator uses
+        if feature not in ("atomic", "cgcnn"):
+            raise ValueError("feature must be 'atomic' or 'cgcnn'")
+        self.cgcnn_table = None
+        if feature == "cgcnn":
+            from .datagenerator import load_cgcnn_table
+
+            self.cgcnn_table, has = load_cgcnn_table(atomic_features)
         n = len(data_energy)
         self.batch_size, self.shuffle, self.use_ring = batch_size, shuffle, use_ring
         wi = 2 if g_update else 3
@@ -37,6 +43,9 @@ class PackedDataset:
         np.cumsum(deg, out=self.edge_offset[1:])
         self.edge_local, self.edge_weight, self.edge_dist = local, weight, dist  # edge_local: index INSIDE its structure
         self.ring = np.concatenate([np.asarray(d[2], dtype=np.float32).reshape(-1, 2) for d in data_energy]) if use_ring else None
+        if self.cgcnn_table is not None and self.atomic.size and (self.atomic.max() >= self.cgcnn_table.shape[0] or not has[self.atomic].all()):
+            missing = sorted({int(z) for z in self.atomic if z >= self.cgcnn_table.shape[0] or not has[z]})
+            raise KeyError("atomic numbers %s are not in the CGCNN table" % missing)
         self.on_epoch_end()
 
     @classmethod
@@ -54,6 +63,7 @@ class PackedDataset:
         self.edge_weight = np.ascontiguousarray(edge_weight, dtype=np.float32)
         self.target = np.ascontiguousarray(target, dtype=np.float32)
         self.ring = np.ascontiguousarray(ring, dtype=np.float32) if ring is not None else None
+        self.cgcnn_table = None
         self.on_epoch_end()
         return self
 
@@ -65,21 +75,22 @@ class PackedDataset:
     def __len__(self):
         return ceil(len(self.target) / self.batch_size)
 
-    def batch(self, idx):
-        """-> (PackedBatch, targets) of batch `idx` (the structures DataIterator.__getitem__(idx) would hold)."""
-        sel = self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size]
+    def _slice(self, sel):
         pk = slice_dataset(self.mol_offset, self.edge_offset, self.atomic, self.ring, self.edge_local, self.edge_dist,
                            self.edge_weight, sel)
+        if self.cgcnn_table is not None:
+            pk.cgcnn = np.ascontiguousarray(self.cgcnn_table[pk.atomic])
         return pk, self.target[sel]
+
+    def batch(self, idx):
+        """-> (PackedBatch, targets) of batch `idx` (the structures DataIterator.__getitem__(idx) would hold)."""
+        return self._slice(self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size])
 
     def batches(self, i0, i1):
         """Batches i0 .. i1-1 as ONE PackedBatch (their structures in order) with ONE native slice call, plus the targets --
         what ``concat_packed([self[i][0] for i in range(i0, i1)])`` builds, without the per-batch Python work.  Structures
         are independent and the packed layout has no per-batch padding, so a group of batches is just a longer batch."""
-        sel = self.indexes[i0 * self.batch_size:i1 * self.batch_size]
-        pk = slice_dataset(self.mol_offset, self.edge_offset, self.atomic, self.ring, self.edge_local, self.edge_dist,
-                           self.edge_weight, sel)
-        return pk, self.target[sel]
+        return self._slice(self.indexes[i0 * self.batch_size:i1 * self.batch_size])
 
     def batch_part(self, idx, rank, world):
         """Rank ``rank``'s contiguous share of batch ``idx`` (data-parallel training: a rank never packs the structures of
@@ -87,10 +98,7 @@ class PackedDataset:
         sel = self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size]
         base, rem = divmod(len(sel), world)
         lo = rank * base + min(rank, rem)
-        sel = sel[lo:lo + base + (1 if rank < rem else 0)]
-        pk = slice_dataset(self.mol_offset, self.edge_offset, self.atomic, self.ring, self.edge_local, self.edge_dist,
-                           self.edge_weight, sel)
-        return pk, self.target[sel]
+        return self._slice(sel[lo:lo + base + (1 if rank < rem else 0)])
 
     def __getitem__(self, idx):
         return self.batch(idx)

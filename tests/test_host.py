@@ -622,3 +622,27 @@ def test_package_does_not_import_torch():
     pkg = os.path.join(ROOT, "scann--material_amd")
     hits = subprocess.run(["grep", "-rnE", r"^\s*(import|from)\s+torch", pkg, "--include=*.py"], capture_output=True, text=True)
     assert hits.stdout.strip() == "", hits.stdout
+
+
+def test_packed_dataset_cgcnn_and_ring_match_data_iterator(tmp_path):
+    """PackedDataset(feature="cgcnn" / use_ring) yields the packed form of what DataIterator yields (datagenerator.py:105-133)."""
+    from scann import _hip
+    from scann.utils import DataIterator, PackedDataset
+
+    de, dn = so.synth_dataset(11, 5, use_ring=True)
+    rng = np.random.default_rng(1)
+    table = {z: rng.standard_normal(92).astype(np.float32) for z in (1, 6, 7, 8, 9)}
+    kw = dict(batch_size=4, use_ring=True, feature="cgcnn", g_update=True, atomic_features=table)
+    it, pd = DataIterator(de, dn, **kw), PackedDataset(de, dn, **kw)
+    assert len(it) == len(pd) == 3
+    for i in range(len(it)):
+        inputs, t = it[i]
+        ref = _hip.pack_inputs(inputs)
+        got, t2 = pd[i]
+        assert np.array_equal(t, t2) and np.array_equal(got.cgcnn, ref.cgcnn) and np.array_equal(got.ring, ref.ring)
+        for f in ("mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+            assert np.array_equal(getattr(got, f), getattr(ref, f)), f
+    grp, _ = pd.batches(0, 3)
+    assert grp.cgcnn.shape == (sum(len(e[0]) for e in de), 92)
+    with pytest.raises(KeyError):
+        PackedDataset(de, dn, batch_size=4, feature="cgcnn", atomic_features={1: table[1], 6: table[6]})
