@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the forward path against the C/OpenMP oracle: many small batches whose structure sizes and
+neighbour-degree distributions are drawn adversarially (isolated atoms, 1-atom neighbours lists, 60..70-neighbour atoms that
+straddle the 64-edge tile limit, 2-atom molecules next to 200-atom ones), on both LocalAttention branches.  Prints the worst
+error per configuration; exits non-zero on any error above the 1e-4 bar."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle"), ROOT]
+import scann_oracle as so
+import scann_oracle_c as soc
+from scann.models.scann_model import HipModel, normalize_config
+
+def rel_err(got, ref):
+    ref = np.asarray(ref, np.float64); got = np.asarray(got, np.float64)
+    scale = max(float(np.sqrt(np.mean(ref * ref))), 1e-30)
+    return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), scale)))
+
+def random_batch(rng, g_update, big=True):
+    n = int(rng.integers(1, 9))
+    de, dn = np.empty(n, dtype=object), np.empty(n, dtype=object)
+    for s in range(n):
+        mode = int(rng.choice(6, p=[.2, .25, .2, .2, .05, .1]))
+        if not big and mode == 4:
+            mode = 3
+        A = int([rng.integers(2, 5), rng.integers(3, 30), rng.integers(3, 30), rng.integers(60, 110), rng.integers(150, 230), rng.integers(2, 40)][mode])
+        nb = []
+        for a in range(A):
+            kind = rng.integers(0, 8)
+            if kind == 0:
+                d = 0
+            elif kind == 1:
+                d = 1
+            elif kind == 2 and A > 66:
+                d = int(rng.integers(60, min(A - 1, 70) + 1))
+            elif kind == 3 and A > 130:
+                d = int(rng.integers(100, min(A - 1, 200) + 1))
+            else:
+                d = int(rng.integers(1, min(12, A - 1) + 1))
+            d = min(d, A - 1)
+            js = rng.choice(np.delete(np.arange(A), a), d, replace=False)
+            ang = rng.uniform(0.4, 3.5, size=max(d, 1))
+            nb.append([[6, int(j), float(ang[k]), float(ang[k] / ang.max()), float(rng.uniform(0.9, 4.0))] for k, j in enumerate(js)])
+        if A >= 2 and all(len(x) == 0 for x in nb):
+            nb[0] = [[6, 1, 1.0, 1.0, 1.5]]
+        de[s] = [[int(z) for z in rng.choice([1, 6, 7, 8, 9], A)], float(rng.normal())]
+        dn[s] = nb
+    return so.pad_batch(de, dn, g_update)
+
+t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 40
+worst = {}
+bad = 0
+for name, over in (("scann_plus", {}), ("base", {"g_update": False}), ("no_norms", {"use_attn_norm": False, "use_ga_norm": False})):
+    cfg = normalize_config(so.default_config("qm9"))
+    cfg["model"].update(over, n_attention=3)
+    w = so.init_weights(cfg, 1234, perturb=True)
+    model = HipModel(cfg, w, device=0, infer=True)
+    rng = np.random.default_rng(hash(name) & 0xFFFF)
+    n_batches, t_stop = 0, time.time() + (t_end - time.time()) / 3
+    while time.time() < t_stop:
+        use_c = cfg["model"]["g_update"]
+        inputs, _ = random_batch(rng, use_c, big=use_c)
+        y, ga = model.predict(inputs)
+        if use_c:
+            y_ref, ga_ref = soc.forward(cfg, w, inputs)
+        else:                                 # the C port covers g_update=True only: numpy oracle in fp64
+            y_ref, ga_ref = so.forward(cfg, w, inputs, dtype=np.float64)
+        y_ref, ga_ref = np.asarray(y_ref).reshape(-1), np.asarray(ga_ref).reshape(ga.shape)
+        y = np.asarray(y).reshape(-1)
+        single = inputs["atom_mask"][..., 0].sum(axis=1) == 1   # 1-atom structures are NaN with use_ga_norm, by the reference's formula
+        ok = ~single
+        e_y = rel_err(y[ok], y_ref[ok]) if ok.any() else 0.0
+        e_g = float(np.max(np.abs(ga[ok] - ga_ref[ok]))) if ok.any() else 0.0
+        tol = 1e-4 if name != "no_norms" else 3e-4   # raw pair sums into a softmax: ill-conditioned (DESIGN.md numerics)
+        if not (e_y <= tol and e_g <= 1e-4) or not np.isfinite(y[ok]).all():
+            bad += 1
+            print("MISMATCH", name, "batch", n_batches, "err_y %.3e err_ga %.3e" % (e_y, e_g), "sizes", inputs["atom_mask"][..., 0].sum(axis=1).tolist())
+        worst[name] = max(worst.get(name, 0.0), e_y)
+        n_batches += 1
+    print("%-12s %4d batches, worst relative error of y %.3e" % (name, n_batches, worst[name]), flush=True)
+sys.exit(1 if bad else 0)
