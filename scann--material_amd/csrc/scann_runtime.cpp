@@ -1170,8 +1170,6 @@ struct scann_train_ws {  // per resident batch, allocated on first use
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   float* wpart = nullptr;  // per-slab partial sums of every weight gradient of a step (WgradCtx::arena)
   size_t wpart_floats = 0;
-  WgradReduceEntry* wtable = nullptr;  // device table of (destination, slots), one entry per gradient tensor
-  int wtable_cap = 0;
   double* sse = nullptr;
   float drop_p = 0.f, attn_p = 0.f;
   unsigned long long seed = 0;
@@ -1200,15 +1198,13 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   // <= 5 over the atom rows (filter_geo centre / neighbour thirds, query, ResidualNorm dense_1 / dense_2), readout 3 over atoms
   // and 1 over structures; each with a bias row per slab
   const size_t Lc = (size_t)h->cfg.n_attention;
-  w.wtable_cap = 32 * (int)Lc + 64;  // entries of the reduce table: <= 20 gradient tensors per layer
   w.wpart_floats = (size_t)(D * D + D) * (Lc * (2 * (size_t)wgrad_slabs(std::max(db->n_edge, 1)) + 5 * (size_t)wgrad_slabs(db->n_atom)) +
                                            3 * (size_t)wgrad_slabs(db->n_atom) + (size_t)wgrad_slabs(db->n_struct)) +
                    // LayerNorm gamma / beta partials: per layer ln_bwd over edges and atoms, attention backward over atoms
                    (size_t)2 * D * Lc * ((size_t)ln_bwd_slots(std::max(db->n_edge, 1)) + (size_t)ln_bwd_slots(db->n_atom) +
                                          (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
   const size_t total = 15 * rowA + 12 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
-                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4) +
-                       align_up((size_t)w.wtable_cap * sizeof(WgradReduceEntry));
+                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4);
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   for (int i = 0; i < 15; ++i) { w.tA[i] = (float*)p; p += rowA; }
@@ -1220,7 +1216,6 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   w.dlut = (float*)p; p += align_up((size_t)h->cfg.n_atoms * D * 4);
   w.sse = (double*)p; p += 256;
   w.wpart = (float*)p; p += align_up(w.wpart_floats * 4);
-  w.wtable = (WgradReduceEntry*)p; p += align_up((size_t)w.wtable_cap * sizeof(WgradReduceEntry));
   if (Lk) {  // slices are [rows,128] without padding between layers: size them from the un-aligned row counts
     w.keep_q = (float*)p; p += Lk * rowA;
     w.keep_V = (float*)p; p += Lk * rowE;
@@ -1419,8 +1414,6 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   };
   WgradCtx wg;
   wg.arena = w.wpart;
-  wg.d_table = w.wtable;
-  wg.table_cap = w.wtable_cap;
 
   // named temporaries
   float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4], *t3 = w.tA[5], *dQ = w.tA[6],
@@ -1454,7 +1447,11 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   launch_linear_sum(t2, h->WgqT, rdgk, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
   float* const dpreA = setA[L & 1][2];                        // the readout counts as "layer L" of the operand-set scheme
   launch_swish_bwd(t0, t4, dpreA, nA, s);                     // dpreA (t2 is still being read beside us)
-  launch_wgrad(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A, fork());
+  {
+    hipStream_t ws = fork();
+    launch_wgrad(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A, ws);
+    if (side) wgrad_flush(wg, ws);
+  }
   mark_layer(L);
   launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
@@ -1562,7 +1559,12 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     wgrad_add(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), A);
     wgrad_add(wg, c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A);
     wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
-    wgrad_launch(wg, fork());  // every weight gradient of this layer (ResidualNorm 2, key, filter_geo 3, query) in ONE launch
+    {  // every weight gradient of this layer (ResidualNorm 2, key, filter_geo 3, query) in ONE launch, then the fixed-order sum of
+       // its partial slots (and of the layer's LayerNorm gamma / beta slots): both beside the next layer's chain
+      hipStream_t ws = fork();
+      wgrad_launch(wg, ws);
+      if (side) wgrad_flush(wg, ws);
+    }
     mark_layer(l);
     launch_linear_sum(dP1, pt.W1T, dP3, pt.W3T, dQ, pt.WqT, dC, A, 1, s);  // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T
     dG_in = dGnext;
@@ -1586,7 +1588,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
                      c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), s);
   }
-  if (wg.off > w.wpart_floats || (int)wg.entries.size() > wg.table_cap)
+  if (wg.off > w.wpart_floats)
     return fail(h, SCANN_ERR_HIP, "scann_train_backward: weight-gradient partial arena overrun");
   join();
   wgrad_flush(wg, s);  // ONE launch adds the per-slab partials of every weight gradient, in slab order

@@ -27,14 +27,15 @@ struct RepackDesc {
 };
 
 // Weight gradients are bit-reproducible: every launch_wgrad* stores per-slab partial sums into slots of `ctx.arena` (bump
-// allocated, never reused within a step) and records (destination, slots); wgrad_flush adds them in slab order with ONE
-// launch at the end of the backward pass.  wgrad_slabs(rows) slots of 128*128 (+128 with a bias) floats per gradient.
+// allocated, never reused within a step) and records (destination, slots); wgrad_flush adds them in slab order (one launch per
+// WGRAD_REDUCE_MAX tensors; the backward pass flushes once per layer, on the side stream).  wgrad_slabs(rows) slots of 128*128 (+128 with a bias) floats per gradient.
 struct WgradReduceEntry {
   float* dst;
   const float* part;
   int32_t n_slab, numel;
 };
 constexpr int WGRAD_MAX_JOBS = 8;
+constexpr int WGRAD_REDUCE_MAX = 24;  // gradient tensors per reduce launch (one layer has <= 19)
 struct WgradCtx {
   struct Job {
     const float *X, *dY;
@@ -44,9 +45,7 @@ struct WgradCtx {
   std::vector<Job> jobs;                  // queued by wgrad_add, launched together by wgrad_launch
   float* arena = nullptr;                 // partial slots (device)
   size_t off = 0;                         // floats used
-  WgradReduceEntry* d_table = nullptr;    // device copy of `entries` (capacity table_cap), filled by wgrad_flush
-  int table_cap = 0;
-  std::vector<WgradReduceEntry> entries;  // one per gradient tensor of the step
+  std::vector<WgradReduceEntry> entries;  // one per gradient tensor since the last wgrad_flush
 };
 int wgrad_slabs(int rows);
 void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows);

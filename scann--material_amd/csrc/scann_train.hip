@@ -272,8 +272,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradSet set) {
 }
 
 // dst[i] += part[0][i] + part[1][i] + ... in slab order, for every gradient tensor of the step (blockIdx.y)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceEntry* __restrict__ table) {
-  const WgradReduceEntry e = table[blockIdx.y];
+struct WgradReduceSet {
+  WgradReduceEntry e[WGRAD_REDUCE_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceSet set) {
+  const WgradReduceEntry e = set.e[blockIdx.y];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= e.numel) return;
   const float* __restrict__ p = e.part + idx;
@@ -301,10 +304,13 @@ int wgrad_slabs(int rows) {
 }
 
 void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
-  const int n = (int)std::min<size_t>(ctx.entries.size(), (size_t)ctx.table_cap);
-  if (n > 0) {
-    (void)hipMemcpyAsync(ctx.d_table, ctx.entries.data(), (size_t)n * sizeof(WgradReduceEntry), hipMemcpyHostToDevice, s);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(D * D / 256, n), dim3(256), 0, s, ctx.d_table);
+  // the (destination, slots) records travel as kernel arguments: no table copy, so a flush can follow each layer's gradient
+  // launch on the side stream
+  for (size_t e0 = 0; e0 < ctx.entries.size(); e0 += WGRAD_REDUCE_MAX) {
+    const int n = (int)std::min<size_t>(WGRAD_REDUCE_MAX, ctx.entries.size() - e0);
+    WgradReduceSet set{};
+    for (int k = 0; k < n; ++k) set.e[k] = ctx.entries[e0 + k];
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(D * D / 256, n), dim3(256), 0, s, set);
   }
   ctx.entries.clear();
 }
