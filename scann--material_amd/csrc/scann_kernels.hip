@@ -19,10 +19,9 @@
 //   basis_kernel  : Gaussian expansion + neighbor_d/neighbor_w MLP (custom_layers.py:63-65,
 //                   scann_model.py:378-389)
 #include "scann_internal.h"
+#include "scann_mma.h"
 
 namespace scann {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Diagnostic build only (-DSCANN_STAMPS): per-workgroup phase timestamps, written to a buffer nothing else reads.
 #ifdef SCANN_STAMPS
@@ -72,78 +71,6 @@ __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4swish(float4 a) { return make_float4(swishf(a.x), swishf(a.y), swishf(a.z), swishf(a.w)); }
 __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-// C/D map of the 32x32 MFMA: register i of lane l holds row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31.
-__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
-
-// ---- split-fp16 projection helpers (shared by the atom and edge kernels; scheme: see the edge-tile section) ------------
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int PLANE_STRIDE = 136;  // halfs per staged row: 128 + 8 pad = 272 B (conflict-free b128 fragment reads)
-
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Consecutive tiles hold neighbouring
-// atoms of the same structures and gather the same centre rows, so give every XCD a CONTIGUOUS run of tiles
-// (bijective for any grid size).  Speed only: any placement is correct.
-__device__ __forceinline__ int xcd_tile(int b, int n) {
-  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
-  return x * q + min(x, r) + i;
-}
-
-// hi / lo fp16 parts of four consecutive fp32 values
-__device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
-  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-  l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-  l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-}
-
-// One wave's slab of a split weight (pack_weight_f16): [wave][k-step][plane hi|lo][lane][8 halfs] -- per k-step and plane
-// one coalesced 1-KiB read.  KS = K / 16 k-steps.
-template <int KS, int KT = KS>
-__device__ __forceinline__ void load_wsplit(const _Float16* __restrict__ Wp, int wave, int lane, f16x8 (&wh)[KS], f16x8 (&wl)[KS], int s0 = 0) {
-  const f16x8* __restrict__ src = reinterpret_cast<const f16x8*>(Wp) + (size_t)wave * (KT * 2 * 64) + lane;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    wh[s] = src[(2 * (s0 + s)) * 64];
-    wl[s] = src[(2 * (s0 + s) + 1) * 64];
-  }
-}
-
-// acc[rt] (transposed: lane = row 32 rt + (lane & 31), registers = 16 of the wave's 32 columns, see mma128T) +=
-// X[rows][0 .. 16 KS) . W[0 .. 16 KS)[32 wave .. +32), X given as hi / lo planes in LDS.  Operand map of
-// v_mfma_f32_32x32x16_f16 (checked with exact integers by tools/mfma_f16_probe.hip): lane l supplies A[i = l & 31][k = 8 (l >> 5) + j]
-// and B[k = 8 (l >> 5) + j][j' = l & 31], j = 0..7; weights are the A operand, so the product comes out transposed.
-template <int KS, bool FIRST = false, int STRIDE = PLANE_STRIDE>
-__device__ __forceinline__ void mma_split(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, const f16x8 (&wh)[KS],
-                                          const f16x8 (&wl)[KS], int lane, f32x16 (&acc)[2]) {
-  const int off = (lane & 31) * STRIDE + 8 * (lane >> 5);
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const f16x8 xh = *reinterpret_cast<const f16x8*>(sH + off + rt * 32 * STRIDE + 16 * s);
-      const f16x8 xl = *reinterpret_cast<const f16x8*>(sL + off + rt * 32 * STRIDE + 16 * s);
-      // FIRST: the chain starts from the inline constant 0 (no zero-fill of the 16 accumulator registers)
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, FIRST && s == 0 ? zero : acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, acc[rt], 0, 0, 0);
-    }
-  }
-}
-
-__device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32); }
-
-// Global access as (uniform base pointer) + (32-bit per-lane BYTE offset): compiles to the saddr form of global_load / global_store
-// -- one offset VGPR per row instead of a 64-bit address pair per tensor (the tensors here are < 4 GiB each: scann_batch_upload
-// checks n_edge * 512 < 2^32).
-__device__ __forceinline__ float4 ld4(const float* __restrict__ base, unsigned byte_off) {
-  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off, const float4 v) {
-  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
-}
-
 // ---- atom-tile kernel ------------------------------------------------------------------------------
 //
 // One workgroup (4 waves) per tile of TA = 64 atom rows, three workgroups per CU; every projection is a split-fp16 MFMA GEMM
@@ -155,22 +82,6 @@ __device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off,
 //   FFN  : c = LN(x + drop(W2 swish(W1 x + b1) + b2))                       ResidualNorm of the previous layer, attention.py:37-40
 //   MODE 0: P1 = c W1 + bg, P3 = c W3, q = c Wq + bq                        centre / neighbour thirds of filter_geo :142-151, query :160
 //   MODE 1: q only (base branch)           MODE 2: z = swish(c Wa + ba); gq = z Wgq + b, gk = z Wgk + b   (scann_model.py:424, attention.py:269-272)
-
-// acc = X . W for the tile staged in (sH, sL), W's halves already in (whA, wlA) / (whB, wlB); when NEXT, the halves of the
-// following weight are requested into the same registers as soon as the MFMAs that read them have been issued.
-template <bool NEXT>
-__device__ __forceinline__ void gemm_tile(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, f16x8 (&whA)[4], f16x8 (&wlA)[4],
-                                          f16x8 (&whB)[4], f16x8 (&wlB)[4], const _Float16* __restrict__ next, int wave, int lane,
-                                          f32x16 (&acc)[2]) {
-  mma_split<4, true>(sH, sL, whA, wlA, lane, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  if (NEXT) load_wsplit<4, 8>(next, wave, lane, whA, wlA, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  if (NEXT) load_wsplit<4, 8>(next, wave, lane, whB, wlB, 4);
-  __builtin_amdgcn_sched_barrier(0);
-}
 
 template <bool FFN, int MODE>
 __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {

@@ -128,7 +128,10 @@ struct scann_handle {
   std::vector<int64_t> spec_off;
   std::vector<RepackDesc> descs;
   size_t arena_floats = 0, o_lut = 0, o_emb = 0, o_Wde = 0, o_bde = 0;
-  struct LayerT { const float *W1T, *W2T, *W3T, *WqT, *WkT, *Wf1T, *Wf2T; };
+  struct LayerT {
+    const float *W1T, *W2T, *W3T, *WqT, *WkT, *Wf1T, *Wf2T;                  // fp32 fragment order (modular backward)
+    const _Float16 *W1Th, *W2Th, *W3Th, *WqTh, *WkTh, *Wf1Th, *Wf2Th;        // split-fp16 images (fused backward kernels)
+  };
   std::vector<LayerT> layersT;  // packed transposes for the backward dX GEMMs
   const float *WaT = nullptr, *WgqT = nullptr, *WgkT = nullptr;
   // training state (scann_train_begin)
@@ -140,6 +143,7 @@ struct scann_handle {
   bool in_train_forward = false;
   unsigned long long train_seed = 0;
   ncclComm_t comm = nullptr;
+  bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
   hipStream_t train_aux = nullptr;       // side stream of the backward pass: weight-gradient GEMMs run beside the data-gradient chain
   std::vector<hipEvent_t> train_ev;      // ring of fork / join events between the two streams
   // reusable scratch of the synchronous scann_forward path (grow-only device arena + pinned host staging)
@@ -495,6 +499,16 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 0, ks == 8 ? -1 : -2});
     return off;
   };
+  auto put_f16T = [&](const float* W) {  // split-fp16 image of W^T ([128,128]; fused backward kernels: dX = dY . W^T)
+    const size_t off = img.size();
+    img.resize(off + (size_t)8 * 2048);
+    std::vector<float> wt((size_t)D * D);
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) wt[(size_t)j * D + i] = W[(size_t)i * D + j];
+    pack_weight_f16(wt.data(), D, D, 8, reinterpret_cast<uint16_t*>(img.data() + off));
+    h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 1, -1});
+    return off;
+  };
   for (const WeightSpec& sp : h->specs)  // the fp16 hi part of a split weight holds |w| * 2^8 < 65504
     if (sp.cols) {
       const float* wp = src[sp.name];
@@ -503,7 +517,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
           return fail(h, SCANN_ERR_UNSUPPORTED, "scann_load_weights: |" + sp.name + "| reaches " + std::to_string(std::fabs(wp[i])) +
                                                     "; the split-fp16 projections need |w| < 255.9 (or the value is not finite)");
     }
-  struct LTOff { size_t W1T, W2T, W3T, WqT, WkT, Wf1T, Wf2T; };
+  struct LTOff { size_t W1T, W2T, W3T, WqT, WkT, Wf1T, Wf2T, W1Th, W2Th, W3Th, WqTh, WkTh, Wf1Th, Wf2Th; };
   std::vector<LTOff> lto(L);
   struct LOff {
     size_t W1p, W3p, bg, Wqp, bq, W2p, Wkp, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, Wf1p, bf1, Wf2p, bf2, lnr_g, lnr_b;
@@ -517,7 +531,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE,
              NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     const float* fg = src[p + "filter_geo/kernel"];
-    lto[i] = LTOff{(size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
+    lto[i] = LTOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
       o.W1p = put_packed(fg);
       o.W1h = put_f16(fg, D, 8);
@@ -528,6 +542,9 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       lto[i].W1T = put_packedT(fg);
       lto[i].W2T = put_packedT(fg + (size_t)D * D);
       lto[i].W3T = put_packedT(fg + (size_t)2 * D * D);
+      lto[i].W1Th = put_f16T(fg);
+      lto[i].W2Th = put_f16T(fg + (size_t)D * D);
+      lto[i].W3Th = put_f16T(fg + (size_t)2 * D * D);
       o.bg = put_raw(src[p + "filter_geo/bias"], D);
       o.lng_g = put_raw(src[p + "layer_norm_g/gamma"], D);
       o.lng_b = put_raw(src[p + "layer_norm_g/beta"], D);
@@ -540,6 +557,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     o.Wqh = put_f16(src[p + "query/kernel"], D, 8);
     lto[i].WqT = put_packedT(src[p + "query/kernel"]);
     lto[i].WkT = put_packedT(src[p + "key/kernel"]);
+    lto[i].WqTh = put_f16T(src[p + "query/kernel"]);
+    lto[i].WkTh = put_f16T(src[p + "key/kernel"]);
     o.bq = put_raw(src[p + "query/bias"], D);
     o.Wkp = put_packed(src[p + "key/kernel"]);
     o.Wkh = put_f16(src[p + "key/kernel"], D, 8);
@@ -550,6 +569,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       const std::string r = "residual_norm_" + std::to_string(i) + "/";
       lto[i].Wf1T = put_packedT(src[r + "dense_1/kernel"]);
       lto[i].Wf2T = put_packedT(src[r + "dense_2/kernel"]);
+      lto[i].Wf1Th = put_f16T(src[r + "dense_1/kernel"]);
+      lto[i].Wf2Th = put_f16T(src[r + "dense_2/kernel"]);
       o.Wf1p = put_packed(src[r + "dense_1/kernel"]);
       o.Wf1h = put_f16(src[r + "dense_1/kernel"], D, 8);
       o.Wf2h = put_f16(src[r + "dense_2/kernel"], D, 8);
@@ -628,8 +649,12 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lp.lnr_g = P(o.lnr_g); lp.lnr_b = P(o.lnr_b);
   }
   h->layersT.assign(L, scann_handle::LayerT{});
-  for (int i = 0; i < L; ++i)
-    h->layersT[i] = scann_handle::LayerT{P(lto[i].W1T), P(lto[i].W2T), P(lto[i].W3T), P(lto[i].WqT), P(lto[i].WkT), P(lto[i].Wf1T), P(lto[i].Wf2T)};
+  for (int i = 0; i < L; ++i) {
+    auto PH = [&](size_t o) { return reinterpret_cast<const _Float16*>(P(o)); };
+    h->layersT[i] = scann_handle::LayerT{P(lto[i].W1T), P(lto[i].W2T), P(lto[i].W3T), P(lto[i].WqT), P(lto[i].WkT), P(lto[i].Wf1T), P(lto[i].Wf2T),
+                                         PH(lto[i].W1Th), PH(lto[i].W2Th), PH(lto[i].W3Th), PH(lto[i].WqTh), PH(lto[i].WkTh), PH(lto[i].Wf1Th),
+                                         PH(lto[i].Wf2Th)};
+  }
   h->WaT = P(oWaT); h->WgqT = P(oWgqT); h->WgkT = P(oWgkT);
   h->arena_floats = img.size(); h->o_lut = olut; h->o_emb = oemb; h->o_Wde = oWe; h->o_bde = obe;
   h->head = HeadParams{P(oWa), P(oba), P(oWgq), P(obgq), P(oWgk), P(obgk),
@@ -1201,7 +1226,8 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   w.wpart_floats = (size_t)(D * D + D) * (Lc * (2 * (size_t)wgrad_slabs(std::max(db->n_edge, 1)) + 5 * (size_t)wgrad_slabs(db->n_atom)) +
                                            3 * (size_t)wgrad_slabs(db->n_atom) + (size_t)wgrad_slabs(db->n_struct)) +
                    // LayerNorm gamma / beta partials: per layer ln_bwd over edges and atoms, attention backward over atoms
-                   (size_t)2 * D * Lc * ((size_t)ln_bwd_slots(std::max(db->n_edge, 1)) + (size_t)ln_bwd_slots(db->n_atom) +
+                   (size_t)2 * D * Lc * ((size_t)std::max(ln_bwd_slots(std::max(db->n_edge, 1)), tile_slots(std::max(db->n_edge, 1))) +
+                                         (size_t)std::max(ln_bwd_slots(db->n_atom), tile_slots(db->n_atom)) +
                                          (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
   const size_t total = 15 * rowA + 12 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
                        align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4);
@@ -1291,6 +1317,10 @@ int scann_train_begin(scann_handle_t* h) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
     h->train_ev.resize(128);
     for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  {
+    const char* e = getenv("SCANN_TRAIN_FUSED");
+    h->train_fused = !(e && e[0] == '0');
   }
   h->t_step = 0;
   return SCANN_OK;
@@ -1456,6 +1486,18 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
+  // fused chains (scann_train_fused.hip): the kept-activation g_update path; SCANN_TRAIN_FUSED=0 selects the modular kernels
+  const bool fused = db->kept && c.g_update && h->train_fused;
+  struct Pend {  // projections of layer l + 1 that still have to be added to dC (d loss / d centres_{l+1})
+    int n = 0;
+    const float* X[3];
+    const _Float16* Wh[3];
+    const float* W[3];
+  } pend;
+  auto flush_pend = [&]() {
+    if (pend.n) launch_linear_sum(pend.X[0], pend.W[0], pend.X[1], pend.W[1], pend.X[2], pend.W[2], dC, A, 1, s);
+    pend.n = 0;
+  };
   for (int l = L - 1; l >= 0; --l) {
     wait_layer(l + 2);  // operand set l & 1 was last used by layer l + 2: its weight-gradient launch must have read it
     if (side) {
@@ -1471,6 +1513,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     const float* Gin = c.g_update ? db->dbg_g + (size_t)l * nE : nullptr;         // geometry entering layer l
     const float* Gout = c.g_update ? db->dbg_g + (size_t)(l + 1) * nE : nullptr;  // geometry leaving layer l (= layer_norm_g output)
 
+    if (pend.n && !(fused && c.use_attn_norm && db->keep_T2)) flush_pend();  // nobody below folds the projections of the layer above in
     // ---- ResidualNorm backward (attention.py:37-40): c_{l+1} = LN(x + drop(W2 swish(W1 x + b1) + b2)), x = ctx ----
     if (c.use_attn_norm) {
       const bool kept_rn = db->kept && db->keep_T2;  // the training forward (atom_kernel) kept pre1, H1 and T2
@@ -1483,6 +1526,19 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
         launch_dropout(t2, nA, w.seed, (unsigned)l, w.drop_p, s);
         launch_add(t2, ctx, nA, s);                            // T2 = x + drop(Y)
       }
+      if (fused && kept_rn) {
+        // one kernel: [dC += the projections of the layer above] -> LayerNorm backward -> Dropout mask -> dense_2^T, swish' -> dense_1^T
+        RnBwdArgs ra{};
+        ra.dC = dC; ra.T2 = T2; ra.pre1 = pre1; ra.gamma = p.lnr_g; ra.Wf2Th = pt.Wf2Th; ra.Wf1Th = pt.Wf1Th;
+        ra.dY = t3; ra.dpre1 = t4; ra.dCtx = dCtx; ra.n_atom = A;
+        ra.drop_p = w.drop_p; ra.drop_seed = w.seed; ra.drop_tag = (unsigned)l;
+        ra.n_pre = pend.n;
+        for (int t = 0; t < pend.n; ++t) { ra.X[t] = pend.X[t]; ra.Wh[t] = pend.Wh[t]; }
+        pend.n = 0;
+        launch_rn_bwd(wg, ra, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), s);
+        wgrad_add(wg, H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A);
+        wgrad_add(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A);
+      } else {
       launch_ln_bwd(wg, T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
       // gradient of the Dense_2 output = dT2 through the Dropout mask, in a buffer of its own: dT2 (dCtx) is the residual path and
       // is accumulated into below, while the queued weight gradient reads its operand at the end of the layer
@@ -1493,6 +1549,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       wgrad_add(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A);
       if (!side) wgrad_launch(wg, s);  // without the kept-activation forward the operands do not survive the layer
       launch_linear(t4, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
+      }
     } else {
       HIPCHK(h, hipMemcpyAsync(dCtx, dC, nA * 4, hipMemcpyDeviceToDevice, s));
     }
@@ -1538,6 +1595,34 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
                     w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
     wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
     if (!side) wgrad_launch(wg, s);  // the recomputed ang / temporaries do not survive the layer: launch now
+    if (fused) {
+      float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
+      // one kernel: dang = dK.Wk^T -> dG'tot = dang * c[j] + dG'(next layer) -> LayerNorm_g backward -> dV = dT * swish'(V) -> dG = dT + dV.W2^T
+      EdgeBwdArgs ea{};
+      ea.dK = edK; ea.c = c_in; ea.dG_in = dG_in; ea.T = TL; ea.V = VL; ea.gamma = p.lng_g; ea.nb = db->edge_col;
+      ea.WkTh = pt.WkTh; ea.W2Th = pt.W2Th; ea.dang = edAng; ea.dV = eU; ea.dG = dGnext; ea.n_edge = E;
+      launch_edge_bwd(wg, ea, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), s);
+      // dC[j] = sum over the edges that point at j of dang * G' (gate), dP3[j] = the same sum of dV, dP1[i] = sum of dV over i's own edges
+      launch_atom_gather3(edAng, Gout, eU, db->edge_offset, db->in_off, db->in_edge, dC, dP1, dP3, A, s);
+      float* fgk = g(la + "filter_geo/kernel");
+      wgrad_add(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E);                     // dW2
+      wgrad_add(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), A);
+      wgrad_add(wg, c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A);
+      wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
+      {
+        hipStream_t ws = fork();
+        wgrad_launch(wg, ws);
+        if (side) wgrad_flush(wg, ws);
+      }
+      mark_layer(l);
+      // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T is folded into the next layer's rn_bwd_kernel (or launched after the loop)
+      pend.n = 3;
+      pend.X[0] = dP1; pend.X[1] = dP3; pend.X[2] = dQ;
+      pend.Wh[0] = pt.W1Th; pend.Wh[1] = pt.W3Th; pend.Wh[2] = pt.WqTh;
+      pend.W[0] = pt.W1T; pend.W[1] = pt.W3T; pend.W[2] = pt.WqT;
+      dG_in = dGnext;
+      continue;
+    }
     launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
     // dC now collects d loss / d centres_l: dC[j] = sum over the edges that point at j of dang * G' (backward of the gate ang = c[j] * G')
     launch_gather_prod_sum(edAng, Gout, db->in_off, db->in_edge, dC, A, 0, s);
@@ -1569,6 +1654,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     launch_linear_sum(dP1, pt.W1T, dP3, pt.W3T, dQ, pt.WqT, dC, A, 1, s);  // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T
     dG_in = dGnext;
   }
+  flush_pend();
   // ---- basis MLP and embedding (scann_model.py:362-389) ----
   if (dG_in)
     launch_basis_bwd(h->basis, db->dist, db->weight, dG_in, E, g("neighbor_d/kernel"), g("neighbor_d/bias"),

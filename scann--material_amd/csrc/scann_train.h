@@ -88,6 +88,35 @@ void launch_dropout_copy(float* dst, const float* src, size_t n, unsigned long l
 void launch_attn_bwd(WgradCtx& ctx, const float* q, const float* K, const int* edge_offset, const float* dctx, const float* gamma, float* dq,
                      float* dK, float* dgamma, float* dbeta, int n_atom, int max_degree, float drop_p, unsigned drop_tag,
                      unsigned long long drop_seed, hipStream_t s);
+// ---- fused backward chains (scann_train_fused.hip) ----
+float* reserve_vec(WgradCtx& ctx, float* dst, int n_slot);  // records (dst, slots) of a gradient vector a kernel stores per workgroup
+int tile_slots(int rows);                                   // workgroups (= gamma / beta slots) of a fused kernel over `rows`
+struct RnBwdArgs {
+  const float *dC, *T2, *pre1, *gamma;          // [n_atom,128] x3, layer_norm gamma
+  const _Float16 *Wf2Th, *Wf1Th;                // split-fp16 images of dense_2^T, dense_1^T
+  float *dY, *dpre1, *dCtx;                     // out [n_atom,128]
+  float *dgamma, *dbeta;                        // per-workgroup slots (set by the launcher)
+  float* dC_out;                                // optional: the complete d loss / d c' (null: not stored)
+  int32_t n_atom;
+  float drop_p;
+  unsigned long long drop_seed;
+  unsigned drop_tag;
+  int32_t n_pre;                                // 0..3 projections of the layer above added to dC first: dC += X[t] . W[t]^T
+  const float* X[3];
+  const _Float16* Wh[3];
+};
+struct EdgeBwdArgs {
+  const float *dK, *c, *dG_in, *T, *V, *gamma;  // [n_edge,128] (c: [n_atom,128]; dG_in may be null), layer_norm_g gamma
+  const int* nb;                                // [n_edge] neighbour atom row
+  const _Float16 *WkTh, *W2Th;                  // split-fp16 images of key^T, filter_geo (geometry third)^T
+  float *dang, *dV, *dG;                        // out [n_edge,128]
+  float *dgamma, *dbeta;
+  int32_t n_edge;
+};
+void launch_rn_bwd(WgradCtx& ctx, RnBwdArgs a, float* dgamma, float* dbeta, hipStream_t s);
+void launch_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, float* dgamma, float* dbeta, hipStream_t s);
+void launch_atom_gather3(const float* dang, const float* G, const float* dV, const int* edge_offset, const int* in_off, const int* in_edge,
+                         float* dC, float* dP1, float* dP3, int n_atom, hipStream_t s);
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);
 void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weight, const float* dgeom, int n_edge, float* dWd,
                       float* dbd, float* dWw, float* dbw, hipStream_t s);

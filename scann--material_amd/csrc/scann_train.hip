@@ -515,7 +515,7 @@ int ln_bwd_slots(int rows) {
   return (rows + 32 * groups - 1) / (32 * groups);
 }
 // records (dst, slots) of one parameter-gradient vector whose per-workgroup partial sums a kernel is about to store
-static float* reserve_vec(WgradCtx& ctx, float* dst, int n_slot, hipStream_t) {
+float* reserve_vec(WgradCtx& ctx, float* dst, int n_slot) {
   float* part = ctx.arena + ctx.off;
   ctx.entries.push_back(WgradReduceEntry{dst, part, n_slot, D});
   ctx.off += (size_t)n_slot * D;
@@ -525,8 +525,8 @@ void launch_ln_bwd(WgradCtx& ctx, const float* x, const float* gamma, const floa
                    int accumulate, hipStream_t s) {
   if (rows <= 0) return;
   const int groups = ln_bwd_groups(rows), n_wg = ln_bwd_slots(rows);
-  float* gp = reserve_vec(ctx, dgamma, n_wg, s);
-  float* bp = reserve_vec(ctx, dbeta, n_wg, s);
+  float* gp = reserve_vec(ctx, dgamma, n_wg);
+  float* bp = reserve_vec(ctx, dbeta, n_wg);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_wg), dim3(256), 0, s, x, gamma, dy, dx, gp, bp, rows, groups, accumulate, LnBwdFuse{});
 }
 // LayerNorm_g backward of LocalAttention with its neighbours fused: dy = dang * c[nb] (+ dg_in) in, dx = dT and dV = dT * swish'(V) out
@@ -534,8 +534,8 @@ void launch_ln_bwd_edge(WgradCtx& ctx, const float* T, const float* gamma, const
                         const float* dg_in, const float* V, float* dT, float* dV, float* dgamma, float* dbeta, int rows, hipStream_t s) {
   if (rows <= 0) return;
   const int groups = ln_bwd_groups(rows), n_wg = ln_bwd_slots(rows);
-  float* gp = reserve_vec(ctx, dgamma, n_wg, s);
-  float* bp = reserve_vec(ctx, dbeta, n_wg, s);
+  float* gp = reserve_vec(ctx, dgamma, n_wg);
+  float* bp = reserve_vec(ctx, dbeta, n_wg);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(n_wg), dim3(256), 0, s, T, gamma, (const float*)nullptr, dT, gp, bp, rows, groups, 0,
                      LnBwdFuse{dang, c, nb, dg_in, V, dV});
 }
@@ -911,8 +911,8 @@ void launch_attn_bwd(WgradCtx& ctx, const float* q, const float* K, const int* e
                      unsigned long long drop_seed, hipStream_t s) {
   if (n_atom <= 0) return;
   const int n_slot = attn_bwd_slots(n_atom, max_degree);
-  float* gp = reserve_vec(ctx, dgamma, n_slot, s);
-  float* bp = reserve_vec(ctx, dbeta, n_slot, s);
+  float* gp = reserve_vec(ctx, dgamma, n_slot);
+  float* bp = reserve_vec(ctx, dbeta, n_slot);
   if (max_degree <= 16) {
     const int apw16 = n_atom >= 16384 ? 8 : 4;
     hipLaunchKernelGGL(attn_bwd16_kernel, dim3((n_atom + 4 * apw16 - 1) / (4 * apw16)), dim3(256), 0, s, q, K, edge_offset, dctx,
@@ -1327,7 +1327,8 @@ __global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float*
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int k = 16 * st + 8 * (lane >> 5) + 2 * jp + u;
-      const float x = k < k_real ? WSCALE * master[d.src + (size_t)k * D + 32 * w + (lane & 31)] : 0.f;
+      const int col = 32 * w + (lane & 31);
+      const float x = k < k_real ? WSCALE * master[d.src + (d.transpose ? (size_t)col * D + k : (size_t)k * D + col)] : 0.f;
       const _Float16 hi = (_Float16)x;
       out[u] = plane ? (_Float16)(x - (float)hi) : hi;
     }

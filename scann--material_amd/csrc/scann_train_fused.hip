@@ -1,0 +1,494 @@
+// Fused backward chains of one LocalAttention + ResidualNorm iteration, on 64-row tiles with the
+// forward kernels' machinery: split-fp16 MFMA projections (scann_mma.h), everything between the GEMMs in the accumulator
+// layout (lane = row, 16 of the wave's 32 columns).  At batch 128 a kernel of the modular backward (scann_train.hip) is one
+// partially filled round of workgroups, i.e. a launch costs its latency chain whatever it computes; these kernels replace
+//   rn_bwd_kernel   : [linear_sum of the layer above] + ln_bwd + dropout_copy + linear(Wf2^T, swish') + linear(Wf1^T)   (5 -> 1)
+//   edge_bwd_kernel : linear(Wk^T) + ln_bwd_edge + linear(W2^T)                                                        (3 -> 1)
+//   atom_gather3_kernel : gather_prod_sum + atom_sums                                                                  (2 -> 1)
+// Gradients are not O(1) like activations, so every GEMM input row is multiplied by a power of two that brings its largest
+// magnitude to 2^12 before the hi / lo fp16 split (exact), and the accumulators by the inverse: the split keeps 22 significant
+// bits relative to the row's maximum whatever the loss scale.
+// Formulas: the exact derivatives of attention.py:37-40 (ResidualNorm) and :141-163 (geometry update, gate, key), as in
+// the modular kernels they replace (scann_train.hip: ln_bwd_kernel, linear_kernel, dropout_copy_kernel).
+#include "scann_internal.h"
+#include "scann_mma.h"
+#include "scann_train.h"
+
+#include <algorithm>
+
+namespace scann {
+
+namespace {
+
+__device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// d/dx [x * sigmoid(x)] = s * (1 + x * (1 - s))
+__device__ __forceinline__ float dsw_(float x) {
+  const float s = sigm_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float f4sum_(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+constexpr float WINV = 1.0f / WSCALE;
+constexpr int STAGE_STRIDE = D + 4;  // floats per row of the gamma / beta staging (aliases the plane buffer)
+
+// scale = 2^(12 - e) for a row whose largest magnitude has binary exponent e (1 for an all-zero row); post = WINV / scale
+__device__ __forceinline__ void row_scale(float rowmax, float& scale, float& post) {
+  const int e = (__float_as_int(rowmax) >> 23) & 0xff;
+  const int se = min(253, 266 - e);  // biased exponent of the scale; e <= 254 -> se >= 12
+  scale = e == 0 ? 1.0f : __int_as_float(se << 23);
+  post = e == 0 ? WINV : __int_as_float((254 - se) << 23) * WINV;
+}
+
+// largest magnitude of the row: this lane's 16 columns, its partner lane, then (through LDS) the row's four waves
+__device__ __forceinline__ void put_rowmax(float* __restrict__ sMax, const float4 (&v)[2][4], int lrow, int lh, int wave) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[rt][j].x), fabsf(v[rt][j].y))), fmaxf(fabsf(v[rt][j].z), fabsf(v[rt][j].w)));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (lh == 0) sMax[(lrow + 32 * rt) * 4 + wave] = m;
+  }
+}
+__device__ __forceinline__ float get_rowmax(const float* __restrict__ sMax, int row) {
+  const float4 m = *reinterpret_cast<const float4*>(&sMax[row * 4]);
+  return fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
+}
+
+// the scaled row -> hi / lo planes
+__device__ __forceinline__ void put_planes(_Float16* __restrict__ sH, _Float16* __restrict__ sL, const float4 (&v)[4], float scale, int row,
+                                           int cbase) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f16x4 h, l;
+    split4(make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale), h, l);
+    *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
+    *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+  }
+}
+
+// LayerNorm statistics of the tile's rows (as in atom_kernel): per-lane partial (mean of 32, M2 of 32) -> LDS
+__device__ __forceinline__ void put_stats(float* __restrict__ sRed, const float4 (&x)[2][4], int lrow, int lh, int wave) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += f4sum_(x[rt][j]);
+    const float mean32 = xor32(s) * (1.0f / 32.0f);
+    float v2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = x[rt][j].x - mean32, b = x[rt][j].y - mean32, c = x[rt][j].z - mean32, d = x[rt][j].w - mean32;
+      v2 += (a * a + b * b) + (c * c + d * d);
+    }
+    const float m2 = xor32(v2);
+    if (lh == 0) *reinterpret_cast<float2*>(&sRed[((lrow + 32 * rt) * 4 + wave) * 2]) = make_float2(mean32, m2);
+  }
+}
+__device__ __forceinline__ void get_stats(const float* __restrict__ sRed, int row, float& mean, float& rstd) {
+  const float4 sa = *reinterpret_cast<const float4*>(&sRed[row * 8]), sb = *reinterpret_cast<const float4*>(&sRed[row * 8 + 4]);
+  mean = ((sa.x + sa.z) + (sb.x + sb.z)) * 0.25f;
+  const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
+  const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
+  rstd = 1.0f / sqrtf(var + 1e-6f);
+}
+
+// LayerNorm backward in the accumulator layout, first half: x -> xhat, dy -> ax = dy * gamma; the row sums of ax and ax * xhat go
+// to sRed, the tile's column sums of dy * xhat and dy (gamma / beta gradients) to the staging buffer (two row tiles pre-added).
+__device__ __forceinline__ void ln_bwd_head(float4 (&x)[2][4], float4 (&dy)[2][4], const float* __restrict__ sStat, const float* __restrict__ sGamma,
+                                            float* __restrict__ sSum, float* __restrict__ stage, float (&rstd)[2], int lrow, int lh, int wave,
+                                            int cbase) {
+  float4 dgm[4], dbt[4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    float mean;
+    get_stats(sStat, lrow + 32 * rt, mean, rstd[rt]);
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 g = *reinterpret_cast<const float4*>(&sGamma[cbase + 8 * j]);
+      const float4 xh = make_float4((x[rt][j].x - mean) * rstd[rt], (x[rt][j].y - mean) * rstd[rt], (x[rt][j].z - mean) * rstd[rt],
+                                    (x[rt][j].w - mean) * rstd[rt]);
+      const float4 d = dy[rt][j];
+      const float4 gx = make_float4(d.x * xh.x, d.y * xh.y, d.z * xh.z, d.w * xh.w);
+      if (rt == 0) {
+        dgm[j] = gx;
+        dbt[j] = d;
+      } else {
+        dgm[j] = make_float4(dgm[j].x + gx.x, dgm[j].y + gx.y, dgm[j].z + gx.z, dgm[j].w + gx.w);
+        dbt[j] = make_float4(dbt[j].x + d.x, dbt[j].y + d.y, dbt[j].z + d.z, dbt[j].w + d.w);
+      }
+      const float4 ax = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      p1 += f4sum_(ax);
+      p2 += (ax.x * xh.x + ax.y * xh.y) + (ax.z * xh.z + ax.w * xh.w);
+      x[rt][j] = xh;
+      dy[rt][j] = ax;
+    }
+    p1 = xor32(p1);
+    p2 = xor32(p2);
+    if (lh == 0) *reinterpret_cast<float2*>(&sSum[((lrow + 32 * rt) * 4 + wave) * 2]) = make_float2(p1, p2);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    *reinterpret_cast<float4*>(&stage[lrow * STAGE_STRIDE + cbase + 8 * j]) = dgm[j];
+    *reinterpret_cast<float4*>(&stage[(32 + lrow) * STAGE_STRIDE + cbase + 8 * j]) = dbt[j];
+  }
+}
+// second half (after the barrier): x := dx = rstd * (ax - mean(ax) - xhat * mean(ax * xhat)); the workgroup's gamma / beta slot
+__device__ __forceinline__ void ln_bwd_tail(float4 (&x)[2][4], const float4 (&ax)[2][4], const float* __restrict__ sSum, const float* __restrict__ stage,
+                                            const float (&rstd)[2], float* __restrict__ dgamma, float* __restrict__ dbeta, int lrow, int tid) {
+  {
+    const int which = tid >> 7, col = tid & (D - 1);
+    float tot = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) tot += stage[(32 * which + r) * STAGE_STRIDE + col];
+    (which ? dbeta : dgamma)[(size_t)blockIdx.x * D + col] = tot;  // summed in slot order by wgrad_reduce_kernel
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = lrow + 32 * rt;
+    const float4 sa = *reinterpret_cast<const float4*>(&sSum[row * 8]), sb = *reinterpret_cast<const float4*>(&sSum[row * 8 + 4]);
+    const float m1 = ((sa.x + sa.z) + (sb.x + sb.z)) * (1.0f / D), m2 = ((sa.y + sa.w) + (sb.y + sb.w)) * (1.0f / D);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = ax[rt][j], xh = x[rt][j];
+      x[rt][j] = make_float4(rstd[rt] * (a.x - m1 - xh.x * m2), rstd[rt] * (a.y - m1 - xh.y * m2), rstd[rt] * (a.z - m1 - xh.z * m2),
+                             rstd[rt] * (a.w - m1 - xh.w * m2));
+    }
+  }
+}
+
+}  // namespace
+
+// ---- ResidualNorm backward (attention.py:37-40): c' = LN(T2), T2 = x + drop(Y), Y = H1 W2 + b2, H1 = swish(pre1), pre1 = x W1 + b1 ----
+// in : dC = d loss / d c' (+ optionally the projections of the layer above: dC += X0 W0^T + X1 W1^T + X2 W2^T), T2, pre1
+// out: dY (operand of dW2), dpre1 (operand of dW1), dCtx = dT2 + dpre1 W1^T, gamma / beta slots
+__global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * 64 * PLANE_STRIDE * 2];  // hi / lo planes | gamma-beta staging
+  __shared__ __attribute__((aligned(16))) float sStat[64 * 8], sSum[64 * 8];
+  __shared__ __attribute__((aligned(16))) float sMax[3][64 * 4];
+  __shared__ __attribute__((aligned(16))) float sGamma[D];
+  _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
+  _Float16* const sL = sH + 64 * PLANE_STRIDE;
+  float* const stage = reinterpret_cast<float*>(sTile);
+  static_assert(64 * STAGE_STRIDE * 4 <= (int)sizeof(sTile), "gamma / beta staging must fit the plane buffer");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
+  const int row0 = blockIdx.x * 64;
+  const int nrows = min(64, a.n_atom - row0);
+
+  f16x8 whA[4], wlA[4], whB[4], wlB[4];
+  const _Float16* const firstW = a.n_pre > 0 ? a.Wh[0] : a.Wf2Th;
+  load_wsplit<4, 8>(firstW, wave, lane, whA, wlA, 0);
+  load_wsplit<4, 8>(firstW, wave, lane, whB, wlB, 4);
+  if (tid < D) sGamma[tid] = a.gamma[tid];
+
+  unsigned off[2];
+  float4 x[2][4], dy[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    off[rt] = ((unsigned)(row0 + min(lrow + 32 * rt, nrows - 1)) * D + cbase) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[rt][j] = ld4(a.T2, off[rt] + 32 * j);
+      dy[rt][j] = ld4(a.dC, off[rt] + 32 * j);
+    }
+  }
+  f32x16 acc[2];
+  // projections of the layer above that end in this tile's rows (scann_train.hip: linear_sum_kernel)
+  for (int t = 0; t < a.n_pre; ++t) {
+    float4 v[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[rt][j] = ld4(a.X[t], off[rt] + 32 * j);
+    put_rowmax(sMax[0], v, lrow, lh, wave);
+    __syncthreads();  // (also: every wave is done with the planes of the previous term)
+    float post[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      float scale;
+      row_scale(get_rowmax(sMax[0], lrow + 32 * rt), scale, post[rt]);
+      put_planes(sH, sL, v[rt], scale, lrow + 32 * rt, cbase);
+    }
+    __syncthreads();
+    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, t + 1 < a.n_pre ? a.Wh[t + 1] : a.Wf2Th, wave, lane, acc);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dy[rt][j].x = fmaf(acc[rt][4 * j], post[rt], dy[rt][j].x);
+        dy[rt][j].y = fmaf(acc[rt][4 * j + 1], post[rt], dy[rt][j].y);
+        dy[rt][j].z = fmaf(acc[rt][4 * j + 2], post[rt], dy[rt][j].z);
+        dy[rt][j].w = fmaf(acc[rt][4 * j + 3], post[rt], dy[rt][j].w);
+      }
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+    if (lrow + 32 * rt >= nrows)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dy[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the end contribute exact zeros
+  if (a.dC_out) {  // the complete d loss / d c' (operand of nothing here; kept for the layer's own consumers when asked)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      if (lrow + 32 * rt < nrows)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st4(a.dC_out, off[rt] + 32 * j, dy[rt][j]);
+  }
+  put_stats(sStat, x, lrow, lh, wave);
+  __syncthreads();  // statistics (and sGamma) visible; the planes are free
+  float rstd[2];
+  ln_bwd_head(x, dy, sStat, sGamma, sSum, stage, rstd, lrow, lh, wave, cbase);
+  __syncthreads();
+  ln_bwd_tail(x, dy, sSum, stage, rstd, a.dgamma, a.dbeta, lrow, tid);  // x = dT2
+  // dY = dT2 through the Dropout mask of the forward (attention.py:29)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = x[rt][j];
+      if (a.drop_p > 0.f) {
+        const size_t e = (size_t)(row0 + lrow + 32 * rt) * D + cbase + 8 * j;
+        v.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
+        v.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
+        v.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
+        v.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
+      }
+      dy[rt][j] = v;
+    }
+  put_rowmax(sMax[1], dy, lrow, lh, wave);
+  __syncthreads();  // row maxima visible; every thread is done with the staging buffer
+  float post[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = lrow + 32 * rt;
+    float scale;
+    row_scale(get_rowmax(sMax[1], row), scale, post[rt]);
+    if (row < nrows)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st4(a.dY, off[rt] + 32 * j, dy[rt][j]);
+    put_planes(sH, sL, dy[rt], scale, row, cbase);
+  }
+  // pre1 rows (for swish') arrive under the GEMM, in the registers dY just left
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dy[rt][j] = ld4(a.pre1, off[rt] + 32 * j);
+  __syncthreads();
+  gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.Wf1Th, wave, lane, acc);  // dH1 = dY . W2^T
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 p = dy[rt][j];
+      dy[rt][j] = make_float4(acc[rt][4 * j] * post[rt] * dsw_(p.x), acc[rt][4 * j + 1] * post[rt] * dsw_(p.y),
+                              acc[rt][4 * j + 2] * post[rt] * dsw_(p.z), acc[rt][4 * j + 3] * post[rt] * dsw_(p.w));  // dpre1
+    }
+  put_rowmax(sMax[2], dy, lrow, lh, wave);
+  __syncthreads();  // every wave is done reading the dY planes
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = lrow + 32 * rt;
+    float scale;
+    row_scale(get_rowmax(sMax[2], row), scale, post[rt]);
+    if (row < nrows)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st4(a.dpre1, off[rt] + 32 * j, dy[rt][j]);
+    put_planes(sH, sL, dy[rt], scale, row, cbase);
+  }
+  __syncthreads();
+  gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);  // dpre1 . W1^T
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+    if (lrow + 32 * rt < nrows)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        st4(a.dCtx, off[rt] + 32 * j,
+            make_float4(fmaf(acc[rt][4 * j], post[rt], x[rt][j].x), fmaf(acc[rt][4 * j + 1], post[rt], x[rt][j].y),
+                        fmaf(acc[rt][4 * j + 2], post[rt], x[rt][j].z), fmaf(acc[rt][4 * j + 3], post[rt], x[rt][j].w)));
+}
+
+// ---- key / gate / geometry-update backward of one layer's edges (attention.py:141-163) -------------------------------------
+// in : dK, centres c (gate ang = c[j] * G'), dG' of the layer below (null for the last layer), T (LayerNorm_g input), V
+// out: dang = dK Wk^T, dV = dT * swish'(V), dG = dT + dV W2^T, gamma / beta slots      (dT = LN_g backward of dang * c[j] + dG')
+__global__ __launch_bounds__(256, 2) void edge_bwd_kernel(EdgeBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * 64 * PLANE_STRIDE * 2];
+  __shared__ __attribute__((aligned(16))) float sStat[64 * 8], sSum[64 * 8];
+  __shared__ __attribute__((aligned(16))) float sMax[2][64 * 4];
+  __shared__ __attribute__((aligned(16))) float sGamma[D];
+  _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
+  _Float16* const sL = sH + 64 * PLANE_STRIDE;
+  float* const stage = reinterpret_cast<float*>(sTile);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
+  const int row0 = blockIdx.x * 64;
+  const int nrows = min(64, a.n_edge - row0);
+
+  f16x8 whA[4], wlA[4], whB[4], wlB[4];
+  load_wsplit<4, 8>(a.WkTh, wave, lane, whA, wlA, 0);
+  load_wsplit<4, 8>(a.WkTh, wave, lane, whB, wlB, 4);
+  if (tid < D) sGamma[tid] = a.gamma[tid];
+
+  unsigned off[2], noff[2];
+  float4 x[2][4], dy[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int rc = row0 + min(lrow + 32 * rt, nrows - 1);
+    off[rt] = ((unsigned)rc * D + cbase) * 4;
+    noff[rt] = ((unsigned)a.nb[rc] * D + cbase) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dy[rt][j] = lrow + 32 * rt < nrows ? ld4(a.dK, off[rt] + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[rt][j] = ld4(a.T, off[rt] + 32 * j);
+    }
+  }
+  put_rowmax(sMax[0], dy, lrow, lh, wave);
+  put_stats(sStat, x, lrow, lh, wave);
+  __syncthreads();
+  float post[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    float scale;
+    row_scale(get_rowmax(sMax[0], lrow + 32 * rt), scale, post[rt]);
+    put_planes(sH, sL, dy[rt], scale, lrow + 32 * rt, cbase);
+  }
+  // the gate's centre rows c[j] arrive under the GEMM
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dy[rt][j] = ld4(a.c, noff[rt] + 32 * j);
+  __syncthreads();
+  f32x16 acc[2];
+  gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.W2Th, wave, lane, acc);  // dang = dK . Wk^T
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const bool live = lrow + 32 * rt < nrows;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 da = make_float4(acc[rt][4 * j] * post[rt], acc[rt][4 * j + 1] * post[rt], acc[rt][4 * j + 2] * post[rt],
+                                    acc[rt][4 * j + 3] * post[rt]);
+      if (live) st4(a.dang, off[rt] + 32 * j, da);
+      const float4 cn = dy[rt][j];
+      float4 g = make_float4(da.x * cn.x, da.y * cn.y, da.z * cn.z, da.w * cn.w);  // d loss / d G' through the gate
+      if (a.dG_in) {
+        const float4 o = ld4(a.dG_in, off[rt] + 32 * j);
+        g = make_float4(g.x + o.x, g.y + o.y, g.z + o.z, g.w + o.w);
+      }
+      dy[rt][j] = live ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();  // every wave is done reading the dK planes: the staging buffer may be written
+  float rstd[2];
+  ln_bwd_head(x, dy, sStat, sGamma, sSum, stage, rstd, lrow, lh, wave, cbase);
+  __syncthreads();
+  ln_bwd_tail(x, dy, sSum, stage, rstd, a.dgamma, a.dbeta, lrow, tid);  // x = dT
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = ld4(a.V, off[rt] + 32 * j), t = x[rt][j];
+      dy[rt][j] = make_float4(t.x * dsw_(v.x), t.y * dsw_(v.y), t.z * dsw_(v.z), t.w * dsw_(v.w));  // dV
+    }
+  put_rowmax(sMax[1], dy, lrow, lh, wave);
+  __syncthreads();  // row maxima visible; every thread is done with the staging buffer
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = lrow + 32 * rt;
+    float scale;
+    row_scale(get_rowmax(sMax[1], row), scale, post[rt]);
+    if (row < nrows)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st4(a.dV, off[rt] + 32 * j, dy[rt][j]);
+    put_planes(sH, sL, dy[rt], scale, row, cbase);
+  }
+  __syncthreads();
+  gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);  // dV . W2^T
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+    if (lrow + 32 * rt < nrows)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        st4(a.dG, off[rt] + 32 * j,
+            make_float4(fmaf(acc[rt][4 * j], post[rt], x[rt][j].x), fmaf(acc[rt][4 * j + 1], post[rt], x[rt][j].y),
+                        fmaf(acc[rt][4 * j + 2], post[rt], x[rt][j].z), fmaf(acc[rt][4 * j + 3], post[rt], x[rt][j].w)));
+}
+
+// ---- the three atom-indexed sums of a layer in one launch ----------------------------------------------------------------
+// dC[a] = sum over the edges e that point AT atom a of dang[e] * G'[e] (gate ang = c[j] * G'), dP3[a] = the same sum of dV[e],
+// dP1[a] = sum of dV over atom a's own CSR row.  Fixed order, no atomics; loads of four edges in flight per step.
+__global__ __launch_bounds__(256) void atom_gather3_kernel(const float4* __restrict__ dang, const float4* __restrict__ G, const float4* __restrict__ dV,
+                                                           const int* __restrict__ edge_offset, const int* __restrict__ in_off,
+                                                           const int* __restrict__ in_edge, float4* __restrict__ dC, float4* __restrict__ dP1,
+                                                           float4* __restrict__ dP3, int n_atom) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_atom * 32) return;
+  const int at = (int)(i >> 5), c4 = (int)(i & 31);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = s, u = s;
+  const int e0 = edge_offset[at], e1 = edge_offset[at + 1], k0 = in_off[at], k1 = in_off[at + 1];
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    size_t o[4];
+    float4 p[4], q[4], r[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) o[m] = (size_t)in_edge[k + m] * 32 + c4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      p[m] = dang[o[m]];
+      q[m] = G[o[m]];
+      r[m] = dV[o[m]];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      s.x += p[m].x * q[m].x; s.y += p[m].y * q[m].y; s.z += p[m].z * q[m].z; s.w += p[m].w * q[m].w;
+      t.x += r[m].x; t.y += r[m].y; t.z += r[m].z; t.w += r[m].w;
+    }
+  }
+  for (; k < k1; ++k) {
+    const size_t o = (size_t)in_edge[k] * 32 + c4;
+    const float4 p = dang[o], q = G[o], r = dV[o];
+    s.x += p.x * q.x; s.y += p.y * q.y; s.z += p.z * q.z; s.w += p.w * q.w;
+    t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+  }
+  int e = e0;
+  for (; e + 4 <= e1; e += 4) {
+    float4 r[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) r[m] = dV[(size_t)(e + m) * 32 + c4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { u.x += r[m].x; u.y += r[m].y; u.z += r[m].z; u.w += r[m].w; }
+  }
+  for (; e < e1; ++e) {
+    const float4 r = dV[(size_t)e * 32 + c4];
+    u.x += r.x; u.y += r.y; u.z += r.z; u.w += r.w;
+  }
+  dC[i] = s;
+  dP3[i] = t;
+  dP1[i] = u;
+}
+
+int tile_slots(int rows) { return (rows + 63) / 64; }
+
+void launch_rn_bwd(WgradCtx& ctx, RnBwdArgs a, float* dgamma, float* dbeta, hipStream_t s) {
+  if (a.n_atom <= 0) return;
+  const int n = tile_slots(a.n_atom);
+  a.dgamma = reserve_vec(ctx, dgamma, n);
+  a.dbeta = reserve_vec(ctx, dbeta, n);
+  hipLaunchKernelGGL(rn_bwd_kernel, dim3(n), dim3(256), 0, s, a);
+}
+void launch_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, float* dgamma, float* dbeta, hipStream_t s) {
+  if (a.n_edge <= 0) return;
+  const int n = tile_slots(a.n_edge);
+  a.dgamma = reserve_vec(ctx, dgamma, n);
+  a.dbeta = reserve_vec(ctx, dbeta, n);
+  hipLaunchKernelGGL(edge_bwd_kernel, dim3(n), dim3(256), 0, s, a);
+}
+void launch_atom_gather3(const float* dang, const float* G, const float* dV, const int* edge_offset, const int* in_off, const int* in_edge,
+                         float* dC, float* dP1, float* dP3, int n_atom, hipStream_t s) {
+  if (n_atom > 0)
+    hipLaunchKernelGGL(atom_gather3_kernel, dim3((unsigned)(((size_t)n_atom * 32 + 255) / 256)), dim3(256), 0, s, (const float4*)dang,
+                       (const float4*)G, (const float4*)dV, edge_offset, in_off, in_edge, (float4*)dC, (float4*)dP1, (float4*)dP3, n_atom);
+}
+
+}  // namespace scann
