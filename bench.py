@@ -197,12 +197,15 @@ def train_bench(args, eng, rdzv):
 
     def step(i):
         rb, t = pool[i % 8], targets[i % 8]
-        sse = eng.train_forward(rb, t, dropout=0.1, seed=i)
-        sse_g, cnt_g = comm.sum_pair(sse, args.batch)
-        eng.zero_grads()
-        eng.train_backward(rb, sse_g, cnt_g)
-        eng.allreduce_grads()
-        eng.adam_step(5e-4 / (1.0 + 1e-5 * i))
+        if args.split_step:  # the step as six calls with host round trips between them (the round-1 / early round-2 sequence)
+            sse = eng.train_forward(rb, t, dropout=0.1, seed=i)
+            sse_g, cnt_g = comm.sum_pair(sse, args.batch)
+            eng.zero_grads()
+            eng.train_backward(rb, sse_g, cnt_g)
+            eng.allreduce_grads()
+            eng.adam_step(5e-4 / (1.0 + 1e-5 * i))
+        else:
+            eng.train_step(rb, t, 5e-4 / (1.0 + 1e-5 * i), dropout=0.1, seed=i)
 
     steps, warm = min(args.steps, 400), max(min(args.warmup, 20), 5)
     for i in range(warm):
@@ -287,6 +290,7 @@ def main():
                     help="extra (BASELINE configs[2]): time data-parallel TRAINING steps instead of the forward metric -- "
                          "forward(train, dropout 0.1) + SSE all-reduce + backward + flat RCCL gradient all-reduce + Adam; "
                          "--batch molecules per GPU per step")
+    ap.add_argument("--split-step", action="store_true", help="--train: forward / backward / Adam as separate calls instead of scann_train_step")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal only: allow more ranks than visible devices (rank r runs on device r %% n_devices); the line "
                          "is then marked \"oversubscribed\" and is not a scaling measurement")

@@ -176,6 +176,12 @@ int scann_allreduce_sse(scann_handle_t* h, double* sse, int64_t* count); /* in-p
 /* g += 2*l2*w on the regularised kernels, then Adam (epsilon outside the sqrt, as tf.keras); lr_t already includes the
  * schedule and the legacy decay 1/(1 + 1e-5*iterations); refreshes the packed device weights */
 int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2);
+/* One whole optimisation step, asynchronous until its end: scann_train_forward, [sum of {sse, count} over the communicator],
+ * scann_zero_grads, scann_train_backward with the loss scale formed on the device, scann_allreduce_grads, scann_adam_step -- the
+ * same kernels and results, without the host round trips between them (one fit step of model.fit, scann_model.py:225-241).
+ * *sse_out / *count_out = the GLOBAL batch's sum of squared errors and size. */
+int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
+                     float beta2, float eps, float l2, double* sse_out, int64_t* count_out);
 int scann_get_grads(scann_handle_t* h, float* out);           /* [scann_param_count] */
 int scann_get_weights(scann_handle_t* h, float* out);         /* current master parameters, same order */
 int scann_comm_unique_id(char* out128);                       /* ncclGetUniqueId on rank 0; broadcast by the caller */

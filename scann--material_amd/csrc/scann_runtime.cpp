@@ -143,6 +143,7 @@ struct scann_handle {
   bool in_train_forward = false;
   unsigned long long train_seed = 0;
   ncclComm_t comm = nullptr;
+  double* h_stat = nullptr;              // pinned {sse, count} of the last scann_train_step
   bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
   hipStream_t train_aux = nullptr;       // side stream of the backward pass: weight-gradient GEMMs run beside the data-gradient chain
   std::vector<hipEvent_t> train_ev;      // ring of fork / join events between the two streams
@@ -404,6 +405,7 @@ void scann_destroy(scann_handle_t* h) {
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->train_aux) (void)hipStreamDestroy(h->train_aux);
+  if (h->h_stat) (void)hipHostFree(h->h_stat);
   for (hipEvent_t e : h->train_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->time_ev) (void)hipEventDestroy(e);
   if (h->sc_db) {
@@ -1188,10 +1190,10 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
 
 struct scann_train_ws {  // per resident batch, allocated on first use
   char* arena = nullptr;
-  float *tA[15] = {};   // [n_atom,128] temporaries (5 of them the second set of the per-layer gradients, see scann_train_backward)
+  std::vector<float*> tA;  // [n_atom,128] temporaries: 5 shared + 5 per layer and readout (operands of that layer's weight gradients)
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128] or null
   float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;
-  float *tE[12] = {};   // [n_edge,128] temporaries
+  std::vector<float*> tE;  // [n_edge,128] temporaries: 8 shared + 2 per layer and readout
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   float* wpart = nullptr;  // per-slab partial sums of every weight gradient of a step (WgradCtx::arena)
   size_t wpart_floats = 0;
@@ -1229,12 +1231,17 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
                    (size_t)2 * D * Lc * ((size_t)std::max(ln_bwd_slots(std::max(db->n_edge, 1)), tile_slots(std::max(db->n_edge, 1))) +
                                          (size_t)std::max(ln_bwd_slots(db->n_atom), tile_slots(db->n_atom)) +
                                          (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
-  const size_t total = 15 * rowA + 12 * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
+  // the operands of a layer's weight gradients live until the end of the step (sets of their own per layer): the gradient launches on
+  // the side stream never have to be waited for before a buffer is reused
+  const size_t nTA = 5 + 5 * (Lc + 1), nTE = 8 + 2 * (Lc + 1);
+  const size_t total = nTA * rowA + nTE * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
                        align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4);
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
-  for (int i = 0; i < 15; ++i) { w.tA[i] = (float*)p; p += rowA; }
-  for (int i = 0; i < 12; ++i) { w.tE[i] = (float*)p; p += rowE; }
+  w.tA.assign(nTA, nullptr);
+  w.tE.assign(nTE, nullptr);
+  for (size_t i = 0; i < nTA; ++i) { w.tA[i] = (float*)p; p += rowA; }
+  for (size_t i = 0; i < nTE; ++i) { w.tE[i] = (float*)p; p += rowE; }
   w.rep = (float*)p; p += rowB;
   w.dpre = (float*)p; p += rowB;
   w.dy = (float*)p; p += align_up((size_t)db->n_struct * 4);
@@ -1360,10 +1367,8 @@ int scann_get_weights(scann_handle_t* h, float* out) {
   return SCANN_OK;
 }
 
-int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, double* sse_out) {
-  if (!h || !db || !targets || !sse_out) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: null argument");
-  if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: call scann_train_begin first");
-  HIPCHK(h, hipSetDevice(h->device));
+// the training forward (activations kept for the backward) and the batch's sum of squared errors + count -> w->sse[0..1]; no sync
+static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, scann_train_ws** wout) {
   scann_train_ws* w = nullptr;
   int r = ensure_train_ws(h, db, &w);
   if (r) return r;
@@ -1387,10 +1392,24 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   if (r) return r;
   HIPCHK(h, hipMemcpyAsync(w->targets, targets, (size_t)db->n_struct * 4, hipMemcpyHostToDevice, s));
   launch_sse(db->y, w->targets, db->n_struct, w->sse, s);
+  *wout = w;
+  return SCANN_OK;
+}
+
+int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, double* sse_out) {
+  if (!h || !db || !targets || !sse_out) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: null argument");
+  if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: call scann_train_begin first");
+  HIPCHK(h, hipSetDevice(h->device));
+  scann_train_ws* w = nullptr;
+  const int r = train_forward_impl(h, db, targets, dropout, seed, &w);
+  if (r) return r;
+  hipStream_t s = h->streams[0];
   HIPCHK(h, hipMemcpyAsync(sse_out, w->sse, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   return SCANN_OK;
 }
+
+static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat);
 
 int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_global, int64_t count_global) {
   if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_train_backward: null argument");
@@ -1403,16 +1422,20 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   if (!h->t_grad || !wp || db->dbg_layers != h->cfg.n_attention)
     return fail(h, SCANN_ERR_INVALID, "scann_train_backward: run scann_train_forward on this batch first");
   HIPCHK(h, hipSetDevice(h->device));
-  scann_train_ws& w = *wp;
+  const double rmse = std::sqrt(sse_global / (double)count_global);
+  const float scale = rmse > 0 ? (float)(1.0 / ((double)count_global * rmse)) : 0.f;
+  return backward_impl(h, db, *wp, scale, nullptr);
+}
+
+// d_stat (device, {global sse, global count}) non-null: the loss scale is formed on the device (scann_train_step: no host round trip)
+static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat) {
   hipStream_t s = h->streams[0];
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
   const size_t nA = (size_t)A * D, nE = (size_t)E * D;
   float* const G = h->t_grad;
   auto g = [&](const std::string& name) { return G + spec_offset(h, name); };
-  const double rmse = std::sqrt(sse_global / (double)count_global);
-  const float scale = rmse > 0 ? (float)(1.0 / ((double)count_global * rmse)) : 0.f;
-  launch_dy(db->y, w.targets, B, scale, w.dy, s);
+  launch_dy(db->y, w.targets, B, scale, d_stat, w.dy, s);
   // Weight-gradient GEMMs are off the critical path (only the final reduce needs them): with the kept-activation forward
   // their operands are never overwritten inside a layer, so they run on a side stream beside the data-gradient chain, which
   // alone does not fill the chip at batch 128.  fork(): side stream waits for everything enqueued so far; join(): main waits
@@ -1433,32 +1456,22 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     (void)hipEventRecord(e, aux);
     (void)hipStreamWaitEvent(s, e, 0);
   };
-  std::vector<hipEvent_t> ev_layer((size_t)L + 1, nullptr);  // recorded on the side stream after layer l's gradient launch (L = readout)
-  auto mark_layer = [&](int l) {
-    if (!side) return;
-    ev_layer[l] = h->train_ev[ev_i++ % h->train_ev.size()];
-    (void)hipEventRecord(ev_layer[l], aux);
-  };
-  auto wait_layer = [&](int l) {  // the main stream may not overwrite operand set l & 1 before layer l's gradients have read it
-    if (side && l <= L && ev_layer[l]) (void)hipStreamWaitEvent(s, ev_layer[l], 0);
-  };
   WgradCtx wg;
   wg.arena = w.wpart;
 
   // named temporaries
-  float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4], *t3 = w.tA[5], *dQ = w.tA[6],
-        *dP1 = w.tA[7], *dP3 = w.tA[8], *t4 = w.tA[9];
-  float *eAng = w.tE[0], *eK = w.tE[1], *edK = w.tE[2], *edAng = w.tE[3], *eU = w.tE[4], *eV = w.tE[5], *eT = w.tE[6],
-        *edGt = w.tE[7], *edGa = w.tE[8], *edGb = w.tE[9];
-  // The operands of a layer's weight gradients (t3, t4, dQ, dP1, dP3, edK, eU) exist twice: layer l uses set l & 1, so its
-  // gradient launch may run beside the whole data-gradient chain of layer l - 1 and is only waited for when layer l - 2 is
-  // about to overwrite the set.
-  float* const setA[2][5] = {{t3, t4, dQ, dP1, dP3}, {w.tA[10], w.tA[11], w.tA[12], w.tA[13], w.tA[14]}};
-  float* const setE[2][2] = {{edK, eU}, {w.tE[10], w.tE[11]}};
+  float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4];
+  float *eAng = w.tE[0], *eK = w.tE[1], *edAng = w.tE[2], *eV = w.tE[3], *eT = w.tE[4], *edGt = w.tE[5], *edGa = w.tE[6], *edGb = w.tE[7];
+  // The operands of a layer's weight gradients (t3, t4, dQ, dP1, dP3, edK, eU) exist once per layer (set L = the readout): the
+  // gradient launch of layer l runs on the side stream beside the data-gradient chains of the layers below and nothing it reads
+  // is overwritten before the end of the step.
+  auto setA = [&](int l, int k) { return w.tA[5 + 5 * (size_t)l + k]; };
+  auto setE = [&](int l, int k) { return w.tE[8 + 2 * (size_t)l + k]; };
+  float *t3 = setA(L, 0), *t4 = setA(L, 1), *dQ = setA(L, 2), *dP1 = setA(L, 3), *dP3 = setA(L, 4), *edK = setE(L, 0), *eU = setE(L, 1);
   const float* cL = db->dbg_c + (size_t)L * nA;  // centres entering after_Lc
 
   // ---- readout (scann_model.py:424-447, attention.py:267-318) ----
-  float* const rdgk = setA[L & 1][0];  // the readout counts as "layer L" of the operand-set scheme: its gradients read set L & 1
+  float* const rdgk = t3;  // the readout is "layer L" of the operand-set scheme
   // forward recompute: preA = cL.Wa + ba (t0), z = swish(preA) (t1); gq, gk, ga, y are still in the batch workspace
   launch_linear(cL, h->head.Wap, h->head.ba, t1, t0, A, 2, s);
   ReadoutBwdArgs ra{};
@@ -1475,14 +1488,13 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
                   g("global_attention/key/bias"), nullptr, nullptr, nullptr, A, ws);
   }
   launch_linear_sum(t2, h->WgqT, rdgk, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
-  float* const dpreA = setA[L & 1][2];                        // the readout counts as "layer L" of the operand-set scheme
+  float* const dpreA = dQ;
   launch_swish_bwd(t0, t4, dpreA, nA, s);                     // dpreA (t2 is still being read beside us)
   {
     hipStream_t ws = fork();
     launch_wgrad(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A, ws);
     if (side) wgrad_flush(wg, ws);
   }
-  mark_layer(L);
   launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
@@ -1499,12 +1511,8 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     pend.n = 0;
   };
   for (int l = L - 1; l >= 0; --l) {
-    wait_layer(l + 2);  // operand set l & 1 was last used by layer l + 2: its weight-gradient launch must have read it
-    if (side) {
-      float* const* a5 = setA[l & 1];
-      t3 = a5[0]; t4 = a5[1]; dQ = a5[2]; dP1 = a5[3]; dP3 = a5[4];
-      edK = setE[l & 1][0]; eU = setE[l & 1][1];
-    }
+    t3 = setA(l, 0); t4 = setA(l, 1); dQ = setA(l, 2); dP1 = setA(l, 3); dP3 = setA(l, 4);
+    edK = setE(l, 0); eU = setE(l, 1);
     const LayerParams& p = h->layers[l];
     const scann_handle::LayerT& pt = h->layersT[l];
     const std::string la = "local_attention_" + std::to_string(l) + "/", rn = "residual_norm_" + std::to_string(l) + "/";
@@ -1614,7 +1622,6 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
         wgrad_launch(wg, ws);
         if (side) wgrad_flush(wg, ws);
       }
-      mark_layer(l);
       // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T is folded into the next layer's rn_bwd_kernel (or launched after the loop)
       pend.n = 3;
       pend.X[0] = dP1; pend.X[1] = dP3; pend.X[2] = dQ;
@@ -1650,7 +1657,6 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
       wgrad_launch(wg, ws);
       if (side) wgrad_flush(wg, ws);
     }
-    mark_layer(l);
     launch_linear_sum(dP1, pt.W1T, dP3, pt.W3T, dQ, pt.WqT, dC, A, 1, s);  // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T
     dG_in = dGnext;
   }
@@ -1682,9 +1688,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   return SCANN_OK;
 }
 
-int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2) {
-  if (!h || !h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_adam_step: call scann_train_begin first");
-  HIPCHK(h, hipSetDevice(h->device));
+static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2) {
   hipStream_t s = h->streams[0];
   h->t_step += 1;
   const double t = (double)h->t_step;
@@ -1697,7 +1701,46 @@ int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, flo
     launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
                      h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
   HIPCHK(h, hipGetLastError());
+  return SCANN_OK;
+}
+
+int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2) {
+  if (!h || !h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_adam_step: call scann_train_begin first");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int r = adam_impl(h, lr_t, beta1, beta2, eps, l2);
+  if (r) return r;
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  return SCANN_OK;
+}
+
+// One optimisation step without a host round trip in the middle: forward, [all-reduce of {sse, count}], backward with the loss scale
+// formed on the device, [all-reduce of the gradients], Adam + weight-image refresh; ONE synchronisation at the end.  Same results as
+// scann_train_forward / scann_allreduce_sse / scann_zero_grads / scann_train_backward / scann_allreduce_grads / scann_adam_step.
+int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
+                     float beta2, float eps, float l2, double* sse_out, int64_t* count_out) {
+  if (!h || !db || !targets || !sse_out || !count_out) return fail(h, SCANN_ERR_INVALID, "scann_train_step: null argument");
+  if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_step: call scann_train_begin first");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->streams[0];
+  scann_train_ws* w = nullptr;
+  int r = train_forward_impl(h, db, targets, dropout, seed, &w);
+  if (r) return r;
+  if (h->comm && h->comm_world > 1) {  // losses.py:5-6 is the RMSE of the GLOBAL batch
+    const ncclResult_t nr = ncclAllReduce(w->sse, w->sse, 2, ncclDouble, ncclSum, h->comm, s);
+    if (nr != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(nr));
+  }
+  if (!h->h_stat) HIPCHK(h, hipHostMalloc((void**)&h->h_stat, 2 * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(h->h_stat, w->sse, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, s));
+  r = backward_impl(h, db, *w, 0.f, w->sse);
+  if (r) return r;
+  r = scann_allreduce_grads(h);
+  if (r) return r;
+  r = adam_impl(h, lr_t, beta1, beta2, eps, l2);
+  if (r) return r;
   HIPCHK(h, hipStreamSynchronize(s));
+  *sse_out = h->h_stat[0];
+  *count_out = (int64_t)(h->h_stat[1] + 0.5);
   return SCANN_OK;
 }
 

@@ -1275,18 +1275,26 @@ __global__ void sse_kernel(const float* __restrict__ y, const float* __restrict_
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = sh[0];
+  if (threadIdx.x == 0) {
+    out[0] = sh[0];
+    out[1] = (double)n;  // the count travels with the sum (scann_train_step all-reduces both)
+  }
 }
 void launch_sse(const float* y, const float* t, int n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(sse_kernel, dim3(1), dim3(256), 0, s, y, t, n, out);
 }
 // d rmse / d y_i = (y_i - t_i) / (count * rmse)   (losses.py:5-6 over the GLOBAL batch)
-__global__ void dy_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, float scale, float* __restrict__ dy) {
+__global__ void dy_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, float scale, const double* __restrict__ stat,
+                          float* __restrict__ dy) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (stat) {  // {global sse, global count} on the device: the same double arithmetic as the host path
+    const double rmse = sqrt(stat[0] / stat[1]);
+    scale = rmse > 0 ? (float)(1.0 / (stat[1] * rmse)) : 0.f;
+  }
   if (i < n) dy[i] = (y[i] - t[i]) * scale;
 }
-void launch_dy(const float* y, const float* t, int n, float scale, float* dy, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(dy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, t, n, scale, dy);
+void launch_dy(const float* y, const float* t, int n, float scale, const double* stat, float* dy, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(dy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, t, n, scale, stat, dy);
 }
 
 // ---- Adam (tf.keras.optimizers.Adam, epsilon 1e-7) + l2 regulariser gradient ------------------------------------------------

@@ -167,16 +167,16 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
         eng.set_attention_dropout(attn_drop if training else 0.0)
         for shard, tgt in _Prefetch(iterator, comm):
             rb = eng.upload(shard)
-            sse = eng.train_forward(rb, tgt, dropout=dropout if training else 0.0, seed=(it * 7919 + 17) & 0xFFFFFFFF)
-            y, _ = eng.download(rb, want_ga=False)
-            sse_g, cnt_g = comm.sum_pair(sse, shard.n_struct)
+            seed = (it * 7919 + 17) & 0xFFFFFFFF
             if training:
+                # one asynchronous sequence on the device: forward, global {sse, count}, backward, gradient all-reduce, Adam
                 lr_t = (epoch_lr if sgdr is not None else cosine_decay(it, hy["lr"], decay_steps, alpha)) / (1.0 + 1e-5 * it)
-                eng.zero_grads()
-                eng.train_backward(rb, sse_g, cnt_g)
-                eng.allreduce_grads()
-                eng.adam_step(lr_t, l2=l2)
+                sse_g, cnt_g = eng.train_step(rb, tgt, lr_t, dropout=dropout, seed=seed, l2=l2)
                 it += 1
+            else:
+                sse = eng.train_forward(rb, tgt, dropout=0.0, seed=seed)
+                sse_g, cnt_g = comm.sum_pair(sse, shard.n_struct)
+            y, _ = eng.download(rb, want_ga=False)
             rb.free()
             loss_sum += math.sqrt(sse_g / cnt_g) * cnt_g
             sabs, _ = comm.sum_pair(float(np.abs(y - tgt).sum()), 0)

@@ -491,3 +491,66 @@ def test_weight_gradients_are_bit_reproducible(hip_lib):
         else:
             assert np.array_equal(grads[0][k], grads[1][k]), k
     rb.free()
+
+
+def test_train_step_equals_the_split_sequence(hip_lib):
+    """scann_train_step (one asynchronous sequence, loss scale formed on the device) ends in the same weights as
+    train_forward / zero_grads / train_backward / adam_step called one by one, and reports the same SSE."""
+    from scann.models.scann_model import HipModel
+
+    cfg, w, pk, targets, _ = setup(n=24, L=3, seed=12)
+    models = [HipModel(cfg, w, device=0) for _ in range(2)]
+    rbs = []
+    for m in models:
+        m.engine.train_begin()
+        rbs.append(m.engine.upload(pk))
+    a, b = models[0].engine, models[1].engine
+    for step in range(3):
+        lr_t = 1e-3 / (1 + 1e-5 * step)
+        sse = a.train_forward(rbs[0], targets, dropout=0.1, seed=step)
+        a.zero_grads()
+        a.train_backward(rbs[0], sse, pk.n_struct)
+        a.adam_step(lr_t)
+        sse_b, cnt_b = b.train_step(rbs[1], targets, lr_t, dropout=0.1, seed=step)
+        # step 0 starts from identical weights; later steps differ by the rounding of the few float-atomic gradient tensors
+        assert cnt_b == pk.n_struct and (sse_b == sse if step == 0 else abs(sse_b - sse) <= 1e-6 * sse), (step, sse, sse_b)
+    wa, wb = a.get_weights(), b.get_weights()
+    atomic = ("embed_atom/", "dense_embed/", "neighbor_d/", "neighbor_w/", "predict_property/")  # float atomics: equal to rounding
+    for k in wa:
+        if k.startswith(atomic):
+            assert np.allclose(wa[k], wb[k], rtol=1e-4, atol=1e-6), k
+        else:
+            assert np.allclose(wa[k], wb[k], rtol=1e-5, atol=1e-7), k
+    for rb in rbs:
+        rb.free()
+
+
+def test_fused_backward_kernels_match_the_modular_ones(hip_lib, monkeypatch):
+    """SCANN_TRAIN_FUSED=0 selects the one-kernel-per-operation backward (exact fp32 MFMA); the fused chains (split-fp16 with
+    per-row scaling) must give the same gradients to rounding -- also with a loss scale 2^-20 (tiny gradients), where an
+    unscaled fp16 split would lose everything."""
+    from scann.models.scann_model import HipModel
+
+    cfg, w, pk, targets, _ = setup(n=32, L=3, seed=21)
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCANN_TRAIN_FUSED", mode)
+        m = HipModel(cfg, w, device=0)
+        eng = m.engine
+        eng.train_begin()
+        rb = eng.upload(pk)
+        for tag, count in (("unit", pk.n_struct), ("tiny", pk.n_struct << 20)):
+            sse = eng.train_forward(rb, targets, dropout=0.1, seed=3)
+            eng.zero_grads()
+            eng.train_backward(rb, sse * (count / pk.n_struct), count)  # same rmse, gradients scaled by n_struct / count
+            grads[mode, tag] = eng.get_grads()
+        rb.free()
+    for tag in ("unit", "tiny"):
+        for k, ref in grads["0", tag].items():
+            scale = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-30
+            err = float(np.max(np.abs(grads["1", tag][k].astype(np.float64) - ref))) / scale
+            assert err < 2e-5, (tag, k, err)
+    # and the tiny-scale gradients are the unit ones times 2^-20 (power of two: exact up to the float atomics' order)
+    for k, ref in grads["1", "unit"].items():
+        scale = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-30
+        assert float(np.max(np.abs(grads["1", "tiny"][k].astype(np.float64) * 2.0 ** 20 - ref))) / scale < 2e-5, k
