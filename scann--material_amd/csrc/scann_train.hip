@@ -10,10 +10,9 @@
 #include <algorithm>
 
 #include "scann_train.h"
+#include "scann_mma.h"
 
 namespace scann {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float swish_(float x) { return x * sigmoidf_(x); }
@@ -207,68 +206,113 @@ struct WgradSet {  // up to WGRAD_MAX_JOBS independent gradients in one launch (
   float* bpart[WGRAD_MAX_JOBS];  // [n_slab][128] bias partials or null
   int32_t rows[WGRAD_MAX_JOBS], chunks[WGRAD_MAX_JOBS];
 };
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradSet set) {
-  // blockIdx.y selects the job: all weight gradients of one LocalAttention / ResidualNorm layer go out in ONE launch
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
+  // blockIdx.y selects the job: all weight gradients of one LocalAttention / ResidualNorm layer go out in ONE launch.
+  // Split-fp16 MFMA with K = rows (v_mfma_f32_32x32x16_f16, three products per operand pair, scann_kernels.hip): a lane's operand is
+  // 8 consecutive ROWS of one column, so every lane fetches its operands straight from global memory in that shape -- wave w the
+  // X^T fragments of features 32 w .. 32 w + 31 (shared with the other waves through LDS, fragment order, conflict-free b128) and
+  // the dY fragments of its own 32 output columns (registers only).  dY is a gradient: each wave scales its dY block by a power
+  // of two that brings the largest magnitude seen so far to 2^12 and rescales its accumulators (exactly) when a later chunk is
+  // larger -- block floating point with a monotone exponent, so the split keeps 22 bits relative to the largest rows, which
+  // dominate the sum.
   const int rows = set.rows[blockIdx.y], chunks = set.chunks[blockIdx.y];
   if (blockIdx.x * 64 * chunks >= rows) return;  // jobs over fewer rows than the largest one
   const float* __restrict__ X = set.X[blockIdx.y];
   const float* __restrict__ dY = set.dY[blockIdx.y];
   float* __restrict__ part = set.part[blockIdx.y] + (size_t)blockIdx.x * D * D;
   float* __restrict__ bpart = set.bpart[blockIdx.y];
-  __shared__ __attribute__((aligned(16))) float sX[64 * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float sD[64 * LDS_STRIDE];
+  __shared__ f16x8 sA[4][4][2][64];  // [k-step][feature tile][hi | lo][lane]: the chunk's X^T fragments (32 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = 32 * wave + (lane & 31), kh = lane >> 5;
   const int slab0 = blockIdx.x * 64 * chunks;
   f32x16 acc[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-  float bsum = 0.f;  // thread tid < 128 owns column tid of db
+  float bsum = 0.f;  // column `col` of db over this lane's rows
+  float C = 0.f;     // the wave's dY scale (a power of two; 0 = nothing but zeros so far)
   for (int chunk = 0; chunk < chunks; ++chunk) {
     const int row0 = slab0 + chunk * 64;
     if (row0 >= rows) break;
     const int nrows = min(64, rows - row0);
-    __syncthreads();
-    {  // sixteen row pieces requested together from clamped rows, masked afterwards (see linear_kernel)
-      const int c4 = tid & 31, rb = tid >> 5;
-      float4 vx[8], vd[8];
+    float xa[4][8], db[4][8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const size_t o = (size_t)(row0 + min(rb + 8 * k, nrows - 1)) * 32 + c4;
-        vx[k] = reinterpret_cast<const float4*>(X)[o];
-        vd[k] = reinterpret_cast<const float4*>(dY)[o];
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // clamped rows, masked afterwards: all 64 loads in flight together
+        const size_t o = (size_t)(row0 + min(16 * s2 + 8 * kh + j, nrows - 1)) * D + col;
+        xa[s2][j] = X[o];
+        db[s2][j] = dY[o];
+      }
+    float mx = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool live = 16 * s2 + 8 * kh + j < nrows;
+        xa[s2][j] = live ? xa[s2][j] : 0.f;
+        db[s2][j] = live ? db[s2][j] : 0.f;
+        bsum += db[s2][j];
+        mx = fmaxf(mx, fabsf(db[s2][j]));
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int r = rb + 8 * k;
-        const float keep = r < nrows ? 1.f : 0.f;  // rows past the end contribute exact zeros
-        *reinterpret_cast<float4*>(&sX[r * LDS_STRIDE + 4 * c4]) = make_float4(vx[k].x * keep, vx[k].y * keep, vx[k].z * keep, vx[k].w * keep);
-        *reinterpret_cast<float4*>(&sD[r * LDS_STRIDE + 4 * c4]) = make_float4(vd[k].x * keep, vd[k].y * keep, vd[k].z * keep, vd[k].w * keep);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    {
+      const int e = (__float_as_int(mx) >> 23) & 0xff;
+      if (e != 0) {
+        const float cn = __int_as_float(min(253, 266 - e) << 23);  // 2^(12 - exponent of the largest magnitude)
+        if (C == 0.f) {
+          C = cn;
+        } else if (cn < C) {  // larger values than any chunk before: bring the accumulators to the new scale (exact)
+          const float f = cn / C;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][i] *= f;
+          C = cn;
+        }
       }
     }
+    const float cs = C == 0.f ? 1.0f : C;
+    __syncthreads();  // every wave is done reading the previous chunk's fragments
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      f16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        h[j] = (_Float16)xa[s2][j];
+        l[j] = (_Float16)(xa[s2][j] - (float)h[j]);
+      }
+      sA[s2][wave][0][lane] = h;
+      sA[s2][wave][1][lane] = l;
+    }
     __syncthreads();
-    if (bpart && tid < D)
-      for (int r = 0; r < 64; ++r) bsum += sD[r * LDS_STRIDE + tid];
-    // k runs over the 64 rows of the chunk: MFMA step s uses rows 2s + (lane>>5)
-    const int h = lane >> 5, f = lane & 31;
-#pragma unroll 4
-    for (int s2 = 0; s2 < 32; ++s2) {
-      const int k = 2 * s2 + h;
-      const float bv = sD[k * LDS_STRIDE + 32 * wave + f];  // B[k][j = 32*wave + f]
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      f16x8 bh, bl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = db[s2][j] * cs;
+        bh[j] = (_Float16)v;
+        bl[j] = (_Float16)(v - (float)bh[j]);
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const float av = sX[k * LDS_STRIDE + 32 * m + f];   // A[i = 32*m + f][k]
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+        const f16x8 ah = sA[s2][m][0][lane], al = sA[s2][m][1][lane];
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
       }
     }
   }
-  const int col = 32 * wave + (lane & 31);
+  const float inv = C == 0.f ? 0.f : 1.0f / C;
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) part[(size_t)(32 * m + acc_row_(i, lane)) * D + col] = acc[m][i];
-  if (bpart && tid < D) bpart[(size_t)blockIdx.x * D + tid] = bsum;
+    for (int i = 0; i < 16; ++i) part[(size_t)(32 * m + acc_row_(i, lane)) * D + col] = acc[m][i] * inv;
+  bsum += __shfl_xor(bsum, 32);
+  if (bpart && kh == 0) bpart[(size_t)blockIdx.x * D + col] = bsum;
 }
 
 // dst[i] += part[0][i] + part[1][i] + ... in slab order, for every gradient tensor of the step (blockIdx.y)
@@ -293,10 +337,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceSet set) {
 }
 
 int wgrad_chunks(int rows) {
-  // slab per workgroup: about one wave of workgroups over the chip (<= 256 slabs), so that the partial slots stay bounded
-  // (<= 256 x 64 KB per gradient) whatever the batch size
+  // slab per workgroup: <= 80 slabs per gradient (a layer's launch is ~7 gradients: a few hundred workgroups), so that the partial
+  // slots (64 KB each) the reduce re-reads stay small whatever the batch size
   const int tiles = (rows + 63) / 64;
-  return std::max(1, (tiles + 191) / 192);
+  return std::max(1, (tiles + 79) / 80);
 }
 int wgrad_slabs(int rows) {
   const int chunks = wgrad_chunks(rows);
