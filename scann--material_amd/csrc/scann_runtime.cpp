@@ -144,6 +144,10 @@ struct scann_handle {
   unsigned long long train_seed = 0;
   ncclComm_t comm = nullptr;
   double* h_stat = nullptr;              // pinned {sse, count} of the last scann_train_step
+  float* h_targets = nullptr;            // pinned staging of the step's targets (read by the loss kernel directly)
+  size_t h_targets_cap = 0;
+  bool grads_zeroed = false;             // the gradient vector is known to be all zeros (Adam of scann_train_step leaves it so)
+  hipStream_t train_aux2 = nullptr;      // second side stream: the basis-MLP gradients beside the embedding chain
   bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
   hipStream_t train_aux = nullptr;       // side stream of the backward pass: weight-gradient GEMMs run beside the data-gradient chain
   std::vector<hipEvent_t> train_ev;      // ring of fork / join events between the two streams
@@ -406,6 +410,8 @@ void scann_destroy(scann_handle_t* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->train_aux) (void)hipStreamDestroy(h->train_aux);
   if (h->h_stat) (void)hipHostFree(h->h_stat);
+  if (h->h_targets) (void)hipHostFree(h->h_targets);
+  if (h->train_aux2) (void)hipStreamDestroy(h->train_aux2);
   for (hipEvent_t e : h->train_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->time_ev) (void)hipEventDestroy(e);
   if (h->sc_db) {
@@ -1322,6 +1328,7 @@ int scann_train_begin(scann_handle_t* h) {
   HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
   if (!h->train_aux && !getenv("SCANN_TRAIN_ONE_STREAM")) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux2, hipStreamNonBlocking));
     h->train_ev.resize(128);
     for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -1343,6 +1350,7 @@ int scann_zero_grads(scann_handle_t* h) {
   if (!h || !h->t_grad) return fail(h, SCANN_ERR_INVALID, "scann_zero_grads: call scann_train_begin first");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, h->streams[0]));
+  h->grads_zeroed = true;
   return SCANN_OK;
 }
 
@@ -1368,7 +1376,8 @@ int scann_get_weights(scann_handle_t* h, float* out) {
 }
 
 // the training forward (activations kept for the backward) and the batch's sum of squared errors + count -> w->sse[0..1]; no sync
-static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, scann_train_ws** wout) {
+static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, scann_train_ws** wout,
+                              bool fused_step) {
   scann_train_ws* w = nullptr;
   int r = ensure_train_ws(h, db, &w);
   if (r) return r;
@@ -1390,8 +1399,20 @@ static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float
   h->train_drop_p = 0.f;
   h->debug = dbg;
   if (r) return r;
-  HIPCHK(h, hipMemcpyAsync(w->targets, targets, (size_t)db->n_struct * 4, hipMemcpyHostToDevice, s));
-  launch_sse(db->y, w->targets, db->n_struct, w->sse, s);
+  // targets: staged in pinned memory that the loss kernel reads directly (it leaves the device copy the backward uses): no copy operation
+  if (h->h_targets_cap < (size_t)db->n_struct) {
+    if (h->h_targets) (void)hipHostFree(h->h_targets);
+    h->h_targets = nullptr;
+    h->h_targets_cap = 0;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_targets, (size_t)db->n_struct * 4));
+    h->h_targets_cap = (size_t)db->n_struct;
+  }
+  memcpy(h->h_targets, targets, (size_t)db->n_struct * 4);
+  const bool single = !(h->comm && h->comm_world > 1);
+  if (fused_step && !h->h_stat) HIPCHK(h, hipHostMalloc((void**)&h->h_stat, 2 * sizeof(double)));
+  // single-rank fused step: the loss kernel also forms d rmse / d y and posts {sse, count} to the pinned pair
+  launch_sse(db->y, h->h_targets, db->n_struct, w->sse, w->targets, fused_step && single ? w->dy : nullptr,
+             fused_step && single ? h->h_stat : nullptr, s);
   *wout = w;
   return SCANN_OK;
 }
@@ -1401,7 +1422,7 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: call scann_train_begin first");
   HIPCHK(h, hipSetDevice(h->device));
   scann_train_ws* w = nullptr;
-  const int r = train_forward_impl(h, db, targets, dropout, seed, &w);
+  const int r = train_forward_impl(h, db, targets, dropout, seed, &w, false);
   if (r) return r;
   hipStream_t s = h->streams[0];
   HIPCHK(h, hipMemcpyAsync(sse_out, w->sse, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1409,7 +1430,7 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   return SCANN_OK;
 }
 
-static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat);
+static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat, bool dy_done);
 
 int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_global, int64_t count_global) {
   if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_train_backward: null argument");
@@ -1424,18 +1445,19 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   HIPCHK(h, hipSetDevice(h->device));
   const double rmse = std::sqrt(sse_global / (double)count_global);
   const float scale = rmse > 0 ? (float)(1.0 / ((double)count_global * rmse)) : 0.f;
-  return backward_impl(h, db, *wp, scale, nullptr);
+  h->grads_zeroed = false;
+  return backward_impl(h, db, *wp, scale, nullptr, false);
 }
 
 // d_stat (device, {global sse, global count}) non-null: the loss scale is formed on the device (scann_train_step: no host round trip)
-static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat) {
+static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat, bool dy_done) {
   hipStream_t s = h->streams[0];
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
   const size_t nA = (size_t)A * D, nE = (size_t)E * D;
   float* const G = h->t_grad;
   auto g = [&](const std::string& name) { return G + spec_offset(h, name); };
-  launch_dy(db->y, w.targets, B, scale, d_stat, w.dy, s);
+  if (!dy_done) launch_dy(db->y, w.targets, B, scale, d_stat, w.dy, s);
   // Weight-gradient GEMMs are off the critical path (only the final reduce needs them): with the kept-activation forward
   // their operands are never overwritten inside a layer, so they run on a side stream beside the data-gradient chain, which
   // alone does not fill the chip at batch 128.  fork(): side stream waits for everything enqueued so far; join(): main waits
@@ -1662,9 +1684,22 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   }
   flush_pend();
   // ---- basis MLP and embedding (scann_model.py:362-389) ----
-  if (dG_in)
+  hipEvent_t ev_basis = nullptr;
+  if (dG_in) {  // a leaf (parameter gradients only): on a stream of its own beside the embedding chain and the last weight gradients
+    hipStream_t bs = s;
+    if (side && h->train_aux2) {
+      hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
+      (void)hipEventRecord(e, s);
+      (void)hipStreamWaitEvent(h->train_aux2, e, 0);
+      bs = h->train_aux2;
+    }
     launch_basis_bwd(h->basis, db->dist, db->weight, dG_in, E, g("neighbor_d/kernel"), g("neighbor_d/bias"),
-                     g("neighbor_w/kernel"), g("neighbor_w/bias"), s);
+                     g("neighbor_w/kernel"), g("neighbor_w/bias"), bs);
+    if (bs != s) {
+      ev_basis = h->train_ev[ev_i++ % h->train_ev.size()];
+      (void)hipEventRecord(ev_basis, bs);
+    }
+  }
   launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, s);
   if (c.use_ring || c.feature_cgcnn) {
     EmbedArgs e = h->embed;
@@ -1683,19 +1718,20 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   if (wg.off > w.wpart_floats)
     return fail(h, SCANN_ERR_HIP, "scann_train_backward: weight-gradient partial arena overrun");
   join();
+  if (ev_basis) (void)hipStreamWaitEvent(s, ev_basis, 0);
   wgrad_flush(wg, s);  // ONE launch adds the per-slab partials of every weight gradient, in slab order
   HIPCHK(h, hipGetLastError());
   return SCANN_OK;
 }
 
-static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2) {
+static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2, int zero_g) {
   hipStream_t s = h->streams[0];
   h->t_step += 1;
   const double t = (double)h->t_step;
   const float lr_hat = (float)((double)lr_t * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
   const size_t n = h->host_master.size();
   // t_l2 holds a 0/1 mask; fold the coefficient in by scaling through the kernel argument
-  launch_adam(h->t_master, h->t_grad, h->t_m, h->t_v, h->t_l2, n, lr_hat, beta1, beta2, eps, l2, s);
+  launch_adam(h->t_master, h->t_grad, h->t_m, h->t_v, h->t_l2, n, lr_hat, beta1, beta2, eps, l2, zero_g, s);
   launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, s);
   if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
     launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
@@ -1707,7 +1743,7 @@ static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, fl
 int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2) {
   if (!h || !h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_adam_step: call scann_train_begin first");
   HIPCHK(h, hipSetDevice(h->device));
-  const int r = adam_impl(h, lr_t, beta1, beta2, eps, l2);
+  const int r = adam_impl(h, lr_t, beta1, beta2, eps, l2, 0);
   if (r) return r;
   HIPCHK(h, hipStreamSynchronize(h->streams[0]));
   return SCANN_OK;
@@ -1723,21 +1759,23 @@ int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = h->streams[0];
   scann_train_ws* w = nullptr;
-  int r = train_forward_impl(h, db, targets, dropout, seed, &w);
+  int r = train_forward_impl(h, db, targets, dropout, seed, &w, true);
   if (r) return r;
-  if (h->comm && h->comm_world > 1) {  // losses.py:5-6 is the RMSE of the GLOBAL batch
+  const bool single = !(h->comm && h->comm_world > 1);
+  if (!single) {  // losses.py:5-6 is the RMSE of the GLOBAL batch
     const ncclResult_t nr = ncclAllReduce(w->sse, w->sse, 2, ncclDouble, ncclSum, h->comm, s);
     if (nr != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(nr));
+    HIPCHK(h, hipMemcpyAsync(h->h_stat, w->sse, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  if (!h->h_stat) HIPCHK(h, hipHostMalloc((void**)&h->h_stat, 2 * sizeof(double)));
-  HIPCHK(h, hipMemcpyAsync(h->h_stat, w->sse, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, s));
-  r = backward_impl(h, db, *w, 0.f, w->sse);
+  if (!h->grads_zeroed) HIPCHK(h, hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, s));
+  h->grads_zeroed = false;
+  r = backward_impl(h, db, *w, 0.f, w->sse, /*dy_done=*/single);
   if (r) return r;
   r = scann_allreduce_grads(h);
   if (r) return r;
-  r = adam_impl(h, lr_t, beta1, beta2, eps, l2);
+  r = adam_impl(h, lr_t, beta1, beta2, eps, l2, /*zero_g=*/1);  // leaves the gradient vector zeroed for the next step
   if (r) return r;
+  h->grads_zeroed = true;
   HIPCHK(h, hipStreamSynchronize(s));
   *sse_out = h->h_stat[0];
   *count_out = (int64_t)(h->h_stat[1] + 0.5);

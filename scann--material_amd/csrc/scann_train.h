@@ -127,10 +127,10 @@ void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const flo
                       float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, hipStream_t s);
 void launch_embed_general_bwd(const EmbedArgs& a, const float* dc0, float* dEmb, float* dWe, float* dbe, float* dWr, float* dbr,
                               float* dWde, float* dbde, hipStream_t s);
-void launch_sse(const float* y, const float* t, int n, double* out, hipStream_t s);
+void launch_sse(const float* y, const float* t, int n, double* out, float* t_dev, float* dy, double* host_stat, hipStream_t s);
 void launch_dy(const float* y, const float* t, int n, float scale, const double* stat, float* dy, hipStream_t s);
-void launch_adam(float* w, const float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,
-                 float eps, float l2, hipStream_t s);
+void launch_adam(float* w, float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,
+                 float eps, float l2, int zero_g, hipStream_t s);
 void launch_repack(const RepackDesc* descs, int n, const float* master, float* arena, hipStream_t s);
 
 }  // namespace scann

@@ -1306,10 +1306,16 @@ void launch_embed_general_bwd(const EmbedArgs& a, const float* dc0, float* dEmb,
 }
 
 // ---- loss ------------------------------------------------------------------------------------------------------------------
-__global__ void sse_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, double* __restrict__ out) {
+// out = {sum (y - t)^2, n}.  Optional extras of scann_train_step (null otherwise): t may be pinned host memory, copied to t_dev on the
+// way; host_stat (pinned) receives the pair without a copy operation; dy = d rmse / d y for a single-rank step (the batch IS the
+// global batch, losses.py:5-6), which saves the separate dy launch.
+__global__ void sse_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, double* __restrict__ out,
+                           float* __restrict__ t_dev, float* __restrict__ dy, double* __restrict__ host_stat) {
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double d = (double)y[i] - (double)t[i];
+    const float ti = t[i];
+    if (t_dev) t_dev[i] = ti;
+    const double d = (double)y[i] - (double)ti;
     s += d * d;
   }
   __shared__ double sh[256];
@@ -1319,13 +1325,23 @@ __global__ void sse_kernel(const float* __restrict__ y, const float* __restrict_
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
+  const double sse = sh[0];
   if (threadIdx.x == 0) {
-    out[0] = sh[0];
+    out[0] = sse;
     out[1] = (double)n;  // the count travels with the sum (scann_train_step all-reduces both)
+    if (host_stat) {
+      host_stat[0] = sse;
+      host_stat[1] = (double)n;
+    }
+  }
+  if (dy) {
+    const double rmse = sqrt(sse / (double)n);
+    const float scale = rmse > 0 ? (float)(1.0 / ((double)n * rmse)) : 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dy[i] = (y[i] - t[i]) * scale;
   }
 }
-void launch_sse(const float* y, const float* t, int n, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(sse_kernel, dim3(1), dim3(256), 0, s, y, t, n, out);
+void launch_sse(const float* y, const float* t, int n, double* out, float* t_dev, float* dy, double* host_stat, hipStream_t s) {
+  hipLaunchKernelGGL(sse_kernel, dim3(1), dim3(256), 0, s, y, t, n, out, t_dev, dy, host_stat);
 }
 // d rmse / d y_i = (y_i - t_i) / (count * rmse)   (losses.py:5-6 over the GLOBAL batch)
 __global__ void dy_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, float scale, const double* __restrict__ stat,
@@ -1344,21 +1360,22 @@ void launch_dy(const float* y, const float* t, int n, float scale, const double*
 // ---- Adam (tf.keras.optimizers.Adam, epsilon 1e-7) + l2 regulariser gradient ------------------------------------------------
 // g += 2*l2*w on regularised kernels; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_hat * m / (sqrt(v) + eps)
 // with lr_hat = lr_t * sqrt(1 - b2^t) / (1 - b1^t) computed by the caller.
-__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ l2mask, size_t n, float lr_hat, float b1, float b2, float eps,
-                            float l2) {
+                            float l2, int zero_g) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i] + 2.0f * l2 * l2mask[i] * w[i];
+  if (zero_g) g[i] = 0.f;  // scann_train_step: the next step starts from a zeroed gradient vector without a memset
   const float mi = b1 * m[i] + (1.0f - b1) * gi;
   const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
   m[i] = mi;
   v[i] = vi;
   w[i] -= lr_hat * mi / (sqrtf(vi) + eps);
 }
-void launch_adam(float* w, const float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,
-                 float eps, float l2, hipStream_t s) {
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, g, m, v, l2mask, n, lr_hat, b1, b2, eps, l2);
+void launch_adam(float* w, float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,
+                 float eps, float l2, int zero_g, hipStream_t s) {
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, g, m, v, l2mask, n, lr_hat, b1, b2, eps, l2, zero_g);
 }
 
 // ---- master weights -> MFMA fragment order (after every optimiser step) --------------------------------------------------------
