@@ -336,11 +336,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceSet set) {
   e.dst[idx] += (s0 + s1) + (s2 + s3);
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(WgradReduceSet set) {
+  constexpr int U = 8;  // independent 16-byte loads in flight
+  const WgradReduceEntry e = set.e[blockIdx.y];
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // float4 index (numel is 128 or 128 * 128)
+  if (idx * 4 >= e.numel) return;
+  const size_t stride = (size_t)(e.numel >> 2);
+  const float4* __restrict__ p = reinterpret_cast<const float4*>(e.part) + idx;
+  float4 s[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (; k + U <= e.n_slab; k += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s[u & 3].x += v[u].x; s[u & 3].y += v[u].y; s[u & 3].z += v[u].z; s[u & 3].w += v[u].w;
+    }
+  }
+  for (; k < e.n_slab; ++k) {
+    const float4 v = p[(size_t)k * stride];
+    s[k & 3].x += v.x; s[k & 3].y += v.y; s[k & 3].z += v.z; s[k & 3].w += v.w;
+  }
+  const float4 t = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                               (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  float* __restrict__ d = e.dst + 4 * (size_t)idx;
+  if ((reinterpret_cast<size_t>(e.dst) & 15) == 0) {
+    const float4 o = *reinterpret_cast<const float4*>(d);
+    *reinterpret_cast<float4*>(d) = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
+  } else {
+    d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w;
+  }
+}
+
 int wgrad_chunks(int rows) {
-  // slab per workgroup: <= 80 slabs per gradient (a layer's launch is ~7 gradients: a few hundred workgroups), so that the partial
-  // slots (64 KB each) the reduce re-reads stay small whatever the batch size
+  // slab per workgroup: at least 4 chunks of 64 rows and <= 80 slabs per gradient (a layer's launch is ~7 gradients: a few hundred
+  // workgroups), so that the partial slots (64 KB each) the reduce re-reads stay small whatever the batch size.  Measured at batch
+  // 128 (profiles/r02_notes.md): 1 -> 4 chunks for the atom-row gradients, 36 -> 9 slabs each, -20 us per step.
   const int tiles = (rows + 63) / 64;
-  return std::max(1, (tiles + 79) / 80);
+  return std::max(std::min(4, tiles), (tiles + 79) / 80);
 }
 int wgrad_slabs(int rows) {
   const int chunks = wgrad_chunks(rows);
@@ -354,7 +390,13 @@ void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
     const int n = (int)std::min<size_t>(WGRAD_REDUCE_MAX, ctx.entries.size() - e0);
     WgradReduceSet set{};
     for (int k = 0; k < n; ++k) set.e[k] = ctx.entries[e0 + k];
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(D * D / 256, n), dim3(256), 0, s, set);
+    // two shapes of the same fixed-order sum: many light threads while the launch is a latency chain beside the data-gradient
+    // kernels (batch 128: 1.18 vs 1.19 ms per step), 16-byte loads with eight in flight once it is bandwidth that counts
+    // (batch 1024: 4.81 vs 5.36 ms)
+    size_t bytes = 0;
+    for (int k = 0; k < n; ++k) bytes += (size_t)set.e[k].n_slab * set.e[k].numel * 4;
+    if (bytes >= ((size_t)24 << 20)) hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(D * D / 4 / 256, n), dim3(256), 0, s, set);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(D * D / 256, n), dim3(256), 0, s, set);
   }
   ctx.entries.clear();
 }
