@@ -232,19 +232,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
     for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
   float bsum = 0.f;  // column `col` of db over this lane's rows
   float C = 0.f;     // the wave's dY scale (a power of two; 0 = nothing but zeros so far)
-  for (int chunk = 0; chunk < chunks; ++chunk) {
-    const int row0 = slab0 + chunk * 64;
-    if (row0 >= rows) break;
-    const int nrows = min(64, rows - row0);
-    float xa[4][8], db[4][8];
+  // operands of a chunk: 8 consecutive rows x this lane's column, for each of the 4 k-steps; clamped rows, masked afterwards, all 64
+  // loads in flight together -- and requested one chunk ahead, under the MFMAs of the current chunk
+  float xa[4][8], db[4][8];
+  const unsigned voff = ((unsigned)(8 * kh) * D + col) * 4;  // byte offset of (row 8 kh, this lane's column) inside a k-step's 16 rows
+  auto fetch_full = [&](int row0) {  // uniform base + one offset register + immediates (saddr form): no per-load address registers
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const char* xs = reinterpret_cast<const char*>(X + (size_t)(row0 + 16 * s2) * D);
+      const char* ds = reinterpret_cast<const char*>(dY + (size_t)(row0 + 16 * s2) * D);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {  // clamped rows, masked afterwards: all 64 loads in flight together
-        const size_t o = (size_t)(row0 + min(16 * s2 + 8 * kh + j, nrows - 1)) * D + col;
-        xa[s2][j] = X[o];
-        db[s2][j] = dY[o];
+      for (int j = 0; j < 8; ++j) {
+        xa[s2][j] = *reinterpret_cast<const float*>(xs + voff + j * D * 4);
+        db[s2][j] = *reinterpret_cast<const float*>(ds + voff + j * D * 4);
       }
+    }
+  };
+  // one chunk: scale bookkeeping, X^T fragments -> LDS, dY fragments -> registers, [next chunk's loads], MFMAs
+  auto consume = [&](int nrows, bool prefetch, int next_row0) {
     float mx = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2)
@@ -287,24 +292,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
       sA[s2][wave][0][lane] = h;
       sA[s2][wave][1][lane] = l;
     }
-    __syncthreads();
+    f16x8 bh[4], bl[4];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      f16x8 bh, bl;
+    for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = db[s2][j] * cs;
-        bh[j] = (_Float16)v;
-        bl[j] = (_Float16)(v - (float)bh[j]);
+        bh[s2][j] = (_Float16)v;
+        bl[s2][j] = (_Float16)(v - (float)bh[s2][j]);
       }
+    __builtin_amdgcn_sched_barrier(0);
+    if (prefetch) fetch_full(next_row0);  // the next chunk's operands arrive under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const f16x8 ah = sA[s2][m][0][lane], al = sA[s2][m][1][lane];
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s2], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s2], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s2], acc[m], 0, 0, 0);
       }
     }
+  };
+  const int slab_rows = min(64 * chunks, rows - slab0), n_full = slab_rows >> 6, rem = slab_rows & 63;
+  if (n_full > 0) fetch_full(slab0);
+  for (int c = 0; c < n_full; ++c) consume(64, c + 1 < n_full, slab0 + 64 * (c + 1));
+  if (rem) {  // the ragged last chunk of the tensor: rows clamped one by one, not pipelined
+    const int row0 = slab0 + 64 * n_full;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const size_t o = (size_t)(row0 + min(16 * s2 + 8 * kh + j, rem - 1)) * D + col;
+        xa[s2][j] = X[o];
+        db[s2][j] = dY[o];
+      }
+    consume(rem, false, 0);
   }
   const float inv = C == 0.f ? 0.f : 1.0f / C;
 #pragma unroll
