@@ -179,9 +179,16 @@ int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, flo
 /* One whole optimisation step, asynchronous until its end: scann_train_forward, [sum of {sse, count} over the communicator],
  * scann_zero_grads, scann_train_backward with the loss scale formed on the device, scann_allreduce_grads, scann_adam_step -- the
  * same kernels and results, without the host round trips between them (one fit step of model.fit, scann_model.py:225-241).
- * *sse_out / *count_out = the GLOBAL batch's sum of squared errors and size. */
+ * *sse_out / *count_out = the GLOBAL batch's sum of squared errors and size.  Adam leaves the gradient vector zeroed (the next step
+ * needs no scann_zero_grads; scann_get_grads after a step returns zeros). */
 int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
                      float beta2, float eps, float l2, double* sse_out, int64_t* count_out);
+/* The same step in two halves: _begin enqueues everything and returns; _end waits for it and returns the pair.  Between the two the
+ * host may assemble and upload the NEXT batch (scann_batch_upload copies on the null stream, which the handle's streams do not wait
+ * for); the batch of the step in flight must not be freed or downloaded before _end.  The gradient vector is left zeroed. */
+int scann_train_step_begin(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
+                           float beta2, float eps, float l2);
+int scann_train_step_end(scann_handle_t* h, double* sse_out, int64_t* count_out);
 int scann_get_grads(scann_handle_t* h, float* out);           /* [scann_param_count] */
 int scann_get_weights(scann_handle_t* h, float* out);         /* current master parameters, same order */
 int scann_comm_unique_id(char* out128);                       /* ncclGetUniqueId on rank 0; broadcast by the caller */

@@ -146,6 +146,7 @@ struct scann_handle {
   double* h_stat = nullptr;              // pinned {sse, count} of the last scann_train_step
   float* h_targets = nullptr;            // pinned staging of the step's targets (read by the loss kernel directly)
   size_t h_targets_cap = 0;
+  bool step_inflight = false;            // between scann_train_step_begin and scann_train_step_end
   bool grads_zeroed = false;             // the gradient vector is known to be all zeros (Adam of scann_train_step leaves it so)
   hipStream_t train_aux2 = nullptr;      // second side stream: the basis-MLP gradients beside the embedding chain
   bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
@@ -1752,9 +1753,10 @@ int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, flo
 // One optimisation step without a host round trip in the middle: forward, [all-reduce of {sse, count}], backward with the loss scale
 // formed on the device, [all-reduce of the gradients], Adam + weight-image refresh; ONE synchronisation at the end.  Same results as
 // scann_train_forward / scann_allreduce_sse / scann_zero_grads / scann_train_backward / scann_allreduce_grads / scann_adam_step.
-int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
-                     float beta2, float eps, float l2, double* sse_out, int64_t* count_out) {
-  if (!h || !db || !targets || !sse_out || !count_out) return fail(h, SCANN_ERR_INVALID, "scann_train_step: null argument");
+int scann_train_step_begin(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
+                           float beta2, float eps, float l2) {
+  if (!h || !db || !targets) return fail(h, SCANN_ERR_INVALID, "scann_train_step: null argument");
+  if (h->step_inflight) return fail(h, SCANN_ERR_INVALID, "scann_train_step_begin: the previous step has not been ended");
   if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_step: call scann_train_begin first");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = h->streams[0];
@@ -1776,10 +1778,26 @@ int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets
   r = adam_impl(h, lr_t, beta1, beta2, eps, l2, /*zero_g=*/1);  // leaves the gradient vector zeroed for the next step
   if (r) return r;
   h->grads_zeroed = true;
-  HIPCHK(h, hipStreamSynchronize(s));
+  h->step_inflight = true;
+  return SCANN_OK;
+}
+
+int scann_train_step_end(scann_handle_t* h, double* sse_out, int64_t* count_out) {
+  if (!h || !sse_out || !count_out) return fail(h, SCANN_ERR_INVALID, "scann_train_step_end: null argument");
+  if (!h->step_inflight) return fail(h, SCANN_ERR_INVALID, "scann_train_step_end: no step in flight");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->step_inflight = false;
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
   *sse_out = h->h_stat[0];
   *count_out = (int64_t)(h->h_stat[1] + 0.5);
   return SCANN_OK;
+}
+
+int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
+                     float beta2, float eps, float l2, double* sse_out, int64_t* count_out) {
+  if (!sse_out || !count_out) return fail(h, SCANN_ERR_INVALID, "scann_train_step: null argument");
+  const int r = scann_train_step_begin(h, db, targets, dropout, seed, lr_t, beta1, beta2, eps, l2);
+  return r ? r : scann_train_step_end(h, sse_out, count_out);
 }
 
 int scann_comm_unique_id(char* out128) {

@@ -85,6 +85,8 @@ SYMBOLS = [
     ("scann_allreduce_sse", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("scann_adam_step", C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     ("scann_train_step", C.c_int, [_P, _P, _P, C.c_float, C.c_uint64] + [C.c_float] * 5 + [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("scann_train_step_begin", C.c_int, [_P, _P, _P, C.c_float, C.c_uint64] + [C.c_float] * 5),
+    ("scann_train_step_end", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("scann_get_grads", C.c_int, [_P, _P]),
     ("scann_get_weights", C.c_int, [_P, _P]),
     ("scann_comm_unique_id", C.c_int, [C.c_char_p]),
@@ -448,6 +450,17 @@ class Engine:
         sse, cnt = C.c_double(), C.c_int64()
         self._check(self.lib.scann_train_step(self._h, rb._h, _ptr(t), float(dropout), int(seed), float(lr_t), float(beta1), float(beta2),
                                               float(eps), float(l2), C.byref(sse), C.byref(cnt)))
+        return sse.value, cnt.value
+
+    def train_step_begin(self, rb, targets, lr_t, dropout=0.0, seed=0, beta1=0.9, beta2=0.999, eps=1e-7, l2=1e-4):
+        """enqueue one step and return; the next batch may be uploaded before train_step_end()"""
+        t = np.ascontiguousarray(targets, dtype=np.float32)
+        self._check(self.lib.scann_train_step_begin(self._h, rb._h, _ptr(t), float(dropout), int(seed), float(lr_t), float(beta1),
+                                                    float(beta2), float(eps), float(l2)))
+
+    def train_step_end(self):
+        sse, cnt = C.c_double(), C.c_int64()
+        self._check(self.lib.scann_train_step_end(self._h, C.byref(sse), C.byref(cnt)))
         return sse.value, cnt.value
 
     def get_grads(self):

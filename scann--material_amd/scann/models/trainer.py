@@ -165,24 +165,37 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
         loss_sum = 0.0
         # Keras Dropout layers are the identity outside training (attention.py:115-116,191): validation runs without them
         eng.set_attention_dropout(attn_drop if training else 0.0)
+        def finish(rb, tgt, pair):
+            # end of a step: wait for the device, fetch the predictions of the step's forward, account
+            nonlocal sse_t, sabs_t, sy, syy, n_t, loss_sum
+            sse_g, cnt_g = pair if pair is not None else eng.train_step_end()
+            y, _ = eng.download(rb, want_ga=False)
+            rb.free()
+            loss_sum += math.sqrt(sse_g / cnt_g) * cnt_g
+            # this rank's partial sums; they are linear, so ONE reduction over the ranks at the end of the epoch is enough
+            sabs_t += float(np.abs(y - tgt).sum()); sy += float(tgt.sum()); syy += float((tgt.astype(np.float64) ** 2).sum())
+            sse_t += sse_g; n_t += cnt_g
+
+        pending = None
         for shard, tgt in _Prefetch(iterator, comm):
-            rb = eng.upload(shard)
+            rb = eng.upload(shard)  # H2D of batch k + 1 while step k (if any) is still running on the device
+            if pending is not None:
+                finish(*pending)
             seed = (it * 7919 + 17) & 0xFFFFFFFF
             if training:
                 # one asynchronous sequence on the device: forward, global {sse, count}, backward, gradient all-reduce, Adam
                 lr_t = (epoch_lr if sgdr is not None else cosine_decay(it, hy["lr"], decay_steps, alpha)) / (1.0 + 1e-5 * it)
-                sse_g, cnt_g = eng.train_step(rb, tgt, lr_t, dropout=dropout, seed=seed, l2=l2)
+                eng.train_step_begin(rb, tgt, lr_t, dropout=dropout, seed=seed, l2=l2)
                 it += 1
+                pending = (rb, tgt, None)
             else:
                 sse = eng.train_forward(rb, tgt, dropout=0.0, seed=seed)
-                sse_g, cnt_g = comm.sum_pair(sse, shard.n_struct)
-            y, _ = eng.download(rb, want_ga=False)
-            rb.free()
-            loss_sum += math.sqrt(sse_g / cnt_g) * cnt_g
-            sabs, _ = comm.sum_pair(float(np.abs(y - tgt).sum()), 0)
-            s1, _ = comm.sum_pair(float(tgt.sum()), 0)
-            s2, _ = comm.sum_pair(float((tgt.astype(np.float64) ** 2).sum()), 0)
-            sse_t += sse_g; sabs_t += sabs; sy += s1; syy += s2; n_t += cnt_g
+                pending = (rb, tgt, comm.sum_pair(sse, shard.n_struct))
+        if pending is not None:
+            finish(*pending)
+        sabs_t, _ = comm.sum_pair(sabs_t, 0)
+        sy, _ = comm.sum_pair(sy, 0)
+        syy, _ = comm.sum_pair(syy, 0)
         ss_tot = syy - sy * sy / max(n_t, 1)
         return loss_sum / max(n_t, 1), sabs_t / max(n_t, 1), 1.0 - sse_t / (ss_tot + 1e-7)
 
