@@ -1010,9 +1010,12 @@ __global__ __launch_bounds__(256) void attn_bwd16_kernel(const float* __restrict
   (which < 2 ? dgamma : dbeta)[(size_t)blockIdx.x * D + 2 * ln + (which & 1)] = tot;  // this workgroup's slot
 }
 
+// atoms per wave of attn_bwd16_kernel: the wave walks its atoms one after the other (each a chain of loads and lane reductions), so
+// as few as fill the chip a few times over (~1,000 workgroups); the per-workgroup gamma / beta slots are tiny
+static int attn_apw16(int n_atom) { return std::min(8, std::max(1, (n_atom + 4095) / 4096)); }
 int attn_bwd_slots(int n_atom, int max_degree) {
   if (max_degree <= 16) {
-    const int apw16 = n_atom >= 16384 ? 8 : 4;
+    const int apw16 = attn_apw16(n_atom);
     return (n_atom + 4 * apw16 - 1) / (4 * apw16);  // one slot per workgroup
   }
   return 4 * ((n_atom + 4 * 2 - 1) / (4 * 2));      // one slot per wave
@@ -1025,7 +1028,7 @@ void launch_attn_bwd(WgradCtx& ctx, const float* q, const float* K, const int* e
   float* gp = reserve_vec(ctx, dgamma, n_slot);
   float* bp = reserve_vec(ctx, dbeta, n_slot);
   if (max_degree <= 16) {
-    const int apw16 = n_atom >= 16384 ? 8 : 4;
+    const int apw16 = attn_apw16(n_atom);
     hipLaunchKernelGGL(attn_bwd16_kernel, dim3((n_atom + 4 * apw16 - 1) / (4 * apw16)), dim3(256), 0, s, q, K, edge_offset, dctx,
                        gamma, dq, dK, gp, bp, n_atom, apw16, drop_p, drop_tag, drop_seed);
     return;
