@@ -626,6 +626,10 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
         y.x *= ewgt[rt]; y.y *= ewgt[rt]; y.z *= ewgt[rt]; y.w *= ewgt[rt];
         float4 ang = f4mul(cn[rt][j], y);
         if (row >= ne) ang = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.keep_ang && row < ne) {  // training forward: geomL (in the V slot) and the gated rows, kept for the backward
+          st4(a.keep_V, eoff[rt] + 32 * j, y);
+          st4(a.keep_ang, eoff[rt] + 32 * j, ang);
+        }
         f16x4 h, l;
         split4(ang, h, l);
         *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;

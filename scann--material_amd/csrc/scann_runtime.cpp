@@ -904,12 +904,12 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (r) return r;
   }
   // keep-mode (training / scann_set_debug): every layer writes its centres, context and geometry straight into its slice of
-  // the per-layer buffers (base branch: no geometry to thread; the slices are filled by copies)
-  const bool direct = h->debug && c.g_update;
+  // the per-layer buffers (base branch: no geometry to thread)
+  const bool direct = h->debug;
   const size_t nA_ = (size_t)db->n_atom * D, nE_ = (size_t)db->n_edge * D;
   auto c_of = [&](int l) { return direct ? db->dbg_c + (size_t)l * nA_ : db->c; };
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
-  auto g_of = [&](int l) { return direct ? db->dbg_g + (size_t)l * nE_ : db->geom; };
+  auto g_of = [&](int l) { return direct && c.g_update ? db->dbg_g + (size_t)l * nE_ : db->geom; };
   if (tm) tm->mark(-1);
   if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
   else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
@@ -977,7 +977,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     EdgeArgs ea{};
     ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
-    ea.geom = g_of(l); ea.geom_out = direct ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
+    ea.geom = g_of(l); ea.geom_out = direct && c.g_update ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
     ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
     if (keep) {
       ea.keep_V = db->keep_V + (size_t)l * nE_; ea.keep_T = db->keep_T + (size_t)l * nE_;
@@ -1226,8 +1226,8 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   const size_t rowA = align_up((size_t)db->n_atom * D * 4), rowE = align_up((size_t)std::max(db->n_edge, 1) * D * 4);
   const size_t rowB = align_up((size_t)db->n_struct * D * 4);
   // per-layer tensors kept by the training forward (edge_kernel_lean on 64-edge tiles): q [A,128]; V, T, ang, K [E,128]
-  const bool keepable = h->cfg.g_update;
-  const size_t Lk = keepable ? (size_t)h->cfg.n_attention : 0;
+  // (base branch: geomL in the V slices, T unused)
+  const size_t Lk = (size_t)h->cfg.n_attention;
   // weight-gradient partial slots: per layer <= 2 gradients over the edge rows (key, filter_geo geometry third; base: key) and
   // <= 5 over the atom rows (filter_geo centre / neighbour thirds, query, ResidualNorm dense_1 / dense_2), readout 3 over atoms
   // and 1 over structures; each with a bias row per slab
@@ -1522,7 +1522,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
   // fused chains (scann_train_fused.hip): the kept-activation g_update path; SCANN_TRAIN_FUSED=0 selects the modular kernels
-  const bool fused = db->kept && c.g_update && h->train_fused;
+  const bool fused = db->kept && h->train_fused;
   struct Pend {  // projections of layer l + 1 that still have to be added to dC (d loss / d centres_{l+1})
     int n = 0;
     const float* X[3];
@@ -1530,7 +1530,9 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     const float* W[3];
   } pend;
   auto flush_pend = [&]() {
-    if (pend.n) launch_linear_sum(pend.X[0], pend.W[0], pend.X[1], pend.W[1], pend.X[2], pend.W[2], dC, A, 1, s);
+    if (pend.n)
+      launch_linear_sum(pend.X[0], pend.W[0], pend.n > 1 ? pend.X[1] : nullptr, pend.n > 1 ? pend.W[1] : nullptr,
+                        pend.n > 2 ? pend.X[2] : nullptr, pend.n > 2 ? pend.W[2] : nullptr, dC, A, 1, s);
     pend.n = 0;
   };
   for (int l = L - 1; l >= 0; --l) {
@@ -1587,19 +1589,42 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
 
     // ---- LocalAttention backward (attention.py:118-216) ----
     if (!c.g_update) {
-      // base SCANN (attention.py:155): geomL = swish(gd.Wf + bf) * weight from the raw basis, no geometry threading
-      launch_linear(c_in, p.Wqp, p.bq, db->q, nullptr, A, 0, s);
-      launch_base_geom(db->gd, p.Wfg, p.bfg, db->weight, eV, E, s);            // geomL (eV)
-      launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
-      launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
-      launch_attn_bwd(wg, db->q, eK, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
+      // base SCANN (attention.py:155): geomL = swish(gd.Wf + bf) * weight from the raw basis, no geometry threading.  The training
+      // forward kept q, geomL (V slices), ang and K of every layer (db->kept); otherwise they are recomputed here.
+      const bool kb = db->kept;
+      const float* qL = kb ? db->keep_q + (size_t)l * nA : db->q;
+      const float* gL = kb ? db->keep_V + (size_t)l * nE : eV;
+      const float* angL = kb ? db->keep_ang + (size_t)l * nE : eAng;
+      const float* KL = kb ? db->keep_K + (size_t)l * nE : eK;
+      if (!kb) {
+        launch_linear(c_in, p.Wqp, p.bq, db->q, nullptr, A, 0, s);
+        launch_base_geom(db->gd, p.Wfg, p.bfg, db->weight, eV, E, s);            // geomL (eV)
+        launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
+        launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
+      }
+      launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-      launch_wgrad(wg, eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);  // also launches the queued ResidualNorm gradients
+      float* const dcn = kb ? eT : eAng;  // per-edge dang * geomL (a temporary; with recomputation the ang buffer is free by now)
+      float* const dgL = kb ? eU : edGt;  // d loss / d geomL: in the layer's operand set when the leaf below runs on the side stream
+      if (!kb) launch_wgrad(wg, eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);  // before eAng is overwritten
+      else wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
       launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
-      launch_edge_dang(c_in, db->edge_col, eV, edAng, nullptr, eAng, edGt, E, s);  // per edge dang*geomL (in eAng) ; dgeomL = dang*c[j]
-      launch_gather_sum(eAng, db->in_off, db->in_edge, dC, A, 0, s);              // dC[j] = sum over the edges that point at j
-      launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, edGt, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), s);
-      launch_wgrad(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A, s);
+      launch_edge_dang(c_in, db->edge_col, gL, edAng, nullptr, dcn, dgL, E, s);  // dcn = dang * geomL ; dgeomL = dang * c[j]
+      launch_gather_sum(dcn, db->in_off, db->in_edge, dC, A, 0, s);            // dC[j] = sum over the edges that point at j
+      wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
+      if (fused) {
+        // the layer's weight gradients, their reduction and the filter_geo leaf beside the chain of the layers below; dC += dq.Wq^T
+        // is folded into the next rn_bwd_kernel
+        hipStream_t ws = fork();
+        wgrad_launch(wg, ws);
+        if (side) wgrad_flush(wg, ws);
+        launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, dgL, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), ws);
+        pend.n = 1;
+        pend.X[0] = dQ; pend.Wh[0] = pt.WqTh; pend.W[0] = pt.WqT;
+        continue;
+      }
+      launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, dgL, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), s);
+      wgrad_launch(wg, s);
       launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
       continue;
     }

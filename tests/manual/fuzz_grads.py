@@ -12,9 +12,11 @@ from scann import _hip
 from scann.models.scann_model import HipModel, normalize_config
 from fuzz_parity_lib import random_batch
 
+import ast
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 cfg = normalize_config(so.default_config("qm9"))
 cfg["model"].update(n_attention=3)
+cfg["model"].update({kv.split("=")[0]: ast.literal_eval(kv.split("=")[1]) for kv in sys.argv[2:]})  # e.g. g_update=False
 w = so.init_weights(cfg, 77, perturb=True)
 engines = {}
 for mode in ("1", "0"):
@@ -25,7 +27,7 @@ for mode in ("1", "0"):
 rng = np.random.default_rng(5)
 t_end, n, worst, bad = time.time() + budget, 0, {}, 0
 while time.time() < t_end:
-    inputs, targets = random_batch(rng, True, big=(n % 7 == 0), max_struct=1 if n % 5 == 0 else 8)
+    inputs, targets = random_batch(rng, cfg["model"]["g_update"], big=(n % 7 == 0), max_struct=1 if n % 5 == 0 else 8)
     pk = _hip.pack_inputs(inputs)
     if np.any(np.diff(pk.mol_offset) == 1):
         continue  # 1-atom structures are NaN with use_ga_norm, by the reference's formula

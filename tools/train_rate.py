@@ -1,28 +1,28 @@
 #!/usr/bin/env python3
-"""Training-step rate (config 3 shape: QM9, batch 128, L=7) on one GPU: forward(train) + backward + Adam per step."""
-import os, sys, time
+"""Training-step time of an architecture variant on resident synthetic QM9-shaped batches:
+    python tools/train_rate.py [batch] [key=value ...]      e.g.  g_update=False   use_attn_norm=False   n_attention=8"""
+import os, sys, time, ast
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), ROOT]
-from scann.models.scann_model import HipModel, normalize_config
 import bench
-cfg = normalize_config({"model": dict(bench.QM9_MODEL), "hyper": {"target": "homo"}})
-model = HipModel(cfg, device=0, seed=1234)
-eng = model.engine
+from scann.models.scann_model import HipModel, normalize_config
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+over = {}
+for kv in sys.argv[2:]:
+    k, v = kv.split("=")
+    over[k] = ast.literal_eval(v)
+cfg = normalize_config({"model": dict(bench.QM9_MODEL, **over), "hyper": {"target": "homo"}})
+eng = HipModel(cfg, device=0, seed=1234).engine
 eng.train_begin()
 rng = np.random.default_rng(0)
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-pks = [bench.synth_packed_batch(rng, B) for _ in range(4)]
-rbs = [eng.upload(p) for p in pks]
-tg = [rng.normal(size=B).astype(np.float32) for _ in pks]
-def step(i):
-    rb, t = rbs[i % 4], tg[i % 4]
-    sse = eng.train_forward(rb, t, dropout=0.1, seed=i)
-    eng.zero_grads(); eng.train_backward(rb, sse, B); eng.allreduce_grads(); eng.adam_step(5e-4)
-for i in range(5): step(i)
-n = 50
+pool = [eng.upload(bench.synth_packed_batch(rng, B)) for _ in range(8)]
+tg = [rng.normal(size=B).astype(np.float32) for _ in pool]
+for i in range(20):
+    eng.train_step(pool[i % 8], tg[i % 8], 5e-4, dropout=0.1, seed=i)
+n = 300
 t0 = time.perf_counter()
-for i in range(n): step(i)
-eng.sync()
-dt = (time.perf_counter() - t0) / n
-print("train step (batch %d, L=7): %.3f ms -> %.0f molecules/s" % (B, dt * 1e3, B / dt))
+for i in range(n):
+    eng.train_step(pool[i % 8], tg[i % 8], 5e-4, dropout=0.1, seed=20 + i)
+dt = time.perf_counter() - t0
+print("batch %d %s: %.3f ms per step = %.0f molecules/s" % (B, over or "SCANN+", dt / n * 1e3, n * B / dt))
