@@ -413,6 +413,17 @@ if rank == 0:                                                                   
     for k in g1:
         scale = max(float(np.sqrt(np.mean(g1[k].astype(np.float64) ** 2))), 1e-12)
         assert float(np.max(np.abs(g[k] - g1[k]))) <= 2e-5 * scale + 1e-9, k  # same sums, different association: rounding only
+# the same optimisation step through scann_train_step (all-reduces on the stream, loss scale formed on the device)
+sse_s, cnt_s = eng.train_step(rb, np.asarray(tgt, np.float32)[lo:hi], 1e-3, dropout=0.0, seed=1)
+ws = eng.get_weights()
+digests = comm.rdzv.allgather(float(sum(np.abs(v.astype(np.float64)).sum() for v in ws.values())))
+assert digests[0] == digests[1], digests                                        # the replicas stay one model
+if rank == 0:
+    assert cnt_s == pk.n_struct and abs(sse_s - sse1) <= 1e-5 * sse1, (sse_s, sse1)
+    ref.zero_grads(); ref.train_backward(rb2, sse1, pk.n_struct); ref.adam_step(1e-3)
+    w1 = ref.get_weights()
+    for k in w1:
+        assert np.allclose(ws[k], w1[k], rtol=1e-4, atol=2e-6), k
     print("RCCL2_OK")
 comm.rdzv.barrier()
 '''
