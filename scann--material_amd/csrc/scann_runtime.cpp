@@ -1333,6 +1333,8 @@ int scann_train_begin(scann_handle_t* h) {
     h->train_ev.resize(128);
     for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  h->grads_zeroed = false;  // (re)allocated gradient vector: contents unknown
+  h->step_inflight = false;
   {
     const char* e = getenv("SCANN_TRAIN_FUSED");
     h->train_fused = !(e && e[0] == '0');
