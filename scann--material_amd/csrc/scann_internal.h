@@ -44,19 +44,19 @@ struct EdgeTile {
 // the MFMA fragment order produced by pack_weight() (see scann_kernels.hip: gemm128).
 struct LayerParams {
   // atom-tile kernel
-  const float *W1p, *W3p, *bg;  // filter_geo rows [0,128) (centre) and [256,384) (neighbour) + bias (fp32 fragment order: training kernels)
-  const float *Wqp, *bq;        // query
-  const _Float16 *W1h, *W3h, *Wqh, *Wf1h, *Wf2h;  // split-fp16 images of the same kernels (atom_kernel)
+  const float *bg;              // filter_geo bias
+  const float *bq;              // query bias
+  const _Float16 *W1h, *W3h, *Wqh, *Wf1h, *Wf2h;  // split-fp16 images (pack_weight_f16): filter_geo rows [0,128) (centre) and [256,384)
+                                                  // (neighbour), query, ResidualNorm dense_1 / dense_2
   // edge-tile kernel
-  const float *W2p;             // filter_geo rows [128,256) (geometry), fp32 fragment order (training kernels)
-  const float *Wkp, *bk;        // key
-  const _Float16 *W2h, *Wkh;    // the same two kernels as split-fp16 images (pack_weight_f16): what edge_kernel multiplies with
+  const float *bk;              // key bias
+  const _Float16 *W2h, *Wkh;    // filter_geo rows [128,256) (geometry) and key as split-fp16 images: what edge_kernel multiplies with
   const _Float16 *Wfh;          // base branch: filter_geo [20,128] zero-padded to K = 32, split-fp16 image
   const float *lng_g, *lng_b;   // layer_norm_g
   const float *ln_g, *ln_b;     // layer_norm
-  const float *Wfg, *bfg;       // base branch (g_update False): filter_geo [20,128] raw + bias
+  const float *Wfg, *bfg;       // base branch (g_update False): filter_geo [20,128] raw + bias (backward of the basis filter)
   // ResidualNorm that follows this LocalAttention (applied at the head of the next atom kernel)
-  const float *Wf1p, *bf1, *Wf2p, *bf2, *lnr_g, *lnr_b;
+  const float *bf1, *bf2, *lnr_g, *lnr_b;
 };
 
 struct HeadParams {

@@ -529,7 +529,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   struct LTOff { size_t W1T, W2T, W3T, WqT, WkT, Wf1T, Wf2T, W1Th, W2Th, W3Th, WqTh, WkTh, Wf1Th, Wf2Th; };
   std::vector<LTOff> lto(L);
   struct LOff {
-    size_t W1p, W3p, bg, Wqp, bq, W2p, Wkp, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, Wf1p, bf1, Wf2p, bf2, lnr_g, lnr_b;
+    size_t bg, bq, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, bf1, bf2, lnr_g, lnr_b;
     size_t W2h, Wkh, Wfh, W1h, W3h, Wqh, Wf1h, Wf2h;
   };
   std::vector<LOff> lo(L);
@@ -537,17 +537,14 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   for (int i = 0; i < L; ++i) {
     const std::string p = "local_attention_" + std::to_string(i) + "/";
     LOff& o = lo[i];
-    o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE,
+    o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE,
              NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     const float* fg = src[p + "filter_geo/kernel"];
     lto[i] = LTOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
-      o.W1p = put_packed(fg);
       o.W1h = put_f16(fg, D, 8);
       o.W3h = put_f16(fg + (size_t)2 * D * D, D, 8);
-      o.W2p = put_packed(fg + (size_t)D * D);
       o.W2h = put_f16(fg + (size_t)D * D, D, 8);
-      o.W3p = put_packed(fg + (size_t)2 * D * D);
       lto[i].W1T = put_packedT(fg);
       lto[i].W2T = put_packedT(fg + (size_t)D * D);
       lto[i].W3T = put_packedT(fg + (size_t)2 * D * D);
@@ -562,14 +559,12 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       o.Wfh = put_f16(fg, NG, 2);
       o.bfg = put_raw(src[p + "filter_geo/bias"], D);
     }
-    o.Wqp = put_packed(src[p + "query/kernel"]);
     o.Wqh = put_f16(src[p + "query/kernel"], D, 8);
     lto[i].WqT = put_packedT(src[p + "query/kernel"]);
     lto[i].WkT = put_packedT(src[p + "key/kernel"]);
     lto[i].WqTh = put_f16T(src[p + "query/kernel"]);
     lto[i].WkTh = put_f16T(src[p + "key/kernel"]);
     o.bq = put_raw(src[p + "query/bias"], D);
-    o.Wkp = put_packed(src[p + "key/kernel"]);
     o.Wkh = put_f16(src[p + "key/kernel"], D, 8);
     o.bk = put_raw(src[p + "key/bias"], D);
     o.ln_g = put_raw(src[p + "layer_norm/gamma"], D);
@@ -580,11 +575,9 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       lto[i].Wf2T = put_packedT(src[r + "dense_2/kernel"]);
       lto[i].Wf1Th = put_f16T(src[r + "dense_1/kernel"]);
       lto[i].Wf2Th = put_f16T(src[r + "dense_2/kernel"]);
-      o.Wf1p = put_packed(src[r + "dense_1/kernel"]);
       o.Wf1h = put_f16(src[r + "dense_1/kernel"], D, 8);
       o.Wf2h = put_f16(src[r + "dense_2/kernel"], D, 8);
       o.bf1 = put_raw(src[r + "dense_1/bias"], D);
-      o.Wf2p = put_packed(src[r + "dense_2/kernel"]);
       o.bf2 = put_raw(src[r + "dense_2/bias"], D);
       o.lnr_g = put_raw(src[r + "layer_norm/gamma"], D);
       o.lnr_b = put_raw(src[r + "layer_norm/beta"], D);
@@ -644,9 +637,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   for (int i = 0; i < L; ++i) {
     const LOff& o = lo[i];
     LayerParams& lp = h->layers[i];
-    lp.W1p = P(o.W1p); lp.W3p = P(o.W3p); lp.bg = P(o.bg);
-    lp.Wqp = P(o.Wqp); lp.bq = P(o.bq);
-    lp.W2p = P(o.W2p); lp.Wkp = P(o.Wkp); lp.bk = P(o.bk);
+    lp.bg = P(o.bg); lp.bq = P(o.bq); lp.bk = P(o.bk);
     lp.lng_g = P(o.lng_g); lp.lng_b = P(o.lng_b); lp.ln_g = P(o.ln_g); lp.ln_b = P(o.ln_b);
     lp.Wfg = P(o.Wfg); lp.bfg = P(o.bfg);
     lp.W2h = reinterpret_cast<const _Float16*>(P(o.W2h)); lp.Wkh = reinterpret_cast<const _Float16*>(P(o.Wkh));
@@ -654,7 +645,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lp.W1h = reinterpret_cast<const _Float16*>(P(o.W1h)); lp.W3h = reinterpret_cast<const _Float16*>(P(o.W3h));
     lp.Wqh = reinterpret_cast<const _Float16*>(P(o.Wqh)); lp.Wf1h = reinterpret_cast<const _Float16*>(P(o.Wf1h));
     lp.Wf2h = reinterpret_cast<const _Float16*>(P(o.Wf2h));
-    lp.Wf1p = P(o.Wf1p); lp.bf1 = P(o.bf1); lp.Wf2p = P(o.Wf2p); lp.bf2 = P(o.bf2);
+    lp.bf1 = P(o.bf1); lp.bf2 = P(o.bf2);
     lp.lnr_g = P(o.lnr_g); lp.lnr_b = P(o.lnr_b);
   }
   h->layersT.assign(L, scann_handle::LayerT{});
@@ -1200,7 +1191,7 @@ struct scann_train_ws {  // per resident batch, allocated on first use
   std::vector<float*> tA;  // [n_atom,128] temporaries: 5 shared + 5 per layer and readout (operands of that layer's weight gradients)
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128] or null
   float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;
-  std::vector<float*> tE;  // [n_edge,128] temporaries: 8 shared + 2 per layer and readout
+  std::vector<float*> tE;  // [n_edge,128] temporaries: 4 shared + 2 per layer and readout
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   float* wpart = nullptr;  // per-slab partial sums of every weight gradient of a step (WgradCtx::arena)
   size_t wpart_floats = 0;
@@ -1240,7 +1231,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
                                          (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
   // the operands of a layer's weight gradients live until the end of the step (sets of their own per layer): the gradient launches on
   // the side stream never have to be waited for before a buffer is reused
-  const size_t nTA = 5 + 5 * (Lc + 1), nTE = 8 + 2 * (Lc + 1);
+  const size_t nTA = 5 + 5 * (Lc + 1), nTE = 4 + 2 * (Lc + 1);
   const size_t total = nTA * rowA + nTE * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
                        align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4);
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
@@ -1443,7 +1434,7 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
     auto it = g_train_ws.find(db);
     if (it != g_train_ws.end()) wp = &it->second;
   }
-  if (!h->t_grad || !wp || db->dbg_layers != h->cfg.n_attention)
+  if (!h->t_grad || !wp || db->dbg_layers != h->cfg.n_attention || !db->kept)
     return fail(h, SCANN_ERR_INVALID, "scann_train_backward: run scann_train_forward on this batch first");
   HIPCHK(h, hipSetDevice(h->device));
   const double rmse = std::sqrt(sse_global / (double)count_global);
@@ -1466,7 +1457,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   // alone does not fill the chip at batch 128.  fork(): side stream waits for everything enqueued so far; join(): main waits
   // for the side stream (start of every layer: the previous layer's temporaries are about to be overwritten).
   hipStream_t aux = h->train_aux;
-  const bool side = db->kept && aux != nullptr;
+  const bool side = aux != nullptr;
   size_t ev_i = 0;
   auto fork = [&]() -> hipStream_t {
     if (!side) return s;
@@ -1486,12 +1477,12 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
 
   // named temporaries
   float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4];
-  float *eAng = w.tE[0], *eK = w.tE[1], *edAng = w.tE[2], *eV = w.tE[3], *eT = w.tE[4], *edGt = w.tE[5], *edGa = w.tE[6], *edGb = w.tE[7];
+  float *edAng = w.tE[0], *eT = w.tE[1], *edGa = w.tE[2], *edGb = w.tE[3];
   // The operands of a layer's weight gradients (t3, t4, dQ, dP1, dP3, edK, eU) exist once per layer (set L = the readout): the
   // gradient launch of layer l runs on the side stream beside the data-gradient chains of the layers below and nothing it reads
   // is overwritten before the end of the step.
   auto setA = [&](int l, int k) { return w.tA[5 + 5 * (size_t)l + k]; };
-  auto setE = [&](int l, int k) { return w.tE[8 + 2 * (size_t)l + k]; };
+  auto setE = [&](int l, int k) { return w.tE[4 + 2 * (size_t)l + k]; };
   float *t3 = setA(L, 0), *t4 = setA(L, 1), *dQ = setA(L, 2), *dP1 = setA(L, 3), *dP3 = setA(L, 4), *edK = setE(L, 0), *eU = setE(L, 1);
   const float* cL = db->dbg_c + (size_t)L * nA;  // centres entering after_Lc
 
@@ -1523,8 +1514,8 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
-  // fused chains (scann_train_fused.hip): the kept-activation g_update path; SCANN_TRAIN_FUSED=0 selects the modular kernels
-  const bool fused = db->kept && h->train_fused;
+  // fused chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0 selects the modular one-kernel-per-operation backward
+  const bool fused = h->train_fused;
   struct Pend {  // projections of layer l + 1 that still have to be added to dC (d loss / d centres_{l+1})
     int n = 0;
     const float* X[3];
@@ -1547,21 +1538,20 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     const float* ctx = db->dbg_ctx + (size_t)l * nA;       // LocalAttention output (after layer_norm)
     const float* Gin = c.g_update ? db->dbg_g + (size_t)l * nE : nullptr;         // geometry entering layer l
     const float* Gout = c.g_update ? db->dbg_g + (size_t)(l + 1) * nE : nullptr;  // geometry leaving layer l (= layer_norm_g output)
+    // tensors the training forward kept (nothing is recomputed): q [A,128]; K, ang, V (base branch: geomL), T [E,128]
+    const float* qL = db->keep_q + (size_t)l * nA;
+    const float* angL = db->keep_ang + (size_t)l * nE;
+    const float* KL = db->keep_K + (size_t)l * nE;
+    const float* VL = db->keep_V + (size_t)l * nE;
+    const float* TL = db->keep_T + (size_t)l * nE;
 
-    if (pend.n && !(fused && c.use_attn_norm && db->keep_T2)) flush_pend();  // nobody below folds the projections of the layer above in
+    if (pend.n && !(fused && c.use_attn_norm)) flush_pend();  // nobody below folds the projections of the layer above in
     // ---- ResidualNorm backward (attention.py:37-40): c_{l+1} = LN(x + drop(W2 swish(W1 x + b1) + b2)), x = ctx ----
     if (c.use_attn_norm) {
-      const bool kept_rn = db->kept && db->keep_T2;  // the training forward (atom_kernel) kept pre1, H1 and T2
-      const float* pre1 = kept_rn ? db->keep_pre1 + (size_t)l * nA : t0;
-      const float* H1 = kept_rn ? db->keep_H1 + (size_t)l * nA : t1;
-      const float* T2 = kept_rn ? db->keep_T2 + (size_t)l * nA : t2;
-      if (!kept_rn) {
-        launch_linear(ctx, p.Wf1p, p.bf1, t1, t0, A, 2, s);   // pre1 (t0), H1 (t1)
-        launch_linear(t1, p.Wf2p, p.bf2, t2, nullptr, A, 0, s);  // Y
-        launch_dropout(t2, nA, w.seed, (unsigned)l, w.drop_p, s);
-        launch_add(t2, ctx, nA, s);                            // T2 = x + drop(Y)
-      }
-      if (fused && kept_rn) {
+      const float* pre1 = db->keep_pre1 + (size_t)l * nA;
+      const float* H1 = db->keep_H1 + (size_t)l * nA;
+      const float* T2 = db->keep_T2 + (size_t)l * nA;
+      if (fused) {
         // one kernel: [dC += the projections of the layer above] -> LayerNorm backward -> Dropout mask -> dense_2^T, swish' -> dense_1^T
         RnBwdArgs ra{};
         ra.dC = dC; ra.T2 = T2; ra.pre1 = pre1; ra.gamma = p.lnr_g; ra.Wf2Th = pt.Wf2Th; ra.Wf1Th = pt.Wf1Th;
@@ -1571,90 +1561,43 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
         for (int t = 0; t < pend.n; ++t) { ra.X[t] = pend.X[t]; ra.Wh[t] = pend.Wh[t]; }
         pend.n = 0;
         launch_rn_bwd(wg, ra, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), s);
-        wgrad_add(wg, H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A);
-        wgrad_add(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A);
       } else {
-      launch_ln_bwd(wg, T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
-      // gradient of the Dense_2 output = dT2 through the Dropout mask, in a buffer of its own: dT2 (dCtx) is the residual path and
-      // is accumulated into below, while the queued weight gradient reads its operand at the end of the layer
-      if (w.drop_p > 0.f) launch_dropout_copy(t3, dCtx, nA, w.seed, (unsigned)l, w.drop_p, s);
-      else HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
-      wgrad_add(wg, H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A);
-      launch_linear(t3, pt.Wf2T, nullptr, t4, const_cast<float*>(pre1), A, 4, s);  // dpre1 = (dY.W2^T) * swish'(pre1)
-      wgrad_add(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A);
-      if (!side) wgrad_launch(wg, s);  // without the kept-activation forward the operands do not survive the layer
-      launch_linear(t4, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);  // dctx = dT2 + dpre1.W1^T
+        launch_ln_bwd(wg, T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx
+        // gradient of the Dense_2 output = dT2 through the Dropout mask, in a buffer of its own: dT2 (dCtx) is the residual path and
+        // is accumulated into below, while the queued weight gradient reads its operand at the end of the layer
+        if (w.drop_p > 0.f) launch_dropout_copy(t3, dCtx, nA, w.seed, (unsigned)l, w.drop_p, s);
+        else HIPCHK(h, hipMemcpyAsync(t3, dCtx, nA * 4, hipMemcpyDeviceToDevice, s));
+        launch_linear(t3, pt.Wf2T, nullptr, t4, const_cast<float*>(pre1), A, 4, s);  // dpre1 = (dY.W2^T) * swish'(pre1)
+        launch_linear(t4, pt.Wf1T, nullptr, dCtx, nullptr, A, 1, s);                 // dctx = dT2 + dpre1.W1^T
       }
+      wgrad_add(wg, H1, t3, g(rn + "dense_2/kernel"), g(rn + "dense_2/bias"), A);
+      wgrad_add(wg, ctx, t4, g(rn + "dense_1/kernel"), g(rn + "dense_1/bias"), A);
     } else {
       HIPCHK(h, hipMemcpyAsync(dCtx, dC, nA * 4, hipMemcpyDeviceToDevice, s));
     }
 
     // ---- LocalAttention backward (attention.py:118-216) ----
-    if (!c.g_update) {
-      // base SCANN (attention.py:155): geomL = swish(gd.Wf + bf) * weight from the raw basis, no geometry threading.  The training
-      // forward kept q, geomL (V slices), ang and K of every layer (db->kept); otherwise they are recomputed here.
-      const bool kb = db->kept;
-      const float* qL = kb ? db->keep_q + (size_t)l * nA : db->q;
-      const float* gL = kb ? db->keep_V + (size_t)l * nE : eV;
-      const float* angL = kb ? db->keep_ang + (size_t)l * nE : eAng;
-      const float* KL = kb ? db->keep_K + (size_t)l * nE : eK;
-      if (!kb) {
-        launch_linear(c_in, p.Wqp, p.bq, db->q, nullptr, A, 0, s);
-        launch_base_geom(db->gd, p.Wfg, p.bfg, db->weight, eV, E, s);            // geomL (eV)
-        launch_edge_ang(c_in, db->edge_col, eV, eAng, E, s);                     // ang = c[j] * geomL
-        launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);                  // K
-      }
-      launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
-                    w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-      float* const dcn = kb ? eT : eAng;  // per-edge dang * geomL (a temporary; with recomputation the ang buffer is free by now)
-      float* const dgL = kb ? eU : edGt;  // d loss / d geomL: in the layer's operand set when the leaf below runs on the side stream
-      if (!kb) launch_wgrad(wg, eAng, edK, g(la + "key/kernel"), g(la + "key/bias"), E, s);  // before eAng is overwritten
-      else wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
-      launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
-      launch_edge_dang(c_in, db->edge_col, gL, edAng, nullptr, dcn, dgL, E, s);  // dcn = dang * geomL ; dgeomL = dang * c[j]
-      launch_gather_sum(dcn, db->in_off, db->in_edge, dC, A, 0, s);            // dC[j] = sum over the edges that point at j
-      wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
-      if (fused) {
-        // the layer's weight gradients, their reduction and the filter_geo leaf beside the chain of the layers below; dC += dq.Wq^T
-        // is folded into the next rn_bwd_kernel
-        hipStream_t ws = fork();
-        wgrad_launch(wg, ws);
-        if (side) wgrad_flush(wg, ws);
-        launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, dgL, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), ws);
-        pend.n = 1;
-        pend.X[0] = dQ; pend.Wh[0] = pt.WqTh; pend.W[0] = pt.WqT;
-        continue;
-      }
-      launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, dgL, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), s);
-      wgrad_launch(wg, s);
-      launch_linear(dQ, pt.WqT, nullptr, dC, nullptr, A, 1, s);
-      continue;
-    }
-    // what the fused forward kernels did not keep is recomputed; with edge_kernel_lean the training forward kept
-    // q, V, T, ang and K of every layer (db->kept), so nothing is
-    const bool kept = db->kept;
-    const float* qL = kept ? db->keep_q + (size_t)l * nA : db->q;
-    const float* angL = kept ? db->keep_ang + (size_t)l * nE : eAng;
-    const float* KL = kept ? db->keep_K + (size_t)l * nE : eK;
-    const float* VL = kept ? db->keep_V + (size_t)l * nE : eV;
-    const float* TL = kept ? db->keep_T + (size_t)l * nE : eT;
-    if (!kept) {
-      {  // P1, P3, q recomputed by the forward kernel itself (one launch; its copy of the input rows goes to a scratch)
-        AtomArgs ra2{};
-        ra2.x = c_in; ra2.n_atom = A; ra2.ffn = 0; ra2.c = t4; ra2.mode = 0;
-        ra2.WAh = p.W1h; ra2.bA = p.bg; ra2.WBh = p.W3h; ra2.WCh = p.Wqh; ra2.bC = p.bq;
-        ra2.oA = db->P1; ra2.oB = db->P3; ra2.oC = db->q;
-        launch_atom(ra2, s);
-      }
-      launch_edge_ang(c_in, db->edge_col, Gout, eAng, E, s);       // ang = c[j] * G'
-      launch_linear(eAng, p.Wkp, p.bk, eK, nullptr, E, 0, s);      // K
-    }
     launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
                     w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
     wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
-    if (!side) wgrad_launch(wg, s);  // the recomputed ang / temporaries do not survive the layer: launch now
+    wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
+    if (!c.g_update) {
+      // base SCANN (attention.py:155): geomL = swish(gd.Wf + bf) * weight from the raw basis (kept in the V slices), no geometry threading
+      launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);            // dang
+      launch_edge_dang(c_in, db->edge_col, VL, edAng, nullptr, eT, eU, E, s);  // eT = dang * geomL ; eU = dgeomL = dang * c[j]
+      launch_gather_sum(eT, db->in_off, db->in_edge, dC, A, 0, s);             // dC[j] = sum over the edges that point at j
+      // the layer's weight gradients, their reduction and the filter_geo leaf beside the chain of the layers below
+      hipStream_t ws = fork();
+      wgrad_launch(wg, ws);
+      if (side) wgrad_flush(wg, ws);
+      launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, eU, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), ws);
+      pend.n = 1;  // dC += dq.Wq^T: folded into the next rn_bwd_kernel (or launched by flush_pend)
+      pend.X[0] = dQ; pend.Wh[0] = pt.WqTh; pend.W[0] = pt.WqT;
+      continue;
+    }
+    // geometry update: G' = LN_g(swish(V) + G), V = G.W2 + P1[i] + P3[j]; gate ang = c[j] * G'
+    float* dGnext = (dG_in == edGa) ? edGb : edGa;  // d loss / d geometry entering layer l
     if (fused) {
-      float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
       // one kernel: dang = dK.Wk^T -> dG'tot = dang * c[j] + dG'(next layer) -> LayerNorm_g backward -> dV = dT * swish'(V) -> dG = dT + dV.W2^T
       EdgeBwdArgs ea{};
       ea.dK = edK; ea.c = c_in; ea.dG_in = dG_in; ea.T = TL; ea.V = VL; ea.gamma = p.lng_g; ea.nb = db->edge_col;
@@ -1662,52 +1605,31 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
       launch_edge_bwd(wg, ea, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), s);
       // dC[j] = sum over the edges that point at j of dang * G' (gate), dP3[j] = the same sum of dV, dP1[i] = sum of dV over i's own edges
       launch_atom_gather3(edAng, Gout, eU, db->edge_offset, db->in_off, db->in_edge, dC, dP1, dP3, A, s);
-      float* fgk = g(la + "filter_geo/kernel");
-      wgrad_add(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E);                     // dW2
-      wgrad_add(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), A);
-      wgrad_add(wg, c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A);
-      wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
-      {
-        hipStream_t ws = fork();
-        wgrad_launch(wg, ws);
-        if (side) wgrad_flush(wg, ws);
-      }
-      // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T is folded into the next layer's rn_bwd_kernel (or launched after the loop)
-      pend.n = 3;
-      pend.X[0] = dP1; pend.X[1] = dP3; pend.X[2] = dQ;
-      pend.Wh[0] = pt.W1Th; pend.Wh[1] = pt.W3Th; pend.Wh[2] = pt.WqTh;
-      pend.W[0] = pt.W1T; pend.W[1] = pt.W3T; pend.W[2] = pt.WqT;
-      dG_in = dGnext;
-      continue;
+    } else {
+      launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
+      launch_gather_prod_sum(edAng, Gout, db->in_off, db->in_edge, dC, A, 0, s);
+      // LayerNorm_g backward with its neighbours fused: in  dG'tot = dang * c[j] + dG'(next layer), out  dT (residual path, -> dGnext)
+      // and dV = dT * swish'(V) (-> eU)
+      launch_ln_bwd_edge(wg, TL, p.lng_g, edAng, c_in, db->edge_col, dG_in, VL, dGnext, eU, g(la + "layer_norm_g/gamma"),
+                         g(la + "layer_norm_g/beta"), E, s);
+      launch_atom_sums(eU, db->edge_offset, db->in_off, db->in_edge, dP1, dP3, A, s);  // dP1[i]: the atom's own edges; dP3[j]: the edges that point at j
+      launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                    // dG += dV.W2^T
     }
-    launch_linear(edK, pt.WkT, nullptr, edAng, nullptr, E, 0, s);  // dang
-    // dC now collects d loss / d centres_l: dC[j] = sum over the edges that point at j of dang * G' (backward of the gate ang = c[j] * G')
-    launch_gather_prod_sum(edAng, Gout, db->in_off, db->in_edge, dC, A, 0, s);
-    // geometry update: G' = LN_g(swish(V) + G), V = G.W2 + P1[i] + P3[j]
-    if (!kept) {
-      launch_linear(Gin, p.W2p, nullptr, eU, nullptr, E, 0, s);
-      launch_edge_v(eU, db->P1, db->P3, db->edge_row, db->edge_col, Gin, eV, eT, E, s);
-    }
-    float* dGnext = (dG_in == edGa) ? edGb : edGa;              // d loss / d geometry entering layer l
-    // LayerNorm_g backward with its neighbours fused: in  dG'tot = dang * c[j] + dG'(next layer), out  dT (residual path, -> dGnext)
-    // and dV = dT * swish'(V) (-> eU)
-    launch_ln_bwd_edge(wg, TL, p.lng_g, edAng, c_in, db->edge_col, dG_in, VL, dGnext, eU, g(la + "layer_norm_g/gamma"),
-                       g(la + "layer_norm_g/beta"), E, s);
-    launch_atom_sums(eU, db->edge_offset, db->in_off, db->in_edge, dP1, dP3, A, s);  // dP1[i]: the atom's own edges; dP3[j]: the edges that point at j
     float* fgk = g(la + "filter_geo/kernel");
-    wgrad_add(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E);                     // dW2
-    launch_linear(eU, pt.W2T, nullptr, dGnext, nullptr, E, 1, s);                // dG += dV.W2^T
-    // per-atom projections
+    wgrad_add(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E);  // dW2
     wgrad_add(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), A);
     wgrad_add(wg, c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A);
-    wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
-    {  // every weight gradient of this layer (ResidualNorm 2, key, filter_geo 3, query) in ONE launch, then the fixed-order sum of
-       // its partial slots (and of the layer's LayerNorm gamma / beta slots): both beside the next layer's chain
+    {  // every weight gradient of this layer (ResidualNorm 2, key, query, filter_geo 3) in ONE launch, then the fixed-order sum of its
+       // partial slots (and of the layer's LayerNorm gamma / beta slots): both beside the chains of the layers below
       hipStream_t ws = fork();
       wgrad_launch(wg, ws);
       if (side) wgrad_flush(wg, ws);
     }
-    launch_linear_sum(dP1, pt.W1T, dP3, pt.W3T, dQ, pt.WqT, dC, A, 1, s);  // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T
+    // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T: folded into the next layer's rn_bwd_kernel (or launched by flush_pend)
+    pend.n = 3;
+    pend.X[0] = dP1; pend.X[1] = dP3; pend.X[2] = dQ;
+    pend.Wh[0] = pt.W1Th; pend.Wh[1] = pt.W3Th; pend.Wh[2] = pt.WqTh;
+    pend.W[0] = pt.W1T; pend.W[1] = pt.W3T; pend.W[2] = pt.WqT;
     dG_in = dGnext;
   }
   flush_pend();

@@ -62,22 +62,16 @@ void launch_linear(const float* X, const float* Wp, const float* bias, float* Y,
 void launch_linear_sum(const float* X0, const float* W0, const float* X1, const float* W1, const float* X2, const float* W2, float* Y,
                        int rows, int accumulate, hipStream_t s);
 void launch_swish_bwd(const float* pre, const float* dout, float* dpre, size_t n, hipStream_t s);
-void launch_add(float* dst, const float* src, size_t n, hipStream_t s);
 void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s);
 int ln_bwd_slots(int rows);
 int attn_bwd_slots(int n_atom, int max_degree);
 void launch_ln_bwd(WgradCtx& ctx, const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int rows,
                    int accumulate, hipStream_t s);
-void launch_edge_ang(const float* c, const int* nb, const float* g, float* ang, int n_edge, hipStream_t s);
 // dcn[e] = dang[e] * g[e] (per edge; summed per neighbour atom with launch_gather_sum), dg_tot = dang * c[nb] (+ dg_in)
 void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dcn,
                       float* dg_tot, int n_edge, hipStream_t s);
 // out[a] (+)= sum of val[e] over the edges whose neighbour is atom a (reverse adjacency in_off / in_edge); fixed order, no atomics
 void launch_gather_sum(const float* val, const int* in_off, const int* in_edge, float* out, int n_atom, int accumulate, hipStream_t s);
-void launch_edge_v(const float* U, const float* P1, const float* P3, const int* ctr, const int* nb, const float* G, float* V,
-                   float* T, int n_edge, hipStream_t s);
-void launch_edge_dv(const float* V, const float* dT, float* dV, int n_edge, hipStream_t s);
-void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s);
 void launch_ln_bwd_edge(WgradCtx& ctx, const float* T, const float* gamma, const float* dang, const float* c, const int* nb,
                         const float* dg_in, const float* V, float* dT, float* dV, float* dgamma, float* dbeta, int rows, hipStream_t s);
 void launch_gather_prod_sum(const float* x, const float* y, const int* in_off, const int* in_edge, float* out, int n_atom, int accumulate,
@@ -120,7 +114,6 @@ void launch_atom_gather3(const float* dang, const float* G, const float* dV, con
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);
 void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weight, const float* dgeom, int n_edge, float* dWd,
                       float* dbd, float* dWw, float* dbw, hipStream_t s);
-void launch_base_geom(const float* gd, const float* Wf, const float* bf, const float* wgt, float* geomL, int n_edge, hipStream_t s);
 void launch_base_geom_bwd(const float* gd, const float* Wf, const float* bf, const float* wgt, const float* dgeomL, int n_edge,
                           float* dWf, float* dbf, hipStream_t s);
 void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const float* emb, const float* W, const float* b,

@@ -480,14 +480,6 @@ void launch_swish_bwd(const float* pre, const float* dout, float* dpre, size_t n
   if (n) hipLaunchKernelGGL(swish_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, dout, dpre, n);
 }
 
-__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] += src[i];
-}
-void launch_add(float* dst, const float* src, size_t n, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
-}
-
 __global__ void dropout_kernel(float* __restrict__ x, size_t n, unsigned long long seed, unsigned tag, float p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= drop_scale(seed, tag, i, p);
@@ -653,15 +645,6 @@ void launch_ln_bwd_edge(WgradCtx& ctx, const float* T, const float* gamma, const
 
 // ---- edge elementwise kernels (thread = float4 chunk of an edge row) -------------------------------------------------
 
-// ang = c[nb] * G'  (attention.py:136,157)
-__global__ void edge_ang_kernel(const float4* __restrict__ c, const int* __restrict__ nb, const float4* __restrict__ g,
-                                float4* __restrict__ ang, int n_edge) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)n_edge * 32) return;
-  const int e = (int)(i >> 5), c4 = (int)(i & 31);
-  const float4 a = c[(size_t)nb[e] * 32 + c4], b = g[i];
-  ang[i] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
-}
 // backward of ang = cn * G':  dcn (per edge; summed over the edges that point AT an atom by gather_sum_kernel) = dang * G',
 // dG'(total) = dang * cn + dG'(from the next layer)
 __global__ void edge_dang_kernel(const float4* __restrict__ c, const int* __restrict__ nb, const float4* __restrict__ g,
@@ -746,66 +729,13 @@ void launch_gather_sum(const float* val, const int* in_off, const int* in_edge, 
     hipLaunchKernelGGL(gather_sum_kernel, dim3((unsigned)(((size_t)n_atom * 32 + 255) / 256)), dim3(256), 0, s, (const float4*)val,
                        in_off, in_edge, (float4*)out, n_atom, accumulate);
 }
-// V = U + P1[ctr] + P3[nb] ; T = swish(V) + G   (attention.py:142-153)
-__global__ void edge_v_kernel(const float4* __restrict__ U, const float4* __restrict__ P1, const float4* __restrict__ P3,
-                              const int* __restrict__ ctr, const int* __restrict__ nb, const float4* __restrict__ G,
-                              float4* __restrict__ V, float4* __restrict__ T, int n_edge) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)n_edge * 32) return;
-  const int e = (int)(i >> 5), c4 = (int)(i & 31);
-  const float4 u = U[i], a = P1[(size_t)ctr[e] * 32 + c4], b = P3[(size_t)nb[e] * 32 + c4], g = G[i];
-  const float4 v = make_float4((a.x + u.x) + b.x, (a.y + u.y) + b.y, (a.z + u.z) + b.z, (a.w + u.w) + b.w);
-  V[i] = v;
-  T[i] = make_float4(swish_(v.x) + g.x, swish_(v.y) + g.y, swish_(v.z) + g.z, swish_(v.w) + g.w);
-}
-// dP1[a] = sum over the CSR row of atom a of dV (the centre-indexed sum needs no atomics)
-__global__ void segment_sum_kernel(const float4* __restrict__ dV, const int* __restrict__ edge_offset, float4* __restrict__ out,
-                                   int n_atom) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)n_atom * 32) return;
-  const int a = (int)(i >> 5), c4 = (int)(i & 31);
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int e = edge_offset[a]; e < edge_offset[a + 1]; ++e) {
-    const float4 v = dV[(size_t)e * 32 + c4];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  out[i] = s;
-}
-void launch_segment_sum(const float* dV, const int* edge_offset, float* out, int n_atom, hipStream_t s) {
-  if (n_atom > 0)
-    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)(((size_t)n_atom * 32 + 255) / 256)), dim3(256), 0, s,
-                       (const float4*)dV, edge_offset, (float4*)out, n_atom);
-}
-
-// dV = dT * swish'(V)   (dP1 = centre-indexed sum, dP3 = neighbour-indexed sum of dV: segment_sum / gather_sum)
-__global__ void edge_dv_kernel(const float4* __restrict__ V, const float4* __restrict__ dT, float4* __restrict__ dV, int n_edge) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)n_edge * 32) return;
-  const float4 v = V[i], t = dT[i];
-  dV[i] = make_float4(t.x * dswish_(v.x), t.y * dswish_(v.y), t.z * dswish_(v.z), t.w * dswish_(v.w));
-}
 #define EDGE_GRID(n_edge) dim3((unsigned)(((size_t)(n_edge) * 32 + 255) / 256)), dim3(256)
-void launch_edge_ang(const float* c, const int* nb, const float* g, float* ang, int n_edge, hipStream_t s) {
-  if (n_edge > 0)
-    hipLaunchKernelGGL(edge_ang_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)c, nb, (const float4*)g, (float4*)ang, n_edge);
-}
 void launch_edge_dang(const float* c, const int* nb, const float* g, const float* dang, const float* dg_in, float* dcn,
                       float* dg_tot, int n_edge, hipStream_t s) {
   if (n_edge > 0)
     hipLaunchKernelGGL(edge_dang_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)c, nb, (const float4*)g,
                        (const float4*)dang, (const float4*)dg_in, (float4*)dcn, (float4*)dg_tot, n_edge);
 }
-void launch_edge_v(const float* U, const float* P1, const float* P3, const int* ctr, const int* nb, const float* G, float* V,
-                   float* T, int n_edge, hipStream_t s) {
-  if (n_edge > 0)
-    hipLaunchKernelGGL(edge_v_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)U, (const float4*)P1, (const float4*)P3, ctr,
-                       nb, (const float4*)G, (float4*)V, (float4*)T, n_edge);
-}
-void launch_edge_dv(const float* V, const float* dT, float* dV, int n_edge, hipStream_t s) {
-  if (n_edge > 0)
-    hipLaunchKernelGGL(edge_dv_kernel, EDGE_GRID(n_edge), 0, s, (const float4*)V, (const float4*)dT, (float4*)dV, n_edge);
-}
-
 // ---- attention backward: one wave per atom, lane l owns features 2l, 2l+1 (head l>>3) -----------------------------
 // forward (attention.py:180-214): e[n,h] = 0.25 sum_d q[h,d] K[n,h,d]; attn = softmax_n(e); pre = sum_n attn K[n] + q;
 // ctx = LN(pre).  Given dctx: dpre = LN'(dctx); dq += dpre; dattn[n,h] = sum_d dpre[h,d] K[n,h,d];
@@ -1201,21 +1131,6 @@ void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weig
 }
 
 // ---- base SCANN branch: geomL = swish(gd.Wf + bf) * weight  (attention.py:155; gd = raw Gaussian basis [E,20]) -------------
-// forward recompute: thread = (edge, column)
-__global__ void base_geom_kernel(const float* __restrict__ gd, const float* __restrict__ Wf, const float* __restrict__ bf,
-                                 const float* __restrict__ wgt, float* __restrict__ geomL, int n_edge) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)n_edge * D) return;
-  const int e = (int)(i / D), col = (int)(i % D);
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < NG; ++k) acc += gd[(size_t)e * NG + k] * Wf[k * D + col];
-  geomL[i] = swish_(acc + bf[col]) * wgt[e];
-}
-void launch_base_geom(const float* gd, const float* Wf, const float* bf, const float* wgt, float* geomL, int n_edge, hipStream_t s) {
-  if (n_edge > 0)
-    hipLaunchKernelGGL(base_geom_kernel, dim3((unsigned)(((size_t)n_edge * D + 255) / 256)), dim3(256), 0, s, gd, Wf, bf, wgt, geomL, n_edge);
-}
 // backward: dpre = dgeomL * weight * swish'(pre); dWf[k][col] += gd[e][k] dpre; dbf[col] += dpre   (32 edges per workgroup)
 __global__ __launch_bounds__(128) void base_geom_bwd_kernel(const float* __restrict__ gd, const float* __restrict__ Wf,
                                                             const float* __restrict__ bf, const float* __restrict__ wgt,
