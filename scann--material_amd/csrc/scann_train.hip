@@ -8,6 +8,7 @@
 // Every formula is the exact derivative of the corresponding forward line cited next to it.
 #include "scann_internal.h"
 #include <algorithm>
+#include <vector>
 
 #include "scann_train.h"
 #include "scann_mma.h"
@@ -408,13 +409,42 @@ int wgrad_slabs(int rows) {
   return (rows + 64 * chunks - 1) / (64 * chunks);
 }
 
+// the 128-wide gradient vectors (biases, LayerNorm gamma / beta): one workgroup of 1,024 threads per vector, eight groups of 128
+// walking the slots k = group, group + 8, ... (four loads in flight each), then the eight group sums added in group order --
+// the slot count of these is the WORKGROUP count of the producing kernel (hundreds), far more than the <= 80 slabs of a matrix
+__global__ __launch_bounds__(1024) void vec_reduce_kernel(WgradReduceSet set) {
+  const WgradReduceEntry e = set.e[blockIdx.x];
+  __shared__ float sg[8][D];
+  const int col = threadIdx.x & (D - 1), grp = threadIdx.x >> 7;
+  const float* __restrict__ p = e.part + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = grp;
+  for (; k + 24 < e.n_slab; k += 32) {
+    s0 += p[(size_t)k * D];
+    s1 += p[(size_t)(k + 8) * D];
+    s2 += p[(size_t)(k + 16) * D];
+    s3 += p[(size_t)(k + 24) * D];
+  }
+  for (; k < e.n_slab; k += 8) s0 += p[(size_t)k * D];
+  sg[grp][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) t += sg[g2][col];
+    e.dst[col] += t;
+  }
+}
+
 void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
   // the (destination, slots) records travel as kernel arguments: no table copy, so a flush can follow each layer's gradient
   // launch on the side stream
-  for (size_t e0 = 0; e0 < ctx.entries.size(); e0 += WGRAD_REDUCE_MAX) {
-    const int n = (int)std::min<size_t>(WGRAD_REDUCE_MAX, ctx.entries.size() - e0);
+  std::vector<WgradReduceEntry> mats, vecs;
+  for (const WgradReduceEntry& e : ctx.entries) (e.numel == D ? vecs : mats).push_back(e);
+  for (size_t e0 = 0; e0 < mats.size(); e0 += WGRAD_REDUCE_MAX) {
+    const int n = (int)std::min<size_t>(WGRAD_REDUCE_MAX, mats.size() - e0);
     WgradReduceSet set{};
-    for (int k = 0; k < n; ++k) set.e[k] = ctx.entries[e0 + k];
+    for (int k = 0; k < n; ++k) set.e[k] = mats[e0 + k];
     // two shapes of the same fixed-order sum: many light threads while the launch is a latency chain beside the data-gradient
     // kernels (batch 128: 1.18 vs 1.19 ms per step), 16-byte loads with eight in flight once it is bandwidth that counts
     // (batch 1024: 4.81 vs 5.36 ms)
@@ -422,6 +452,12 @@ void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
     for (int k = 0; k < n; ++k) bytes += (size_t)set.e[k].n_slab * set.e[k].numel * 4;
     if (bytes >= ((size_t)24 << 20)) hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(D * D / 4 / 256, n), dim3(256), 0, s, set);
     else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(D * D / 256, n), dim3(256), 0, s, set);
+  }
+  for (size_t e0 = 0; e0 < vecs.size(); e0 += WGRAD_REDUCE_MAX) {
+    const int n = (int)std::min<size_t>(WGRAD_REDUCE_MAX, vecs.size() - e0);
+    WgradReduceSet set{};
+    for (int k = 0; k < n; ++k) set.e[k] = vecs[e0 + k];
+    hipLaunchKernelGGL(vec_reduce_kernel, dim3(n), dim3(1024), 0, s, set);
   }
   ctx.entries.clear();
 }
