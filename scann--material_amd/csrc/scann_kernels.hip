@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
         inv = rstd * g.w; y.w = fmaf(acc[rt][4 * j + 3], inv, be.w - mean * inv);
         float4 ang = f4mul(cn[rt][j], y);  // attention.py:157
         if (row < ne) {
-          st4(gout, eoff[rt] + 32 * j, y);  // threaded to the next layer (scann_model.py:415)
+          if (!a.geom_dead) st4(gout, eoff[rt] + 32 * j, y);  // threaded to the next layer (scann_model.py:415)
           if (a.keep_ang) st4(a.keep_ang, eoff[rt] + 32 * j, ang);
         } else {
           ang = make_float4(0.f, 0.f, 0.f, 0.f);  // ragged tail rows stay defined (and zero) for the MFMA
