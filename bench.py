@@ -204,18 +204,30 @@ def train_bench(args, eng, rdzv):
             eng.train_backward(rb, sse_g, cnt_g)
             eng.allreduce_grads()
             eng.adam_step(5e-4 / (1.0 + 1e-5 * i))
-        else:
-            eng.train_step(rb, t, 5e-4 / (1.0 + 1e-5 * i), dropout=0.1, seed=i)
+        else:  # two steps in flight: step i + 1 is enqueued before step i is waited for (what trainer.fit does)
+            eng.train_step_begin(rb, t, 5e-4 / (1.0 + 1e-5 * i), dropout=0.1, seed=i)
+            inflight[0] += 1
+            if inflight[0] == 2:
+                eng.train_step_end()
+                inflight[0] -= 1
+
+    inflight = [0]
+
+    def drain():
+        while inflight[0]:
+            eng.train_step_end()
+            inflight[0] -= 1
+        eng.sync()
 
     steps, warm = min(args.steps, 400), max(min(args.warmup, 20), 5)
     for i in range(warm):
         step(i)
-    eng.sync()
+    drain()
     rdzv.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         step(warm + i)
-    eng.sync()
+    drain()
     elapsed = time.perf_counter() - t0
     rdzv.barrier()
     elapsed = rdzv.allreduce_max(elapsed)

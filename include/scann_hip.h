@@ -126,6 +126,7 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
 /* Resident-batch path (inputs already in HBM; used for pipelined inference and by bench.py). */
 int scann_batch_upload(scann_handle_t* h, const scann_batch_t* batch, scann_dbatch_t** out);
 void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);
+void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db); /* see scann_train_step_begin */
 int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot); /* async */
 int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out); /* syncs that batch */
 int scann_sync(scann_handle_t* h); /* all streams of the handle */
@@ -183,12 +184,15 @@ int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, flo
  * needs no scann_zero_grads; scann_get_grads after a step returns zeros). */
 int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
                      float beta2, float eps, float l2, double* sse_out, int64_t* count_out);
-/* The same step in two halves: _begin enqueues everything and returns; _end waits for it and returns the pair.  Between the two the
- * host may assemble and upload the NEXT batch (scann_batch_upload copies on the null stream, which the handle's streams do not wait
- * for); the batch of the step in flight must not be freed or downloaded before _end.  The gradient vector is left zeroed. */
+/* The same step in two halves: _begin enqueues everything and returns; _end waits for the OLDEST step in flight and returns its
+ * {sse, count, sum |y - target|} (global over the communicator).  Up to TWO steps may be in flight: the host assembles, uploads
+ * (scann_batch_upload copies on the null stream, which the handle's streams do not wait for) and begins step k + 1 while the
+ * device still runs step k, so the device never waits for the host.  A batch must not be freed or downloaded before the _end of
+ * its step; scann_batch_release then frees it without the device-wide synchronisation of scann_batch_free.  The gradient vector
+ * is left zeroed. */
 int scann_train_step_begin(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
                            float beta2, float eps, float l2);
-int scann_train_step_end(scann_handle_t* h, double* sse_out, int64_t* count_out);
+int scann_train_step_end(scann_handle_t* h, double* sse_out, int64_t* count_out, double* abs_err_out /* sum |y - target|, or NULL */);
 int scann_get_grads(scann_handle_t* h, float* out);           /* [scann_param_count] */
 int scann_get_weights(scann_handle_t* h, float* out);         /* current master parameters, same order */
 int scann_comm_unique_id(char* out128);                       /* ncclGetUniqueId on rank 0; broadcast by the caller */

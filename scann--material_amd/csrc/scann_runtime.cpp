@@ -143,10 +143,13 @@ struct scann_handle {
   bool in_train_forward = false;
   unsigned long long train_seed = 0;
   ncclComm_t comm = nullptr;
-  double* h_stat = nullptr;              // pinned {sse, count} of the last scann_train_step
-  float* h_targets = nullptr;            // pinned staging of the step's targets (read by the loss kernel directly)
-  size_t h_targets_cap = 0;
-  bool step_inflight = false;            // between scann_train_step_begin and scann_train_step_end
+  // scann_train_step_begin / _end: up to two steps may be enqueued before the first is ended (the host prepares step k + 1 while the
+  // device runs step k); slot = step number & 1.  Slot 2 of the targets belongs to the synchronous scann_train_forward.
+  double* h_stat = nullptr;              // pinned [2][4]: {sse, count, sum |y - t|} of the step in that slot
+  float* h_targets[3] = {nullptr, nullptr, nullptr};  // pinned staging of a step's targets (read by the loss kernel directly)
+  size_t h_targets_cap[3] = {0, 0, 0};
+  hipEvent_t step_ev[2] = {nullptr, nullptr};         // recorded at the end of the step in that slot
+  int64_t step_begun = 0, step_ended = 0;
   bool grads_zeroed = false;             // the gradient vector is known to be all zeros (Adam of scann_train_step leaves it so)
   hipStream_t train_aux2 = nullptr;      // second side stream: the basis-MLP gradients beside the embedding chain
   bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
@@ -171,6 +174,7 @@ struct scann_dbatch {
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128], training forward (owned by the train workspace)
   float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;  // ResidualNorm intermediates, [L][n_atom,128]
   bool kept = false;  // the last training forward filled them
+  hipEvent_t busy_ev = nullptr;  // end of the last scann_train_step that used the batch (scann_batch_release)
   int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
   int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
@@ -411,7 +415,10 @@ void scann_destroy(scann_handle_t* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->train_aux) (void)hipStreamDestroy(h->train_aux);
   if (h->h_stat) (void)hipHostFree(h->h_stat);
-  if (h->h_targets) (void)hipHostFree(h->h_targets);
+  for (float* t : h->h_targets)
+    if (t) (void)hipHostFree(t);
+  for (hipEvent_t e : h->step_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->train_aux2) (void)hipStreamDestroy(h->train_aux2);
   for (hipEvent_t e : h->train_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->time_ev) (void)hipEventDestroy(e);
@@ -690,6 +697,24 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   if (!db) return;
   if (h) (void)hipSetDevice(h->device);
   if (h) (void)hipDeviceSynchronize();
+  if (db->arena && db->owns_arena) cached_free(db->arena);
+  cached_free(db->dbg_c);
+  cached_free(db->dbg_g);
+  cached_free(db->dbg_ctx);
+  if (db->stamps) (void)hipFree(db->stamps);
+  free_train_ws(db);
+  delete db;
+}
+
+// scann_batch_free without the device-wide synchronisation: for a batch whose last use was a scann_train_step that has been ended
+// (its event has fired) while a LATER step on another batch may still be running.  Falls back to the synchronising free otherwise.
+void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db) {
+  if (!db) return;
+  if (!h || !db->busy_ev || hipEventQuery(db->busy_ev) != hipSuccess) {
+    scann_batch_free(h, db);
+    return;
+  }
+  (void)hipSetDevice(h->device);
   if (db->arena && db->owns_arena) cached_free(db->arena);
   cached_free(db->dbg_c);
   cached_free(db->dbg_g);
@@ -1326,7 +1351,7 @@ int scann_train_begin(scann_handle_t* h) {
     for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   h->grads_zeroed = false;  // (re)allocated gradient vector: contents unknown
-  h->step_inflight = false;
+  h->step_begun = h->step_ended = 0;
   {
     const char* e = getenv("SCANN_TRAIN_FUSED");
     h->train_fused = !(e && e[0] == '0');
@@ -1372,7 +1397,8 @@ int scann_get_weights(scann_handle_t* h, float* out) {
 
 // the training forward (activations kept for the backward) and the batch's sum of squared errors + count -> w->sse[0..1]; no sync
 static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, scann_train_ws** wout,
-                              bool fused_step) {
+                              int slot) {  // slot 0 / 1: a scann_train_step in that slot; 2: the synchronous scann_train_forward
+  const bool fused_step = slot < 2;
   scann_train_ws* w = nullptr;
   int r = ensure_train_ws(h, db, &w);
   if (r) return r;
@@ -1395,19 +1421,22 @@ static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float
   h->debug = dbg;
   if (r) return r;
   // targets: staged in pinned memory that the loss kernel reads directly (it leaves the device copy the backward uses): no copy operation
-  if (h->h_targets_cap < (size_t)db->n_struct) {
-    if (h->h_targets) (void)hipHostFree(h->h_targets);
-    h->h_targets = nullptr;
-    h->h_targets_cap = 0;
-    HIPCHK(h, hipHostMalloc((void**)&h->h_targets, (size_t)db->n_struct * 4));
-    h->h_targets_cap = (size_t)db->n_struct;
+  if (h->h_targets_cap[slot] < (size_t)db->n_struct) {
+    if (h->h_targets[slot]) {
+      HIPCHK(h, hipStreamSynchronize(s));  // an earlier step may still be reading the buffer that is about to be replaced
+      (void)hipHostFree(h->h_targets[slot]);
+    }
+    h->h_targets[slot] = nullptr;
+    h->h_targets_cap[slot] = 0;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_targets[slot], (size_t)db->n_struct * 4));
+    h->h_targets_cap[slot] = (size_t)db->n_struct;
   }
-  memcpy(h->h_targets, targets, (size_t)db->n_struct * 4);
+  memcpy(h->h_targets[slot], targets, (size_t)db->n_struct * 4);
   const bool single = !(h->comm && h->comm_world > 1);
-  if (fused_step && !h->h_stat) HIPCHK(h, hipHostMalloc((void**)&h->h_stat, 2 * sizeof(double)));
-  // single-rank fused step: the loss kernel also forms d rmse / d y and posts {sse, count} to the pinned pair
-  launch_sse(db->y, h->h_targets, db->n_struct, w->sse, w->targets, fused_step && single ? w->dy : nullptr,
-             fused_step && single ? h->h_stat : nullptr, s);
+  if (fused_step && !h->h_stat) HIPCHK(h, hipHostMalloc((void**)&h->h_stat, 2 * 4 * sizeof(double)));
+  // single-rank fused step: the loss kernel also forms d rmse / d y and posts {sse, count, sum |y - t|} to the slot's pinned triple
+  launch_sse(db->y, h->h_targets[slot], db->n_struct, w->sse, w->targets, fused_step && single ? w->dy : nullptr,
+             fused_step && single ? h->h_stat + 4 * slot : nullptr, s);
   *wout = w;
   return SCANN_OK;
 }
@@ -1417,7 +1446,7 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_forward: call scann_train_begin first");
   HIPCHK(h, hipSetDevice(h->device));
   scann_train_ws* w = nullptr;
-  const int r = train_forward_impl(h, db, targets, dropout, seed, &w, false);
+  const int r = train_forward_impl(h, db, targets, dropout, seed, &w, 2);
   if (r) return r;
   hipStream_t s = h->streams[0];
   HIPCHK(h, hipMemcpyAsync(sse_out, w->sse, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1706,18 +1735,19 @@ int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, flo
 int scann_train_step_begin(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
                            float beta2, float eps, float l2) {
   if (!h || !db || !targets) return fail(h, SCANN_ERR_INVALID, "scann_train_step: null argument");
-  if (h->step_inflight) return fail(h, SCANN_ERR_INVALID, "scann_train_step_begin: the previous step has not been ended");
+  if (h->step_begun - h->step_ended >= 2) return fail(h, SCANN_ERR_INVALID, "scann_train_step_begin: two steps are already in flight; end one first");
+  const int slot = (int)(h->step_begun & 1);
   if (!h->t_master) return fail(h, SCANN_ERR_INVALID, "scann_train_step: call scann_train_begin first");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = h->streams[0];
   scann_train_ws* w = nullptr;
-  int r = train_forward_impl(h, db, targets, dropout, seed, &w, true);
+  int r = train_forward_impl(h, db, targets, dropout, seed, &w, slot);
   if (r) return r;
   const bool single = !(h->comm && h->comm_world > 1);
   if (!single) {  // losses.py:5-6 is the RMSE of the GLOBAL batch
-    const ncclResult_t nr = ncclAllReduce(w->sse, w->sse, 2, ncclDouble, ncclSum, h->comm, s);
+    const ncclResult_t nr = ncclAllReduce(w->sse, w->sse, 3, ncclDouble, ncclSum, h->comm, s);
     if (nr != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(nr));
-    HIPCHK(h, hipMemcpyAsync(h->h_stat, w->sse, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->h_stat + 4 * slot, w->sse, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (!h->grads_zeroed) HIPCHK(h, hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, s));
   h->grads_zeroed = false;
@@ -1728,18 +1758,23 @@ int scann_train_step_begin(scann_handle_t* h, scann_dbatch_t* db, const float* t
   r = adam_impl(h, lr_t, beta1, beta2, eps, l2, /*zero_g=*/1);  // leaves the gradient vector zeroed for the next step
   if (r) return r;
   h->grads_zeroed = true;
-  h->step_inflight = true;
+  if (!h->step_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->step_ev[slot], hipEventDisableTiming));
+  HIPCHK(h, hipEventRecord(h->step_ev[slot], s));
+  db->busy_ev = h->step_ev[slot];
+  h->step_begun += 1;
   return SCANN_OK;
 }
 
-int scann_train_step_end(scann_handle_t* h, double* sse_out, int64_t* count_out) {
+int scann_train_step_end(scann_handle_t* h, double* sse_out, int64_t* count_out, double* abs_err_out) {
   if (!h || !sse_out || !count_out) return fail(h, SCANN_ERR_INVALID, "scann_train_step_end: null argument");
-  if (!h->step_inflight) return fail(h, SCANN_ERR_INVALID, "scann_train_step_end: no step in flight");
+  if (h->step_begun == h->step_ended) return fail(h, SCANN_ERR_INVALID, "scann_train_step_end: no step in flight");
   HIPCHK(h, hipSetDevice(h->device));
-  h->step_inflight = false;
-  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
-  *sse_out = h->h_stat[0];
-  *count_out = (int64_t)(h->h_stat[1] + 0.5);
+  const int slot = (int)(h->step_ended & 1);  // the OLDEST step in flight
+  h->step_ended += 1;
+  HIPCHK(h, hipEventSynchronize(h->step_ev[slot]));
+  *sse_out = h->h_stat[4 * slot];
+  *count_out = (int64_t)(h->h_stat[4 * slot + 1] + 0.5);
+  if (abs_err_out) *abs_err_out = h->h_stat[4 * slot + 2];
   return SCANN_OK;
 }
 
@@ -1747,7 +1782,7 @@ int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets
                      float beta2, float eps, float l2, double* sse_out, int64_t* count_out) {
   if (!sse_out || !count_out) return fail(h, SCANN_ERR_INVALID, "scann_train_step: null argument");
   const int r = scann_train_step_begin(h, db, targets, dropout, seed, lr_t, beta1, beta2, eps, l2);
-  return r ? r : scann_train_step_end(h, sse_out, count_out);
+  return r ? r : scann_train_step_end(h, sse_out, count_out, nullptr);
 }
 
 int scann_comm_unique_id(char* out128) {

@@ -1327,32 +1327,39 @@ void launch_embed_general_bwd(const EmbedArgs& a, const float* dc0, float* dEmb,
 }
 
 // ---- loss ------------------------------------------------------------------------------------------------------------------
-// out = {sum (y - t)^2, n}.  Optional extras of scann_train_step (null otherwise): t may be pinned host memory, copied to t_dev on the
+// out = {sum (y - t)^2, n, sum |y - t|}.  Optional extras of scann_train_step (null otherwise): t may be pinned host memory, copied to t_dev on the
 // way; host_stat (pinned) receives the pair without a copy operation; dy = d rmse / d y for a single-rank step (the batch IS the
 // global batch, losses.py:5-6), which saves the separate dy launch.
 __global__ void sse_kernel(const float* __restrict__ y, const float* __restrict__ t, int n, double* __restrict__ out,
                            float* __restrict__ t_dev, float* __restrict__ dy, double* __restrict__ host_stat) {
-  double s = 0.0;
+  double s = 0.0, ab = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float ti = t[i];
     if (t_dev) t_dev[i] = ti;
     const double d = (double)y[i] - (double)ti;
     s += d * d;
+    ab += fabs(d);
   }
-  __shared__ double sh[256];
-  sh[threadIdx.x] = s;
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = ab;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
     __syncthreads();
   }
-  const double sse = sh[0];
+  const double sse = sh[0][0];
   if (threadIdx.x == 0) {
     out[0] = sse;
-    out[1] = (double)n;  // the count travels with the sum (scann_train_step all-reduces both)
+    out[1] = (double)n;  // the count and the absolute-error sum travel with the sum of squares (scann_train_step all-reduces the three)
+    out[2] = sh[1][0];
     if (host_stat) {
       host_stat[0] = sse;
       host_stat[1] = (double)n;
+      host_stat[2] = sh[1][0];
     }
   }
   if (dy) {

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("scann_forward_padded", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("scann_batch_upload", C.c_int, [_P, C.POINTER(Batch), C.POINTER(_P)]),
     ("scann_batch_free", None, [_P, _P]),
+    ("scann_batch_release", None, [_P, _P]),
     ("scann_forward_resident", C.c_int, [_P, _P, C.c_int]),
     ("scann_batch_download", C.c_int, [_P, _P, _P, _P]),
     ("scann_sync", C.c_int, [_P]),
@@ -86,7 +87,7 @@ SYMBOLS = [
     ("scann_adam_step", C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     ("scann_train_step", C.c_int, [_P, _P, _P, C.c_float, C.c_uint64] + [C.c_float] * 5 + [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("scann_train_step_begin", C.c_int, [_P, _P, _P, C.c_float, C.c_uint64] + [C.c_float] * 5),
-    ("scann_train_step_end", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("scann_train_step_end", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("scann_get_grads", C.c_int, [_P, _P]),
     ("scann_get_weights", C.c_int, [_P, _P]),
     ("scann_comm_unique_id", C.c_int, [C.c_char_p]),
@@ -290,6 +291,12 @@ class ResidentBatch:
             self.engine.lib.scann_batch_free(self.engine._h, self._h)
         self._h = None
 
+    def release(self):
+        """free() without the device-wide synchronisation: after train_step_end() of the step that used the batch"""
+        if self._h is not None and self.engine._h is not None:
+            self.engine.lib.scann_batch_release(self.engine._h, self._h)
+        self._h = None
+
     def __del__(self):
         try:
             self.free()
@@ -459,9 +466,10 @@ class Engine:
                                                     float(beta2), float(eps), float(l2)))
 
     def train_step_end(self):
-        sse, cnt = C.c_double(), C.c_int64()
-        self._check(self.lib.scann_train_step_end(self._h, C.byref(sse), C.byref(cnt)))
-        return sse.value, cnt.value
+        """wait for the OLDEST step in flight (up to two may be); returns its global (sse, count, sum |y - target|)"""
+        sse, cnt, sabs = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.scann_train_step_end(self._h, C.byref(sse), C.byref(cnt), C.byref(sabs)))
+        return sse.value, cnt.value, sabs.value
 
     def get_grads(self):
         flat = np.empty(self.param_count(), dtype=np.float32)

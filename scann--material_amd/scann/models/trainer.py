@@ -166,33 +166,41 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
         # Keras Dropout layers are the identity outside training (attention.py:115-116,191): validation runs without them
         eng.set_attention_dropout(attn_drop if training else 0.0)
         def finish(rb, tgt, pair):
-            # end of a step: wait for the device, fetch the predictions of the step's forward, account
+            # end of a step: wait for the device, account.  Training steps report their own global {sse, count, sum |y - t|};
+            # validation batches were run synchronously and hand over (sse, count) plus the downloaded predictions.
             nonlocal sse_t, sabs_t, sy, syy, n_t, loss_sum
-            sse_g, cnt_g = pair if pair is not None else eng.train_step_end()
-            y, _ = eng.download(rb, want_ga=False)
-            rb.free()
+            if pair is None:
+                sse_g, cnt_g, sabs_g = eng.train_step_end()
+                rb.release()  # no device-wide synchronisation: the next step may already be running
+                sabs_t += sabs_g if comm.rank == 0 else 0.0  # already summed over the ranks
+            else:
+                sse_g, cnt_g = pair
+                y, _ = eng.download(rb, want_ga=False)
+                rb.free()
+                sabs_t += float(np.abs(y - tgt).sum())
             loss_sum += math.sqrt(sse_g / cnt_g) * cnt_g
             # this rank's partial sums; they are linear, so ONE reduction over the ranks at the end of the epoch is enough
-            sabs_t += float(np.abs(y - tgt).sum()); sy += float(tgt.sum()); syy += float((tgt.astype(np.float64) ** 2).sum())
+            sy += float(tgt.sum()); syy += float((tgt.astype(np.float64) ** 2).sum())
             sse_t += sse_g; n_t += cnt_g
 
-        pending = None
+        pending = []
         for shard, tgt in _Prefetch(iterator, comm):
             rb = eng.upload(shard)  # H2D of batch k + 1 while step k (if any) is still running on the device
-            if pending is not None:
-                finish(*pending)
             seed = (it * 7919 + 17) & 0xFFFFFFFF
             if training:
-                # one asynchronous sequence on the device: forward, global {sse, count}, backward, gradient all-reduce, Adam
+                # one asynchronous sequence on the device: forward, global {sse, count}, backward, gradient all-reduce, Adam; step
+                # k + 1 is enqueued BEFORE step k is waited for, so the device never idles while the host works
                 lr_t = (epoch_lr if sgdr is not None else cosine_decay(it, hy["lr"], decay_steps, alpha)) / (1.0 + 1e-5 * it)
                 eng.train_step_begin(rb, tgt, lr_t, dropout=dropout, seed=seed, l2=l2)
                 it += 1
-                pending = (rb, tgt, None)
+                pending.append((rb, tgt, None))
+                if len(pending) == 2:
+                    finish(*pending.pop(0))
             else:
                 sse = eng.train_forward(rb, tgt, dropout=0.0, seed=seed)
-                pending = (rb, tgt, comm.sum_pair(sse, shard.n_struct))
-        if pending is not None:
-            finish(*pending)
+                finish(rb, tgt, comm.sum_pair(sse, shard.n_struct))
+        while pending:
+            finish(*pending.pop(0))
         sabs_t, _ = comm.sum_pair(sabs_t, 0)
         sy, _ = comm.sum_pair(sy, 0)
         syy, _ = comm.sum_pair(syy, 0)

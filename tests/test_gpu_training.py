@@ -565,3 +565,60 @@ def test_fused_backward_kernels_match_the_modular_ones(hip_lib, monkeypatch):
     for k, ref in grads["1", "unit"].items():
         scale = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-30
         assert float(np.max(np.abs(grads["1", "tiny"][k].astype(np.float64) * 2.0 ** 20 - ref))) / scale < 2e-5, k
+
+
+def test_two_steps_in_flight_equal_one_at_a_time(hip_lib):
+    """scann_train_step_begin may be called for step k + 1 before scann_train_step_end of step k (the device then never waits for
+    the host): same weights as ending every step before the next begins, the reported {sse, count, sum |y - t|} belong to the
+    right step, a third begin is refused, and the batches are released without a device-wide synchronisation."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg, w, pk, targets, _ = setup(n=20, L=2, seed=31)
+    de, dn = so.synth_dataset(14, 77)
+    inputs2, targets2 = so.pad_batch(de, dn, cfg["model"]["g_update"])
+    pk2 = _hip.pack_inputs(inputs2)
+    batches = [(pk, targets), (pk2, targets2), (pk, targets), (pk2, targets2), (pk, targets)]
+    results = {}
+    for mode in ("serial", "pipelined"):
+        eng = HipModel(cfg, w, device=0).engine
+        eng.train_begin()
+        stats, pending = [], []
+        for i, (b, t) in enumerate(batches):
+            rb = eng.upload(b)
+            eng.train_step_begin(rb, t, 1e-3, dropout=0.1, seed=i)
+            pending.append(rb)
+            if mode == "serial" or len(pending) == 2:
+                stats.append(eng.train_step_end())
+                pending.pop(0).release()
+        while pending:
+            stats.append(eng.train_step_end())
+            pending.pop(0).release()
+        results[mode] = (stats, eng.get_weights())
+        if mode == "pipelined":  # a third step in flight is refused (and nothing is left in flight afterwards)
+            extra = [eng.upload(pk) for _ in range(3)]
+            eng.train_step_begin(extra[0], targets, 1e-3)
+            eng.train_step_begin(extra[1], targets, 1e-3)
+            with pytest.raises(RuntimeError):
+                eng.train_step_begin(extra[2], targets, 1e-3)
+            eng.train_step_end()
+            eng.train_step_end()
+            with pytest.raises(RuntimeError):
+                eng.train_step_end()
+            for rb in extra:
+                rb.release()
+    assert [s[1] for s in results["serial"][0]] == [20, 14, 20, 14, 20]
+    for a, b in zip(results["serial"][0], results["pipelined"][0]):
+        assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-6 * a[0] and abs(a[2] - b[2]) <= 1e-6 * a[2], (a, b)
+    atomic = ("embed_atom/", "dense_embed/", "neighbor_d/", "neighbor_w/", "predict_property/")
+    for k, v in results["serial"][1].items():
+        assert np.allclose(v, results["pipelined"][1][k], rtol=1e-4 if k.startswith(atomic) else 1e-5, atol=1e-6), k
+    # sum |y - t| reported by the step = what the forward of the same weights gives
+    eng = HipModel(cfg, w, device=0).engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets, dropout=0.1, seed=0)
+    y, _ = eng.download(rb, want_ga=False)
+    first = results["serial"][0][0]
+    assert abs(first[0] - sse) <= 1e-6 * sse and abs(first[2] - float(np.abs(y - targets).sum())) <= 1e-5 * first[2]
+    rb.free()

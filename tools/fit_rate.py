@@ -33,22 +33,23 @@ comm = Communicator(eng)
 def epoch():
     it = 0
     t_up = t_issue = t_end = 0.0
-    pending = None
+    pending = []
     for shard, tgt in _Prefetch(ds, comm):
-        t0 = time.perf_counter(); rb = eng.upload(shard)          # overlaps the step in flight
-        t1 = time.perf_counter()
-        if pending is not None:
-            eng.train_step_end(); eng.download(pending, want_ga=False); pending.free()
-        t2 = time.perf_counter(); eng.train_step_begin(rb, tgt, 5e-4, dropout=0.1, seed=it)
+        t0 = time.perf_counter(); rb = eng.upload(shard)          # overlaps the step(s) in flight
+        t1 = time.perf_counter(); eng.train_step_begin(rb, tgt, 5e-4, dropout=0.1, seed=it)
+        t2 = time.perf_counter()
+        pending.append(rb)
+        if len(pending) == 2:
+            eng.train_step_end(); pending.pop(0).release()
         t3 = time.perf_counter()
-        pending = rb
-        t_up += t1 - t0; t_end += t2 - t1; t_issue += t3 - t2
+        t_up += t1 - t0; t_issue += t2 - t1; t_end += t3 - t2
         it += 1
-    eng.train_step_end(); eng.download(pending, want_ga=False); pending.free()
+    while pending:
+        eng.train_step_end(); pending.pop(0).release()
     return it, t_up, t_issue, t_end
 
 epoch()  # warm
 t0 = time.perf_counter(); it, t_up, t_step, t_dl = epoch(); dt = time.perf_counter() - t0
 print("fit inner loop: %d steps of %d molecules in %.3f s = %.0f molecules/s (%.3f ms/step: upload %.3f, issuing the step %.3f, waiting for the "
-      "previous step + download + free %.3f, waiting for the prefetch thread %.3f)"
+      "oldest step in flight + release %.3f, waiting for the prefetch thread %.3f)"
       % (it, B, dt, it * B / dt, dt / it * 1e3, t_up / it * 1e3, t_step / it * 1e3, t_dl / it * 1e3, (dt - t_up - t_step - t_dl) / it * 1e3))
