@@ -22,13 +22,15 @@ from fuzz_parity_lib import random_batch
 t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 40
 worst = {}
 bad = 0
-for name, over in (("scann_plus", {}), ("base", {"g_update": False}), ("no_norms", {"use_attn_norm": False, "use_ga_norm": False})):
-    cfg = normalize_config(so.default_config("qm9"))
+VARIANTS = (("scann_plus", "qm9", {}), ("base", "qm9", {"g_update": False}), ("no_norms", "qm9", {"use_attn_norm": False, "use_ga_norm": False}),
+            ("mp2018", "mp2018", {}))  # vocabulary 95, embedding 128, gaussian_d 6 (species are still drawn from H C N O F)
+for name, base, over in VARIANTS:
+    cfg = normalize_config(so.default_config(base))
     cfg["model"].update(over, n_attention=3)
     w = so.init_weights(cfg, 1234, perturb=True)
     model = HipModel(cfg, w, device=0, infer=True)
     rng = np.random.default_rng(hash(name) & 0xFFFF)
-    n_batches, t_stop = 0, time.time() + (t_end - time.time()) / 3
+    n_batches, t_stop = 0, time.time() + (t_end - time.time()) / (len(VARIANTS) - [v[0] for v in VARIANTS].index(name))
     while time.time() < t_stop:
         use_c = cfg["model"]["g_update"]
         inputs, _ = random_batch(rng, use_c, big=use_c)
