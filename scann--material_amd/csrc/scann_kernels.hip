@@ -73,7 +73,7 @@ __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a
 
 // ---- atom-tile kernel ------------------------------------------------------------------------------
 //
-// One workgroup (4 waves) per tile of TA = 64 atom rows, three workgroups per CU; every projection is a split-fp16 MFMA GEMM
+// One workgroup (4 waves) per tile of 64 (or, for small launches, 32: launch_atom) atom rows, three (four) workgroups per CU; every projection is a split-fp16 MFMA GEMM
 // of the tile (hi / lo planes in ONE LDS buffer in which x, the ResidualNorm hidden row, the centres and -- readout --
 // swish(after_Lc) take turns) against a 128x128 weight streamed from L2 in two halves of 32 VGPRs, the next half always
 // requested while the current one multiplies.  Everything between the GEMMs happens in the accumulator layout (lane = row,
@@ -83,18 +83,19 @@ __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a
 //   MODE 0: P1 = c W1 + bg, P3 = c W3, q = c Wq + bq                        centre / neighbour thirds of filter_geo :142-151, query :160
 //   MODE 1: q only (base branch)           MODE 2: z = swish(c Wa + ba); gq = z Wgq + b, gk = z Wgk + b   (scann_model.py:424, attention.py:269-272)
 
-template <bool FFN, int MODE>
-__global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
+template <bool FFN, int MODE, int RT>
+__global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) {
 #pragma clang fp contract(off)  // fusions are written out: both row-tile copies of a formula round alike (see edge_kernel)
-  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TA * PLANE_STRIDE * 2];  // hi / lo planes of the current GEMM input
-  __shared__ __attribute__((aligned(16))) float sRed[TA * 8];  // LayerNorm partial statistics [row][wave][mean, m2]
+  constexpr int TAR = 32 * RT;  // atom rows per tile
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TAR * PLANE_STRIDE * 2];  // hi / lo planes of the current GEMM input
+  __shared__ __attribute__((aligned(16))) float sRed[TAR * 8];  // LayerNorm partial statistics [row][wave][mean, m2]
   __shared__ __attribute__((aligned(16))) float sPar[7 * D];   // bf1 | bf2 | lnr_g | lnr_b | bA | bC | bD
   _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
-  _Float16* const sL = sH + TA * PLANE_STRIDE;
+  _Float16* const sL = sH + TAR * PLANE_STRIDE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
-  const int row0 = blockIdx.x * TA;
-  const int nrows = min(TA, a.n_atom - row0);
+  const int row0 = blockIdx.x * TAR;
+  const int nrows = min(TAR, a.n_atom - row0);
   constexpr float WINV = 1.0f / WSCALE;
   // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
   const _Float16* const firstW = MODE == 1 ? a.WCh : a.WAh;
@@ -115,10 +116,10 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   }
   // x rows of the tile in the accumulator layout, straight into registers (they stay there for the residual); rows clamped,
   // never guarded, and zero-filled afterwards so that the MFMAs see defined data
-  float4 xr[2][4];
-  unsigned ooff[2];  // byte offset of (output row, this lane's first column) in an [n_atom,128] tensor
+  float4 xr[RT][4];
+  unsigned ooff[RT];  // byte offset of (output row, this lane's first column) in an [n_atom,128] tensor
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int rc = row0 + min(lrow + 32 * rt, nrows - 1);
     const int src = a.x_index ? a.x_index[rc] : rc;
     ooff[rt] = ((unsigned)(row0 + lrow + 32 * rt) * D + cbase) * 4;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
     for (int j = 0; j < 4; ++j) xr[rt][j] = ld4(a.x, soff + 32 * j);
   }
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int row = lrow + 32 * rt;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -152,14 +153,14 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   __syncthreads();
   STAMP(a.stamps, 1);
 
-  f32x16 acc[2];
+  f32x16 acc[RT];
   if (FFN) {
     // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
-    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.Wf2h, wave, lane, acc);
+    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.Wf2h, wave, lane, acc);
     STAMP(a.stamps, 2);
     __syncthreads();  // every wave is done reading the x planes
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = lrow + 32 * rt;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -180,11 +181,11 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
     __syncthreads();
     STAMP(a.stamps, 3);
     // y = h W2 + b2 ; t = x + drop(y)
-    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, firstW, wave, lane, acc);
+    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, firstW, wave, lane, acc);
     STAMP(a.stamps, 4);
-    float mean32[2], m2[2];
+    float mean32[RT], m2[RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = lrow + 32 * rt;
       float s = 0.f;
 #pragma unroll
@@ -215,13 +216,13 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
       m2[rt] = xor32(v2);
     }
     if (lh == 0) {
-      *reinterpret_cast<float2*>(&sRed[(lrow * 4 + wave) * 2]) = make_float2(mean32[0], m2[0]);
-      *reinterpret_cast<float2*>(&sRed[((lrow + 32) * 4 + wave) * 2]) = make_float2(mean32[1], m2[1]);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float2*>(&sRed[((lrow + 32 * rt) * 4 + wave) * 2]) = make_float2(mean32[rt], m2[rt]);
     }
     __syncthreads();  // statistics complete; every wave is done reading the hidden planes
     STAMP(a.stamps, 5);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = lrow + 32 * rt;
       const float4 sa = *reinterpret_cast<const float4*>(&sRed[row * 8]), sb = *reinterpret_cast<const float4*>(&sRed[row * 8 + 4]);
       const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * 0.25f;
@@ -250,10 +251,10 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   }
 
   if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
-    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WBh, wave, lane, acc);
+    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WBh, wave, lane, acc);
     STAMP(a.stamps, 7);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 bg = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
@@ -261,10 +262,10 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
           st4(a.oA, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bg.x), fmaf(acc[rt][4 * j + 1], WINV, bg.y),
                                                    fmaf(acc[rt][4 * j + 2], WINV, bg.z), fmaf(acc[rt][4 * j + 3], WINV, bg.w)));
       }
-    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
+    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
     STAMP(a.stamps, 9);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (lrow + 32 * rt < nrows)
@@ -272,10 +273,10 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
   }
   if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
     STAMP(a.stamps, 10);
-    gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
+    gemm_tile<false, RT>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
     STAMP(a.stamps, 11);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 bq = *reinterpret_cast<const float4*>(&sPar[5 * D + cbase + 8 * j]);
@@ -286,10 +287,10 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
     STAMP(a.stamps, 12);
   }
   if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
-    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
+    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
     __syncthreads();  // every wave is done reading the centre planes
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = lrow + 32 * rt;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -303,9 +304,9 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
       }
     }
     __syncthreads();
-    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.WDh, wave, lane, acc);
+    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WDh, wave, lane, acc);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 bq = *reinterpret_cast<const float4*>(&sPar[5 * D + cbase + 8 * j]);
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
           st4(a.oC, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bq.x), fmaf(acc[rt][4 * j + 1], WINV, bq.y),
                                                    fmaf(acc[rt][4 * j + 2], WINV, bq.z), fmaf(acc[rt][4 * j + 3], WINV, bq.w)));
       }
-    gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
+    gemm_tile<false, RT>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 bk = *reinterpret_cast<const float4*>(&sPar[6 * D + cbase + 8 * j]);
@@ -328,8 +329,16 @@ __global__ __launch_bounds__(256, 3) void atom_kernel(AtomArgs a) {
 
 void launch_atom(const AtomArgs& a, hipStream_t s) {
   if (a.n_atom <= 0) return;
-  const dim3 grid((a.n_atom + TA - 1) / TA), block(256);
-#define SCANN_ATOM_CASE(F, M) hipLaunchKernelGGL((atom_kernel<F, M>), grid, block, 0, s, a)
+  // 32-row tiles (<= 128 VGPRs, 22 KB of LDS: four workgroups per CU = 1,024 slots) while they all fit ONE round of workgroups: the
+  // launch is then the latency chain of a tile, and a 32-row tile's chain is shorter (one batch per launch: 490 k -> 568 k
+  // molecules/s, training step 1.14 -> 1.09 ms).  Beyond that 64-row tiles (half the weight traffic per row).
+  const int rows = a.n_atom <= 32 * 1024 ? 32 : 64;
+  const dim3 grid((a.n_atom + rows - 1) / rows), block(256);
+#define SCANN_ATOM_CASE(F, M)                                                                  \
+  do {                                                                                         \
+    if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((atom_kernel<F, M, 2>), grid, block, 0, s, a);                     \
+  } while (0)
   if (a.ffn) {
     if (a.mode == 0) SCANN_ATOM_CASE(true, 0);
     else if (a.mode == 1) SCANN_ATOM_CASE(true, 1);

@@ -48,15 +48,15 @@ __device__ __forceinline__ void load_wsplit(const _Float16* __restrict__ Wp, int
 // X[rows][0 .. 16 KS) . W[0 .. 16 KS)[32 wave .. +32), X given as hi / lo planes in LDS.  Operand map of
 // v_mfma_f32_32x32x16_f16 (checked with exact integers by tools/mfma_f16_probe.hip): lane l supplies A[i = l & 31][k = 8 (l >> 5) + j]
 // and B[k = 8 (l >> 5) + j][j' = l & 31], j = 0..7; weights are the A operand, so the product comes out transposed.
-template <int KS, bool FIRST = false, int STRIDE = PLANE_STRIDE>
+template <int KS, bool FIRST = false, int STRIDE = PLANE_STRIDE, int RT = 2>
 __device__ __forceinline__ void mma_split(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, const f16x8 (&wh)[KS],
-                                          const f16x8 (&wl)[KS], int lane, f32x16 (&acc)[2]) {
+                                          const f16x8 (&wl)[KS], int lane, f32x16 (&acc)[RT]) {
   const int off = (lane & 31) * STRIDE + 8 * (lane >> 5);
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const f16x8 xh = *reinterpret_cast<const f16x8*>(sH + off + rt * 32 * STRIDE + 16 * s);
       const f16x8 xl = *reinterpret_cast<const f16x8*>(sL + off + rt * 32 * STRIDE + 16 * s);
       // FIRST: the chain starts from the inline constant 0 (no zero-fill of the 16 accumulator registers)
@@ -81,15 +81,15 @@ __device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off,
 
 // acc = X . W for the tile staged in (sH, sL), W's halves already in (whA, wlA) / (whB, wlB); when NEXT, the halves of the
 // following weight are requested into the same registers as soon as the MFMAs that read them have been issued.
-template <bool NEXT>
+template <bool NEXT, int RT = 2>
 __device__ __forceinline__ void gemm_tile(const _Float16* __restrict__ sH, const _Float16* __restrict__ sL, f16x8 (&whA)[4], f16x8 (&wlA)[4],
                                           f16x8 (&whB)[4], f16x8 (&wlB)[4], const _Float16* __restrict__ next, int wave, int lane,
-                                          f32x16 (&acc)[2]) {
-  mma_split<4, true>(sH, sL, whA, wlA, lane, acc);
+                                          f32x16 (&acc)[RT]) {
+  mma_split<4, true, PLANE_STRIDE, RT>(sH, sL, whA, wlA, lane, acc);
   __builtin_amdgcn_sched_barrier(0);
   if (NEXT) load_wsplit<4, 8>(next, wave, lane, whA, wlA, 0);
   __builtin_amdgcn_sched_barrier(0);
-  mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
+  mma_split<4, false, PLANE_STRIDE, RT>(sH + 64, sL + 64, whB, wlB, lane, acc);
   __builtin_amdgcn_sched_barrier(0);
   if (NEXT) load_wsplit<4, 8>(next, wave, lane, whB, wlB, 4);
   __builtin_amdgcn_sched_barrier(0);

@@ -980,7 +980,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
 #ifdef SCANN_STAMPS
     if (getenv("SCANN_STAMP_ATOM") && l >= 1 && l < L) {  // phase clocks of atom_kernel<true, 0> (the last such launch wins)
-      const int nt = (db->n_atom + TA - 1) / TA;
+      const int nt = (db->n_atom + 31) / 32;  // 32- or 64-row tiles (launch_atom): room for either
       if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)nt * 16 * sizeof(unsigned long long)));
       a.stamps = db->stamps;
       db->n_stamp = nt;
