@@ -145,6 +145,7 @@ struct EdgeArgs {
   // V = G.W2 + P1[i] + P3[j], T = swish(V) + G (LayerNorm_g input), ang = c[j] * geom', K = ang.Wk + bk -- all [n_edge,128]
   float *keep_V, *keep_T, *keep_ang, *keep_K;
   float* geom_out;             // where geom' goes (null: in place) -- keep-mode writes each layer's geometry to its own slice
+  int32_t tile_rows;           // 32 | 64: edge rows per tile of this batch's plan (selects the kernel instantiation)
   int32_t geom_dead;           // last layer of an inference forward: nobody reads geom' (scann_model.py:415-421 threads it to the NEXT layer only)
   const float* gd;             // [n_edge,20] raw distance basis (base)
   const float* edge_weight;    // [n_edge] (base)

@@ -374,11 +374,11 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 // Range: |activation| and |weight * 256| must stay below 65504 (scann_load_weights refuses larger weights; activations here
 // are LayerNorm / swish outputs of O(1..10)).
 
-template <bool GUPD>
-__global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
+template <bool GUPD, int RT>
+__global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) {
 #pragma clang fp contract(off)  // fusions are written out (fmaf): both unrolled row-tile copies of a formula must round alike,
                                 // so that a row's result does not depend on where in a tile it lands (batch-composition invariance)
-  constexpr int TEK = 64;
+  constexpr int TEK = 32 * RT;  // edge rows per tile: 64 (three workgroups per CU) or, for launches of one round, 32 (four)
   // hi / lo planes of the A operand (G or the basis, then ang): 2 x 64 x 272 B; afterwards K as fp32 [64][LDS_STRIDE]
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TEK * PLANE_STRIDE * 2];
   __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];  // P1 rows, then query rows of the tile's atoms, then context
@@ -417,11 +417,11 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
     load_wsplit<2>(a.p.Wfh, wave, lane, th, tl);
     whA[0] = th[0]; whA[1] = th[1]; wlA[0] = tl[0]; wlA[1] = tl[1];
   }
-  unsigned nboff[2];  // byte offset of (neighbour atom row, this lane's first column) in an [n_atom,128] tensor
-  int ctr[2];         // tile-local centre atom of this lane's two edge rows
-  float ewgt[2] = {0.f, 0.f};
+  unsigned nboff[RT];  // byte offset of (neighbour atom row, this lane's first column) in an [n_atom,128] tensor
+  int ctr[RT];         // tile-local centre atom of this lane's two edge rows
+  float ewgt[RT] = {};
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int e = ne > 0 ? eb + min(lrow + 32 * rt, nem1) : 0;
     nboff[rt] = ((unsigned)(ne > 0 ? a.edge_col[e] : 0) * D + cbase) * 4;
     ctr[rt] = ne > 0 ? a.edge_row[e] - tile.atom_begin : 0;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   const float bkc = a.p.bk[tid & (D - 1)];
   const float par0 = GUPD ? (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)] : a.p.bfg[tid & (D - 1)];
   const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
-  float4 greg[2][4];
+  float4 greg[RT][4];
   {
     const int r = tid >> 2, sub = tid & 3;  // staging map of the base branch: 4 threads per edge row
     const int rs = r < ne ? r : nem1;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
       // for the residual (attention.py:153); a tile without edges reads (and ignores) a valid row
       const float* gsrc = ne > 0 ? a.geom : a.P1;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         const unsigned goff = ((ne > 0 ? (unsigned)(eb + min(lrow + 32 * rt, nem1)) : (unsigned)tile.atom_begin) * D + cbase) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) greg[rt][j] = ld4(gsrc, goff + 32 * j);
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
         *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
       }
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         const int row = lrow + 32 * rt;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -482,8 +482,10 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
         if (r >= ne || c4 > 4) gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         f16x4 h, l;
         split4(gv[i], h, l);
-        *reinterpret_cast<f16x4*>(sH + r * PLANE_STRIDE + 4 * c4) = h;
-        *reinterpret_cast<f16x4*>(sL + r * PLANE_STRIDE + 4 * c4) = l;
+        if (r < TEK) {  // (32-row tiles: the upper half of the staging threads has no row)
+          *reinterpret_cast<f16x4*>(sH + r * PLANE_STRIDE + 4 * c4) = h;
+          *reinterpret_cast<f16x4*>(sL + r * PLANE_STRIDE + 4 * c4) = l;
+        }
       }
     }
   }
@@ -494,21 +496,21 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   __syncthreads();
   STAMP(a.stamps, 1);
 
-  float4 p3r[2][4];
-  f32x16 acc[2];
+  float4 p3r[RT][4];
+  f32x16 acc[RT];
   if (GUPD) {
-    mma_split<4, true>(sH, sL, whA, wlA, lane, acc);
+    mma_split<4, true, PLANE_STRIDE, RT>(sH, sL, whA, wlA, lane, acc);
     __builtin_amdgcn_sched_barrier(0);
     // gathered neighbour thirds P3[j] = c_j W3 (into the registers the first weight half leaves): in flight over the second half
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) p3r[rt][j] = ld4(a.P3, nboff[rt] + 32 * j);
     __builtin_amdgcn_sched_barrier(0);
-    mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
+    mma_split<4, false, PLANE_STRIDE, RT>(sH + 64, sL + 64, whB, wlB, lane, acc);
   } else {
     f16x8 th[2] = {whA[0], whA[1]}, tl[2] = {wlA[0], wlA[1]};
-    mma_split<2, true>(sH, sL, th, tl, lane, acc);
+    mma_split<2, true, PLANE_STRIDE, RT>(sH, sL, th, tl, lane, acc);
   }
   STAMP(a.stamps, 2);
   __builtin_amdgcn_sched_barrier(0);
@@ -517,14 +519,16 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   const int qa = tid >> 5;  // query rows qa, qa + 8, qa + 16 of the tile go through this thread
   const unsigned qoff = (unsigned)tile.atom_begin * (D * 4) + (tid & 31) * 16;
   float4 q0, q1, q2;
-  float4 cn[2][4];
-  const unsigned eoff[2] = {((unsigned)(eb + lrow) * D + cbase) * 4, ((unsigned)(eb + lrow + 32) * D + cbase) * 4};  // (edge row, first column) bytes
+  float4 cn[RT][4];
+  unsigned eoff[RT];  // (edge row, first column) bytes
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) eoff[rt] = ((unsigned)(eb + lrow + 32 * rt) * D + cbase) * 4;
   float* const gout = a.geom_out ? a.geom_out : a.geom;
   if (GUPD) {
     // geometry update (attention.py:141-153) on the accumulators: T = swish(U + P1[i] + P3[j]) + G
-    float mean32[2], m2[2];
+    float mean32[RT], m2[RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = lrow + 32 * rt;
       const float* p1 = sQ + ctr[rt] * LDS_STRIDE + cbase;
       float s = 0.f;
@@ -558,13 +562,13 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
       __builtin_amdgcn_sched_barrier(0);  // one row tile at a time: hoisting both tiles' LDS reads costs 40 VGPRs (spills)
     }
     if (lh == 0) {
-      *reinterpret_cast<float2*>(&sE[((lrow) * 4 + wave) * 2]) = make_float2(mean32[0], m2[0]);
-      *reinterpret_cast<float2*>(&sE[((lrow + 32) * 4 + wave) * 2]) = make_float2(mean32[1], m2[1]);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float2*>(&sE[((lrow + 32 * rt) * 4 + wave) * 2]) = make_float2(mean32[rt], m2[rt]);
     }
     __builtin_amdgcn_sched_barrier(0);
     // the P3 registers are free: neighbour centre rows c[j] (attention.py:136) and the key weights land over the barrier
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
     load_wsplit<4, 8>(a.p.Wkh, wave, lane, whA, wlA, 0);  // first half of the key weights; the second half is requested at the GEMM
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
     q2 = ld4(a.q, qoff + min(qa + 16, natom - 1) * (D * 4));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = lrow + 32 * rt;
       const float4 sa = *reinterpret_cast<const float4*>(&sE[row * 8]), sb = *reinterpret_cast<const float4*>(&sE[row * 8 + 4]);
       const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * 0.25f;
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   } else {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
     load_wsplit<4, 8>(a.p.Wkh, wave, lane, whA, wlA, 0);
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     // base SCANN: geomL = swish(gd Wf + bf) * weight (attention.py:155); ang = c[j] * geomL
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int row = lrow + 32 * rt;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -656,14 +660,14 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   // K = ang . Wk + bk (attention.py:163); the second half of Wk arrives under the first half's MFMAs
   load_wsplit<4, 8>(a.p.Wkh, wave, lane, whB, wlB, 4);
   __builtin_amdgcn_sched_barrier(0);
-  mma_split<4, true>(sH, sL, whA, wlA, lane, acc);
-  mma_split<4>(sH + 64, sL + 64, whB, wlB, lane, acc);
+  mma_split<4, true, PLANE_STRIDE, RT>(sH, sL, whA, wlA, lane, acc);
+  mma_split<4, false, PLANE_STRIDE, RT>(sH + 64, sL + 64, whB, wlB, lane, acc);
   STAMP(a.stamps, 5);
   // logits e[n, h] = (q[i, h, :] * 16^-0.5) . K[n, h, :] (attention.py:180-183) from the accumulators: this lane holds 8 of the
   // 16 columns of heads 2 wave (j = 0, 1) and 2 wave + 1 (j = 2, 3) of its rows; its partner lane (^32) holds the other 8
-  float lg[2][2];
+  float lg[RT][2];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const float* qrow = sQ + ctr[rt] * LDS_STRIDE + cbase;
 #pragma unroll
     for (int hp = 0; hp < 2; ++hp) {
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256, 3) void edge_kernel(EdgeArgs a) {
   }
   __syncthreads();  // every wave is done reading the ang planes: K may overwrite them
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int row = lrow + 32 * rt;
     sE[row * NHEAD + 2 * wave + lh] = lh ? lg[rt][1] : lg[rt][0];
 #pragma unroll
@@ -829,8 +833,14 @@ void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf,
 void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
   const dim3 grid(a.n_tile), block(256);
-  if (a.g_update) hipLaunchKernelGGL((edge_kernel<true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((edge_kernel<false>), grid, block, 0, s, a);
+  // tile_rows is the height the batch's tile plan was made for (scann_batch_upload: 32 for launches of one round of workgroups)
+  if (a.tile_rows == 32) {
+    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((edge_kernel<false, 1>), grid, block, 0, s, a);
+  } else {
+    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((edge_kernel<false, 2>), grid, block, 0, s, a);
+  }
 }
 
 // ---- basis kernel ----------------------------------------------------------------------------------

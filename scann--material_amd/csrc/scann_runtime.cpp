@@ -757,9 +757,16 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   int tile_rows = TE_MAX;
   {
     std::string err;
-    const int r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles,
-                             tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err);
+    int r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles,
+                       tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err);
     if (r) return fail(h, r, "scann_batch_upload: " + err);
+    // A launch that fits ONE round of workgroups is the latency chain of a tile: 32-row tiles (four workgroups per CU = 1,024 slots)
+    // make that chain shorter.  Only when no atom needs chunking at 32 rows.
+    if (E > 0 && E <= 32 * 1024 && max_degree <= 32) {
+      r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, 32, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
+                     &tile_rows, &max_degree, &n_slot, err);
+      if (r) return fail(h, r, "scann_batch_upload: " + err);
+    }
   }
   const int32_t n_big = (int32_t)big_tab.size() / 3;
   HIPCHK(h, hipSetDevice(h->device));
@@ -991,7 +998,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (h->debug && !direct) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
     if (l == L) break;
     EdgeArgs ea{};
-    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update;
+    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update; ea.tile_rows = db->tile_rows;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = g_of(l); ea.geom_out = direct && c.g_update ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
     ea.geom_dead = (l == L - 1 && !h->debug) ? 1 : 0;  // the geometry leaving the last layer is never consumed (141 MB of writes per 16-batch launch)
