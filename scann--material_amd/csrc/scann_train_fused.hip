@@ -41,9 +41,10 @@ __device__ __forceinline__ void row_scale(float rowmax, float& scale, float& pos
 }
 
 // largest magnitude of the row: this lane's 16 columns, its partner lane, then (through LDS) the row's four waves
-__device__ __forceinline__ void put_rowmax(float* __restrict__ sMax, const float4 (&v)[2][4], int lrow, int lh, int wave) {
+template <int RT>
+__device__ __forceinline__ void put_rowmax(float* __restrict__ sMax, const float4 (&v)[RT][4], int lrow, int lh, int wave) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float m = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -70,9 +71,10 @@ __device__ __forceinline__ void put_planes(_Float16* __restrict__ sH, _Float16* 
 }
 
 // LayerNorm statistics of the tile's rows (as in atom_kernel): per-lane partial (mean of 32, M2 of 32) -> LDS
-__device__ __forceinline__ void put_stats(float* __restrict__ sRed, const float4 (&x)[2][4], int lrow, int lh, int wave) {
+template <int RT>
+__device__ __forceinline__ void put_stats(float* __restrict__ sRed, const float4 (&x)[RT][4], int lrow, int lh, int wave) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s += f4sum_(x[rt][j]);
@@ -97,12 +99,13 @@ __device__ __forceinline__ void get_stats(const float* __restrict__ sRed, int ro
 
 // LayerNorm backward in the accumulator layout, first half: x -> xhat, dy -> ax = dy * gamma; the row sums of ax and ax * xhat go
 // to sRed, the tile's column sums of dy * xhat and dy (gamma / beta gradients) to the staging buffer (two row tiles pre-added).
-__device__ __forceinline__ void ln_bwd_head(float4 (&x)[2][4], float4 (&dy)[2][4], const float* __restrict__ sStat, const float* __restrict__ sGamma,
-                                            float* __restrict__ sSum, float* __restrict__ stage, float (&rstd)[2], int lrow, int lh, int wave,
+template <int RT>
+__device__ __forceinline__ void ln_bwd_head(float4 (&x)[RT][4], float4 (&dy)[RT][4], const float* __restrict__ sStat, const float* __restrict__ sGamma,
+                                            float* __restrict__ sSum, float* __restrict__ stage, float (&rstd)[RT], int lrow, int lh, int wave,
                                             int cbase) {
   float4 dgm[4], dbt[4];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float mean;
     get_stats(sStat, lrow + 32 * rt, mean, rstd[rt]);
     float p1 = 0.f, p2 = 0.f;
@@ -137,8 +140,9 @@ __device__ __forceinline__ void ln_bwd_head(float4 (&x)[2][4], float4 (&dy)[2][4
   }
 }
 // second half (after the barrier): x := dx = rstd * (ax - mean(ax) - xhat * mean(ax * xhat)); the workgroup's gamma / beta slot
-__device__ __forceinline__ void ln_bwd_tail(float4 (&x)[2][4], const float4 (&ax)[2][4], const float* __restrict__ sSum, const float* __restrict__ stage,
-                                            const float (&rstd)[2], float* __restrict__ dgamma, float* __restrict__ dbeta, int lrow, int tid) {
+template <int RT>
+__device__ __forceinline__ void ln_bwd_tail(float4 (&x)[RT][4], const float4 (&ax)[RT][4], const float* __restrict__ sSum, const float* __restrict__ stage,
+                                            const float (&rstd)[RT], float* __restrict__ dgamma, float* __restrict__ dbeta, int lrow, int tid) {
   {
     const int which = tid >> 7, col = tid & (D - 1);
     float tot = 0.f;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void ln_bwd_tail(float4 (&x)[2][4], const float4 (&ax
     (which ? dbeta : dgamma)[(size_t)blockIdx.x * D + col] = tot;  // summed in slot order by wgrad_reduce_kernel
   }
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int row = lrow + 32 * rt;
     const float4 sa = *reinterpret_cast<const float4*>(&sSum[row * 8]), sb = *reinterpret_cast<const float4*>(&sSum[row * 8 + 4]);
     const float m1 = ((sa.x + sa.z) + (sb.x + sb.z)) * (1.0f / D), m2 = ((sa.y + sa.w) + (sb.y + sb.w)) * (1.0f / D);
@@ -165,19 +169,21 @@ __device__ __forceinline__ void ln_bwd_tail(float4 (&x)[2][4], const float4 (&ax
 // ---- ResidualNorm backward (attention.py:37-40): c' = LN(T2), T2 = x + drop(Y), Y = H1 W2 + b2, H1 = swish(pre1), pre1 = x W1 + b1 ----
 // in : dC = d loss / d c' (+ optionally the projections of the layer above: dC += X0 W0^T + X1 W1^T + X2 W2^T), T2, pre1
 // out: dY (operand of dW2), dpre1 (operand of dW1), dCtx = dT2 + dpre1 W1^T, gamma / beta slots
-__global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * 64 * PLANE_STRIDE * 2];  // hi / lo planes | gamma-beta staging
-  __shared__ __attribute__((aligned(16))) float sStat[64 * 8], sSum[64 * 8];
-  __shared__ __attribute__((aligned(16))) float sMax[3][64 * 4];
+template <int RT>
+__global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void rn_bwd_kernel(RnBwdArgs a) {
+  constexpr int TR = 32 * RT;  // rows per tile
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * 64 * PLANE_STRIDE * 2];  // hi / lo planes of <= 64 rows | gamma-beta staging (64 rows of fp32 either way)
+  __shared__ __attribute__((aligned(16))) float sStat[TR * 8], sSum[TR * 8];
+  __shared__ __attribute__((aligned(16))) float sMax[3][TR * 4];
   __shared__ __attribute__((aligned(16))) float sGamma[D];
   _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
-  _Float16* const sL = sH + 64 * PLANE_STRIDE;
+  _Float16* const sL = sH + TR * PLANE_STRIDE;
   float* const stage = reinterpret_cast<float*>(sTile);
   static_assert(64 * STAGE_STRIDE * 4 <= (int)sizeof(sTile), "gamma / beta staging must fit the plane buffer");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
-  const int row0 = blockIdx.x * 64;
-  const int nrows = min(64, a.n_atom - row0);
+  const int row0 = blockIdx.x * TR;
+  const int nrows = min(TR, a.n_atom - row0);
 
   f16x8 whA[4], wlA[4], whB[4], wlB[4];
   const _Float16* const firstW = a.n_pre > 0 ? a.Wh[0] : a.Wf2Th;
@@ -185,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
   load_wsplit<4, 8>(firstW, wave, lane, whB, wlB, 4);
   if (tid < D) sGamma[tid] = a.gamma[tid];
 
-  unsigned off[2];
-  float4 x[2][4], dy[2][4];
+  unsigned off[RT];
+  float4 x[RT][4], dy[RT][4];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     off[rt] = ((unsigned)(row0 + min(lrow + 32 * rt, nrows - 1)) * D + cbase) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -196,27 +202,27 @@ __global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
       dy[rt][j] = ld4(a.dC, off[rt] + 32 * j);
     }
   }
-  f32x16 acc[2];
+  f32x16 acc[RT];
   // projections of the layer above that end in this tile's rows (scann_train.hip: linear_sum_kernel)
   for (int t = 0; t < a.n_pre; ++t) {
-    float4 v[2][4];
+    float4 v[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[rt][j] = ld4(a.X[t], off[rt] + 32 * j);
-    put_rowmax(sMax[0], v, lrow, lh, wave);
+    put_rowmax<RT>(sMax[0], v, lrow, lh, wave);
     __syncthreads();  // (also: every wave is done with the planes of the previous term)
-    float post[2];
+    float post[RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float scale;
       row_scale(get_rowmax(sMax[0], lrow + 32 * rt), scale, post[rt]);
       put_planes(sH, sL, v[rt], scale, lrow + 32 * rt, cbase);
     }
     __syncthreads();
-    gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, t + 1 < a.n_pre ? a.Wh[t + 1] : a.Wf2Th, wave, lane, acc);
+    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, t + 1 < a.n_pre ? a.Wh[t + 1] : a.Wf2Th, wave, lane, acc);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         dy[rt][j].x = fmaf(acc[rt][4 * j], post[rt], dy[rt][j].x);
@@ -226,26 +232,26 @@ __global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
       }
   }
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
     if (lrow + 32 * rt >= nrows)
 #pragma unroll
       for (int j = 0; j < 4; ++j) dy[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the end contribute exact zeros
   if (a.dC_out) {  // the complete d loss / d c' (operand of nothing here; kept for the layer's own consumers when asked)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
       if (lrow + 32 * rt < nrows)
 #pragma unroll
         for (int j = 0; j < 4; ++j) st4(a.dC_out, off[rt] + 32 * j, dy[rt][j]);
   }
-  put_stats(sStat, x, lrow, lh, wave);
+  put_stats<RT>(sStat, x, lrow, lh, wave);
   __syncthreads();  // statistics (and sGamma) visible; the planes are free
-  float rstd[2];
-  ln_bwd_head(x, dy, sStat, sGamma, sSum, stage, rstd, lrow, lh, wave, cbase);
+  float rstd[RT];
+  ln_bwd_head<RT>(x, dy, sStat, sGamma, sSum, stage, rstd, lrow, lh, wave, cbase);
   __syncthreads();
-  ln_bwd_tail(x, dy, sSum, stage, rstd, a.dgamma, a.dbeta, lrow, tid);  // x = dT2
+  ln_bwd_tail<RT>(x, dy, sSum, stage, rstd, a.dgamma, a.dbeta, lrow, tid);  // x = dT2
   // dY = dT2 through the Dropout mask of the forward (attention.py:29)
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float4 v = x[rt][j];
@@ -258,11 +264,11 @@ __global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
       }
       dy[rt][j] = v;
     }
-  put_rowmax(sMax[1], dy, lrow, lh, wave);
+  put_rowmax<RT>(sMax[1], dy, lrow, lh, wave);
   __syncthreads();  // row maxima visible; every thread is done with the staging buffer
-  float post[2];
+  float post[RT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int row = lrow + 32 * rt;
     float scale;
     row_scale(get_rowmax(sMax[1], row), scale, post[rt]);
@@ -273,23 +279,23 @@ __global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
   }
   // pre1 rows (for swish') arrive under the GEMM, in the registers dY just left
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dy[rt][j] = ld4(a.pre1, off[rt] + 32 * j);
   __syncthreads();
-  gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.Wf1Th, wave, lane, acc);  // dH1 = dY . W2^T
+  gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.Wf1Th, wave, lane, acc);  // dH1 = dY . W2^T
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 p = dy[rt][j];
       dy[rt][j] = make_float4(acc[rt][4 * j] * post[rt] * dsw_(p.x), acc[rt][4 * j + 1] * post[rt] * dsw_(p.y),
                               acc[rt][4 * j + 2] * post[rt] * dsw_(p.z), acc[rt][4 * j + 3] * post[rt] * dsw_(p.w));  // dpre1
     }
-  put_rowmax(sMax[2], dy, lrow, lh, wave);
+  put_rowmax<RT>(sMax[2], dy, lrow, lh, wave);
   __syncthreads();  // every wave is done reading the dY planes
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int row = lrow + 32 * rt;
     float scale;
     row_scale(get_rowmax(sMax[2], row), scale, post[rt]);
@@ -299,9 +305,9 @@ __global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
     put_planes(sH, sL, dy[rt], scale, row, cbase);
   }
   __syncthreads();
-  gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);  // dpre1 . W1^T
+  gemm_tile<false, RT>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);  // dpre1 . W1^T
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
     if (lrow + 32 * rt < nrows)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -313,28 +319,30 @@ __global__ __launch_bounds__(256, 2) void rn_bwd_kernel(RnBwdArgs a) {
 // ---- key / gate / geometry-update backward of one layer's edges (attention.py:141-163) -------------------------------------
 // in : dK, centres c (gate ang = c[j] * G'), dG' of the layer below (null for the last layer), T (LayerNorm_g input), V
 // out: dang = dK Wk^T, dV = dT * swish'(V), dG = dT + dV W2^T, gamma / beta slots      (dT = LN_g backward of dang * c[j] + dG')
-__global__ __launch_bounds__(256, 2) void edge_bwd_kernel(EdgeBwdArgs a) {
+template <int RT>
+__global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void edge_bwd_kernel(EdgeBwdArgs a) {
+  constexpr int TR = 32 * RT;  // rows per tile
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * 64 * PLANE_STRIDE * 2];
-  __shared__ __attribute__((aligned(16))) float sStat[64 * 8], sSum[64 * 8];
-  __shared__ __attribute__((aligned(16))) float sMax[2][64 * 4];
+  __shared__ __attribute__((aligned(16))) float sStat[TR * 8], sSum[TR * 8];
+  __shared__ __attribute__((aligned(16))) float sMax[2][TR * 4];
   __shared__ __attribute__((aligned(16))) float sGamma[D];
   _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
-  _Float16* const sL = sH + 64 * PLANE_STRIDE;
+  _Float16* const sL = sH + TR * PLANE_STRIDE;
   float* const stage = reinterpret_cast<float*>(sTile);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
-  const int row0 = blockIdx.x * 64;
-  const int nrows = min(64, a.n_edge - row0);
+  const int row0 = blockIdx.x * TR;
+  const int nrows = min(TR, a.n_edge - row0);
 
   f16x8 whA[4], wlA[4], whB[4], wlB[4];
   load_wsplit<4, 8>(a.WkTh, wave, lane, whA, wlA, 0);
   load_wsplit<4, 8>(a.WkTh, wave, lane, whB, wlB, 4);
   if (tid < D) sGamma[tid] = a.gamma[tid];
 
-  unsigned off[2], noff[2];
-  float4 x[2][4], dy[2][4];
+  unsigned off[RT], noff[RT];
+  float4 x[RT][4], dy[RT][4];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int rc = row0 + min(lrow + 32 * rt, nrows - 1);
     off[rt] = ((unsigned)rc * D + cbase) * 4;
     noff[rt] = ((unsigned)a.nb[rc] * D + cbase) * 4;
@@ -344,26 +352,26 @@ __global__ __launch_bounds__(256, 2) void edge_bwd_kernel(EdgeBwdArgs a) {
       x[rt][j] = ld4(a.T, off[rt] + 32 * j);
     }
   }
-  put_rowmax(sMax[0], dy, lrow, lh, wave);
-  put_stats(sStat, x, lrow, lh, wave);
+  put_rowmax<RT>(sMax[0], dy, lrow, lh, wave);
+  put_stats<RT>(sStat, x, lrow, lh, wave);
   __syncthreads();
-  float post[2];
+  float post[RT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float scale;
     row_scale(get_rowmax(sMax[0], lrow + 32 * rt), scale, post[rt]);
     put_planes(sH, sL, dy[rt], scale, lrow + 32 * rt, cbase);
   }
   // the gate's centre rows c[j] arrive under the GEMM
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dy[rt][j] = ld4(a.c, noff[rt] + 32 * j);
   __syncthreads();
-  f32x16 acc[2];
-  gemm_tile<true>(sH, sL, whA, wlA, whB, wlB, a.W2Th, wave, lane, acc);  // dang = dK . Wk^T
+  f32x16 acc[RT];
+  gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.W2Th, wave, lane, acc);  // dang = dK . Wk^T
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const bool live = lrow + 32 * rt < nrows;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -380,21 +388,21 @@ __global__ __launch_bounds__(256, 2) void edge_bwd_kernel(EdgeBwdArgs a) {
     }
   }
   __syncthreads();  // every wave is done reading the dK planes: the staging buffer may be written
-  float rstd[2];
-  ln_bwd_head(x, dy, sStat, sGamma, sSum, stage, rstd, lrow, lh, wave, cbase);
+  float rstd[RT];
+  ln_bwd_head<RT>(x, dy, sStat, sGamma, sSum, stage, rstd, lrow, lh, wave, cbase);
   __syncthreads();
-  ln_bwd_tail(x, dy, sSum, stage, rstd, a.dgamma, a.dbeta, lrow, tid);  // x = dT
+  ln_bwd_tail<RT>(x, dy, sSum, stage, rstd, a.dgamma, a.dbeta, lrow, tid);  // x = dT
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 v = ld4(a.V, off[rt] + 32 * j), t = x[rt][j];
       dy[rt][j] = make_float4(t.x * dsw_(v.x), t.y * dsw_(v.y), t.z * dsw_(v.z), t.w * dsw_(v.w));  // dV
     }
-  put_rowmax(sMax[1], dy, lrow, lh, wave);
+  put_rowmax<RT>(sMax[1], dy, lrow, lh, wave);
   __syncthreads();  // row maxima visible; every thread is done with the staging buffer
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int row = lrow + 32 * rt;
     float scale;
     row_scale(get_rowmax(sMax[1], row), scale, post[rt]);
@@ -404,9 +412,9 @@ __global__ __launch_bounds__(256, 2) void edge_bwd_kernel(EdgeBwdArgs a) {
     put_planes(sH, sL, dy[rt], scale, row, cbase);
   }
   __syncthreads();
-  gemm_tile<false>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);  // dV . W2^T
+  gemm_tile<false, RT>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);  // dV . W2^T
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
     if (lrow + 32 * rt < nrows)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -468,21 +476,26 @@ __global__ __launch_bounds__(256) void atom_gather3_kernel(const float4* __restr
   dP1[i] = u;
 }
 
-int tile_slots(int rows) { return (rows + 63) / 64; }
+// 32-row tiles while the launch fits one round of workgroups (three per CU): it is then the latency chain of a tile, and a 32-row
+// tile's chain is shorter (same choice as launch_atom / the edge-tile plan); 64-row tiles beyond
+static int fused_tile_rows(int rows) { return rows <= 32 * 768 ? 32 : 64; }
+int tile_slots(int rows) { return (rows + fused_tile_rows(rows) - 1) / fused_tile_rows(rows); }
 
 void launch_rn_bwd(WgradCtx& ctx, RnBwdArgs a, float* dgamma, float* dbeta, hipStream_t s) {
   if (a.n_atom <= 0) return;
   const int n = tile_slots(a.n_atom);
   a.dgamma = reserve_vec(ctx, dgamma, n);
   a.dbeta = reserve_vec(ctx, dbeta, n);
-  hipLaunchKernelGGL(rn_bwd_kernel, dim3(n), dim3(256), 0, s, a);
+  if (fused_tile_rows(a.n_atom) == 32) hipLaunchKernelGGL(rn_bwd_kernel<1>, dim3(n), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(rn_bwd_kernel<2>, dim3(n), dim3(256), 0, s, a);
 }
 void launch_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, float* dgamma, float* dbeta, hipStream_t s) {
   if (a.n_edge <= 0) return;
   const int n = tile_slots(a.n_edge);
   a.dgamma = reserve_vec(ctx, dgamma, n);
   a.dbeta = reserve_vec(ctx, dbeta, n);
-  hipLaunchKernelGGL(edge_bwd_kernel, dim3(n), dim3(256), 0, s, a);
+  if (fused_tile_rows(a.n_edge) == 32) hipLaunchKernelGGL(edge_bwd_kernel<1>, dim3(n), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(edge_bwd_kernel<2>, dim3(n), dim3(256), 0, s, a);
 }
 void launch_atom_gather3(const float* dang, const float* G, const float* dV, const int* edge_offset, const int* in_off, const int* in_edge,
                          float* dC, float* dP1, float* dP3, int n_atom, hipStream_t s) {
