@@ -1534,20 +1534,16 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   ra.dgq = t2; ra.dgk = rdgk; ra.rep_out = w.rep; ra.dpre_out = w.dpre;
   ra.dwo = g("predict_property/kernel"); ra.dbo = g("predict_property/bias");
   launch_readout_bwd(ra, s);
-  {
-    hipStream_t ws = fork();
-    launch_wgrad(wg, w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B, ws);
-    launch_wgrad3(wg, t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), rdgk, g("global_attention/key/kernel"),
-                  g("global_attention/key/bias"), nullptr, nullptr, nullptr, A, ws);
-  }
+  // the readout's four weight gradients ride with the first layer's launch on the side stream (their operands -- rep, dpre, z = t1,
+  // dgq = t2, dgk and dpreA in the readout's operand set -- are not written again before the end of the step): no fork of their own,
+  // each of which costs the main stream ~7 us (tools/fork_probe.hip)
+  wgrad_add(wg, w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B);
+  wgrad_add(wg, t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), A);
+  wgrad_add(wg, t1, rdgk, g("global_attention/key/kernel"), g("global_attention/key/bias"), A);
   launch_linear_sum(t2, h->WgqT, rdgk, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
   float* const dpreA = dQ;
   launch_swish_bwd(t0, t4, dpreA, nA, s);                     // dpreA (t2 is still being read beside us)
-  {
-    hipStream_t ws = fork();
-    launch_wgrad(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A, ws);
-    if (side) wgrad_flush(wg, ws);
-  }
+  wgrad_add(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A);
   launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
@@ -1704,6 +1700,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   }
   if (wg.off > w.wpart_floats)
     return fail(h, SCANN_ERR_HIP, "scann_train_backward: weight-gradient partial arena overrun");
+  if (!wg.jobs.empty()) wgrad_launch(wg, s);  // a model without LocalAttention layers: the readout's gradients were never launched
   join();
   if (ev_basis) (void)hipStreamWaitEvent(s, ev_basis, 0);
   wgrad_flush(wg, s);  // ONE launch adds the per-slab partials of every weight gradient, in slab order

@@ -51,10 +51,6 @@ int wgrad_slabs(int rows);
 void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows);
 void wgrad_launch(WgradCtx& ctx, hipStream_t s);
 void wgrad_flush(WgradCtx& ctx, hipStream_t s);
-void launch_wgrad(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s);
-// up to three weight gradients that share the left operand X in one launch (null dY1 / dY2: fewer)
-void launch_wgrad3(WgradCtx& ctx, const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
-                   const float* dY2, float* dW2, float* db2, int rows, hipStream_t s);
 
 void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags, hipStream_t s);
 

@@ -493,18 +493,6 @@ void wgrad_launch(WgradCtx& ctx, hipStream_t s) {
   }
   ctx.jobs.clear();
 }
-void launch_wgrad3(WgradCtx& ctx, const float* X, const float* dY0, float* dW0, float* db0, const float* dY1, float* dW1, float* db1,
-                   const float* dY2, float* dW2, float* db2, int rows, hipStream_t s) {
-  wgrad_add(ctx, X, dY0, dW0, db0, rows);
-  if (dY1) wgrad_add(ctx, X, dY1, dW1, db1, rows);
-  if (dY2) wgrad_add(ctx, X, dY2, dW2, db2, rows);
-  wgrad_launch(ctx, s);
-}
-void launch_wgrad(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, hipStream_t s) {
-  wgrad_add(ctx, X, dY, dW, db, rows);
-  wgrad_launch(ctx, s);
-}
-
 // ---- elementwise ---------------------------------------------------------------------------------------------------
 
 __global__ void swish_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dout,
