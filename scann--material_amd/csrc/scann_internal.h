@@ -123,6 +123,7 @@ struct AtomArgs {
   // training forward: ResidualNorm intermediates the backward would otherwise recompute (null in inference), [n_atom,128]:
   // pre1 = x W1 + b1, H1 = swish(pre1), T2 = x + drop(H1 W2 + b2) (the LayerNorm input)
   float *keep_pre1, *keep_H1, *keep_T2;
+  float *keep_preA, *keep_z;   // mode 2, training forward: after_Lc pre-activation and swish output [n_atom,128]
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS, env SCANN_STAMP_ATOM=1) only: [n_tiles,16] phase clocks
 };
 void launch_atom(const AtomArgs& a, hipStream_t s);

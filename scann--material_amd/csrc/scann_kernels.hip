@@ -295,8 +295,13 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 bv = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
-        const float4 z = f4swish(make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
-                                             fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w)));
+        const float4 pre = make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
+                                       fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
+        const float4 z = f4swish(pre);
+        if (a.keep_preA && row < nrows) {  // training forward: after_Lc pre-activation and output, kept for the backward
+          st4(a.keep_preA, ooff[rt] + 32 * j, pre);
+          st4(a.keep_z, ooff[rt] + 32 * j, z);
+        }
         f16x4 h, l;
         split4(z, h, l);
         *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;

@@ -173,6 +173,7 @@ struct scann_dbatch {
   EdgeTile* tiles = nullptr;
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128], training forward (owned by the train workspace)
   float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;  // ResidualNorm intermediates, [L][n_atom,128]
+  float *keep_preA = nullptr, *keep_z = nullptr;  // after_Lc pre-activation / output [n_atom,128]
   bool kept = false;  // the last training forward filled them
   hipEvent_t busy_ev = nullptr;  // end of the last scann_train_step that used the batch (scann_batch_release)
   int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
@@ -984,6 +985,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       a.mode = 2;
       a.WAh = h->head.Wah; a.bA = h->head.ba; a.WCh = h->head.Wgqh; a.bC = h->head.bgq; a.WDh = h->head.Wgkh; a.bD = h->head.bgk;
       a.oB = db->gk; a.oC = db->gq;
+      if (direct && h->in_train_forward && db->keep_preA) { a.keep_preA = db->keep_preA; a.keep_z = db->keep_z; }
     }
 #ifdef SCANN_STAMPS
     if (getenv("SCANN_STAMP_ATOM") && l >= 1 && l < L) {  // phase clocks of atom_kernel<true, 0> (the last such launch wins)
@@ -1224,6 +1226,7 @@ struct scann_train_ws {  // per resident batch, allocated on first use
   std::vector<float*> tA;  // [n_atom,128] temporaries: 5 shared + 5 per layer and readout (operands of that layer's weight gradients)
   float *keep_q = nullptr, *keep_V = nullptr, *keep_T = nullptr, *keep_ang = nullptr, *keep_K = nullptr;  // [L][rows,128] or null
   float *keep_pre1 = nullptr, *keep_H1 = nullptr, *keep_T2 = nullptr;
+  float *keep_preA = nullptr, *keep_z = nullptr;
   std::vector<float*> tE;  // [n_edge,128] temporaries: 4 shared + 2 per layer and readout
   float *rep = nullptr, *dpre = nullptr, *dy = nullptr, *targets = nullptr, *dlut = nullptr;
   float* wpart = nullptr;  // per-slab partial sums of every weight gradient of a step (WgradCtx::arena)
@@ -1266,7 +1269,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   // the side stream never have to be waited for before a buffer is reused
   const size_t nTA = 5 + 5 * (Lc + 1), nTE = 4 + 2 * (Lc + 1);
   const size_t total = nTA * rowA + nTE * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
-                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + align_up(w.wpart_floats * 4);
+                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + 2 * rowA + align_up(w.wpart_floats * 4);
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   w.tA.assign(nTA, nullptr);
@@ -1288,6 +1291,8 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
     w.keep_K = (float*)p; p += Lk * rowE;
     w.keep_pre1 = (float*)p; p += Lk * rowA;
     w.keep_H1 = (float*)p; p += Lk * rowA;
+    w.keep_preA = (float*)p; p += rowA;
+    w.keep_z = (float*)p; p += rowA;
     w.keep_T2 = (float*)p; p += Lk * rowA;
   }
   return SCANN_OK;
@@ -1415,6 +1420,7 @@ static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float
   w->seed = seed;
   db->keep_q = w->keep_q; db->keep_V = w->keep_V; db->keep_T = w->keep_T; db->keep_ang = w->keep_ang; db->keep_K = w->keep_K;
   db->keep_pre1 = w->keep_pre1; db->keep_H1 = w->keep_H1; db->keep_T2 = w->keep_T2;
+  db->keep_preA = w->keep_preA; db->keep_z = w->keep_z;
   db->kept = false;
   const bool dbg = h->debug;
   h->debug = true;  // keep centres / geometry / context of every layer (and, with edge_kernel_lean, q / V / T / ang / K)
@@ -1525,8 +1531,9 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
 
   // ---- readout (scann_model.py:424-447, attention.py:267-318) ----
   float* const rdgk = t3;  // the readout is "layer L" of the operand-set scheme
-  // forward recompute: preA = cL.Wa + ba (t0), z = swish(preA) (t1); gq, gk, ga, y are still in the batch workspace
-  launch_linear(cL, h->head.Wap, h->head.ba, t1, t0, A, 2, s);
+  // the training forward kept preA = cL.Wa + ba and z = swish(preA); gq, gk, ga, y are still in the batch workspace
+  t0 = db->keep_preA;
+  t1 = db->keep_z;
   ReadoutBwdArgs ra{};
   ra.mol_offset = db->mol_offset; ra.n_struct = B; ra.max_atoms = db->max_atoms; ra.use_ga_norm = c.use_ga_norm;
   ra.gq = db->gq; ra.gk = db->gk; ra.ga = db->ga; ra.dy = w.dy;
@@ -1540,9 +1547,8 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   wgrad_add(wg, w.rep, w.dpre, g("bf_property/kernel"), g("bf_property/bias"), B);
   wgrad_add(wg, t1, t2, g("global_attention/query/kernel"), g("global_attention/query/bias"), A);
   wgrad_add(wg, t1, rdgk, g("global_attention/key/kernel"), g("global_attention/key/bias"), A);
-  launch_linear_sum(t2, h->WgqT, rdgk, h->WgkT, nullptr, nullptr, t4, A, 0, s);  // dz = dgq.Wgq^T + dgk.Wgk^T
   float* const dpreA = dQ;
-  launch_swish_bwd(t0, t4, dpreA, nA, s);                     // dpreA (t2 is still being read beside us)
+  launch_linear_sum(t2, h->WgqT, rdgk, h->WgkT, nullptr, nullptr, dpreA, A, 0, s, t0);  // dpreA = (dgq.Wgq^T + dgk.Wgk^T) * swish'(preA)
   wgrad_add(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A);
   launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 

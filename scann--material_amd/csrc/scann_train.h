@@ -55,8 +55,9 @@ void wgrad_flush(WgradCtx& ctx, hipStream_t s);
 void launch_linear(const float* X, const float* Wp, const float* bias, float* Y, float* P, int rows, int flags, hipStream_t s);
 
 // Y (+)= X0.W0 + X1.W1 + X2.W2 (packed [128,128] kernels; null X1 / X2: fewer terms)
+// swish_pre (optional): the result is multiplied by swish'(swish_pre) before it is stored (fused swish backward)
 void launch_linear_sum(const float* X0, const float* W0, const float* X1, const float* W1, const float* X2, const float* W2, float* Y,
-                       int rows, int accumulate, hipStream_t s);
+                       int rows, int accumulate, hipStream_t s, const float* swish_pre = nullptr);
 void launch_swish_bwd(const float* pre, const float* dout, float* dpre, size_t n, hipStream_t s);
 void launch_dropout(float* x, size_t n, unsigned long long seed, unsigned tag, float p, hipStream_t s);
 int ln_bwd_slots(int rows);

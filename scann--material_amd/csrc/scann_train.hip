@@ -136,7 +136,8 @@ struct LinearSumArgs {
   const float* Wp[3];
   int n;
 };
-__global__ __launch_bounds__(256) void linear_sum_kernel(LinearSumArgs a, float* __restrict__ Y, int rows, int accumulate) {
+__global__ __launch_bounds__(256) void linear_sum_kernel(LinearSumArgs a, float* __restrict__ Y, int rows, int accumulate,
+                                                         const float* __restrict__ P) {
   __shared__ __attribute__((aligned(16))) float sX[32 * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * 32;
@@ -182,18 +183,24 @@ __global__ __launch_bounds__(256) void linear_sum_kernel(LinearSumArgs a, float*
   }
   if ((lane & 31) < nrows) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<float4*>(Y + (size_t)(row0 + (lane & 31)) * D + cb + 8 * j) =
-          make_float4(acc[4 * j] + yold[j].x, acc[4 * j + 1] + yold[j].y, acc[4 * j + 2] + yold[j].z, acc[4 * j + 3] + yold[j].w);
+    for (int j = 0; j < 4; ++j) {
+      const size_t o = (size_t)(row0 + (lane & 31)) * D + cb + 8 * j;
+      float4 v = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+      if (P) {  // fused swish backward: the sum is d loss / d swish(P)
+        const float4 pr = *reinterpret_cast<const float4*>(P + o);
+        v = make_float4(v.x * dswish_(pr.x), v.y * dswish_(pr.y), v.z * dswish_(pr.z), v.w * dswish_(pr.w));
+      }
+      *reinterpret_cast<float4*>(Y + o) = make_float4(v.x + yold[j].x, v.y + yold[j].y, v.z + yold[j].z, v.w + yold[j].w);
+    }
   }
 }
 void launch_linear_sum(const float* X0, const float* W0, const float* X1, const float* W1, const float* X2, const float* W2, float* Y,
-                       int rows, int accumulate, hipStream_t s) {
+                       int rows, int accumulate, hipStream_t s, const float* swish_pre) {
   if (rows <= 0) return;
   LinearSumArgs a{};
   a.X[0] = X0; a.Wp[0] = W0; a.X[1] = X1; a.Wp[1] = W1; a.X[2] = X2; a.Wp[2] = W2;
   a.n = X2 ? 3 : (X1 ? 2 : 1);
-  hipLaunchKernelGGL(linear_sum_kernel, dim3((rows + 31) / 32), dim3(256), 0, s, a, Y, rows, accumulate);
+  hipLaunchKernelGGL(linear_sum_kernel, dim3((rows + 31) / 32), dim3(256), 0, s, a, Y, rows, accumulate, swish_pre);
 }
 
 // ---- weight gradient: dW[i][j] += sum_rows X[row][i] dY[row][j];  db[j] += sum_rows dY[row][j] ---------------------
