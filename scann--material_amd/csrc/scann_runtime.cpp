@@ -134,6 +134,7 @@ struct scann_handle {
   };
   std::vector<LayerT> layersT;  // packed transposes for the backward dX GEMMs
   const float *WaT = nullptr, *WgqT = nullptr, *WgkT = nullptr;
+  const _Float16* WaTh = nullptr;  // split-fp16 image of after_Lc^T (folded into the first rn_bwd_kernel)
   // training state (scann_train_begin)
   float *t_master = nullptr, *t_grad = nullptr, *t_m = nullptr, *t_v = nullptr, *t_l2 = nullptr;
   RepackDesc* t_descs = nullptr;
@@ -591,6 +592,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       o.lnr_b = put_raw(src[r + "layer_norm/beta"], D);
     }
   }
+  const size_t oWaTh = put_f16T(src["after_Lc/kernel"]);
   const size_t oWaT = put_packedT(src["after_Lc/kernel"]), oWgqT = put_packedT(src["global_attention/query/kernel"]),
                oWgkT = put_packedT(src["global_attention/key/kernel"]);
   const size_t oWah = put_f16(src["after_Lc/kernel"], D, 8), oWgqh = put_f16(src["global_attention/query/kernel"], D, 8),
@@ -664,6 +666,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
                                          PH(lto[i].Wf2Th)};
   }
   h->WaT = P(oWaT); h->WgqT = P(oWgqT); h->WgkT = P(oWgkT);
+  h->WaTh = reinterpret_cast<const _Float16*>(P(oWaTh));
   h->arena_floats = img.size(); h->o_lut = olut; h->o_emb = oemb; h->o_Wde = oWe; h->o_bde = obe;
   h->head = HeadParams{P(oWa), P(oba), P(oWgq), P(obgq), P(oWgk), P(obgk),
                        reinterpret_cast<const _Float16*>(P(oWah)), reinterpret_cast<const _Float16*>(P(oWgqh)),
@@ -1550,7 +1553,6 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   float* const dpreA = dQ;
   launch_linear_sum(t2, h->WgqT, rdgk, h->WgkT, nullptr, nullptr, dpreA, A, 0, s, t0);  // dpreA = (dgq.Wgq^T + dgk.Wgk^T) * swish'(preA)
   wgrad_add(wg, cL, dpreA, g("after_Lc/kernel"), g("after_Lc/bias"), A);
-  launch_linear(dpreA, h->WaT, nullptr, dC, nullptr, A, 0, s);   // d loss / d centres_L
 
   const float* dG_in = nullptr;  // gradient w.r.t. the geometry leaving layer l (none for the last layer)
   // fused chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0 selects the modular one-kernel-per-operation backward
@@ -1560,13 +1562,19 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     const float* X[3];
     const _Float16* Wh[3];
     const float* W[3];
+    bool fresh = false;  // dC holds nothing yet: the terms ARE d loss / d centres (first use: dpreA.Wa^T of the readout)
   } pend;
   auto flush_pend = [&]() {
     if (pend.n)
       launch_linear_sum(pend.X[0], pend.W[0], pend.n > 1 ? pend.X[1] : nullptr, pend.n > 1 ? pend.W[1] : nullptr,
-                        pend.n > 2 ? pend.X[2] : nullptr, pend.n > 2 ? pend.W[2] : nullptr, dC, A, 1, s);
+                        pend.n > 2 ? pend.X[2] : nullptr, pend.n > 2 ? pend.W[2] : nullptr, dC, A, pend.fresh ? 0 : 1, s);
     pend.n = 0;
+    pend.fresh = false;
   };
+  // d loss / d centres_L = dpreA.Wa^T: folded into the first rn_bwd_kernel (or launched by flush_pend)
+  pend.n = 1;
+  pend.X[0] = dpreA; pend.Wh[0] = h->WaTh; pend.W[0] = h->WaT;
+  pend.fresh = true;
   for (int l = L - 1; l >= 0; --l) {
     t3 = setA(l, 0); t4 = setA(l, 1); dQ = setA(l, 2); dP1 = setA(l, 3); dP3 = setA(l, 4);
     edK = setE(l, 0); eU = setE(l, 1);
@@ -1593,12 +1601,13 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
       if (fused) {
         // one kernel: [dC += the projections of the layer above] -> LayerNorm backward -> Dropout mask -> dense_2^T, swish' -> dense_1^T
         RnBwdArgs ra{};
-        ra.dC = dC; ra.T2 = T2; ra.pre1 = pre1; ra.gamma = p.lnr_g; ra.Wf2Th = pt.Wf2Th; ra.Wf1Th = pt.Wf1Th;
+        ra.dC = pend.fresh ? nullptr : dC; ra.T2 = T2; ra.pre1 = pre1; ra.gamma = p.lnr_g; ra.Wf2Th = pt.Wf2Th; ra.Wf1Th = pt.Wf1Th;
         ra.dY = t3; ra.dpre1 = t4; ra.dCtx = dCtx; ra.n_atom = A;
         ra.drop_p = w.drop_p; ra.drop_seed = w.seed; ra.drop_tag = (unsigned)l;
         ra.n_pre = pend.n;
         for (int t = 0; t < pend.n; ++t) { ra.X[t] = pend.X[t]; ra.Wh[t] = pend.Wh[t]; }
         pend.n = 0;
+        pend.fresh = false;
         launch_rn_bwd(wg, ra, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), s);
       } else {
         launch_ln_bwd(wg, T2, p.lnr_g, dC, dCtx, g(rn + "layer_norm/gamma"), g(rn + "layer_norm/beta"), A, 0, s);  // dT2 -> dCtx

@@ -83,7 +83,7 @@ void launch_attn_bwd(WgradCtx& ctx, const float* q, const float* K, const int* e
 float* reserve_vec(WgradCtx& ctx, float* dst, int n_slot);  // records (dst, slots) of a gradient vector a kernel stores per workgroup
 int tile_slots(int rows);                                   // workgroups (= gamma / beta slots) of a fused kernel over `rows`
 struct RnBwdArgs {
-  const float *dC, *T2, *pre1, *gamma;          // [n_atom,128] x3, layer_norm gamma
+  const float *dC, *T2, *pre1, *gamma;          // [n_atom,128] x3 (dC may be null: zeros), layer_norm gamma
   const _Float16 *Wf2Th, *Wf1Th;                // split-fp16 images of dense_2^T, dense_1^T
   float *dY, *dpre1, *dCtx;                     // out [n_atom,128]
   float *dgamma, *dbeta;                        // per-workgroup slots (set by the launcher)

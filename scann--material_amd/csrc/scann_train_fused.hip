@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void rn_bwd_kernel(RnBwdArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       x[rt][j] = ld4(a.T2, off[rt] + 32 * j);
-      dy[rt][j] = ld4(a.dC, off[rt] + 32 * j);
+      dy[rt][j] = a.dC ? ld4(a.dC, off[rt] + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);  // null: the pre-terms are the whole gradient
     }
   }
   f32x16 acc[RT];
