@@ -177,6 +177,7 @@ struct scann_dbatch {
   float *keep_preA = nullptr, *keep_z = nullptr;  // after_Lc pre-activation / output [n_atom,128]
   bool kept = false;  // the last training forward filled them
   hipEvent_t busy_ev = nullptr;  // end of the last scann_train_step that used the batch (scann_batch_release)
+  bool idle = false;             // nothing enqueued on the batch since its last scann_batch_download returned (scann_batch_release)
   int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
   int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
@@ -711,10 +712,12 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
 }
 
 // scann_batch_free without the device-wide synchronisation: for a batch whose last use was a scann_train_step that has been ended
-// (its event has fired) while a LATER step on another batch may still be running.  Falls back to the synchronising free otherwise.
+// (its event has fired), or a forward whose results have been downloaded (scann_batch_download waits for the batch's stream), while
+// LATER work on other batches may still be running.  Falls back to the synchronising free otherwise.
 void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db) {
   if (!db) return;
-  if (!h || !db->busy_ev || hipEventQuery(db->busy_ev) != hipSuccess) {
+  const bool step_done = db->busy_ev && hipEventQuery(db->busy_ev) == hipSuccess;
+  if (!h || !(step_done || db->idle)) {
     scann_batch_free(h, db);
     return;
   }
@@ -922,6 +925,7 @@ int ensure_debug(scann_handle* h, scann_dbatch* db) {
 // The forward graph of create_model (scann_model.py:362-447) as a launch schedule on one stream.
 // kind codes for the timer: 0 basis, 1 atom, 2 edge, 3 readout.
 int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
+  db->idle = false;  // work is being enqueued on the batch (scann_batch_release)
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention;
@@ -1080,6 +1084,7 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
   HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
   if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
+  db->idle = true;
   return SCANN_OK;
 }
 

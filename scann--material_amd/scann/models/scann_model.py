@@ -132,17 +132,20 @@ class HipModel:
         ns = eng.num_streams()
         pending, ys, gas, ts = [], [], [], []
 
-        def drain():
-            for rb, sizes in pending:
-                y, ga = eng.download(rb, want_ga=want_ga)
-                ys.append(y)
-                if want_ga:
-                    gas.append(ga)
-                rb.free()
-            pending.clear()
+        def fetch_oldest():
+            # a rolling window of `ns` groups in flight (one per stream): only the OLDEST is waited for, and its batch is released
+            # without a device-wide synchronisation, so the device keeps running the younger groups while the host slices and
+            # uploads the next one
+            rb = pending.pop(0)
+            y, ga = eng.download(rb, want_ga=want_ga)
+            ys.append(y)
+            if want_ga:
+                gas.append(ga)
+            rb.release()
 
         n = len(dataset)
         grouped = getattr(dataset, "batches", None)  # PackedDataset: a whole group with one native slice call
+        k = 0
         for g0 in range(0, n, group):
             if grouped is not None:
                 pk, tgt = grouped(g0, min(n, g0 + group))
@@ -155,11 +158,13 @@ class HipModel:
                     ts.append(np.asarray(tgt, dtype=np.float32))
                 pk = _hip.concat_packed(parts) if len(parts) > 1 else parts[0]
             rb = eng.upload(pk)
-            eng.forward_resident(rb, len(pending))
-            pending.append((rb, None))
             if len(pending) >= ns:
-                drain()
-        drain()
+                fetch_oldest()  # frees the stream slot the new group is about to use
+            eng.forward_resident(rb, k)
+            k += 1
+            pending.append(rb)
+        while pending:
+            fetch_oldest()
         return np.concatenate(ys), (np.concatenate(gas) if want_ga else None), np.concatenate(ts)
 
     def summary(self):
