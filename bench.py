@@ -252,6 +252,7 @@ def end_to_end(cfg, batches, batch_size, seconds=1.5):
     from scann.utils import PackedDataset
 
     mol, eoff, atomic, local, dist, wgt = [0], [0], [], [], [], []
+    batches = list(batches) * max(1, 65536 // max(1, len(batches) * batch_size))  # >= 65,536 molecules: the pipeline's steady state, not its ramp
     for b in batches:
         base = np.repeat(b.mol_offset[:-1], np.diff(b.mol_offset))            # first atom row of every atom's structure
         deg = np.diff(b.edge_offset)
