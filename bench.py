@@ -244,6 +244,45 @@ def train_bench(args, eng, rdzv):
     rdzv.barrier()
 
 
+def training_leg(cfg, batches, batch_size, seconds=1.0):
+    """configs[2] beside the headline: one optimisation step (forward + backward + Adam, dropout 0.1) per resident batch, two steps
+    in flight as trainer.fit runs them.  `bench.py --train` is the full (multi-rank) version of this leg."""
+    import numpy as np
+    from scann.models.scann_model import HipModel
+
+    model = HipModel(cfg, device=int(os.environ.get("LOCAL_RANK", "0")), seed=1234)
+    eng = model.engine
+    eng.train_begin()
+    rng = np.random.default_rng(7)
+    pool = [eng.upload(b) for b in batches[:8]]
+    targets = [rng.normal(size=batch_size).astype(np.float32) for _ in pool]
+    inflight, done = 0, 0
+
+    def run(n, i0):
+        nonlocal inflight
+        for i in range(i0, i0 + n):
+            eng.train_step_begin(pool[i % 8], targets[i % 8], 5e-4 / (1.0 + 1e-5 * i), dropout=0.1, seed=i)
+            inflight += 1
+            if inflight == 2:
+                eng.train_step_end()
+                inflight -= 1
+        while inflight:
+            eng.train_step_end()
+            inflight -= 1
+
+    run(20, 0)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        run(100, 20 + done)
+        done += 100
+    dt = time.perf_counter() - t0
+    for rb in pool:
+        rb.free()
+    eng.close()
+    return {"value": done * batch_size / dt, "unit": "molecules/s", "ms_per_step": dt / done * 1e3, "steps": done, "batch": batch_size,
+            "what": "forward + backward + Adam on resident batches (configs[2], 1 rank), two steps in flight"}
+
+
 def end_to_end(cfg, batches, batch_size, seconds=1.5):
     """Host-inclusive rate of the dataset path behind SCANN.evaluate / predict_model.py: a host PackedDataset (flat CSR in
     host memory) -> native slicing -> H2D -> forward -> D2H, pipelined over 4 streams (HipModel.predict_dataset)."""
@@ -488,6 +527,8 @@ def main():
             for rb in singles:
                 rb.free()
             out["end_to_end"] = end_to_end(cfg, batches, args.batch)
+            if args.config == "qm9" and not args.worst:
+                out["training_step"] = training_leg(cfg, batches, args.batch)
         if not args.no_cpu_baseline and not args.no_extras and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
