@@ -51,7 +51,6 @@ struct LayerParams {
   // edge-tile kernel
   const float *bk;              // key bias
   const _Float16 *W2h, *Wkh;    // filter_geo rows [128,256) (geometry) and key as split-fp16 images: what edge_kernel multiplies with
-  const _Float16 *W2p, *Wkp;    // the same two kernels with the accumulator k order inside a k-step (edge_rows_kernel)
   const _Float16 *Wfh;          // base branch: filter_geo [20,128] zero-padded to K = 32, split-fp16 image
   const float *lng_g, *lng_b;   // layer_norm_g
   const float *ln_g, *ln_b;     // layer_norm
@@ -161,31 +160,6 @@ struct EdgeArgs {
   LayerParams p;
 };
 void launch_edge(const EdgeArgs& a, hipStream_t s);
-
-// Row-owner edge kernel (scann_edge_rows.hip): one wave per tile of <= 32 edges of whole atoms, both weights resident in LDS,
-// one persistent workgroup per CU pulling tiles from eight work queues.  g_update inference only (nothing kept for a backward).
-struct EdgeRowsArgs {
-  const int2* tiles;           // per tile: {first edge, number of edges (<= 32) | scan steps << 8}
-  int32_t n_tile;
-  int32_t* qcnt;               // eight queue heads, 32 ints apart, zero at launch
-  const int32_t* iso;          // atoms without edges (their context is LayerNorm(query))
-  int32_t n_iso;
-  const int32_t* edge_offset;  // [n_atom+1]
-  const int32_t* edge_col;     // [n_edge]
-  const int32_t* edge_row;     // [n_edge]
-  const int32_t* edge_seg;     // [n_edge] position of the edge inside its atom's run | degree of the atom << 8
-  const float* geom;           // [n_edge,128] in
-  float* geom_out;             // out (null: in place)
-  int32_t geom_dead;           // last layer: geom' is not stored
-  int32_t geom_in_tiled, geom_out_tiled;  // geometry rows in the per-tile piece-plane layout (see edge_rows_kernel) instead of row-major
-  const float *c, *P1, *P3, *q;  // [n_atom,128]
-  float* ctx;                  // [n_atom,128] out: LayerNorm(context)
-  const _Float16 *W2p, *Wkp;   // split-fp16 images with the accumulator k order (pack_weight_f16 perm)
-  const float *lng_g, *lng_b, *bk, *ln_g, *ln_b;
-  int32_t diag;                // timing experiments only (env SCANN_ROWS_DIAG): 1 P3 from the centre row, 2 c from the centre row, 4 no context scan, 8 no geom' store
-  unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS) only: [workgroups * 8 waves][16] per-phase cycle sums, else null
-};
-void launch_edge_rows(const EdgeRowsArgs& a, int n_cu, hipStream_t s);
 // softmax merge of the chunk tiles of every big atom (+ unscaled-query residual + LayerNorm, attention.py:189-214)
 void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,
                        const float* ln_b, float* ctx, hipStream_t s);
@@ -210,19 +184,11 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
                std::vector<int32_t>& big_tab, std::vector<int32_t>& edge_row, int* tile_rows_out, int32_t* max_degree,
                int32_t* n_slot, std::string& err);
 
-// Host-side tile plan of edge_rows_kernel: runs of whole atoms with <= 32 edges, one wave each.  rows_tiles gets {first edge,
-// edges | scan steps << 8} per tile (scan steps = ceil(log2(largest degree in the tile))), iso the atoms without edges.
-// edge_seg[e] = position of e inside its atom's run | degree << 8.  Returns false (and clears everything) when an atom has more than 32 neighbours: such a batch stays on edge_kernel.
-bool plan_row_tiles(const int32_t* edge_offset, int32_t A, std::vector<int32_t>& rows_tiles, std::vector<int32_t>& iso,
-                    std::vector<int32_t>& edge_seg);
-
 // Host-side permutation of a row-major [128,128] (in,out) kernel into MFMA fragment order.
 void pack_weight(const float* W, int ld, float* Wp);
 // Split-fp16 image of rows [0, k_real) of a row-major [*,128] kernel for v_mfma_f32_32x32x16_f16 (edge_kernel: mma_split):
 // [wave 4][k-step ks][plane hi|lo][lane 64][8 halfs], element j of lane l = fp16 part of WSCALE * W[16 s + 8 (l >> 5) + j][32 w + (l & 31)]
 // (zero for k >= k_real).  4 * ks * 2 * 64 * 8 halfs = ks * 2048 floats' worth of bytes.
-// perm: k order of the accumulator layout inside a k-step -- element j of lane l = W[16 s + 8 (j >> 2) + 4 (l >> 5) + (j & 3)][..]: an
-// accumulator tile (lane = row, registers 8 s .. 8 s + 7) is then the B operand of k-step s as it stands (edge_rows_kernel).
-void pack_weight_f16(const float* W, int ld, int k_real, int ks, uint16_t* out, bool perm = false);
+void pack_weight_f16(const float* W, int ld, int k_real, int ks, uint16_t* out);
 
 }  // namespace scann

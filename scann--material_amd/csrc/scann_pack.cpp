@@ -92,46 +92,6 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
   return SCANN_OK;
 }
 
-bool plan_row_tiles(const int32_t* edge_offset, int32_t A, std::vector<int32_t>& rows_tiles, std::vector<int32_t>& iso,
-                    std::vector<int32_t>& edge_seg) {
-  rows_tiles.clear();
-  iso.clear();
-  edge_seg.assign((size_t)edge_offset[A], 0);
-  auto steps_of = [](int deg) {
-    int k = 0;
-    while ((1 << k) < deg) ++k;
-    return k;
-  };
-  int32_t begin = 0, count = 0, maxdeg = 0;
-  for (int a = 0; a < A; ++a) {
-    const int32_t e0 = edge_offset[a], deg = edge_offset[a + 1] - e0;
-    if (deg > 32) {
-      rows_tiles.clear();
-      iso.clear();
-      edge_seg.clear();
-      return false;
-    }
-    for (int32_t k = 0; k < deg; ++k) edge_seg[(size_t)e0 + k] = k | (deg << 8);
-    if (deg == 0) {
-      iso.push_back(a);
-      continue;
-    }
-    if (count + deg > 32) {
-      rows_tiles.push_back(begin);
-      rows_tiles.push_back(count | (steps_of(maxdeg) << 8));
-      begin = e0; count = 0; maxdeg = 0;
-    }
-    if (count == 0) begin = e0;
-    count += deg;
-    maxdeg = std::max(maxdeg, deg);
-  }
-  if (count > 0) {
-    rows_tiles.push_back(begin);
-    rows_tiles.push_back(count | (steps_of(maxdeg) << 8));
-  }
-  return true;
-}
-
 }  // namespace scann
 
 extern "C" {

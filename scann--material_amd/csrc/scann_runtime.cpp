@@ -116,7 +116,6 @@ struct scann_handle {
   std::vector<hipEvent_t> time_ev;  // pairs (start, stop)
   std::vector<int> time_edges;
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
-  int edge_rows = 0;   // env SCANN_EDGE_ROWS=1: row-owner edge kernel (experiment, 6 % slower than edge_kernel: profiles/r03_notes.md)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -184,12 +183,6 @@ struct scann_dbatch {
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
   float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
   int32_t n_big = 0, n_slot = 0;
-  // plan of edge_rows_kernel (null: the batch has an atom above 32 neighbours, or the base branch)
-  int2* row_tiles = nullptr;
-  int32_t* iso = nullptr;
-  int32_t* edge_seg = nullptr;
-  int32_t* qcnt = nullptr;   // [n_attention][8 heads x 32 ints] work-queue heads, zeroed at the start of every forward
-  int32_t n_row_tile = 0, n_iso = 0;
   // workspace
   float *geom = nullptr, *gd = nullptr, *c = nullptr, *ctx = nullptr, *P1 = nullptr, *P3 = nullptr, *q = nullptr;
   float *gq = nullptr, *gk = nullptr, *ga = nullptr, *y = nullptr;
@@ -346,12 +339,12 @@ static float f16_bits_to_f32(uint16_t h) {
   memcpy(&out, &x, 4);
   return out;
 }
-void pack_weight_f16(const float* W, int ld, int k_real, int ks, uint16_t* out, bool perm) {
+void pack_weight_f16(const float* W, int ld, int k_real, int ks, uint16_t* out) {
   for (int w = 0; w < 4; ++w)
     for (int s = 0; s < ks; ++s)
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
-          const int k = perm ? 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3) : 16 * s + 8 * (lane >> 5) + j;
+          const int k = 16 * s + 8 * (lane >> 5) + j;
           const float x = k < k_real ? WSCALE * W[(size_t)k * ld + 32 * w + (lane & 31)] : 0.f;
           const uint16_t hi = f32_to_f16_bits(x);
           const uint16_t lo = f32_to_f16_bits(x - f16_bits_to_f32(hi));
@@ -394,7 +387,6 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->device = device_id;
   h->specs = build_specs(*cfg);
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
-  if (const char* er = getenv("SCANN_EDGE_ROWS")) h->edge_rows = atoi(er) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -526,13 +518,6 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 0, ks == 8 ? -1 : -2});
     return off;
   };
-  auto put_f16p = [&](const float* W) {  // split-fp16 image with the accumulator k order (edge_rows_kernel)
-    const size_t off = img.size();
-    img.resize(off + (size_t)8 * 2048);
-    pack_weight_f16(W, D, D, 8, reinterpret_cast<uint16_t*>(img.data() + off), true);
-    h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 0, -3});
-    return off;
-  };
   auto put_f16T = [&](const float* W) {  // split-fp16 image of W^T ([128,128]; fused backward kernels: dX = dY . W^T)
     const size_t off = img.size();
     img.resize(off + (size_t)8 * 2048);
@@ -555,7 +540,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   std::vector<LTOff> lto(L);
   struct LOff {
     size_t bg, bq, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, bf1, bf2, lnr_g, lnr_b;
-    size_t W2h, Wkh, Wfh, W1h, W3h, Wqh, Wf1h, Wf2h, W2p, Wkp;
+    size_t W2h, Wkh, Wfh, W1h, W3h, Wqh, Wf1h, Wf2h;
   };
   std::vector<LOff> lo(L);
   const size_t NONE = (size_t)-1;
@@ -563,15 +548,13 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     const std::string p = "local_attention_" + std::to_string(i) + "/";
     LOff& o = lo[i];
     o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE,
-             NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
+             NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     const float* fg = src[p + "filter_geo/kernel"];
     lto[i] = LTOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
       o.W1h = put_f16(fg, D, 8);
       o.W3h = put_f16(fg + (size_t)2 * D * D, D, 8);
       o.W2h = put_f16(fg + (size_t)D * D, D, 8);
-      o.W2p = put_f16p(fg + (size_t)D * D);
-      o.Wkp = put_f16p(src[p + "key/kernel"]);
       lto[i].W1T = put_packedT(fg);
       lto[i].W2T = put_packedT(fg + (size_t)D * D);
       lto[i].W3T = put_packedT(fg + (size_t)2 * D * D);
@@ -670,7 +653,6 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lp.Wfg = P(o.Wfg); lp.bfg = P(o.bfg);
     lp.W2h = reinterpret_cast<const _Float16*>(P(o.W2h)); lp.Wkh = reinterpret_cast<const _Float16*>(P(o.Wkh));
     lp.Wfh = reinterpret_cast<const _Float16*>(P(o.Wfh));
-    lp.W2p = reinterpret_cast<const _Float16*>(P(o.W2p)); lp.Wkp = reinterpret_cast<const _Float16*>(P(o.Wkp));
     lp.W1h = reinterpret_cast<const _Float16*>(P(o.W1h)); lp.W3h = reinterpret_cast<const _Float16*>(P(o.W3h));
     lp.Wqh = reinterpret_cast<const _Float16*>(P(o.Wqh)); lp.Wf1h = reinterpret_cast<const _Float16*>(P(o.Wf1h));
     lp.Wf2h = reinterpret_cast<const _Float16*>(P(o.Wf2h));
@@ -794,8 +776,6 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     }
   }
   const int32_t n_big = (int32_t)big_tab.size() / 3;
-  std::vector<int32_t> row_tiles, iso, edge_seg;
-  const bool rows_plan = h->cfg.g_update && E > 0 && max_degree <= 32 && plan_row_tiles(b->edge_offset, A, row_tiles, iso, edge_seg);
   HIPCHK(h, hipSetDevice(h->device));
   scann_dbatch* db = nullptr;
   if (scratch) {
@@ -822,10 +802,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_tpart = take(n_big ? tiles.size() * 4 : 0), o_big = take((size_t)n_big * 3 * 4);
   const size_t o_inoff = take((size_t)(A + 1) * 4), o_inedge = take((size_t)E * 4);
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
-  const size_t o_rt = take(rows_plan ? row_tiles.size() * 4 : 0), o_iso = take(rows_plan ? iso.size() * 4 : 0);
-  const size_t o_seg = take(rows_plan ? (size_t)E * 4 : 0);
   const size_t in_bytes = off;
-  const size_t o_qcnt = take(rows_plan ? (size_t)std::max(h->cfg.n_attention, 1) * 8 * 32 * 4 : 0);
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
   const size_t o_geom = take(h->cfg.g_update ? rowE : 0), o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
   const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
@@ -881,11 +858,6 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     std::vector<int32_t> fill(in_off, in_off + A);
     for (int e = 0; e < E; ++e) in_edge[fill[b->edge_col[e]]++] = e;
   }
-  if (rows_plan) {
-    memcpy(img.data() + o_rt, row_tiles.data(), row_tiles.size() * 4);
-    if (!iso.empty()) memcpy(img.data() + o_iso, iso.data(), iso.size() * 4);
-    memcpy(img.data() + o_seg, edge_seg.data(), (size_t)E * 4);
-  }
   if (n_big) {
     memcpy(img.data() + o_tpart, tile_part.data(), tiles.size() * 4);
     memcpy(img.data() + o_big, big_tab.data(), (size_t)n_big * 3 * 4);
@@ -912,10 +884,6 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->c = (float*)(a0 + o_c); db->ctx = (float*)(a0 + o_ctx); db->P1 = (float*)(a0 + o_P1); db->P3 = (float*)(a0 + o_P3);
   db->q = (float*)(a0 + o_q); db->gq = (float*)(a0 + o_gq); db->gk = (float*)(a0 + o_gk);
   db->ga = (float*)(a0 + o_ga); db->y = (float*)(a0 + o_y);
-  if (rows_plan) {
-    db->row_tiles = (int2*)(a0 + o_rt); db->iso = (int32_t*)(a0 + o_iso); db->edge_seg = (int32_t*)(a0 + o_seg); db->qcnt = (int32_t*)(a0 + o_qcnt);
-    db->n_row_tile = (int32_t)(row_tiles.size() / 2); db->n_iso = (int32_t)iso.size();
-  }
   if (n_big) {
     db->tile_part = (int32_t*)(a0 + o_tpart); db->big_tab = (int32_t*)(a0 + o_big); db->part_buf = (float*)(a0 + o_pbuf);
   }
@@ -973,9 +941,6 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   auto c_of = [&](int l) { return direct ? db->dbg_c + (size_t)l * nA_ : db->c; };
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
   auto g_of = [&](int l) { return direct && c.g_update ? db->dbg_g + (size_t)l * nE_ : db->geom; };
-  // edge_rows_kernel (one wave per <= 32-edge tile, weights resident in LDS) whenever nothing has to be kept for a backward pass
-  const bool use_rows = h->edge_rows && c.g_update && db->row_tiles && !h->in_train_forward && L > 0;
-  if (use_rows) HIPCHK(h, hipMemsetAsync(db->qcnt, 0, (size_t)L * 8 * 32 * 4, s));
   if (tm) tm->mark(-1);
   if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
   else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
@@ -1074,32 +1039,8 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       db->n_stamp = db->n_tile;
     }
 #endif
-    if (use_rows) {
-      EdgeRowsArgs ra{};
-      ra.tiles = db->row_tiles; ra.n_tile = db->n_row_tile; ra.qcnt = db->qcnt + (size_t)l * 8 * 32;
-      ra.iso = db->iso; ra.n_iso = db->n_iso;
-      ra.edge_offset = db->edge_offset; ra.edge_col = db->edge_col; ra.edge_row = db->edge_row; ra.edge_seg = db->edge_seg;
-      ra.geom = ea.geom; ra.geom_out = ea.geom_out; ra.geom_dead = ea.geom_dead;
-      // between two launches of this kernel the geometry lives in its tiled layout (nobody else reads it); the basis kernel
-      // writes row-major, and so does every layer in debug mode (scann_debug_read)
-      ra.geom_in_tiled = (l > 0 && !h->debug) ? 1 : 0; ra.geom_out_tiled = h->debug ? 0 : 1;
-      ra.c = ea.c; ra.P1 = ea.P1; ra.P3 = ea.P3; ra.q = ea.q; ra.ctx = ea.ctx;
-      ra.W2p = ea.p.W2p; ra.Wkp = ea.p.Wkp;
-      ra.lng_g = ea.p.lng_g; ra.lng_b = ea.p.lng_b; ra.bk = ea.p.bk; ra.ln_g = ea.p.ln_g; ra.ln_b = ea.p.ln_b;
-      if (const char* dg = getenv("SCANN_ROWS_DIAG")) ra.diag = atoi(dg);
-#ifdef SCANN_STAMPS
-      if (!getenv("SCANN_STAMP_ATOM")) {
-        const int nw = 8 * std::min((db->n_row_tile + 7) / 8, h->n_cu);
-        if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)nw * 16 * sizeof(unsigned long long)));
-        ra.stamps = db->stamps;
-        db->n_stamp = nw;
-      }
-#endif
-      launch_edge_rows(ra, h->n_cu, s);
-    } else {
-      launch_edge(ea, s);
-      launch_edge_merge(db->big_tab, db->n_big, db->part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, s);
-    }
+    launch_edge(ea, s);
+    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);

@@ -23,8 +23,7 @@ struct RepackDesc {
   int64_t dst;        // element offset into the weight arena
   int32_t transpose;  // packed image of W^T instead of W (backward dX GEMMs)
   int32_t raw;        // > 0: plain copy of this many elements (<= 16384); 0: 128x128 fp32 fragment-order pack;
-                      // -1: split-fp16 image of a [128,128] kernel, -2: of a [20,128] kernel padded to K = 32 (pack_weight_f16),
-                      // -3: of a [128,128] kernel with the accumulator k order (pack_weight_f16 perm)
+                      // -1: split-fp16 image of a [128,128] kernel, -2: of a [20,128] kernel padded to K = 32 (pack_weight_f16)
 };
 
 // Weight gradients are bit-reproducible: every launch_wgrad* stores per-slab partial sums into slots of `ctx.arena` (bump

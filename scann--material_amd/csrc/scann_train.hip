@@ -1412,14 +1412,13 @@ __global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float*
     return;
   }
   if (d.raw < 0) {  // split-fp16 image (pack_weight_f16): this thread writes one 4-byte slot = halfs j, j + 1 of one lane
-    const int ks = d.raw == -2 ? 2 : 8, k_real = d.raw == -2 ? NG : D;  // -3: [128,128] with the accumulator k order (pack_weight_f16 perm)
+    const int ks = d.raw == -1 ? 8 : 2, k_real = d.raw == -1 ? D : NG;
     if (idx >= ks * 2048) return;
     const int jp = idx & 3, lane = (idx >> 2) & 63, plane = (idx >> 8) & 1, sw = idx >> 9, st = sw % ks, w = sw / ks;
     _Float16 out[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = 2 * jp + u;
-      const int k = d.raw == -3 ? 16 * st + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3) : 16 * st + 8 * (lane >> 5) + j;
+      const int k = 16 * st + 8 * (lane >> 5) + 2 * jp + u;
       const int col = 32 * w + (lane & 31);
       const float x = k < k_real ? WSCALE * master[d.src + (d.transpose ? (size_t)col * D + k : (size_t)k * D + col)] : 0.f;
       const _Float16 hi = (_Float16)x;
