@@ -103,8 +103,16 @@ def edge_flops(E):
 
 
 def edge_bytes(A, E):
-    """Algorithmic HBM bytes of one edge-kernel launch: per edge the geometry row in and out and
-    two indices, per atom the four rows every tile needs once (c, P1, P3, q) and the context row out."""
+    """ALGORITHMIC HBM bytes of one edge-kernel launch = SURVEY.md 8(d)(ii), the layer-streamed model, per layer: geometry row
+    in and out + index and mask per edge, centres in and out per atom (gathered neighbour rows are served on-chip and counted
+    once per atom): E (2 d 4 + 8) + A (2 d 4).  This is what roofline.frac is computed from."""
+    return E * (2 * D * 4 + 8) + A * (2 * D * 4)
+
+
+def edge_bytes_design(A, E):
+    """What THIS design's edge kernel has to move per launch: the same per-edge bytes, but FIVE atom rows
+    (c, P1, P3, q in; context out) because the per-atom projections live in atom_kernel.  Reported beside the algorithmic
+    figure, never as the roofline fraction."""
     return E * (2 * D * 4 + 8) + A * (5 * D * 4)
 
 
@@ -230,12 +238,16 @@ def train_bench(args, eng, rdzv):
     drain()
     elapsed = time.perf_counter() - t0
     rdzv.barrier()
+    per_rank = rdzv.gather([elapsed])  # every rank's own time for the K steps (rank 0 gets the list)
     elapsed = rdzv.allreduce_max(elapsed)
     if rank == 0:
         print(json.dumps({
             "metric": "QM9 molecules/s training (forward + backward + Adam)", "value": world * steps * args.batch / elapsed,
             "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rank_ms_per_step": [float(t[0]) / steps * 1e3 for t in per_rank],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (projections: split-fp16 hi/lo operands, 3 v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; everything else fp32)",
+            "data": "synthetic",
             "config": {"workload": "configs[2]: QM9 training, configs/model_qm9.yaml, %d molecules per GPU per step, dropout 0.1, "
                                    "RCCL flat gradient all-reduce (%d floats)" % (args.batch, eng.param_count()),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world}}), flush=True)
@@ -453,6 +465,7 @@ def main():
             e_launch, us = E * gmax, 1e3 * float(np.mean([p["ms_edge"] / max(p["n_edge_launch"], 1) for p in prof]))
         a_launch = e_launch * A / E
         alg_flops, alg_bytes = edge_flops(e_launch), edge_bytes(a_launch, e_launch)
+        des_bytes = edge_bytes_design(a_launch, e_launch)
         tfl = alg_flops / (us * 1e-6) / 1e12
         tbs = alg_bytes / (us * 1e-6) / 1e12
         kinfo = {}
@@ -471,9 +484,16 @@ def main():
                 "achieved": tbs * 1e3 if hbm_bound else tfl * passes, "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else pipe_peak,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": frac_hbm if hbm_bound else frac_mfma,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                "traffic_over_algorithmic": traffic["hbm_bytes_per_launch"] / alg_bytes if traffic else None,
+                "traffic_source": ("profiles/edge_kernel.json[%s]: STATIC rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
+                                   "and launch size (tools/pmc_run.sh), not measured in this run; fabric-side counters that include "
+                                   "Infinity-Cache hits (a 16-batch layer's working set fits the 256 MB cache)" % wkey) if traffic else None,
                 "avg_launch_us": us, "launches_sampled": live_n,
-                "algorithmic": {"flops_per_launch": alg_flops, "bytes_per_launch": alg_bytes, "edges_per_launch": e_launch,
+                "algorithmic": {"model": "SURVEY.md 8(d)(ii): E (2 d 4 + 8) + A (2 d 4) bytes, E (4 d^2 + 4 d) FLOPs per launch",
+                                "flops_per_launch": alg_flops, "bytes_per_launch": alg_bytes, "edges_per_launch": e_launch,
                                 "tflops": tfl, "tbytes_per_s": tbs},
+                "design_bytes": {"model": "this design's edge kernel: E (2 d 4 + 8) + A (5 d 4) -- c, P1, P3, q in and the context out per atom",
+                                 "bytes_per_launch": des_bytes, "frac_of_hbm_peak": des_bytes / (us * 1e-6) / 1e12 / PEAK_HBM_TBS},
                 "mfma": {"pipe": kinfo.get("mfma_pipe", "f32"), "passes": passes, "executed_tflops": tfl * passes, "peak": pipe_peak,
                          "frac": frac_mfma, "frac_of_fp32_mfma_peak_algorithmic": tfl / PEAK_FP32_MFMA_TFLOPS},
                 "hbm": {"achieved_gbs": tbs * 1e3, "peak_gbs": PEAK_HBM_TBS * 1e3, "frac": frac_hbm},
@@ -487,7 +507,9 @@ def main():
             "metric": "QM9 molecules/s forward" if args.config != "mp2018" else "MP2018-shaped structures/s forward",
             "value": value, "unit": "molecules/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (projections: split-fp16 hi/lo operands, 3 v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; everything else fp32)",
+            "data": "synthetic",
             "config": {"workload": ("configs[1]: QM9-shaped%s, configs/model_qm9.yaml (SCANN+, L=7, d=128, H=8), "
                                     "batch=128 per step, forward" % (" worst-case 29x12" if args.worst else ""))
                        if args.config == "qm9" else
@@ -499,6 +521,7 @@ def main():
                        "parallelism": "dp%d (independent shards, no collective)" % world},
             "timing": {"repeats": repeats, "timed_region_ms_median": elapsed * 1e3, "timed_region_ms_min": float(per_repeat.min()) * 1e3,
                        "timed_region_ms_max": float(per_repeat.max()) * 1e3, "prewarm_s": args.prewarm,
+                       "rank_median_ms": [float(np.median(t)) * 1e3 for t in all_times],
                        "rule": "each repeat = EXACTLY --steps batches between sync+barrier pairs; value from the median repeat (max over ranks)"},
             "host_issue_ms_per_step": t_issue / repeats / args.steps * 1e3,
             "whole_path_tflops_min": world * args.steps * total_flops_min(A, E, L_cfg, emb_cfg) / elapsed / 1e12,

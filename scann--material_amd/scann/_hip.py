@@ -113,6 +113,12 @@ def load_library(path=None):
         raise OSError(
             "libscann_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C scann--material_amd/csrc`; this package has no CPU fallback" % p)
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        # one process per GPU: RCCL shares buffers between the ranks through dmabuf IPC, which this driver only offers with
+        # the legacy mode off (else hipIpcGetMemHandle: invalid argument).  The HSA runtime reads the variable when it starts,
+        # i.e. at the first HIP call of the process -- so it is set HERE, before the library is even loaded.  spawn_ranks sets
+        # it for its children; ranks made by torch.distributed.run get it this way.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(p)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)

@@ -70,6 +70,26 @@ def keras_default_init(specs, seed=None):
     return w
 
 
+def save_container(path, config, weights):
+    """Write the weight container ATOMICALLY: the bytes go to a temporary file in the same directory, which then replaces
+    ``path`` (os.replace).  A reader -- another rank loading the best checkpoint, a monitoring script -- sees the previous
+    complete file or the new complete file, never a partial one."""
+    buf = io.BytesIO()
+    np.savez(buf, __config__=np.array(json.dumps(config)), **weights)
+    folder = os.path.dirname(os.path.abspath(path))
+    os.makedirs(folder, exist_ok=True)
+    tmp = os.path.join(folder, ".%s.%d.tmp" % (os.path.basename(path), os.getpid()))
+    try:
+        with open(tmp, "wb") as f:
+            f.write(buf.getvalue())
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 class HipModel:
     """Stand-in for the ``tf.keras.Model`` that ``create_model`` returns (scann_model.py:449):
     ``predict`` runs the whole forward graph on the GPU."""
@@ -100,11 +120,7 @@ class HipModel:
     def save(self, path):
         """Weight container: a zip (npz) of the named fp32 tensors plus the yaml config as JSON.
         Takes the place of the Keras full-model HDF5 (scann_model.py:166-177)."""
-        buf = io.BytesIO()
-        np.savez(buf, __config__=np.array(json.dumps(self.config)), **self._weights)
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        with open(path, "wb") as f:
-            f.write(buf.getvalue())
+        save_container(path, self.config, self._weights)
 
     # -- inference ---------------------------------------------------------------------------------
     def predict(self, inputs, batch_size=None, verbose=0, **_):
@@ -301,6 +317,10 @@ class SCANN:
         devices of the node from this process (scann.parallel.MultiGpuPredictor; no collective)."""
         from sklearn.metrics import mean_absolute_error, r2_score
 
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) != 0:
+            # data-parallel job: the test set, report.txt and hist_data.npy belong to rank 0 alone (the ranks hold the same
+            # model after training; trainer.fit ends with a barrier, so the best checkpoint is complete before rank 0 loads it)
+            return None, None
         if not hasattr(self, "model") or self.model is None:
             print("Load best validation weight for predicting testset", "\n")
             t = self.config["hyper"]["target"]

@@ -9,6 +9,7 @@ slice of structures, and the ranks exchange exactly two things per step over RCC
 from __future__ import annotations
 
 import math
+import os
 import queue
 import threading
 import time
@@ -85,6 +86,8 @@ class Communicator:
         self.rdzv = rendezvous if rendezvous is not None else Rendezvous()
         self.rank, self.world = self.rdzv.rank, self.rdzv.world
         if self.world > 1:
+            # (HSA_ENABLE_IPC_MODE_LEGACY=0, which RCCL across processes needs on this driver, is set by _hip.load_library
+            # before the first HIP call of a rank -- here it would be too late)
             uid = self.rdzv.broadcast(_hip.comm_unique_id() if self.rank == 0 else None)
             engine.comm_init(uid, self.rank, self.world)
             engine.broadcast_weights(0)
@@ -99,40 +102,90 @@ class Communicator:
         return self.engine.allreduce_sse(a, b) if self.world > 1 else (a, b)
 
 
+def dp_batches(iterator, world):
+    """-> (number of steps, fold_tail).  With ``world`` ranks every rank needs at least one structure of every global batch
+    (an empty shard cannot run a step, and the other ranks would wait in the step's all-reduce for ever).  A final batch with
+    fewer structures than ranks is therefore folded into the batch before it -- the same decision on every rank, because it
+    depends on the dataset size, the batch size and the world size only."""
+    n = len(iterator)
+    if world <= 1 or n <= 1:
+        return n, False
+    total, bs = getattr(iterator, "indexes", None), getattr(iterator, "batch_size", None)
+    if total is None or not bs:
+        return n, False
+    tail = len(total) - (n - 1) * int(bs)
+    return (n - 1, True) if 0 < tail < world else (n, False)
+
+
 class _Prefetch:
     """Host pipeline of ``fit``: batch k+1 is assembled (``iterator[k+1]`` + CSR packing + this rank's slice) on a worker
     thread while the GPU runs step k.  The reference gets the same overlap from Keras' ``workers=4,
     use_multiprocessing=True`` (scann_model.py:239-240)."""
 
     def __init__(self, iterator, comm):
-        self.it, self.comm, self.n = iterator, comm, len(iterator)
+        self.it, self.comm = iterator, comm
+        self.n, self.fold_tail = dp_batches(iterator, comm.world)
+        total = getattr(iterator, "indexes", None)
+        if comm.world > 1 and total is not None and len(total) < comm.world:
+            raise ValueError("data-parallel run with %d ranks over a dataset of %d structures: every rank needs at least one "
+                             "structure per step" % (comm.world, len(total)))
         self.q = queue.Queue(maxsize=2)
+        self.stop = threading.Event()
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
     def _one(self, b):
+        fold = self.fold_tail and b == self.n - 1  # the last step also takes the short final batch
         part = getattr(self.it, "batch_part", None)
         if part is not None and self.comm.world > 1:  # PackedDataset: only this rank's structures are ever packed
-            shard, target = part(b, self.comm.rank, self.comm.world)
+            shard, target = part(b, self.comm.rank, self.comm.world, to_end=True) if fold else part(b, self.comm.rank, self.comm.world)
             return shard, np.asarray(target, dtype=np.float32)
         inputs, target = self.it[b]
         packed = inputs if isinstance(inputs, _hip.PackedBatch) else _hip.pack_inputs(inputs)
+        target = np.asarray(target, dtype=np.float32)
+        if fold:
+            inputs2, target2 = self.it[b + 1]
+            packed = _hip.concat_packed([packed, inputs2 if isinstance(inputs2, _hip.PackedBatch) else _hip.pack_inputs(inputs2)])
+            target = np.concatenate([target, np.asarray(target2, dtype=np.float32)])
         shard, sl = self.comm.shard(packed)
-        return shard, np.asarray(target, dtype=np.float32)[sl]
+        return shard, target[sl]
+
+    def _put(self, item):
+        while not self.stop.is_set():
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def _run(self):
         try:
             for b in range(self.n):
-                self.q.put(self._one(b))
+                if not self._put(self._one(b)):
+                    return
         except BaseException as e:  # surfaced in the training thread
-            self.q.put(e)
+            self._put(e)
+
+    def close(self):
+        """Stop the worker (the consumer gave up mid-epoch): nothing stays blocked on the queue holding packed batches."""
+        self.stop.set()
+        while True:
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                break
+        self.t.join(timeout=5.0)
 
     def __iter__(self):
-        for _ in range(self.n):
-            item = self.q.get()
-            if isinstance(item, BaseException):
-                raise item
-            yield item
+        try:
+            for _ in range(self.n):
+                item = self.q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            self.close()
 
 
 def fit(scann, epochs=1000, dropout=0.1, verbose=True):
@@ -184,23 +237,40 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
             sse_t += sse_g; n_t += cnt_g
 
         pending = []
-        for shard, tgt in _Prefetch(iterator, comm):
-            rb = eng.upload(shard)  # H2D of batch k + 1 while step k (if any) is still running on the device
-            seed = (it * 7919 + 17) & 0xFFFFFFFF
-            if training:
-                # one asynchronous sequence on the device: forward, global {sse, count}, backward, gradient all-reduce, Adam; step
-                # k + 1 is enqueued BEFORE step k is waited for, so the device never idles while the host works
-                lr_t = (epoch_lr if sgdr is not None else cosine_decay(it, hy["lr"], decay_steps, alpha)) / (1.0 + 1e-5 * it)
-                eng.train_step_begin(rb, tgt, lr_t, dropout=dropout, seed=seed, l2=l2)
-                it += 1
-                pending.append((rb, tgt, None))
-                if len(pending) == 2:
-                    finish(*pending.pop(0))
-            else:
-                sse = eng.train_forward(rb, tgt, dropout=0.0, seed=seed)
-                finish(rb, tgt, comm.sum_pair(sse, shard.n_struct))
-        while pending:
-            finish(*pending.pop(0))
+        try:
+            for shard, tgt in _Prefetch(iterator, comm):
+                rb = eng.upload(shard)  # H2D of batch k + 1 while step k (if any) is still running on the device
+                seed = (it * 7919 + 17) & 0xFFFFFFFF
+                if training:
+                    # one asynchronous sequence on the device: forward, global {sse, count}, backward, gradient all-reduce, Adam;
+                    # step k + 1 is enqueued BEFORE step k is waited for, so the device never idles while the host works
+                    lr_t = (epoch_lr if sgdr is not None else cosine_decay(it, hy["lr"], decay_steps, alpha)) / (1.0 + 1e-5 * it)
+                    pending.append((rb, tgt, None))
+                    eng.train_step_begin(rb, tgt, lr_t, dropout=dropout, seed=seed, l2=l2)
+                    it += 1
+                    if len(pending) == 2:
+                        finish(*pending.pop(0))
+                else:
+                    pending.append((rb, tgt, False))
+                    sse = eng.train_forward(rb, tgt, dropout=0.0, seed=seed)
+                    pending.pop()
+                    finish(rb, tgt, comm.sum_pair(sse, shard.n_struct))
+            while pending:
+                finish(*pending.pop(0))
+        except BaseException:
+            # a step in flight holds its resident batch: end what can be ended and release the batches before the error travels
+            # on (a failed peer may never complete the collective of a step, so every call here is guarded)
+            for rb, _, pair in pending:
+                try:
+                    if pair is None:
+                        eng.train_step_end()
+                except Exception:
+                    pass
+                try:
+                    rb.free()
+                except Exception:
+                    pass
+            raise
         sabs_t, _ = comm.sum_pair(sabs_t, 0)
         sy, _ = comm.sum_pair(sy, 0)
         syy, _ = comm.sum_pair(syy, 0)
@@ -234,4 +304,5 @@ def fit(scann, epochs=1000, dropout=0.1, verbose=True):
             if wait >= 200:  # EarlyStopping(monitor="val_mae", patience=200), scann_model.py:179
                 break
     model._weights = eng.get_weights()
+    comm.rdzv.barrier()  # every rank is done (and rank 0's last checkpoint is on disk) before anybody goes on to evaluate or exit
     return hist

@@ -8,6 +8,7 @@ that has initialised the GPU must never be the one that forks or execs the ranks
 from __future__ import annotations
 
 import os
+import secrets
 import socket
 import subprocess
 import sys
@@ -28,7 +29,8 @@ def spawn_ranks(argv, n, env=None, timeout=None):
     so rank 0's report reaches the caller's stdout.  Returns the largest exit code."""
     base = dict(os.environ if env is None else env)
     base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-                SCANN_RDZV_ID=uuid.uuid4().hex)
+                SCANN_RDZV_ID=uuid.uuid4().hex,
+                SCANN_RDZV_SECRET=secrets.token_hex(32))  # per-job secret of the ranks' TCP rendezvous (never on the command line)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     procs = []
     for r in range(n):

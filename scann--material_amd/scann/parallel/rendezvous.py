@@ -4,18 +4,24 @@ The ranks of a data-parallel job (one process per GPU) need three host-side exch
 ``ncclUniqueId`` from rank 0 to everybody before ``scann_comm_init``, a barrier, and small reductions of Python numbers
 (the max of a wall time in ``bench.py``).  Everything on the data path goes over RCCL inside ``libscann_hip.so``.
 
-Rank 0 listens on the first free port of a fixed candidate list derived from ``MASTER_PORT`` (the port itself belongs to
-the launcher: ``torch.distributed.run`` keeps its own store there); the other ranks walk the same list until a server
-answers the handshake token of THIS job.  Works under ``torch.distributed.run`` (RANK / WORLD_SIZE / MASTER_ADDR /
-MASTER_PORT in the environment) and under ``scann.parallel.launch.spawn_ranks`` (same variables, set by the parent).
+Rank 0 listens on LOOPBACK (``SCANN_RDZV_BIND`` overrides the address) on the first free port of a fixed candidate list
+derived from ``MASTER_PORT`` (the port itself belongs to the launcher: ``torch.distributed.run`` keeps its own store there);
+the other ranks walk the same list until a server answers the handshake token of THIS job.  The token is a hash over the
+job's coordinates AND a random per-job secret: ``SCANN_RDZV_SECRET`` when the launcher provides one
+(``scann.parallel.launch.spawn_ranks`` does), otherwise a file of mode 0600 that rank 0 writes and the other ranks of the
+same user read.  Messages are length-prefixed JSON (numbers, lists, None, bytes as hex) -- nothing received from the
+socket is ever unpickled or evaluated.  Works under ``torch.distributed.run`` (RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT in the environment) and under ``spawn_ranks`` (same variables, set by the parent).
 """
 from __future__ import annotations
 
 import hashlib
+import json
 import os
-import pickle
+import secrets
 import socket
 import struct
+import tempfile
 import time
 
 _MAGIC = b"SCANNRDZ"
@@ -26,13 +32,71 @@ def _candidates(master_port):
     return [base + 13 * k for k in range(24)]
 
 
-def _token(addr, port, world):
+def _token(addr, port, world, secret):
     run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "|" + os.environ.get("SCANN_RDZV_ID", "")
-    return hashlib.sha256(("%s|%s|%d|%s" % (addr, port, world, run)).encode()).digest()[:16]
+    return hashlib.sha256(("%s|%s|%d|%s|%s" % (addr, port, world, run, secret)).encode()).digest()[:16]
+
+
+def _secret_path(addr, port, world):
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "|" + os.environ.get("SCANN_RDZV_ID", "")
+    tag = hashlib.sha256(("%s|%s|%d|%s" % (addr, port, world, run)).encode()).hexdigest()[:16]
+    return os.path.join(tempfile.gettempdir(), "scann_rdzv_%d_%s.key" % (os.getuid(), tag))
+
+
+def _write_secret(path):
+    """Rank 0: a fresh random secret in a file only this user can read (replaces a stale file of an earlier job)."""
+    value = secrets.token_hex(32)
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "w") as f:
+        f.write(value)
+    return value
+
+
+def _read_secret(path):
+    try:
+        st = os.stat(path)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            return None  # not ours, or readable by others: never trust it
+        with open(path) as f:
+            value = f.read().strip()
+        return value if len(value) == 64 else None
+    except OSError:
+        return None
+
+
+def _enc(obj):
+    if isinstance(obj, (bytes, bytearray)):
+        return {"__bytes__": bytes(obj).hex()}
+    if isinstance(obj, (list, tuple)):
+        return [_enc(x) for x in obj]
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if hasattr(obj, "item") and getattr(obj, "shape", None) == ():  # NumPy scalar
+        return obj.item()
+    if hasattr(obj, "tolist"):
+        return _enc(obj.tolist())
+    raise TypeError("rendezvous: cannot send a %s (numbers, strings, None, bytes and lists of them only)" % type(obj).__name__)
+
+
+def _dec(obj):
+    if isinstance(obj, dict):
+        if set(obj) != {"__bytes__"} or not isinstance(obj["__bytes__"], str):
+            raise ValueError("rendezvous: malformed message")
+        return bytes.fromhex(obj["__bytes__"])
+    if isinstance(obj, list):
+        return [_dec(x) for x in obj]
+    return obj
+
+
+_MAX_MESSAGE = 64 << 20
 
 
 def _send(sock, obj):
-    data = pickle.dumps(obj, protocol=4)
+    data = json.dumps(_enc(obj), allow_nan=True).encode()
     sock.sendall(struct.pack("<Q", len(data)) + data)
 
 
@@ -48,7 +112,9 @@ def _recv_exact(sock, n):
 
 def _recv(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > _MAX_MESSAGE:
+        raise ConnectionError("rendezvous: oversized message")
+    return _dec(json.loads(_recv_exact(sock, n).decode()))
 
 
 class Rendezvous:
@@ -61,17 +127,22 @@ class Rendezvous:
         self.port = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
         self._peers = []   # rank 0: sockets of ranks 1..world-1, by rank
         self._sock = None  # other ranks: socket to rank 0
+        self._secret_file = None
         if self.world <= 1:
             return
-        tok = _token(self.addr, self.port, self.world)
+        bind = os.environ.get("SCANN_RDZV_BIND", "127.0.0.1")  # the ranks of one node: loopback unless told otherwise
+        env_secret = os.environ.get("SCANN_RDZV_SECRET")
+        spath = _secret_path(self.addr, self.port, self.world)
         deadline = time.time() + timeout
         if self.rank == 0:
+            tok = _token(self.addr, self.port, self.world, env_secret if env_secret else _write_secret(spath))
+            self._secret_file = None if env_secret else spath
             srv = None
             for p in _candidates(self.port):
                 s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
                 try:
-                    s.bind((self.addr, p))
+                    s.bind((bind, p))
                     srv = s
                     break
                 except OSError:
@@ -103,11 +174,17 @@ class Rendezvous:
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
-            hello = _MAGIC + tok + struct.pack("<i", self.rank)
             while self._sock is None:
+                secret = env_secret if env_secret else _read_secret(spath)  # re-read every round: rank 0 may not have written it yet
+                if secret is None:
+                    if time.time() > deadline:
+                        raise TimeoutError("rendezvous: rank %d found no job secret (%s)" % (self.rank, spath))
+                    time.sleep(0.05)
+                    continue
+                hello = _MAGIC + _token(self.addr, self.port, self.world, secret) + struct.pack("<i", self.rank)
                 for p in _candidates(self.port):
                     try:
-                        s = socket.create_connection((self.addr, p), timeout=2.0)
+                        s = socket.create_connection((bind, p), timeout=2.0)
                         s.sendall(hello)
                         if _recv_exact(s, 2) == b"OK":
                             s.settimeout(None)
@@ -161,3 +238,9 @@ class Rendezvous:
             except OSError:
                 pass
         self._peers, self._sock = [], None
+        if self._secret_file:
+            try:
+                os.unlink(self._secret_file)
+            except OSError:
+                pass
+            self._secret_file = None

@@ -92,10 +92,12 @@ class PackedDataset:
         are independent and the packed layout has no per-batch padding, so a group of batches is just a longer batch."""
         return self._slice(self.indexes[i0 * self.batch_size:i1 * self.batch_size])
 
-    def batch_part(self, idx, rank, world):
+    def batch_part(self, idx, rank, world, to_end=False):
         """Rank ``rank``'s contiguous share of batch ``idx`` (data-parallel training: a rank never packs the structures of
-        the other ranks).  Same split as ``scann.parallel.rank_slice`` applied to the whole batch."""
-        sel = self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size]
+        the other ranks).  Same split as ``scann.parallel.rank_slice`` applied to the whole batch.  ``to_end``: the batch
+        also takes every structure after it (a final batch with fewer structures than ranks is folded into its predecessor,
+        ``scann.models.trainer.dp_batches``)."""
+        sel = self.indexes[idx * self.batch_size:] if to_end else self.indexes[idx * self.batch_size:(idx + 1) * self.batch_size]
         base, rem = divmod(len(sel), world)
         lo = rank * base + min(rank, rem)
         return self._slice(sel[lo:lo + base + (1 if rank < rem else 0)])

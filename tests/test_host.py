@@ -542,6 +542,76 @@ def test_rendezvous_three_ranks_without_torch(tmp_path):
     assert spawn_ranks([str(script)], 3, timeout=120) == 0
 
 
+def test_rendezvous_file_secret_and_no_pickle(tmp_path):
+    """Under torch.distributed.run no launcher hands the ranks a secret: rank 0 writes one to a 0600 file, the others read it.
+    A stranger that knows every public coordinate of the job but not the secret is turned away, and nothing that arrives on
+    the socket is unpickled (messages are JSON)."""
+    import pickle
+    import socket
+    import struct
+    import threading
+
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.parallel import rendezvous as rz
+
+    script = tmp_path / "rdzv_worker2.py"
+    script.write_text("ROOT = %r\n" % ROOT + r"""
+import os, sys
+sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+from scann.parallel.rendezvous import Rendezvous
+r = Rendezvous()
+assert r.allreduce_sum(r.rank + 1) == 3
+assert r.broadcast(b"\x00\xffid" if r.rank == 0 else None) == b"\x00\xffid"
+r.close()
+""")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("SCANN_RDZV_SECRET", "SCANN_RDZV_ID", "TORCHELASTIC_RUN_ID")}
+    env.update(WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+
+    # a stranger hammering the candidate ports with the public coordinates and a pickle that would run code if it were loaded
+    stop, hits = threading.Event(), []
+    marker = tmp_path / "pwned"
+
+    class Boom:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+
+    def stranger():
+        blob = pickle.dumps(Boom())
+        while not stop.is_set():
+            for p in rz._candidates(port):
+                try:
+                    c = socket.create_connection(("127.0.0.1", p), timeout=0.2)
+                    c.sendall(rz._MAGIC + rz._token("127.0.0.1", port, 2, "") + struct.pack("<i", 1))
+                    c.settimeout(0.2)
+                    try:
+                        if c.recv(2) == b"OK":
+                            hits.append(p)
+                            c.sendall(struct.pack("<Q", len(blob)) + blob)
+                    except OSError:
+                        pass
+                    c.close()
+                except OSError:
+                    pass
+
+    t = threading.Thread(target=stranger, daemon=True)
+    t.start()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    codes = [p.wait(timeout=120) for p in procs]
+    stop.set()
+    t.join(timeout=5)
+    assert codes == [0, 0]
+    assert not hits and not marker.exists()
+    path = rz._secret_path("127.0.0.1", port, 2)
+    assert not os.path.exists(path)  # rank 0 removes its key file when it closes
+    with pytest.raises(TypeError):
+        rz._enc(object())
+    assert rz._dec(rz._enc([1, 2.5, None, b"\x01\x02", [np.float32(3.0)]])) == [1, 2.5, None, b"\x01\x02", [3.0]]
+
+
 def test_bench_gpus_n_spawns_n_ranks_itself():
     """`python bench.py --gpus 2` with no launcher: the parent spawns two ranks (before touching HIP) and returns their
     status.  Without a GPU every rank stops at the device check -- loudly, and the parent reports the failure."""
@@ -646,3 +716,139 @@ def test_packed_dataset_cgcnn_and_ring_match_data_iterator(tmp_path):
     assert grp.cgcnn.shape == (sum(len(e[0]) for e in de), 92)
     with pytest.raises(KeyError):
         PackedDataset(de, dn, batch_size=4, feature="cgcnn", atomic_features={1: table[1], 6: table[6]})
+
+
+# ---- round 3: the data-parallel host loop (trainer.fit) with a short final batch, atomic checkpoints, rank-0 evaluate ------------
+
+_DP_FIT_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle")]
+import scann_oracle as so
+from scann import _hip
+from scann.models import trainer
+from scann.models.scann_model import SCANN, save_container
+from scann.utils import PackedDataset
+
+_hip.comm_unique_id = lambda: bytes(range(128))      # no GPU here: the communicator id is a stand-in, RCCL is never called
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+
+
+class RB:
+    def __init__(self, shard): self.shard = shard
+    def release(self): pass
+    def free(self): pass
+
+
+class StubEngine:
+    """The calls trainer.fit makes, with the step's collectives done over the rendezvous: a rank that skipped a step (or made
+    one more) would leave the others waiting -- exactly the hang an empty shard used to cause."""
+    def __init__(self): self.q, self.seen, self.val_seen, self.steps = [], [], [], 0
+    def train_begin(self): pass
+    def set_attention_dropout(self, p): pass
+    def comm_init(self, uid, r, w): assert uid == bytes(range(128)) and (r, w) == (rank, world)
+    def broadcast_weights(self, root): pass
+    def upload(self, shard):
+        assert shard.n_struct > 0, "empty shard"
+        return RB(shard)
+    def train_step_begin(self, rb, tgt, lr, dropout=0.0, seed=0, l2=0.0):
+        assert len(tgt) == rb.shard.n_struct
+        self.q.append(self.rdzv.allgather([float((tgt ** 2).sum()), len(tgt), float(np.abs(tgt).sum())]))
+        self.seen.extend(int(t) for t in tgt); self.steps += 1
+    def train_step_end(self):
+        parts = self.q.pop(0)
+        return sum(p[0] for p in parts), int(sum(p[1] for p in parts)), sum(p[2] for p in parts)
+    def train_forward(self, rb, tgt, dropout=0.0, seed=0):
+        self.val_seen.extend(int(t) for t in tgt)
+        return float((tgt ** 2).sum())
+    def allreduce_sse(self, a, b):
+        parts = self.rdzv.allgather([float(a), int(b)])
+        return sum(p[0] for p in parts), int(sum(p[1] for p in parts))
+    def download(self, rb, want_ga=False): return np.zeros(rb.shard.n_struct, np.float32), None
+    def get_weights(self): return {"w": np.full(4, self.steps, np.float32)}
+
+
+class Model:
+    def __init__(self, eng, cfg): self.engine, self.config, self._weights = eng, cfg, {}
+    def save(self, path): save_container(path, self.config, self._weights)
+
+
+de, dn = so.synth_dataset(21 + 11, 5)
+for i, d in enumerate(de):
+    d[1] = float(i)                                   # the target identifies the structure
+out = os.environ["DP_OUT"]
+cfg = {"model": {"use_drop": False}, "hyper": {"save_path": out, "target": "t", "scheduler": "cosine", "min_lr": 1e-5, "lr": 1e-3}}
+sc = SCANN.__new__(SCANN)
+sc.config, sc.mean, sc.std = cfg, 0.0, 1.0
+eng = StubEngine()
+sc.model = Model(eng, cfg)
+kw = dict(batch_size=10, use_ring=False, feature="atomic", g_update=True, atomic_features=None)
+sc.trainIter = PackedDataset(data_energy=de[:21], data_neighbor=dn[:21], shuffle=False, **kw)   # 21 = 10 + 10 + 1: tail < world
+sc.validIter = PackedDataset(data_energy=de[21:], data_neighbor=dn[21:], shuffle=False, **kw)   # 11 = 10 + 1
+orig = trainer.Communicator.__init__
+def init(self, engine, rendezvous=None):
+    orig(self, engine, rendezvous)
+    engine.rdzv = self.rdzv
+trainer.Communicator.__init__ = init
+hist = trainer.fit(sc, epochs=2, verbose=False)
+assert trainer.dp_batches(sc.trainIter, world) == (2, True) and trainer.dp_batches(sc.validIter, world) == (1, True)
+assert eng.steps == 2 * 2, eng.steps                  # two steps per epoch on EVERY rank
+seen = eng.rdzv.allgather([eng.seen, eng.val_seen])
+if rank == 0:
+    train_all = sorted(t for s, _ in seen for t in s)
+    assert train_all == sorted(list(range(21)) * 2), train_all          # every structure once per epoch, none lost to the tail
+    assert sorted(t for _, v in seen for t in v) == sorted(list(range(21, 32)) * 2)
+    assert all(len(s) > 0 for s, _ in seen)
+    z = np.load(os.path.join(out + "_t", "models", "model_t.h5"))
+    assert "w" in z.files and json.loads(str(z["__config__"]))["hyper"]["target"] == "t"
+    assert not [f for f in os.listdir(os.path.join(out + "_t", "models")) if f.endswith(".tmp")]
+    assert len(hist["loss"]) == 2
+else:
+    assert sc.evaluate() == (None, None)              # report.txt belongs to rank 0
+    assert not os.path.exists(os.path.join(out + "_t", "report.txt"))
+print("DPFIT_OK %d" % rank)
+'''
+
+
+def test_two_rank_fit_with_a_short_final_batch(tmp_path):
+    """trainer.fit on two CPU ranks (engine replaced by a stand-in whose collectives go over the rendezvous): a final batch
+    with fewer structures than ranks is folded into the one before it on every rank alike, nobody gets an empty shard, nobody
+    hangs, rank 0 alone writes the (atomically replaced) checkpoint, and evaluate is a no-op on the other ranks."""
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.parallel.launch import spawn_ranks
+
+    script = tmp_path / "dp_fit_worker.py"
+    script.write_text("ROOT = %r\n" % ROOT + _DP_FIT_WORKER)
+    env = dict(os.environ, DP_OUT=str(tmp_path / "run"))
+    assert spawn_ranks([str(script)], 2, env=env, timeout=180) == 0
+
+
+def test_checkpoint_replace_is_atomic(tmp_path):
+    """A reader polling the checkpoint while it is rewritten again and again never sees a partial file."""
+    import threading
+
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.models.scann_model import save_container
+
+    path = str(tmp_path / "models" / "m.h5")
+    w = {"a": np.arange(200000, dtype=np.float32)}
+    save_container(path, {"k": 0}, w)
+    stop, bad = threading.Event(), []
+
+    def reader():
+        while not stop.is_set():
+            try:
+                z = np.load(path)
+                if z["a"].shape != (200000,):
+                    bad.append("shape")
+            except Exception as e:  # a torn file would raise BadZipFile / ValueError
+                bad.append(repr(e))
+
+    t = threading.Thread(target=reader)
+    t.start()
+    for k in range(30):
+        save_container(path, {"k": k}, w)
+    stop.set()
+    t.join()
+    assert not bad, bad[:3]
+    assert os.listdir(os.path.dirname(path)) == ["m.h5"]
