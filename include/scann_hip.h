@@ -30,7 +30,9 @@ typedef enum scann_status {
   SCANN_ERR_NO_DEVICE = -3,   /* no HIP device / device_id out of range */
   SCANN_ERR_HIP = -4,         /* a HIP runtime call failed (see scann_last_error) */
   SCANN_ERR_WEIGHTS = -5,     /* weights missing / wrong shape / not loaded */
-  SCANN_ERR_OOM = -6
+  SCANN_ERR_OOM = -6,
+  SCANN_ERR_RANGE = -7        /* an activation or a weight left the range of the split-fp16 projections (|x| < 65504, |w| < 255.9):
+                                 the results of the call are not valid; scann_last_error names the layer and the site */
 } scann_status;
 
 /* Model hyper-parameters: the `model:` section of configs/ *.yaml as read by create_model

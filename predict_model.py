@@ -22,16 +22,25 @@ def main(args):
     scann = SCANN(config, os.path.join(args.trained_model, "models", "model_{}.h5".format(target)), mode="infer")
     print("Load data for trained model: ", config["hyper"]["data_energy_path"])
     scann.prepare_dataset(split=False)
-    ga_scores, struct_energy, y = [], [], []
+    # the reference loops predict_data over the batches (predict_model.py:49-62); the same per-batch results come out of the
+    # pipelined dataset path (batches fused per launch sequence, uploads / launches / downloads overlapped over the streams)
     data = scann.dataIter
-    for i in range(len(data)):
-        inputs, t = data[i]
-        energy, attn_global = scann.predict_data(inputs)
-        ga_scores.extend(attn_global)
-        struct_energy.extend(list(np.squeeze(energy, -1)))
-        y.extend(list(t))
-        if i % 10 == 0:
-            print((i + 1) * data.batch_size)
+    yp, ga, yt = scann.model.predict_dataset(data, want_ga=True)
+    struct_energy = list(np.asarray(yp) * scann.std + scann.mean)   # predict_data's de-normalisation (scann_model.py:315-319)
+    y = list(yt)
+    # GA scores in the reference's shape: one [M, 1] array per structure, M = largest structure of ITS batch (zeros behind the
+    # structure's own atoms: the softmax of the -1e9 mask)
+    counts = [len(data.data_energy[i][0]) for i in data.indexes]
+    off = np.concatenate([[0], np.cumsum(counts)])
+    ga_scores = []
+    for b0 in range(0, len(counts), data.batch_size):
+        sel = range(b0, min(len(counts), b0 + data.batch_size))
+        m = max(counts[i] for i in sel)
+        for i in sel:
+            a = np.zeros((m, 1), dtype=np.float32)
+            a[:counts[i], 0] = ga[off[i]:off[i + 1]]
+            ga_scores.append(a)
+    print(len(y))
     print(r2_score(struct_energy, y), mean_absolute_error(struct_energy, y))
     print("Save prediction and GA score")
     pickle.dump(ga_scores, open(os.path.join(args.trained_model, "ga_scores_{}.pickle".format(target)), "wb"))

@@ -31,6 +31,18 @@ __host__ __device__ inline float drop_scale(unsigned long long seed, unsigned ta
   const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
   return u < p ? 0.f : 1.0f / (1.0f - p);
 }
+// Range guard of the split-fp16 projections (|activation| and |weight| * 2^8 must stay below 65504, the largest fp16): an operand
+// that overflows becomes inf in its hi part, the product NaN, and the NaN reaches the statistics of the next LayerNorm.  The
+// kernels therefore test every LayerNorm variance (and the one activation that no LayerNorm follows) for finiteness and, on
+// failure, store (site << 8 | layer + 1) in a host-pinned word that the entry points returning results check after their
+// synchronisation (SCANN_ERR_RANGE).  Sites: 1 layer_norm_g, 2 layer_norm (context), 3 ResidualNorm, 4 after_Lc activation,
+// 5 a weight after an optimiser step.
+__device__ __forceinline__ void flag_range(int32_t* flag, int site, int layer) {
+  if (flag && *reinterpret_cast<volatile int32_t*>(flag) == 0)  // the first report stands: kernels run in layer order on their stream
+    *flag = (site << 8) | (layer + 1);
+}
+constexpr float RANGE_FINITE = 3.0e38f;  // !(x < RANGE_FINITE): inf or NaN
+
 constexpr unsigned DROP_TAG_ATTN = 2000;   // + layer: Dropout(0.05) on attention weights, element = edge * 8 + head
 constexpr unsigned DROP_TAG_EMBED = 1000;  // Dropout(0.1) after dense_embed (scann_model.py:374); ResidualNorm l uses tag l
 
@@ -125,6 +137,8 @@ struct AtomArgs {
   float *keep_pre1, *keep_H1, *keep_T2;
   float *keep_preA, *keep_z;   // mode 2, training forward: after_Lc pre-activation and swish output [n_atom,128]
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS, env SCANN_STAMP_ATOM=1) only: [n_tiles,16] phase clocks
+  int32_t* range_flag;         // host-pinned range-guard word (flag_range) or null
+  int32_t layer;               // layer whose projections this launch computes (for the range-guard message)
 };
 void launch_atom(const AtomArgs& a, hipStream_t s);
 
@@ -157,12 +171,14 @@ struct EdgeArgs {
   uint32_t attn_drop_tag;
   unsigned long long attn_drop_seed;
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS) only: [n_tile,16] phase clocks, else null
+  int32_t* range_flag;         // host-pinned range-guard word (flag_range) or null
+  int32_t layer;
   LayerParams p;
 };
 void launch_edge(const EdgeArgs& a, hipStream_t s);
 // softmax merge of the chunk tiles of every big atom (+ unscaled-query residual + LayerNorm, attention.py:189-214)
 void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,
-                       const float* ln_b, float* ctx, hipStream_t s);
+                       const float* ln_b, float* ctx, int32_t* range_flag, int layer, hipStream_t s);
 
 struct ReadoutArgs {
   const int32_t* mol_offset;  // [n_struct+1]

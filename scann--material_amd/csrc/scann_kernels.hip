@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
       const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
       const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
       const float rstd = 1.0f / sqrtf(var + 1e-6f);
+      if (!(var < RANGE_FINITE) && row < nrows) flag_range(a.range_flag, 3, a.layer - 1);  // an operand of the ResidualNorm overflowed fp16
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + cbase + 8 * j]);
@@ -298,6 +299,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
         const float4 pre = make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
                                        fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
         const float4 z = f4swish(pre);
+        // no LayerNorm follows this activation: test it directly (its hi part feeds the GlobalAttention projections)
+        if (!(fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))) < 65504.f) && row < nrows) flag_range(a.range_flag, 4, a.layer);
         if (a.keep_preA && row < nrows) {  // training forward: after_Lc pre-activation and output, kept for the backward
           st4(a.keep_preA, ooff[rt] + 32 * j, pre);
           st4(a.keep_z, ooff[rt] + 32 * j, z);
@@ -593,6 +596,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
       const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
       const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
       const float rstd = 1.0f / sqrtf(var + 1e-6f);
+      if (!(var < RANGE_FINITE) && row < ne) flag_range(a.range_flag, 1, a.layer);  // an operand of the geometry update overflowed fp16
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 g = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
@@ -775,6 +779,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
       v += __shfl_xor(v, 1);
       v += __shfl_xor(v, 2);
       v += __shfl_xor(v, 4);
+      if (!(v < RANGE_FINITE)) flag_range(a.range_flag, 2, a.layer);  // the gated rows or the keys overflowed fp16
       const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -800,7 +805,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 // add the unscaled query and apply the LayerNorm (attention.py:189-214).  One workgroup of 128 threads per such atom.
 __global__ __launch_bounds__(128) void edge_merge_kernel(const int32_t* __restrict__ big_tab, const float* __restrict__ part_buf,
                                                          const float* __restrict__ q, const float* __restrict__ ln_g,
-                                                         const float* __restrict__ ln_b, float* __restrict__ ctx) {
+                                                         const float* __restrict__ ln_b, float* __restrict__ ctx,
+                                                         int32_t* __restrict__ range_flag, int layer) {
   __shared__ float sRed[2][2];
   const int c = threadIdx.x, atom = big_tab[3 * blockIdx.x], s0 = big_tab[3 * blockIdx.x + 1], ns = big_tab[3 * blockIdx.x + 2];
   const float* pb = part_buf + (size_t)s0 * 3 * D + c;
@@ -825,14 +831,16 @@ __global__ __launch_bounds__(128) void edge_merge_kernel(const int32_t* __restri
   for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
   if ((c & 63) == 0) sRed[1][c >> 6] = v;
   __syncthreads();
+  if (!(sRed[1][0] + sRed[1][1] < RANGE_FINITE) && c == 0) flag_range(range_flag, 2, layer);
   const float rstd = 1.0f / sqrtf((sRed[1][0] + sRed[1][1]) * (1.0f / D) + 1e-6f);
   const float inv = rstd * ln_g[c];
   ctx[(size_t)atom * D + c] = t * inv + (ln_b[c] - mean * inv);
 }
 
 void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,
-                       const float* ln_b, float* ctx, hipStream_t s) {
-  if (n_big > 0) hipLaunchKernelGGL(edge_merge_kernel, dim3(n_big), dim3(128), 0, s, big_tab, part_buf, q, ln_g, ln_b, ctx);
+                       const float* ln_b, float* ctx, int32_t* range_flag, int layer, hipStream_t s) {
+  if (n_big > 0)
+    hipLaunchKernelGGL(edge_merge_kernel, dim3(n_big), dim3(128), 0, s, big_tab, part_buf, q, ln_g, ln_b, ctx, range_flag, layer);
 }
 
 void launch_edge(const EdgeArgs& a, hipStream_t s) {

@@ -163,6 +163,7 @@ struct scann_handle {
   size_t sc_host_cap = 0;
   struct scann_dbatch* sc_db = nullptr;
   int comm_world = 1;
+  int32_t* range_flag = nullptr;  // host-pinned, written by the kernels' range guard (flag_range), read after a synchronisation
 };
 
 struct scann_dbatch {
@@ -203,6 +204,23 @@ int fail(scann_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg;
   else g_create_error = msg;
   return code;
+}
+
+// After a synchronisation: did a kernel of the finished work trip the range guard (flag_range)?  The word is cleared, so the handle
+// stays usable once the caller has dealt with the cause.
+int check_range(scann_handle* h, const char* where) {
+  if (!h->range_flag) return SCANN_OK;
+  const int32_t code = *reinterpret_cast<volatile int32_t*>(h->range_flag);
+  if (!code) return SCANN_OK;
+  *h->range_flag = 0;
+  const int site = code >> 8, layer = (code & 0xff) - 1;
+  static const char* const names[] = {"?", "layer_norm_g statistics (geometry update)", "layer_norm statistics (attention context)",
+                                      "ResidualNorm statistics", "after_Lc activation", "a weight after the optimiser step"};
+  std::string m = std::string(where) + ": value outside the range of the split-fp16 projections (|activation| < 65504, |weight| < 255.9): " +
+                  (site >= 1 && site <= 5 ? names[site] : names[0]);
+  if (site != 5) m += layer >= h->cfg.n_attention ? ", readout" : ", local_attention_" + std::to_string(layer);
+  m += "; the results of this call are not valid";
+  return fail(h, SCANN_ERR_RANGE, m);
 }
 
 #define HIPCHK(h, expr)                                                                               \
@@ -396,6 +414,11 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
     delete h;
     return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipSetDevice failed");
   }
+  if (hipHostMalloc((void**)&h->range_flag, 64, hipHostMallocDefault) != hipSuccess) {
+    delete h;
+    return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipHostMalloc failed");
+  }
+  *h->range_flag = 0;
   for (int i = 0; i < h->nstream; ++i) {
     if (hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking) != hipSuccess) {
       delete h;
@@ -418,6 +441,7 @@ void scann_destroy(scann_handle_t* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->train_aux) (void)hipStreamDestroy(h->train_aux);
   if (h->h_stat) (void)hipHostFree(h->h_stat);
+  if (h->range_flag) (void)hipHostFree(h->range_flag);
   for (float* t : h->h_targets)
     if (t) (void)hipHostFree(t);
   for (hipEvent_t e : h->step_ev)
@@ -978,6 +1002,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       }
     }
     a.c = c_of(l);
+    a.range_flag = h->range_flag; a.layer = l;
     if (h->train_drop_p > 0.f) {  // training-mode Dropout(0.1) layers (scann_model.py:374, attention.py:29)
       a.drop_p = (l == 0 || c.use_attn_norm) ? h->train_drop_p : 0.f;
       a.drop_seed = h->train_seed;
@@ -1018,6 +1043,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       db->kept = true;
     }
     ea.p = h->layers[l];
+    ea.range_flag = h->range_flag; ea.layer = l;
     const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) {
@@ -1040,7 +1066,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
 #endif
     launch_edge(ea, s);
-    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, s);
+    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, h->range_flag, l, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);
@@ -1085,7 +1111,7 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
   if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   db->idle = true;
-  return SCANN_OK;
+  return check_range(h, "scann_batch_download");
 }
 
 int scann_sync(scann_handle_t* h) {
@@ -1472,7 +1498,7 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
   hipStream_t s = h->streams[0];
   HIPCHK(h, hipMemcpyAsync(sse_out, w->sse, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
-  return SCANN_OK;
+  return check_range(h, "scann_train_forward");
 }
 
 static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat, bool dy_done);
@@ -1736,7 +1762,7 @@ static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, fl
   const size_t n = h->host_master.size();
   // t_l2 holds a 0/1 mask; fold the coefficient in by scaling through the kernel argument
   launch_adam(h->t_master, h->t_grad, h->t_m, h->t_v, h->t_l2, n, lr_hat, beta1, beta2, eps, l2, zero_g, s);
-  launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, s);
+  launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, h->range_flag, s);
   if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
     launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
                      h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
@@ -1750,7 +1776,7 @@ int scann_adam_step(scann_handle_t* h, float lr_t, float beta1, float beta2, flo
   const int r = adam_impl(h, lr_t, beta1, beta2, eps, l2, 0);
   if (r) return r;
   HIPCHK(h, hipStreamSynchronize(h->streams[0]));
-  return SCANN_OK;
+  return check_range(h, "scann_adam_step");
 }
 
 // One optimisation step without a host round trip in the middle: forward, [all-reduce of {sse, count}], backward with the loss scale
@@ -1794,12 +1820,12 @@ int scann_train_step_end(scann_handle_t* h, double* sse_out, int64_t* count_out,
   if (h->step_begun == h->step_ended) return fail(h, SCANN_ERR_INVALID, "scann_train_step_end: no step in flight");
   HIPCHK(h, hipSetDevice(h->device));
   const int slot = (int)(h->step_ended & 1);  // the OLDEST step in flight
-  h->step_ended += 1;
   HIPCHK(h, hipEventSynchronize(h->step_ev[slot]));
+  h->step_ended += 1;  // only now: after a failed wait the slot still counts as in flight (its buffers are not reused)
   *sse_out = h->h_stat[4 * slot];
   *count_out = (int64_t)(h->h_stat[4 * slot + 1] + 0.5);
   if (abs_err_out) *abs_err_out = h->h_stat[4 * slot + 2];
-  return SCANN_OK;
+  return check_range(h, "scann_train_step_end");
 }
 
 int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets, float dropout, uint64_t seed, float lr_t, float beta1,
@@ -1838,7 +1864,7 @@ int scann_broadcast_weights(scann_handle_t* h, int root) {
   hipStream_t s = h->streams[0];
   const ncclResult_t r = ncclBroadcast(h->t_master, h->t_master, h->host_master.size(), ncclFloat, root, h->comm, s);
   if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
-  launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, s);
+  launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, h->range_flag, s);
   if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
     launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
                      h->cfg.embedding_dim, h->d_weights + h->o_lut, s);

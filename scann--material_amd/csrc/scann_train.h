@@ -121,6 +121,6 @@ void launch_sse(const float* y, const float* t, int n, double* out, float* t_dev
 void launch_dy(const float* y, const float* t, int n, float scale, const double* stat, float* dy, hipStream_t s);
 void launch_adam(float* w, float* g, float* m, float* v, const float* l2mask, size_t n, float lr_hat, float b1, float b2,
                  float eps, float l2, int zero_g, hipStream_t s);
-void launch_repack(const RepackDesc* descs, int n, const float* master, float* arena, hipStream_t s);
+void launch_repack(const RepackDesc* descs, int n, const float* master, float* arena, int32_t* range_flag, hipStream_t s);
 
 }  // namespace scann

@@ -1403,7 +1403,8 @@ void launch_adam(float* w, float* g, float* m, float* v, const float* l2mask, si
 
 // ---- master weights -> MFMA fragment order (after every optimiser step) --------------------------------------------------------
 // dst[((w*16 + t)*64 + lane)*4 + i] = M[8t + 4(lane>>5) + i][32w + (lane&31)], M = W (ld 128) or W^T.
-__global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float* __restrict__ master, float* __restrict__ arena) {
+__global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float* __restrict__ master, float* __restrict__ arena,
+                              int32_t* __restrict__ range_flag) {
   const RepackDesc d = descs[blockIdx.y];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 16383
   if (idx >= D * D) return;
@@ -1422,6 +1423,7 @@ __global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float*
       const int col = 32 * w + (lane & 31);
       const float x = k < k_real ? WSCALE * master[d.src + (d.transpose ? (size_t)col * D + k : (size_t)k * D + col)] : 0.f;
       const _Float16 hi = (_Float16)x;
+      if (!(fabsf(x) < 65504.f)) flag_range(range_flag, 5, -1);  // the optimiser pushed a weight past 65504 / 2^8 (or made it NaN)
       out[u] = plane ? (_Float16)(x - (float)hi) : hi;
     }
     reinterpret_cast<_Float16*>(arena + d.dst)[2 * idx] = out[0];
@@ -1432,8 +1434,8 @@ __global__ void repack_kernel(const RepackDesc* __restrict__ descs, const float*
   const int k = 8 * t + 4 * (lane >> 5) + i, j = 32 * w + (lane & 31);
   arena[d.dst + idx] = d.transpose ? master[d.src + (size_t)j * D + k] : master[d.src + (size_t)k * D + j];
 }
-void launch_repack(const RepackDesc* descs, int n, const float* master, float* arena, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(repack_kernel, dim3(D * D / 256, n), dim3(256), 0, s, descs, master, arena);
+void launch_repack(const RepackDesc* descs, int n, const float* master, float* arena, int32_t* range_flag, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(repack_kernel, dim3(D * D / 256, n), dim3(256), 0, s, descs, master, arena, range_flag);
 }
 
 }  // namespace scann

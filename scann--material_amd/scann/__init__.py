@@ -2,4 +2,4 @@
 
 ``from scann.models import SCANN`` keeps working; the Keras graph is replaced by libscann_hip.so.
 """
-__all__ = ["models", "layers", "utils"]
+__all__ = ["models", "parallel", "utils"]  # (the reference's scann.layers are the HIP kernels here: csrc/)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCANN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libscann_hip.so")
 
 SCANN_OK = 0
-STATUS = {0: "OK", -1: "INVALID", -2: "UNSUPPORTED", -3: "NO_DEVICE", -4: "HIP", -5: "WEIGHTS", -6: "OOM"}
+STATUS = {0: "OK", -1: "INVALID", -2: "UNSUPPORTED", -3: "NO_DEVICE", -4: "HIP", -5: "WEIGHTS", -6: "OOM", -7: "RANGE"}
 
 
 class ScannHipError(RuntimeError):

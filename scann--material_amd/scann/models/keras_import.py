@@ -57,17 +57,43 @@ def _leaf(wname):
     return wname.rsplit("/", 1)[-1].split(":")[0]
 
 
-def _pairs(weights, leaves):
-    """Consecutive (leaves[0], leaves[1]) pairs among ``weights`` in file order, e.g. every (kernel, bias) or (gamma, beta)."""
-    out, i = [], 0
+def _sublayer(wname):
+    """'local_attention/layer_normalization_7/gamma:0' -> ('layer_normalization', 7); no numeric suffix -> (name, 0)."""
+    parts = wname.split("/")
+    sub = parts[-2] if len(parts) >= 2 else ""
+    m = re.fullmatch(r"(.*?)_(\d+)", sub)
+    return (m.group(1), int(m.group(2))) if m else (sub, 0)
+
+
+def _pairs(weights, leaves, where=""):
+    """The (leaves[0], leaves[1]) pairs among ``weights`` -- every (kernel, bias) or (gamma, beta) of the auto-named sub-layers --
+    in the sub-layers' CREATION order.  Keras gives those sub-layers a global counter suffix (``layer_normalization_7``,
+    ``dense_3``): where the weight names carry it, the pairs are ordered by that number (the name path, not the position in the
+    file, identifies the sub-layer); a file whose order disagrees with the numbers is reported with a warning.  Names without
+    a path fall back to the file order."""
+    import warnings
+
     ws = [(n, a) for n, a in weights if _leaf(n) in leaves]
+    out, i = [], 0
     while i + 1 < len(ws):
         if _leaf(ws[i][0]) == leaves[0] and _leaf(ws[i + 1][0]) == leaves[1]:
-            out.append((ws[i][1], ws[i + 1][1]))
+            out.append((_sublayer(ws[i][0]), _sublayer(ws[i + 1][0]), ws[i][1], ws[i + 1][1]))
             i += 2
         else:
             i += 1
-    return out
+    for s0, s1, _, _ in out:
+        if s0 != s1:
+            raise ValueError("%s: %s and %s of one pair come from different sub-layers (%s, %s)" % (where, leaves[0], leaves[1], s0, s1))
+    named = all(s0[0] and "/" in n for (s0, _, _, _), (n, _) in zip(out, ws[::2]))
+    if named and len({s0[0] for s0, _, _, _ in out}) == 1:
+        by_number = sorted(out, key=lambda t: t[0][1])
+        if [t[0] for t in by_number] != [t[0] for t in out]:
+            warnings.warn("%s: sub-layers appear in the file as %s; using their creation order %s" %
+                          (where, [t[0] for t in out], [t[0] for t in by_number]))
+        out = by_number
+    elif len(out) > 1:
+        warnings.warn("%s: sub-layer names carry no creation counter; relying on the order of weight_names" % where)
+    return [(a, b) for _, _, a, b in out]
 
 
 def map_keras_weights(layers):
@@ -107,7 +133,7 @@ def map_keras_weights(layers):
                     out[p + "%s/%s" % (sub, _leaf(n))] = a
         if any("/value/" in "/" + n for n, _ in weights):
             raise ValueError("LocalAttention with v_proj=True is not what create_model builds (scann_model.py:396)")
-        lns = _pairs(weights, ("gamma", "beta"))
+        lns = _pairs(weights, ("gamma", "beta"), "local_attention %d" % k)
         if len(lns) not in (1, 2):
             raise ValueError("local_attention %d: expected 1 or 2 LayerNormalization sub-layers, found %d" % (k, len(lns)))
         out[p + "layer_norm/gamma"], out[p + "layer_norm/beta"] = lns[0]
@@ -116,7 +142,7 @@ def map_keras_weights(layers):
     for k, idx in enumerate(sorted(rn)):
         weights = rn[idx]
         p = "residual_norm_%d/" % k
-        dense, lns = _pairs(weights, ("kernel", "bias")), _pairs(weights, ("gamma", "beta"))
+        dense, lns = _pairs(weights, ("kernel", "bias"), "residual_norm %d" % k), _pairs(weights, ("gamma", "beta"), "residual_norm %d" % k)
         if len(dense) != 2 or len(lns) != 1:
             raise ValueError("residual_norm %d: expected two Dense layers and one LayerNormalization" % k)
         (out[p + "dense_1/kernel"], out[p + "dense_1/bias"]), (out[p + "dense_2/kernel"], out[p + "dense_2/bias"]) = dense
@@ -209,3 +235,49 @@ def load_keras_h5(path, config=None):
     if hints.get("relu_out"):
         cfg["hyper"]["target"] = "e_b"  # the only target with the mrelu head (scann_model.py:446)
     return cfg, dict(weights)
+
+
+def expected_param_count(model):
+    """Parameters of the graph ``create_model`` builds for these architecture keys (scann_model.py:329-453; the tensor list of
+    ``scann_weight_name``), without a device."""
+    d, dg, do, emb, L = model["local_dim"], model["global_dim"], model["dense_out"], model["embedding_dim"], model["n_attention"]
+    n = 92 * emb + emb if model.get("feature") == "cgcnn" else model["n_atoms"] * emb
+    cin = emb + (10 if model.get("use_ring") else 0)
+    n += (2 * 10 + 10 if model.get("use_ring") else 0) + cin * d + d
+    if model.get("g_update"):
+        n += 2 * (20 * d + d)
+    per = 2 * (d * d + d) + ((3 * d if model.get("g_update") else 20) * d + d) + 2 * d + (2 * d if model.get("g_update") else 0)
+    if model.get("use_attn_norm"):
+        per += 2 * (d * d + d) + 2 * d
+    n += L * per
+    return n + (d * dg + dg) + 2 * (dg * dg + dg) + (dg * do + do) + (do + 1)
+
+
+def mapping_report(path, config=None):
+    """What a maintainer wants to see the day a real reference checkpoint is at hand: every tensor of the
+    file mapped to exactly one container name, none left over, the parameter count of the architecture the file implies,
+    and the hyper-parameters read from it.  Raises on any mismatch; returns the report as a dict."""
+    layers, mc = read_keras_layers(path)
+    file_tensors = [(lname, wname, np.asarray(a, dtype=np.float32)) for lname, ws in layers.items() for wname, a in ws]
+    weights = map_keras_weights(layers)
+    inferred, hints = infer_model_config(weights, mc)
+
+    def finger(a):
+        a = np.asarray(a, dtype=np.float64)
+        return (a.shape, float(a.sum()), float(np.abs(a).sum()), float(a.ravel()[0]) if a.size else 0.0)
+
+    src = sorted(finger(a) for _, _, a in file_tensors)
+    dst = sorted(finger(a) for a in weights.values())
+    if src != dst:
+        raise ValueError("checkpoint %s: %d tensors in the file, %d mapped -- the two sets differ" % (path, len(src), len(dst)))
+    model = dict((config or {}).get("model", {}))
+    model.update(inferred)
+    n_param = int(sum(a.size for a in weights.values()))
+    want = expected_param_count(model)
+    if n_param != want:
+        raise ValueError("checkpoint %s: %d parameters, the architecture it implies has %d" % (path, n_param, want))
+    if not all(np.isfinite(a).all() for a in weights.values()):
+        raise ValueError("checkpoint %s holds non-finite weights" % path)
+    return {"tensors": len(src), "parameters": n_param, "model": inferred, "hints": hints,
+            "map": [(lname + "/" + wname if not wname.startswith(lname) else wname, tuple(a.shape)) for lname, wname, a in file_tensors],
+            "names": list(weights)}

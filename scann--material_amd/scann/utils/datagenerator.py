@@ -11,20 +11,27 @@ import os
 from .general import pad_sequence
 
 
+CGCNN_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cgcnn_atom_init.json")
+
+
 def load_cgcnn_table(table=None):
-    """The 92-d CGCNN element descriptors the reference keeps as a Python dict (scann/utils/atomic_data.py, used at
-    datagenerator.py:109-110).  That table is not shipped here: pass a mapping {Z: 92 floats} or the path of a JSON file in
-    the public CGCNN `atom_init.json` format (keys "1", "2", ...), or point SCANN_CGCNN_TABLE at one.  -> float32 [Zmax+1, 92]
-    with row 0 = zeros (padding), and the mask of the elements present."""
+    """The 92-d CGCNN element descriptors the reference keeps as a Python dict (scann/utils/dataset/atomic_data.py:27-531, used
+    at datagenerator.py:109-110).  Default: the table shipped as a data file (``utils/data/cgcnn_atom_init.json``, written by
+    tools/make_cgcnn_table.py); a mapping {Z: 92 floats}, the path of a JSON file in the public ``atom_init.json`` format
+    (keys "1", "2", ...) or ``SCANN_CGCNN_TABLE`` override it.  -> float32 [Zmax+1, 92] with row 0 = zeros (padding), and the
+    mask of the elements present."""
     if table is None:
-        table = os.environ.get("SCANN_CGCNN_TABLE")
-        if not table:
-            raise FileNotFoundError(
-                "feature='cgcnn' needs the CGCNN element table: pass atomic_features={Z: [92 floats]} (or a path to a JSON "
-                "file in atom_init.json format) or set SCANN_CGCNN_TABLE")
+        table = os.environ.get("SCANN_CGCNN_TABLE") or CGCNN_TABLE_PATH
     if isinstance(table, (str, os.PathLike)):
         with open(table) as f:
             table = json.load(f)
+        if "ones" in table and "dim" in table:  # the shipped compact form: indices of the ones of every binary vector
+            dense = {}
+            for k, idx in table["ones"].items():
+                v = np.zeros(int(table["dim"]), dtype=np.float32)
+                v[idx] = 1.0
+                dense[k] = v
+            table = dense
     items = {int(k): np.asarray(v, dtype=np.float32) for k, v in table.items()}
     if not items or any(v.shape != (92,) for v in items.values()):
         raise ValueError("CGCNN table: every element needs 92 values")

@@ -1,6 +1,9 @@
-"""Host batch helpers with the reference's names and semantics (scann/utils/general.py:14-144).
-Only the parts that feed the forward path; the pymatgen / openbabel file loaders are out of scope."""
+"""Host batch helpers with the reference's names and semantics (scann/utils/general.py:14-246).
+The parts that feed the forward path, plus the README's ``load_file`` for the formats that need no pymatgen (xyz, extended
+xyz, POSCAR); the other pymatgen / openbabel file loaders are out of scope."""
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
@@ -98,3 +101,71 @@ def prepare_input_pmt(struct, d_t=4.0, w_t=0.4, angle=True):
 
     neighbors = compute_voronoi_neighbor(struct, d_thresh=d_t, w_thresh=w_t)
     return prepare_input_from_neighbors(struct.atomic_numbers, neighbors, angle)
+
+
+def process_xyz_pmt(file):
+    """``{"Atoms", "Coords"[, "Lattice"]}`` of an xyz file whose comment line may carry ``Lattice="..."`` (general.py:147-175).
+    The reference stores the cell under the misspelt key ``"Latiice"``; both spellings are set here."""
+    from .voronoi_neighbor import Structure, read_xyz
+
+    st = read_xyz(file)
+    out = {"Atoms": list(st.species), "Coords": [list(map(float, c)) for c in st.cart_coords]}
+    if isinstance(st, Structure):
+        out["Lattice"] = out["Latiice"] = [list(map(float, row)) for row in st.lattice]
+    return out
+
+
+def _read_poscar(path):
+    """VASP 5 POSCAR / CONTCAR: scale, three lattice vectors, element symbols, counts, [Selective dynamics], Direct | Cartesian."""
+    from .voronoi_neighbor import Structure
+
+    with open(path) as f:
+        lines = [ln.strip() for ln in f.read().splitlines()]
+    scale = float(lines[1].split()[0])
+    lat = np.array([[float(x) for x in lines[i].split()[:3]] for i in (2, 3, 4)])
+    lat = lat * scale if scale > 0 else lat * (abs(scale) / abs(np.linalg.det(lat))) ** (1.0 / 3.0)
+    symbols = lines[5].split()
+    if symbols[0].isdigit():
+        raise ValueError("POSCAR without an element line (VASP 4 format)")
+    counts = [int(x) for x in lines[6].split()]
+    k = 7
+    if lines[k][:1] in "sS":
+        k += 1
+    direct = lines[k][:1] not in "cCkK"
+    n = sum(counts)
+    xyz = np.array([[float(x) for x in lines[k + 1 + i].split()[:3]] for i in range(n)])
+    species = [s for s, c in zip(symbols, counts) for _ in range(c)]
+    if not direct:
+        xyz = xyz * (scale if scale > 0 else 1.0)
+    return Structure(lat, species, xyz, coords_are_cartesian=not direct)
+
+
+def load_file(file, mol=False):
+    """README entry point (general.py:178-203): the structure in ``file`` as an object ``prepare_input_pmt`` accepts.
+    ``mol=True`` (or an xyz file without a cell): the molecule is put into the reference's periodic box, every edge
+    max(10, extent + 0.1) Angstrom.  xyz / extended xyz / POSCAR are read here; for anything else pymatgen is used when it is
+    installed.  Like the reference, a file that cannot be read yields a message and ``None``."""
+    from .voronoi_neighbor import Molecule, Structure, boxed, read_xyz
+
+    try:
+        name = os.path.basename(str(file))
+        ext = os.path.splitext(name)[1].lower()
+        if ext in (".xyz", ".extxyz"):
+            st = read_xyz(file)
+            if isinstance(st, Molecule) or mol:
+                st = boxed(st if isinstance(st, Molecule) else Molecule(st.species, st.cart_coords))
+            return st
+        if name.upper().startswith(("POSCAR", "CONTCAR")) or ext in (".vasp", ".poscar"):
+            st = _read_poscar(file)
+            return boxed(Molecule(st.species, st.cart_coords)) if mol else st
+        try:
+            from pymatgen.core import Molecule as PmgMolecule, Structure as PmgStructure
+        except ImportError:
+            raise ValueError("format needs pymatgen, which is not installed")
+        if mol:
+            m = PmgMolecule.from_file(file)
+            return boxed(Molecule([str(s) for s in m.species], m.cart_coords))
+        return PmgStructure.from_file(file)
+    except Exception as e:  # the reference swallows every error here and returns None (general.py:201-203)
+        print("Can not read file using Pymatgen. Please check the file format", "(%s)" % e)
+        return None

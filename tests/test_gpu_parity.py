@@ -550,3 +550,32 @@ def test_keras_h5_checkpoint_loads_and_predicts(hip_lib, tmp_path):
     y0, ga0 = model.predict(inputs)
     assert np.array_equal(y1, y0) and np.array_equal(ga1, ga0)
     assert scann.model.config["model"]["n_attention"] == cfg["model"]["n_attention"]
+
+
+def test_activation_outside_the_split_fp16_range_is_an_error_not_a_nan(hip_lib):
+    """The projections carry every operand as fp16 hi + lo parts: an activation beyond 65504 would become inf, then NaN.  The
+    kernels test every LayerNorm variance downstream of a split (and the one activation no LayerNorm follows); the call that
+    returns the results fails with SCANN_ERR_RANGE and names the layer -- it does not hand back NaNs.  The handle stays usable."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    w = so.init_weights(cfg, 1234, perturb=True)
+    de, dn = so.synth_dataset(6, 0)
+    inputs, _ = so.pad_batch(de, dn, True)
+    y_ok = HipModel(cfg, w, device=0).predict(inputs)
+    assert np.isfinite(y_ok).all()
+    bad = dict(w)
+    bad["local_attention_1/layer_norm_g/gamma"] = (w["local_attention_1/layer_norm_g/gamma"] * 3.0e5).astype(np.float32)  # geom' ~ 3e5
+    model = HipModel(cfg, bad, device=0)
+    with pytest.raises(_hip.ScannHipError) as ei:
+        model.predict(inputs)
+    assert ei.value.code == -7 and "local_attention_" in str(ei.value) and "65504" in str(ei.value), str(ei.value)
+    model.set_weights(w)  # same handle, sane weights again: the flag was cleared by the failed call
+    assert np.array_equal(model.predict(inputs), y_ok)
+    # the activation with no LayerNorm behind it: after_Lc
+    bad = dict(w)
+    bad["after_Lc/bias"] = (w["after_Lc/bias"] + 1.0e5).astype(np.float32)
+    with pytest.raises(_hip.ScannHipError) as ei:
+        HipModel(cfg, bad, device=0).predict(inputs)
+    assert ei.value.code == -7 and "after_Lc" in str(ei.value), str(ei.value)

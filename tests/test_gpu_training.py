@@ -56,6 +56,46 @@ def grad_errors(got, ref):
     return out
 
 
+def test_mrelu_backward_is_the_identity(hip_lib):
+    """target="e_b": predict_property goes through mrelu (scann_model.py:446), max(x, 0) forward with an IDENTITY gradient
+    (custom_layers.py:6-15) -- structures whose output is clipped to 0 still push their full error back.  The output bias is
+    shifted so that about half of the pre-activations are negative."""
+    import torch_ref
+    from scann.models.scann_model import HipModel
+
+    cfg, w, pk, targets, model = setup(n=12)
+    y_pre, _ = torch_ref.forward_packed(cfg, w, pk)
+    w = dict(w)
+    w["predict_property/bias"] = (w["predict_property/bias"] - np.median(y_pre)).astype(np.float32)
+    cfg["hyper"]["target"] = "e_b"
+    model = HipModel(cfg, w, device=0)
+    y = model.predict(pk)
+    assert (y == 0).sum() >= 3 and (y > 0).sum() >= 3, y.ravel()
+    y_ref, _ = torch_ref.forward_packed(cfg, w, pk)
+    assert np.allclose(y, y_ref, rtol=1e-4, atol=1e-5)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    rmse, _ = check_grads(got, cfg, w, pk, targets)
+    assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 1e-5 * max(rmse, 1e-6)
+    # the clipped structures DO contribute: with torch.relu's zero gradient there the head gradient would differ visibly
+    import torch
+
+    W = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    cfg_lin = {"model": cfg["model"], "hyper": dict(cfg["hyper"], target="homo")}
+    yy, _ = torch_ref.forward_packed(cfg_lin, W, pk, as_tensor=True)
+    t = torch.tensor(np.asarray(targets), dtype=torch.float64).reshape(-1, 1)
+    torch.sqrt(torch.mean((torch.relu(yy) - t) ** 2)).backward()
+    g_zero = W["predict_property/kernel"].grad.numpy()
+    scale = float(np.abs(g_zero).max())
+    assert float(np.abs(got["predict_property/kernel"].reshape(g_zero.shape) - g_zero).max()) > 1e-2 * scale
+    rb.free()
+
+
 @pytest.mark.parametrize("over", [dict(), dict(use_attn_norm=False), dict(use_ga_norm=False), dict(g_update=False)],
                          ids=["qm9", "no_attn_norm", "no_ga_norm", "base"])
 def test_gradients_match_autograd(hip_lib, over):
@@ -622,4 +662,20 @@ def test_two_steps_in_flight_equal_one_at_a_time(hip_lib):
     y, _ = eng.download(rb, want_ga=False)
     first = results["serial"][0][0]
     assert abs(first[0] - sse) <= 1e-6 * sse and abs(first[2] - float(np.abs(y - targets).sum())) <= 1e-5 * first[2]
+    rb.free()
+
+
+def test_weight_pushed_out_of_range_by_the_optimiser_is_an_error(hip_lib):
+    """scann_load_weights refuses |w| >= 255.9 (the fp16 hi part of w * 2^8 must be finite); after an optimiser step the device
+    re-splits the weights itself -- a step that pushes a weight past the limit must surface as SCANN_ERR_RANGE, not as inf."""
+    from scann import _hip
+
+    cfg, w, pk, targets, model = setup()
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    eng.train_step(rb, targets, 1e-3, dropout=0.0, seed=1)  # an ordinary step is fine
+    with pytest.raises(_hip.ScannHipError) as ei:
+        eng.train_step(rb, targets, 1.0e3, dropout=0.0, seed=2)  # Adam moves every weight by ~lr: far past 255.9
+    assert ei.value.code == -7 and "weight" in str(ei.value), str(ei.value)
     rb.free()

@@ -483,8 +483,8 @@ def test_data_iterator_cgcnn_features(tmp_path, monkeypatch):
     path = tmp_path / "atom_init.json"
     path.write_text(json.dumps(table))
     monkeypatch.delenv("SCANN_CGCNN_TABLE", raising=False)
-    with pytest.raises(FileNotFoundError):
-        DataIterator(de, dn, batch_size=3, feature="cgcnn")
+    it0 = DataIterator(de, dn, batch_size=6, feature="cgcnn")  # no table given: the one shipped with the package
+    assert it0[0][0]["atomic"].shape[-1] == 92
     ref = DataIterator(de, dn, batch_size=3, g_update=True)
     for it in (DataIterator(de, dn, batch_size=3, feature="cgcnn", g_update=True, atomic_features=str(path)),
                DataIterator(de, dn, batch_size=3, feature="cgcnn", g_update=True, atomic_features={int(k): v for k, v in table.items()})):
@@ -852,3 +852,59 @@ def test_checkpoint_replace_is_atomic(tmp_path):
     t.join()
     assert not bad, bad[:3]
     assert os.listdir(os.path.dirname(path)) == ["m.h5"]
+
+
+# ---- round 3: README helpers (load_file / process_xyz_pmt), the shipped CGCNN table, package star-import -------------------------
+
+def test_readme_load_file_and_prepare_input(tmp_path, capsys):
+    """README.md:102-119: ``from scann.utils import load_file, prepare_input_pmt``.  xyz (boxed like the reference's mol path),
+    extended xyz with a cell, POSCAR; an unreadable file gives the reference's message and None (general.py:201-203)."""
+    from scann.utils import load_file, prepare_input_pmt, process_xyz_pmt
+
+    xyz = tmp_path / "w.xyz"
+    xyz.write_text("3\nwater\nO 0.0 0.0 0.12\nH 0.0 0.76 -0.47\nH 0.0 -0.76 -0.47\n")
+    st = load_file(str(xyz))
+    assert st.atomic_numbers == (8, 1, 1) and np.allclose(np.diag(st.lattice), 10.0)  # max(10, extent + 0.1)
+    assert np.allclose(np.linalg.norm(st.cart_coords[0] - st.cart_coords[1]), np.hypot(0.76, 0.59))
+    inputs = prepare_input_pmt(st, d_t=4.0, w_t=0.4, angle=False)
+    assert set(inputs) == {"atomic", "atom_mask", "neighbors", "neighbor_mask", "neighbor_weight", "neighbor_distance"}
+    assert inputs["atomic"].tolist() == [[8, 1, 1]] and inputs["neighbor_mask"].any()
+    d = process_xyz_pmt(str(xyz))
+    assert d["Atoms"] == ["O", "H", "H"] and len(d["Coords"]) == 3 and "Lattice" not in d
+    ext = tmp_path / "c.xyz"
+    ext.write_text('2\nLattice="4.0 0 0 0 4.0 0 0 0 4.0" Properties=species:S:1:pos:R:3\nNa 0 0 0\nCl 2 2 2\n')
+    d = process_xyz_pmt(str(ext))
+    assert d["Latiice"] == d["Lattice"] == [[4.0, 0, 0], [0, 4.0, 0], [0, 0, 4.0]]  # the reference's key spelling is kept too
+    assert np.allclose(load_file(str(ext)).lattice, 4.0 * np.eye(3))
+    pos = tmp_path / "POSCAR"
+    pos.write_text("NaCl\n1.0\n5.64 0 0\n0 5.64 0\n0 0 5.64\nNa Cl\n1 1\nDirect\n0 0 0\n0.5 0.5 0.5\n")
+    st = load_file(str(pos))
+    assert st.species == ["Na", "Cl"] and np.allclose(st.cart_coords[1], 2.82)
+    assert load_file(str(tmp_path / "missing.cif")) is None
+    assert "Can not read file using Pymatgen" in capsys.readouterr().out
+
+
+def test_cgcnn_table_ships_with_the_package():
+    """feature="cgcnn" works without the caller supplying the element table (the reference keeps it in
+    scann/utils/dataset/atomic_data.py and looks it up at datagenerator.py:109-110)."""
+    from scann.utils import DataIterator
+    from scann.utils.datagenerator import load_cgcnn_table
+
+    table, has = load_cgcnn_table()
+    assert table.shape == (101, 92) and has.all() and not table[0].any()
+    assert set(np.unique(table)) == {0.0, 1.0}
+    assert table[1].nonzero()[0].tolist() == [1, 19, 30, 36, 46, 64, 73, 78, 86]  # hydrogen's row of atom_init.json
+    assert (table[1:].sum(1) >= 6).all() and (table[1:].sum(1) <= 9).all()
+    de, dn = so.synth_dataset(4, 0)
+    it = DataIterator(de, dn, batch_size=4, feature="cgcnn", g_update=True)
+    inputs, _ = it[0]
+    assert inputs["atomic"].shape[-1] == 92 and inputs["atomic"].dtype == np.float32
+
+
+def test_package_star_import():
+    import subprocess
+
+    code = "import sys; sys.path.insert(0, %r); from scann import *; print(models.SCANN.__name__, utils.load_file.__name__, parallel.Rendezvous.__name__)" % \
+        os.path.join(ROOT, "scann--material_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["SCANN", "load_file", "Rendezvous"], r.stderr

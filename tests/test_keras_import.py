@@ -161,3 +161,99 @@ def test_container_to_keras_h5_and_back(tmp_path, name):
     for key in ("n_attention", "g_update", "use_attn_norm", "use_ga_norm", "use_ring", "feature", "gaussian_d", "embedding_dim", "num_head"):
         assert got_cfg["model"][key] == cfg["model"][key], (key, got_cfg["model"][key], cfg["model"][key])
     assert got_cfg["hyper"]["target"] == ("e_b" if name == "e_b" else "homo") and got_cfg["hyper"]["batch_size"] == 128
+
+
+
+def test_expected_param_count_matches_the_survey():
+    from scann.models.keras_import import expected_param_count
+    from scann.models.scann_model import normalize_config
+
+    cfg = normalize_config(so.default_config("qm9"))
+    assert expected_param_count(cfg["model"]) == 890977  # parameter count at the QM9 config
+    for over in CASES.values():
+        c = normalize_config(so.default_config("qm9"))
+        c["model"].update(over, n_attention=3)
+        w = so.init_weights(c, 1)
+        assert expected_param_count(c["model"]) == sum(int(v.size) for v in w.values()), over
+
+
+def test_sublayer_order_comes_from_the_name_path_not_the_file_order():
+    """Keras numbers auto-named sub-layers globally (layer_normalization_7, dense_3): the importer orders an attention layer's two
+    LayerNormalizations by that number, so a file that lists them the other way round is still mapped right (with a warning)."""
+    from scann.models.keras_import import map_keras_weights
+
+    cfg = so.default_config("qm9")
+    cfg["model"]["n_attention"] = 2
+    w = so.init_weights(cfg, 5, perturb=True)
+    layers = _keras_nested(cfg, w)
+    ws = layers["local_attention"]
+    gb = [t for t in ws if t[0].endswith(("gamma:0", "beta:0"))]
+    layers["local_attention"] = [t for t in ws if t not in gb] + gb[2:] + gb[:2]  # layer_norm_g's pair first
+    with pytest.warns(UserWarning, match="creation order"):
+        got = map_keras_weights(layers)
+    for k in w:
+        assert np.array_equal(got[k], w[k]), k
+
+
+@pytest.mark.skipif(H5PY_PYTHON is None, reason="no interpreter with h5py to write the Keras-layout file")
+def test_mapping_report_and_check_tool(tmp_path):
+    """tools/keras_h5_to_container.py --check on a Keras-layout file: every tensor mapped exactly once, none left over, parameter
+    count of the architecture; a file with a tensor too many fails."""
+    from scann.models.keras_import import mapping_report
+    from scann.models.scann_model import normalize_config
+
+    cfg = normalize_config(so.default_config("qm9"))
+    w = so.init_weights(cfg, 7, perturb=True)
+    npz, h5 = tmp_path / "model.npz", tmp_path / "model_keras.h5"
+    np.savez(npz, __config__=np.array(json.dumps(cfg)), **w)
+    subprocess.run([H5PY_PYTHON, os.path.join(ROOT, "tools", "make_keras_h5_fixture.py"), str(npz), str(h5)], check=True)
+    rep = mapping_report(str(h5))
+    assert rep["tensors"] == len(w) and rep["parameters"] == 890977 and set(rep["names"]) == set(w)
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "keras_h5_to_container.py"), "--check", str(h5)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "CHECK OK" in r.stdout and "890977 parameters" in r.stdout, r.stderr[-500:]
+
+
+# ---- the day a checkpoint written by TensorFlow itself is at hand ---------------------------------------------------------------
+# SCANN_REF_H5=<.../model_<target>.h5> [SCANN_REF_CONFIG=<.../config.yaml>] python -m pytest tests/test_keras_import.py -k reference_checkpoint
+
+REF_H5, REF_CFG = os.environ.get("SCANN_REF_H5"), os.environ.get("SCANN_REF_CONFIG")
+
+
+def _ref_config():
+    if not REF_CFG:
+        return None
+    import yaml
+
+    return yaml.safe_load(open(REF_CFG))
+
+
+@pytest.mark.skipif(not REF_H5, reason="SCANN_REF_H5 not set: no reference-written checkpoint at hand (README.md:126, figshare)")
+def test_reference_checkpoint_maps_completely():
+    """A real ModelCheckpoint file (scann_model.py:166-177): every HDF5 tensor mapped exactly once, none left over, parameter
+    count = the architecture the file implies; use_ring is read from the file (the published QM9 models take a 7th input
+    `ring_aromatic`, qm9_pretrained.ipynb cell 5)."""
+    from scann.models.keras_import import load_keras_h5, mapping_report
+
+    rep = mapping_report(REF_H5, _ref_config())
+    assert rep["tensors"] == len(rep["names"]) and rep["parameters"] > 0
+    cfg, w = load_keras_h5(REF_H5, _ref_config())
+    assert cfg["model"]["use_ring"] == ("extra_embed/kernel" in w)
+    assert cfg["model"]["local_dim"] == 128 and cfg["model"]["num_head"] == 8, "outside what the kernels implement"
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not REF_H5, reason="SCANN_REF_H5 not set: no reference-written checkpoint at hand")
+def test_reference_checkpoint_runs_a_finite_forward():
+    from scann.models import SCANN
+    from scann.models.keras_import import load_keras_h5
+
+    cfg, _ = load_keras_h5(REF_H5, _ref_config())
+    cfg.setdefault("hyper", {}).setdefault("target", "homo")
+    sc = SCANN(cfg, pretrained=REF_H5, mode="infer")
+    de, dn = so.synth_dataset(8, 0)
+    inputs, _ = so.pad_batch(de, dn, cfg["model"]["g_update"])
+    if cfg["model"]["use_ring"]:
+        inputs["ring_aromatic"] = np.zeros(inputs["atomic"].shape + (2,), np.int32)
+    y, ga = sc.model.predict(inputs)
+    assert y.shape == (8, 1) and np.isfinite(y).all() and np.isfinite(ga).all()

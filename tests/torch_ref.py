@@ -10,6 +10,23 @@ REGULARIZED = ("query/kernel", "key/kernel", "filter_geo/kernel", "dense_1/kerne
                "after_Lc/kernel", "bf_property/kernel")  # kernel_regularizer=l2(1e-4): attention.py:27-28,95-109,260-265; scann_model.py:428,441
 
 
+def _mrelu(x):
+    """mrelu of the reference (custom_layers.py:6-15): forward max(x, 0), backward the IDENTITY -- a tf.custom_gradient whose
+    grad(dy) returns dy, also where x < 0 (torch.relu would pass a zero there)."""
+    import torch
+
+    class MRelu(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return torch.clamp(t, min=0)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    return MRelu.apply(x)
+
+
 def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64"):
     """Training loss of the reference (scann_model.py:210-214: RMSE + sum of l2(1e-4) kernel regularisers) and its
     gradient w.r.t. every tensor, by torch autograd in fp64 (``dtype="float32"``: the same graph in single precision --
@@ -105,7 +122,7 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_s
         rep = (at[:, None] * gk[a0:a1]).sum(0)
         y = lin(F.silu(lin(rep, "bf_property")), "predict_property")
         if config.get("hyper", {}).get("target") == "e_b":
-            y = torch.relu(y)
+            y = _mrelu(y)
         ys.append(y)
         gas.append(at)
     if as_tensor:

@@ -3,6 +3,7 @@
 scann_model.py:166-177) into this package's weight container (.npz: named fp32 tensors + config JSON).
 
   python tools/keras_h5_to_container.py model_homo.h5 out.npz [config.yaml]
+  python tools/keras_h5_to_container.py --check model_homo.h5 [config.yaml]   (print the tensor map and verify it, write nothing)
 
 Pure Python (scann/utils/hdf5_lite.py): needs neither h5py nor TensorFlow.  `config.yaml` (the file train.py dumps next to
 the checkpoint) supplies the hyper-parameters the HDF5 file does not determine.  SCANN(config, pretrained="model_homo.h5",
@@ -15,11 +16,29 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scann--material_amd"))
 
-from scann.models.keras_import import load_keras_h5  # noqa: E402
+from scann.models.keras_import import load_keras_h5, mapping_report  # noqa: E402
 from scann.models.scann_model import normalize_config  # noqa: E402
 
 
+def check(argv):
+    """Every tensor of the file mapped exactly once, none left over, parameter count = the architecture's; with a GPU also one
+    finite forward.  The day a checkpoint written by TensorFlow itself is at hand, this is the command to run on it."""
+    config = None
+    if len(argv) > 3:
+        import yaml
+
+        config = yaml.safe_load(open(argv[3]))
+    rep = mapping_report(argv[2], config)
+    for (src, shape), dst in zip(rep["map"], rep["names"]):
+        print("%-70s %-14s" % (src, shape))
+    print("container names:", ", ".join(rep["names"]))
+    print("%d tensors, %d parameters; read from the file: %s %s" % (rep["tensors"], rep["parameters"], rep["model"], rep["hints"]))
+    print("CHECK OK")
+
+
 def main(argv):
+    if len(argv) >= 3 and argv[1] == "--check":
+        return check(argv)
     if len(argv) < 3:
         raise SystemExit(__doc__)
     config = None
