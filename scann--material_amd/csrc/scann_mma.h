@@ -25,11 +25,24 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
   return x * q + min(x, r) + i;
 }
 
-// hi / lo fp16 parts of four consecutive fp32 values
+// hi / lo fp16 parts of four consecutive fp32 values: hi = fp16(x) (round to nearest), lo = fp16(x - hi).  Written out as the
+// eight instructions it takes -- two packed conversions, the four exact residuals x - hi as v_fma_mix_f32 (which reads the
+// fp16 half of a register as an fp32 operand: no separate conversion back), two packed conversions -- because hipcc makes 15
+// of the plain C form (scalar and packed conversions of the same values, conversions back, subtractions).  Same bits.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
-  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-  l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-  l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+  unsigned h01, h23, l01, l23;
+  float r0, r1, r2, r3;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(v.x), "v"(v.y));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(v.z), "v"(v.w));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v.x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v.y));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v.z));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v.w));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l01) : "v"(r0), "v"(r1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l23) : "v"(r2), "v"(r3));
+  h = __builtin_bit_cast(f16x4, u32x2{h01, h23});
+  l = __builtin_bit_cast(f16x4, u32x2{l01, l23});
 }
 
 // One wave's slab of a split weight (pack_weight_f16): [wave][k-step][plane hi|lo][lane][8 halfs] -- per k-step and plane
