@@ -5,6 +5,7 @@ ctypes releases the GIL during every library call, so N threads keep N GPUs busy
 from __future__ import annotations
 
 import threading
+import time
 
 import numpy as np
 
@@ -82,10 +83,17 @@ class MultiGpuPredictor:
         runs = self._runs(costs, len(self.models))
         out, err = [None] * len(runs), []
 
+        stats = [None] * len(runs)
+
         def work(k, lo, hi):
             try:
                 part = _Run(dataset, lo, hi) if items is None else items[lo:hi]
+                w0, c0 = time.perf_counter(), time.thread_time()
                 out[k] = self.models[k].predict_dataset(part, group=group, want_ga=want_ga)
+                # wall time of the run and CPU time THIS thread burnt for it (slicing, packing, ctypes glue, copies into pinned
+                # memory; waiting for the device costs none): the host's share of the work, per device thread
+                stats[k] = {"device": self.devices[k], "structures": int(len(out[k][0])), "wall_s": time.perf_counter() - w0,
+                            "host_cpu_s": time.thread_time() - c0}
             except BaseException as e:  # surfaced in the caller's thread
                 err.append(e)
 
@@ -96,6 +104,7 @@ class MultiGpuPredictor:
             t.join()
         if err:
             raise err[0]
+        self.last_stats = stats
         y = np.concatenate([o[0] for o in out])
         ga = np.concatenate([o[1] for o in out]) if want_ga else None
         return y, ga, np.concatenate([o[2] for o in out])

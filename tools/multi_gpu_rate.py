@@ -46,6 +46,42 @@ ds = PackedDataset.from_arrays(mol, np.concatenate(atomic), eoff, np.concatenate
                                np.zeros(N, np.float32), batch_size=B)
 t_build = time.perf_counter() - t0
 ndev = _hip.load_library().scann_device_count()
+
+# Where does a device thread's time go?  Every entry point of the library is wrapped with a timer (ctypes releases the GIL inside
+# the call): thread wall time - time inside the library = Python time of that thread, which is what the threads of ONE process
+# have to share (the GIL).  N device threads can be fed as long as the sum of their Python shares stays below the wall time.
+import threading  # noqa: E402
+
+_tl = threading.local()
+_lib = _hip.load_library()
+for _name, _, _ in _hip.SYMBOLS:
+    _fn = getattr(_lib, _name)
+
+    def _timed(*a, _fn=_fn):
+        t = time.perf_counter()
+        try:
+            return _fn(*a)
+        finally:
+            _tl.inside = getattr(_tl, "inside", 0.0) + time.perf_counter() - t
+    setattr(_lib, _name, _timed)
+_orig_work = MultiGpuPredictor.predict_dataset
+_py_share = []
+_orig_hm = None
+from scann.models.scann_model import HipModel  # noqa: E402
+
+_hm_predict = HipModel.predict_dataset
+
+
+def _hm_timed(self, *a, **k):
+    _tl.inside = 0.0
+    w0 = time.perf_counter()
+    out = _hm_predict(self, *a, **k)
+    wall = time.perf_counter() - w0
+    _py_share.append({"wall_s": wall, "in_library_s": _tl.inside, "python_s": wall - _tl.inside, "structures": int(len(out[0]))})
+    return out
+
+
+HipModel.predict_dataset = _hm_timed
 for n in counts:
     devices = [d % max(ndev, 1) for d in range(n)]
     multi = MultiGpuPredictor(cfg, None, devices=devices, seed=1234)
@@ -54,8 +90,13 @@ for n in counts:
     y, _, _ = multi.predict_dataset(ds, group=8)
     dt = time.perf_counter() - t0
     assert y.shape == (N,) and np.isfinite(y).all()
+    st = _py_share[-n:]
+    cpu_us = 1e6 * sum(s["python_s"] for s in st) / N  # Python (GIL-held) microseconds per molecule, summed over the device threads
     print(json.dumps({"metric": "QM9 molecules/s forward, host-inclusive, strong scaling", "value": N / dt, "unit": "molecules/s",
                       "n_handles": n, "devices": devices, "distinct_devices": len(set(devices)), "molecules": N, "seconds": dt,
+                      "python_us_per_molecule": cpu_us,
+                      "host_ceiling_molecules_per_s": 1e6 / cpu_us,  # the device threads of one process share the GIL for this part
+                      "per_thread": st,
                       "path": "host PackedDataset -> per-device thread: slice, upload, forward, download; outputs concatenated in order",
                       "dataset_build_s": t_build}), flush=True)
     for m in multi.models:
