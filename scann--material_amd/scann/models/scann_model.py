@@ -329,10 +329,16 @@ class SCANN:
         runner = self.model
         n_gpu = int(gpus if gpus is not None else self.config["hyper"].get("gpus", 1))
         if n_gpu > 1:
-            from ..parallel import MultiGpuPredictor
+            from ..parallel import MultiGpuPredictor, MultiProcessPredictor
 
-            runner = MultiGpuPredictor(self.config, self.model.get_weights(), devices=list(range(n_gpu)))
+            # hyper.gpu_processes: one worker PROCESS per device instead of one thread (no shared interpreter; PackedDataset only)
+            if self.config["hyper"].get("gpu_processes") and hasattr(data, "batches"):
+                runner = MultiProcessPredictor(self.config, self.model.get_weights(), devices=list(range(n_gpu)))
+            else:
+                runner = MultiGpuPredictor(self.config, self.model.get_weights(), devices=list(range(n_gpu)))
         yp, _, yt = runner.predict_dataset(data)  # same per-batch results as the reference's predict loop (:264-271)
+        if hasattr(runner, "close"):
+            runner.close()
         y_predict, y = list(yp), list(yt)
         mae = mean_absolute_error(y, y_predict) * self.std
         r2 = r2_score(y, y_predict)

@@ -4,7 +4,8 @@ path -- each rank runs its shard on its own handle and the host concatenates the
 the RCCL exchanges inside libscann_hip.so; the ranks find each other through ``Rendezvous`` (loopback TCP, no torch)."""
 from .launch import spawn_ranks
 from .multi_gpu import MultiGpuPredictor
+from .multi_proc import MultiProcessPredictor
 from .rendezvous import Rendezvous
 from .shard import concat_outputs, rank_slice, slice_packed, split_packed
 
-__all__ = ["split_packed", "slice_packed", "rank_slice", "concat_outputs", "MultiGpuPredictor", "Rendezvous", "spawn_ranks"]
+__all__ = ["split_packed", "slice_packed", "rank_slice", "concat_outputs", "MultiGpuPredictor", "MultiProcessPredictor", "Rendezvous", "spawn_ranks"]

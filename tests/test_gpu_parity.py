@@ -4,6 +4,8 @@ Tolerance: BASELINE.json north_star asks <= 1e-4 relative on fp32 outputs.  Elem
 |gpu - oracle| <= RTOL * max(|oracle|, scale) with scale = RMS of the oracle tensor, so values that
 happen to sit near zero are judged against the tensor's own magnitude.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -579,3 +581,27 @@ def test_activation_outside_the_split_fp16_range_is_an_error_not_a_nan(hip_lib):
     with pytest.raises(_hip.ScannHipError) as ei:
         HipModel(cfg, bad, device=0).predict(inputs)
     assert ei.value.code == -7 and "after_Lc" in str(ei.value), str(ei.value)
+
+
+def test_process_per_gpu_predictor_equals_single_handle(hip_lib):
+    """MultiProcessPredictor: one worker PROCESS per device (spawned: fresh interpreters), the dataset's CSR arrays in shared
+    memory, outputs in a shared array -- the same bytes as one handle predicting the whole dataset.  Two workers on the one GPU
+    of this box rehearse the plumbing; inference needs no collective."""
+    from scann.models.scann_model import HipModel, normalize_config
+    from scann.parallel import MultiProcessPredictor
+    from scann.utils import PackedDataset
+
+    cfg = normalize_config(so.default_config("qm9"))
+    cfg["model"]["n_attention"] = 2
+    w = so.init_weights(cfg, 21, perturb=True)
+    de, dn = so.synth_dataset(37, 6)
+    ds = PackedDataset(data_energy=de, data_neighbor=dn, batch_size=5, use_ring=False, feature="atomic", g_update=True,
+                       atomic_features=None, shuffle=False)
+    ref_y, ref_ga, ref_t = HipModel(cfg, w, device=0, infer=True).predict_dataset(ds, group=2, want_ga=True)
+    with MultiProcessPredictor(cfg, w, devices=[0, 0], infer=True) as mp:
+        y, ga, t = mp.predict_dataset(ds, group=2, want_ga=True)
+        y2, _, _ = mp.predict_dataset(ds, group=3)  # the shared dataset is reused
+        assert np.array_equal(y, ref_y) and np.array_equal(ga, ref_ga) and np.array_equal(t, ref_t)
+        assert np.array_equal(y2, ref_y)
+        mp.forget(ds)
+
