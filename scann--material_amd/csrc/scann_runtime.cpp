@@ -1793,20 +1793,31 @@ int scann_train_step_begin(scann_handle_t* h, scann_dbatch_t* db, const float* t
   scann_train_ws* w = nullptr;
   int r = train_forward_impl(h, db, targets, dropout, seed, &w, slot);
   if (r) return r;
+  // From here on kernels of this step are queued: a failure below must not leave the slot's pinned buffers (targets, statistics)
+  // looking free while that work is still running -- drain the stream before the error goes back (the step is not counted).
+  auto drained = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    if (h->train_aux) (void)hipStreamSynchronize(h->train_aux);
+    if (h->train_aux2) (void)hipStreamSynchronize(h->train_aux2);
+    h->grads_zeroed = false;
+    return code;
+  };
   const bool single = !(h->comm && h->comm_world > 1);
   if (!single) {  // losses.py:5-6 is the RMSE of the GLOBAL batch
     const ncclResult_t nr = ncclAllReduce(w->sse, w->sse, 3, ncclDouble, ncclSum, h->comm, s);
-    if (nr != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(nr));
-    HIPCHK(h, hipMemcpyAsync(h->h_stat + 4 * slot, w->sse, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (nr != ncclSuccess) return drained(fail(h, SCANN_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(nr)));
+    if (hipMemcpyAsync(h->h_stat + 4 * slot, w->sse, 3 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
+      return drained(fail(h, SCANN_ERR_HIP, "scann_train_step_begin: hipMemcpyAsync(statistics) failed"));
   }
-  if (!h->grads_zeroed) HIPCHK(h, hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, s));
+  if (!h->grads_zeroed && hipMemsetAsync(h->t_grad, 0, h->host_master.size() * 4, s) != hipSuccess)
+    return drained(fail(h, SCANN_ERR_HIP, "scann_train_step_begin: hipMemsetAsync(gradients) failed"));
   h->grads_zeroed = false;
   r = backward_impl(h, db, *w, 0.f, w->sse, /*dy_done=*/single);
-  if (r) return r;
+  if (r) return drained(r);
   r = scann_allreduce_grads(h);
-  if (r) return r;
+  if (r) return drained(r);
   r = adam_impl(h, lr_t, beta1, beta2, eps, l2, /*zero_g=*/1);  // leaves the gradient vector zeroed for the next step
-  if (r) return r;
+  if (r) return drained(r);
   h->grads_zeroed = true;
   if (!h->step_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->step_ev[slot], hipEventDisableTiming));
   HIPCHK(h, hipEventRecord(h->step_ev[slot], s));
