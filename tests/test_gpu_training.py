@@ -283,6 +283,20 @@ def test_cli_train_then_predict_model(hip_lib, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "predict_model.py"), out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert os.path.exists(out + "/ga_scores_homo.pickle") and os.path.exists(out + "/energy_pre_homo.pickle")
+    # the pickles in the reference's shapes (predict_model.py:60-92): one [M, 1] GA array per structure, M = the largest structure
+    # of ITS batch of 16 (zeros behind the structure's own atoms), scores of a structure sum to 1; [targets, predictions] lists
+    import pickle
+
+    ga = pickle.load(open(out + "/ga_scores_homo.pickle", "rb"))
+    y, pred = pickle.load(open(out + "/energy_pre_homo.pickle", "rb"))
+    data = np.load(e_path, allow_pickle=True)
+    sizes = [len(d["Atomic"]) for d in data]
+    assert len(ga) == len(y) == len(pred) == 64
+    for b0 in range(0, 64, 16):
+        m = max(sizes[b0:b0 + 16])
+        for i in range(b0, b0 + 16):
+            assert ga[i].shape == (m, 1) and abs(float(ga[i][:sizes[i]].sum()) - 1.0) < 1e-4 and not ga[i][sizes[i]:].any()
+    assert np.isfinite(np.asarray(pred, dtype=np.float64)).all()
 
 
 def drop_scale_np(seed, tag, idx, p):
