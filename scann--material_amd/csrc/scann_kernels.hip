@@ -1029,6 +1029,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
   extern __shared__ float sDyn[];  // [4][npad] partial row sums, then [npad] scores / attention
   __shared__ float sRep[D];
+  __shared__ float sHead[D];
   __shared__ float sRed[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a0 = a.mol_offset[blockIdx.x];
@@ -1123,12 +1124,25 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
   }
   __syncthreads();
   // bf_property + predict_property (scann_model.py:437-447)
+  // (both halves of the workgroup walk 64 of the 128 input features each, 16 weight loads in flight: the 128 dependent-in-order
+  // loads of a one-thread-per-output loop were the longest wait of this kernel)
   float part = 0.f;
-  if (tid < D) {
-    float hsum = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < D; ++k) hsum += sRep[k] * a.p.Wb[k * D + tid];
-    part = swish_exact(hsum + a.p.bb[tid]) * a.p.wo[tid];
+  {
+    const int f = tid & (D - 1), half = tid >> 7;
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;  // four interleaved chains, fixed association
+    const float* __restrict__ wcol = a.p.Wb + (size_t)(64 * half) * D + f;
+    const float* __restrict__ rp = sRep + 64 * half;
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      h0 = fmaf(rp[k], wcol[(size_t)k * D], h0);
+      h1 = fmaf(rp[k + 1], wcol[(size_t)(k + 1) * D], h1);
+      h2 = fmaf(rp[k + 2], wcol[(size_t)(k + 2) * D], h2);
+      h3 = fmaf(rp[k + 3], wcol[(size_t)(k + 3) * D], h3);
+    }
+    const float hs = (h0 + h1) + (h2 + h3);
+    if (half == 1) sHead[f] = hs;
+    __syncthreads();
+    if (half == 0) part = swish_exact((hs + sHead[f]) + a.p.bb[f]) * a.p.wo[f];
   }
   part = wave_sum(part);
   if (lane == 0) sRed[wave] = part;
