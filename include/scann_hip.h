@@ -138,7 +138,8 @@ int scann_num_streams(const scann_handle_t* h);
 int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t* prof);
 
 /* Live kernel timing inside a pipelined run: while enabled, every `every`-th forward brackets each of its edge-kernel
- * launches with HIP events on the launch stream.  scann_edge_timing_read (after scann_sync) returns the average launch
+ * launches (not the first layer's launch of an inference forward, which has the basis MLP fused in: a different kernel) with
+ * HIP events on the launch stream.  scann_edge_timing_read (after scann_sync) returns the average launch
  * duration in microseconds and the number of launches sampled, and clears the samples. */
 int scann_edge_timing(scann_handle_t* h, int every);
 int scann_edge_timing_read(scann_handle_t* h, double* avg_us, int64_t* n_launches, double* avg_edges);

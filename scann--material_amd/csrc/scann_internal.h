@@ -163,7 +163,12 @@ struct EdgeArgs {
   int32_t tile_rows;           // 32 | 64: edge rows per tile of this batch's plan (selects the kernel instantiation)
   int32_t geom_dead;           // last layer of an inference forward: nobody reads geom' (scann_model.py:415-421 threads it to the NEXT layer only)
   const float* gd;             // [n_edge,20] raw distance basis (base)
-  const float* edge_weight;    // [n_edge] (base)
+  const float* edge_weight;    // [n_edge] (base; g_update with fuse_basis: the second input of the basis MLP)
+  // first layer of an inference forward (g_update, 64-row tiles): the tile's geometry rows are COMPUTED from (dist, weight) in the
+  // prologue -- basis_kernel's arithmetic on the tile's rows -- instead of being written by basis_kernel and read back here
+  int32_t fuse_basis;
+  const float* dist;           // [n_edge]
+  BasisParams basis;
   const float *c, *P1, *P3, *q;  // [n_atom,128]
   float* ctx;                  // [n_atom,128] out: LayerNorm(context)
   // training with use_drop: Dropout(0.05) on the attention weights (attention.py:116,191); 0 in inference

@@ -382,10 +382,27 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 // Range: |activation| and |weight * 256| must stay below 65504 (scann_load_weights refuses larger weights; activations here
 // are LayerNorm / swish outputs of O(1..10)).
 
-template <bool GUPD, int RT>
+//
+// FB (g_update, 64-row tiles, first layer of an inference forward): the geometry rows come out of basis_kernel's arithmetic, done
+// here on the tile's rows (Gaussian expansions -> planes -> two K = 20 products -> bias, swish, product), not out of memory.
+constexpr int BASIS_STRIDE = 72;  // halfs per staged basis row: 64 + 8 pad = 144 B (conflict-free b128 fragment reads)
+// exp(-(x - c)^2 / 0.25)  (custom_layers.py:63-65, width 0.5 squared at :51)
+__device__ __forceinline__ float gauss(float x, float c) {
+  const float d = x - c;
+  return expf(-(d * d) / 0.25f);
+}
+// v_exp_f32 form for the fused basis MLP: |abs error| <= ~2e-8 (value * |arg| * 6e-8 peaks at arg = -1)
+__device__ __forceinline__ float gauss_fast(float x, float c) {
+  const float d = x - c;
+  return fast_exp(-(d * d) * 4.0f);
+}
+
+
+template <bool GUPD, int RT, bool FB = false>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) {
 #pragma clang fp contract(off)  // fusions are written out (fmaf): both unrolled row-tile copies of a formula must round alike,
                                 // so that a row's result does not depend on where in a tile it lands (batch-composition invariance)
+  static_assert(!FB || GUPD, "the fused basis exists for the g_update kernel only");
   constexpr int TEK = 32 * RT;  // edge rows per tile: 64 (three workgroups per CU) or, for launches of one round, 32 (four)
   // hi / lo planes of the A operand (G or the basis, then ang): 2 x 64 x 272 B; afterwards K as fp32 [64][LDS_STRIDE]
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TEK * PLANE_STRIDE * 2];
@@ -418,8 +435,10 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
   // one weight slab at a time, in two halves of 4 k-steps (A: k < 64, B: k >= 64): W2 (base branch: Wf, 2 k-steps in A), later Wk
   f16x8 whA[4], wlA[4], whB[4], wlB[4];
   if (GUPD) {
-    load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
-    load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+    if (!FB) {  // (FB: requested after the basis products, whose operands and accumulators need the registers first)
+      load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
+      load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+    }
   } else {
     f16x8 th[2], tl[2];
     load_wsplit<2>(a.p.Wfh, wave, lane, th, tl);
@@ -452,12 +471,61 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
       }
       // geometry rows G of the tile's edges in the ACCUMULATOR layout, straight into registers: they stay there, exact fp32,
       // for the residual (attention.py:153); a tile without edges reads (and ignores) a valid row
-      const float* gsrc = ne > 0 ? a.geom : a.P1;
+      if (FB) {
+        // geom0 rows of the tile = swish(Gauss(dist) Wd + bd) * swish(Gauss(weight) Ww + bw) (scann_model.py:378-389): basis_kernel's
+        // instruction sequence on this tile's rows (a row's result does not depend on where in a tile it sits), the basis planes
+        // staged in the plane buffer the geometry rows take over afterwards
+        _Float16* const bH = reinterpret_cast<_Float16*>(sTile);
+        _Float16* const bL = bH + TEK * BASIS_STRIDE;
+        f16x8 bdh[2], bdl[2], bwh[2], bwl[2];
+        load_wsplit<2>(a.basis.Wdh, wave, lane, bdh, bdl);
+        load_wsplit<2>(a.basis.Wwh, wave, lane, bwh, bwl);
+        {
+          const float xd = ne > 0 ? a.dist[eb + rs] : 0.f, xw = ne > 0 ? a.edge_weight[eb + rs] : 0.f;
+          f16x8 gh[2], gl[2];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const unsigned goff = ((ne > 0 ? (unsigned)(eb + min(lrow + 32 * rt, nem1)) : (unsigned)tile.atom_begin) * D + cbase) * 4;
+          for (int i = 0; i < 8; ++i) {
+            const int k = 8 * sub + i;
+            const float cdk = a.basis.cd[min(k, NG - 1)], cwk = a.basis.cw[min(k, NG - 1)];
+            const float vd = (k < NG && r < ne) ? gauss_fast(xd, cdk) : 0.f, vw = (k < NG && r < ne) ? gauss_fast(xw, cwk) : 0.f;
+            gh[0][i] = (_Float16)vd; gl[0][i] = (_Float16)(vd - (float)gh[0][i]);
+            gh[1][i] = (_Float16)vw; gl[1][i] = (_Float16)(vw - (float)gh[1][i]);
+          }
+          if (RT == 2 || r < TEK) {  // (32-row tiles: the upper half of the staging threads has no row)
+            *reinterpret_cast<f16x8*>(bH + r * BASIS_STRIDE + 8 * sub) = gh[0];
+            *reinterpret_cast<f16x8*>(bL + r * BASIS_STRIDE + 8 * sub) = gl[0];
+            *reinterpret_cast<f16x8*>(bH + r * BASIS_STRIDE + 32 + 8 * sub) = gh[1];
+            *reinterpret_cast<f16x8*>(bL + r * BASIS_STRIDE + 32 + 8 * sub) = gl[1];
+          }
+        }
+        __syncthreads();
+        f32x16 accd[RT], accw[RT];
+        mma_split<2, true, BASIS_STRIDE, RT>(bH, bL, bdh, bdl, lane, accd);
+        mma_split<2, true, BASIS_STRIDE, RT>(bH + 32, bL + 32, bwh, bwl, lane, accw);
+        load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
+        load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+        constexpr float WINV0 = 1.0f / WSCALE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) greg[rt][j] = ld4(gsrc, goff + 32 * j);
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 bd = *reinterpret_cast<const float4*>(a.basis.bd + cbase + 8 * j);
+            const float4 bw = *reinterpret_cast<const float4*>(a.basis.bw + cbase + 8 * j);
+            const float4 sd = f4swish(make_float4(fmaf(accd[rt][4 * j], WINV0, bd.x), fmaf(accd[rt][4 * j + 1], WINV0, bd.y),
+                                                  fmaf(accd[rt][4 * j + 2], WINV0, bd.z), fmaf(accd[rt][4 * j + 3], WINV0, bd.w)));
+            const float4 sw = f4swish(make_float4(fmaf(accw[rt][4 * j], WINV0, bw.x), fmaf(accw[rt][4 * j + 1], WINV0, bw.y),
+                                                  fmaf(accw[rt][4 * j + 2], WINV0, bw.z), fmaf(accw[rt][4 * j + 3], WINV0, bw.w)));
+            greg[rt][j] = f4mul(sd, sw);
+          }
+        __syncthreads();  // every wave is done reading the basis planes: the geometry planes may overwrite them
+      } else {
+        const float* gsrc = ne > 0 ? a.geom : a.P1;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const unsigned goff = ((ne > 0 ? (unsigned)(eb + min(lrow + 32 * rt, nem1)) : (unsigned)tile.atom_begin) * D + cbase) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) greg[rt][j] = ld4(gsrc, goff + 32 * j);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -847,7 +915,10 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
   const dim3 grid(a.n_tile), block(256);
   // tile_rows is the height the batch's tile plan was made for (scann_batch_upload: 32 for launches of one round of workgroups)
-  if (a.tile_rows == 32) {
+  if (a.fuse_basis && a.g_update) {
+    if (a.tile_rows == 32) hipLaunchKernelGGL((edge_kernel<true, 1, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((edge_kernel<true, 2, true>), grid, block, 0, s, a);
+  } else if (a.tile_rows == 32) {
     if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((edge_kernel<false, 1>), grid, block, 0, s, a);
   } else {
@@ -858,21 +929,9 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
 
 // ---- basis kernel ----------------------------------------------------------------------------------
 
-// exp(-(x - c)^2 / 0.25)  (custom_layers.py:63-65, width 0.5 squared at :51)
-__device__ __forceinline__ float gauss(float x, float c) {
-  const float d = x - c;
-  return expf(-(d * d) / 0.25f);
-}
-// v_exp_f32 form for the fused basis MLP: |abs error| <= ~2e-8 (value * |arg| * 6e-8 peaks at arg = -1)
-__device__ __forceinline__ float gauss_fast(float x, float c) {
-  const float d = x - c;
-  return fast_exp(-(d * d) * 4.0f);
-}
-
 // geom0 = swish(G(dist) Wd + bd) * swish(G(weight) Ww + bw) for a tile of 64 edges: the two K = 20 products run on the matrix
 // pipe (split-fp16, K padded to 32; the VALU form of round 1 issued 2,600 instructions per wave and was VALU-bound at 92 us
 // per 16-batch launch), bias / swish / product in the accumulator layout, rows stored in 16-byte pieces.
-constexpr int BASIS_STRIDE = 72;  // halfs per staged row: 64 + 8 pad = 144 B (conflict-free b128 fragment reads)
 __global__ __launch_bounds__(256) void basis_kernel(BasisParams p, const float* __restrict__ dist,
                                                     const float* __restrict__ weight, int n_edge,
                                                     float* __restrict__ geom) {

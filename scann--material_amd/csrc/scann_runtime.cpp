@@ -116,6 +116,7 @@ struct scann_handle {
   std::vector<hipEvent_t> time_ev;  // pairs (start, stop)
   std::vector<int> time_edges;
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
+  int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -405,6 +406,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->device = device_id;
   h->specs = build_specs(*cfg);
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
+  if (const char* fb = getenv("SCANN_FUSE_BASIS")) h->fuse_basis = atoi(fb) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -966,7 +968,11 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
   auto g_of = [&](int l) { return direct && c.g_update ? db->dbg_g + (size_t)l * nE_ : db->geom; };
   if (tm) tm->mark(-1);
-  if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
+  // inference: the first layer's edge kernel computes its geometry rows from (dist, weight) itself -- geom0 is never written by a
+  // basis launch and read back (282 MB of the 16-batch forward's traffic and one launch)
+  const bool fuse_basis = h->fuse_basis && c.g_update && L > 0 && !h->debug && !h->in_train_forward && db->n_edge > 0;
+  if (fuse_basis) {}
+  else if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
   else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
   if (tm) tm->mark(0);
   if (h->debug && !direct && c.g_update && db->n_edge) HIPCHK(h, hipMemcpyAsync(db->dbg_g, db->geom, rowE, hipMemcpyDeviceToDevice, s));
@@ -1035,6 +1041,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update; ea.tile_rows = db->tile_rows;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = g_of(l); ea.geom_out = direct && c.g_update ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
+    if (fuse_basis && l == 0) { ea.fuse_basis = 1; ea.dist = db->dist; ea.basis = h->basis; }
     ea.geom_dead = (l == L - 1 && !h->debug) ? 1 : 0;  // the geometry leaving the last layer is never consumed (141 MB of writes per 16-batch launch)
     ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
     if (keep) {
@@ -1044,7 +1051,8 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
     ea.p = h->layers[l];
     ea.range_flag = h->range_flag; ea.layer = l;
-    const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0;
+    // (the first layer's launch with the basis MLP fused in is a different kernel: not part of edge_kernel's sampled average)
+    const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) {
       (void)hipEventCreate(&ev0);

@@ -605,3 +605,23 @@ def test_process_per_gpu_predictor_equals_single_handle(hip_lib):
         assert np.array_equal(y2, ref_y)
         mp.forget(ds)
 
+
+
+def test_first_layer_computes_its_geometry_rows_itself(hip_lib, monkeypatch):
+    """Inference launches on 64-row tiles never write geom0: the first layer's edge kernel runs the basis MLP on its own rows.  Same
+    bytes as the two-kernel path (SCANN_FUSE_BASIS=0), and within the contract of the oracle."""
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    w = so.init_weights(cfg, 1234, perturb=True)
+    de, dn = so.synth_dataset(384, 21, "qm9")  # > 32 Ki edges: the plan uses 64-row tiles
+    inputs, _ = so.pad_batch(de, dn, g_update=True)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SCANN_FUSE_BASIS", flag)
+        out[flag] = HipModel(cfg, w, device=0, infer=True).predict(inputs)
+    assert int(inputs["neighbor_mask"].sum()) > 32 * 1024
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    sub = {k: v[:48] for k, v in inputs.items()}
+    y_ref, _ = so.forward(cfg, w, sub, np.float32)
+    assert rel_err(out["1"][0][:48], y_ref) <= RTOL
