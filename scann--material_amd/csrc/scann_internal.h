@@ -167,6 +167,10 @@ struct EdgeArgs {
   // first layer of an inference forward (g_update, 64-row tiles): the tile's geometry rows are COMPUTED from (dist, weight) in the
   // prologue -- basis_kernel's arithmetic on the tile's rows -- instead of being written by basis_kernel and read back here
   int32_t fuse_basis;
+  // ... and, with the per-species embedding table (feature = "atomic", no ring input), the layer's atom rows c, P1, P3, q are
+  // functions of the atomic number alone: they are [n_species,128] tables computed when the weights change, the kernel indexes them
+  // through species[atom], and the first atom launch of the forward does not happen at all
+  const int32_t* species;      // [n_atom] atomic numbers, or null: c, P1, P3, q are per-atom arrays
   const float* dist;           // [n_edge]
   BasisParams basis;
   const float *c, *P1, *P3, *q;  // [n_atom,128]

@@ -450,7 +450,9 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int e = ne > 0 ? eb + min(lrow + 32 * rt, nem1) : 0;
-    nboff[rt] = ((unsigned)(ne > 0 ? a.edge_col[e] : 0) * D + cbase) * 4;
+    int nb = ne > 0 ? a.edge_col[e] : 0;
+    if (FB && a.species) nb = a.species[nb];  // row of the per-species tables
+    nboff[rt] = ((unsigned)nb * D + cbase) * 4;
     ctr[rt] = ne > 0 ? a.edge_row[e] - tile.atom_begin : 0;
     if (!GUPD) ewgt[rt] = ne > 0 ? a.edge_weight[e] : 0.f;
   }
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int idx = tid + 256 * i, la = min(idx >> 5, natom - 1), c4 = idx & 31;
-        p1reg[i] = ld4(a.P1, ((unsigned)(tile.atom_begin + la) * 32 + c4) * 16);
+        const int arow = FB && a.species ? a.species[tile.atom_begin + la] : tile.atom_begin + la;
+        p1reg[i] = ld4(a.P1, ((unsigned)arow * 32 + c4) * 16);
       }
       // geometry rows G of the tile's edges in the ACCUMULATOR layout, straight into registers: they stay there, exact fp32,
       // for the residual (attention.py:153); a tile without edges reads (and ignores) a valid row
@@ -593,7 +596,11 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 
   constexpr float WINV = 1.0f / WSCALE;
   const int qa = tid >> 5;  // query rows qa, qa + 8, qa + 16 of the tile go through this thread
-  const unsigned qoff = (unsigned)tile.atom_begin * (D * 4) + (tid & 31) * 16;
+  const unsigned qoff = (tid & 31) * 16;
+  // byte offset of the row of tile-local atom la (clamped by the caller) in an [n_atom,128] tensor / the per-species table
+  const auto arow_off = [&](int la) __attribute__((always_inline)) {
+    return qoff + (unsigned)(FB && a.species ? a.species[tile.atom_begin + la] : tile.atom_begin + la) * (D * 4);
+  };
   float4 q0, q1, q2;
   float4 cn[RT][4];
   unsigned eoff[RT];  // (edge row, first column) bytes
@@ -652,9 +659,9 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
     __syncthreads();  // statistics complete; every wave is done with the G planes and the P1 rows
     STAMP(a.stamps, 3);
     // query rows of the tile's atoms: requested now, parked in sQ (the P1 rows are dead) before the key GEMM
-    q0 = ld4(a.q, qoff + min(qa, natom - 1) * (D * 4));
-    q1 = ld4(a.q, qoff + min(qa + 8, natom - 1) * (D * 4));
-    q2 = ld4(a.q, qoff + min(qa + 16, natom - 1) * (D * 4));
+    q0 = ld4(a.q, arow_off(min(qa, natom - 1)));
+    q1 = ld4(a.q, arow_off(min(qa + 8, natom - 1)));
+    q2 = ld4(a.q, arow_off(min(qa + 16, natom - 1)));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -700,9 +707,9 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
     __syncthreads();  // every wave is done reading the basis planes
     STAMP(a.stamps, 3);
     // query rows of the tile's atoms: requested now, parked in sQ (the P1 rows are dead) before the key GEMM
-    q0 = ld4(a.q, qoff + min(qa, natom - 1) * (D * 4));
-    q1 = ld4(a.q, qoff + min(qa + 8, natom - 1) * (D * 4));
-    q2 = ld4(a.q, qoff + min(qa + 16, natom - 1) * (D * 4));
+    q0 = ld4(a.q, arow_off(min(qa, natom - 1)));
+    q1 = ld4(a.q, arow_off(min(qa + 8, natom - 1)));
+    q2 = ld4(a.q, arow_off(min(qa + 16, natom - 1)));
     __builtin_amdgcn_sched_barrier(0);
     // base SCANN: geomL = swish(gd Wf + bf) * weight (attention.py:155); ang = c[j] * geomL
 #pragma unroll

@@ -117,11 +117,16 @@ struct scann_handle {
   std::vector<int> time_edges;
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
   int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
+  int species_tables = 1;  // env SCANN_SPECIES_TABLES=0: the first layer's atom rows come from an atom launch, not from per-species tables
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
   BasisParams basis{};
   const float* lut = nullptr;  // [n_atoms,128] swish(Embedding . dense_embed)
+  // per-species rows of the first layer (feature = "atomic" without ring): P1 = lut W1 + bg, P3 = lut W3, q = lut Wq + bq of layer 0
+  // [n_atoms,128] each and a copy of the centres; recomputed on the next inference forward after the weights changed (sp_dirty)
+  float *sp_c = nullptr, *sp_P1 = nullptr, *sp_P3 = nullptr, *sp_q = nullptr;
+  bool sp_dirty = true;
   const float* cd = nullptr;   // distance Gaussian centres
   EmbedArgs embed{};           // weight pointers of the general embedding path (use_ring / cgcnn)
   // canonical (spec-order) flat parameter vector and how the device arena is derived from it
@@ -407,6 +412,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->specs = build_specs(*cfg);
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* fb = getenv("SCANN_FUSE_BASIS")) h->fuse_basis = atoi(fb) != 0;
+  if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -438,6 +444,7 @@ void scann_destroy(scann_handle_t* h) {
   for (int i = 0; i < MAX_STREAM; ++i)
     if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
   if (h->d_weights) (void)hipFree(h->d_weights);
+  if (h->sp_c) (void)hipFree(h->sp_c);
   for (void* q : {(void*)h->t_master, (void*)h->t_grad, (void*)h->t_m, (void*)h->t_v, (void*)h->t_l2, (void*)h->t_descs})
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
@@ -706,6 +713,12 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   h->embed.emb_dim = c.embedding_dim;
   h->embed.emb = P(oemb); h->embed.We = P(oWc); h->embed.be = P(obc); h->embed.Wr = P(oWr); h->embed.br = P(obr);
   h->embed.Wde = P(oWe); h->embed.bde = P(obe);
+  h->sp_dirty = true;
+  if (!general_embed && !h->sp_c && c.g_update) {  // c | P1 | P3 | q tables of the first layer, one allocation
+    const size_t tab = (size_t)c.n_atoms * D;
+    HIPCHK(h, hipMalloc((void**)&h->sp_c, 4 * tab * sizeof(float)));
+    h->sp_P1 = h->sp_c + tab; h->sp_P3 = h->sp_c + 2 * tab; h->sp_q = h->sp_c + 3 * tab;
+  }
   if (!general_embed) {
     // Embedding + dense_embed folded into a per-species table, computed on the device.
     launch_embed_lut(P(oemb), P(oWe), P(obe), c.n_atoms, c.embedding_dim, h->d_weights + olut, h->streams[0]);
@@ -986,6 +999,21 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     launch_embed(e, s);
     if (tm) tm->mark(0);
   }
+  // first layer from per-species tables: no atom launch at all (see EdgeArgs::species)
+  // (not with chunked atoms: edge_merge_kernel reads the query rows per atom)
+  const bool species0 = fuse_basis && h->species_tables && !general_embed && h->train_drop_p == 0.f && h->sp_c && db->n_big == 0;
+  if (species0 && h->sp_dirty) {
+    AtomArgs a{};
+    a.n_atom = c.n_atoms; a.x = h->lut; a.ffn = 0; a.c = h->sp_c;
+    a.range_flag = h->range_flag; a.layer = 0;
+    const LayerParams& p = h->layers[0];
+    a.mode = 0;
+    a.WAh = p.W1h; a.bA = p.bg; a.WBh = p.W3h; a.WCh = p.Wqh; a.bC = p.bq;
+    a.oA = h->sp_P1; a.oB = h->sp_P3; a.oC = h->sp_q;
+    launch_atom(a, s);
+    HIPCHK(h, hipStreamSynchronize(s));  // once per weight change: forwards on the handle's other streams read the tables too
+    h->sp_dirty = false;
+  }
   for (int l = 0; l <= L; ++l) {
     // training forward through edge_kernel_lean: q, V, T, ang, K of every layer are kept for the backward
     const bool keep = direct && h->in_train_forward && db->keep_K && l < L;
@@ -1033,7 +1061,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       db->n_stamp = nt;
     }
 #endif
-    launch_atom(a, s);
+    if (!(species0 && l == 0)) launch_atom(a, s);
     if (tm) tm->mark(l < L ? 1 : 3);
     if (h->debug && !direct) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
     if (l == L) break;
@@ -1044,6 +1072,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (fuse_basis && l == 0) { ea.fuse_basis = 1; ea.dist = db->dist; ea.basis = h->basis; }
     ea.geom_dead = (l == L - 1 && !h->debug) ? 1 : 0;  // the geometry leaving the last layer is never consumed (141 MB of writes per 16-batch launch)
     ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
+    if (species0 && l == 0) { ea.species = db->atomic; ea.c = h->sp_c; ea.P1 = h->sp_P1; ea.P3 = h->sp_P3; ea.q = h->sp_q; }
     if (keep) {
       ea.keep_V = db->keep_V + (size_t)l * nE_; ea.keep_T = db->keep_T + (size_t)l * nE_;
       ea.keep_ang = db->keep_ang + (size_t)l * nE_; ea.keep_K = db->keep_K + (size_t)l * nE_;
@@ -1771,6 +1800,7 @@ static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, fl
   // t_l2 holds a 0/1 mask; fold the coefficient in by scaling through the kernel argument
   launch_adam(h->t_master, h->t_grad, h->t_m, h->t_v, h->t_l2, n, lr_hat, beta1, beta2, eps, l2, zero_g, s);
   launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, h->range_flag, s);
+  h->sp_dirty = true;
   if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
     launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
                      h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
@@ -1884,6 +1914,7 @@ int scann_broadcast_weights(scann_handle_t* h, int root) {
   const ncclResult_t r = ncclBroadcast(h->t_master, h->t_master, h->host_master.size(), ncclFloat, root, h->comm, s);
   if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
   launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, h->range_flag, s);
+  h->sp_dirty = true;
   if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
     launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
                      h->cfg.embedding_dim, h->d_weights + h->o_lut, s);

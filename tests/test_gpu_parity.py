@@ -608,8 +608,9 @@ def test_process_per_gpu_predictor_equals_single_handle(hip_lib):
 
 
 def test_first_layer_computes_its_geometry_rows_itself(hip_lib, monkeypatch):
-    """Inference launches on 64-row tiles never write geom0: the first layer's edge kernel runs the basis MLP on its own rows.  Same
-    bytes as the two-kernel path (SCANN_FUSE_BASIS=0), and within the contract of the oracle."""
+    """Inference launches never write geom0: the first layer's edge kernel runs the basis MLP on its own rows, and with the per-species
+    embedding table it takes c, P1, P3, q from per-species tables instead of an atom launch.  Same bytes as the plain path
+    (SCANN_FUSE_BASIS=0), on 64- and 32-row tiles, and within the contract of the oracle."""
     from scann.models.scann_model import HipModel
 
     cfg = so.default_config("qm9")
@@ -617,11 +618,18 @@ def test_first_layer_computes_its_geometry_rows_itself(hip_lib, monkeypatch):
     de, dn = so.synth_dataset(384, 21, "qm9")  # > 32 Ki edges: the plan uses 64-row tiles
     inputs, _ = so.pad_batch(de, dn, g_update=True)
     out = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("SCANN_FUSE_BASIS", flag)
+    for flag in ("1", "0", "basis only"):  # fused + per-species tables | two-kernel path, atom launch | fused basis, atom launch
+        monkeypatch.setenv("SCANN_FUSE_BASIS", "0" if flag == "0" else "1")
+        monkeypatch.setenv("SCANN_SPECIES_TABLES", "1" if flag == "1" else "0")
         out[flag] = HipModel(cfg, w, device=0, infer=True).predict(inputs)
     assert int(inputs["neighbor_mask"].sum()) > 32 * 1024
-    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    for flag in ("0", "basis only"):
+        assert np.array_equal(out["1"][0], out[flag][0]) and np.array_equal(out["1"][1], out[flag][1])
+    small = {k: v[:16] for k, v in inputs.items()}  # one round of 32-row tiles: the other instantiation
+    monkeypatch.setenv("SCANN_FUSE_BASIS", "1")
+    monkeypatch.setenv("SCANN_SPECIES_TABLES", "1")
+    ys = HipModel(cfg, w, device=0, infer=True).predict(small)
+    assert np.array_equal(ys[0], out["0"][0][:16])
     sub = {k: v[:48] for k, v in inputs.items()}
     y_ref, _ = so.forward(cfg, w, sub, np.float32)
     assert rel_err(out["1"][0][:48], y_ref) <= RTOL
