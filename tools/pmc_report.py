@@ -35,7 +35,8 @@ open(os.path.join(root, "profiles", "%s_counters.txt" % tag), "w").write("\n".jo
 print("\n".join(lines))
 if "--traffic" in sys.argv:
     key = sys.argv[sys.argv.index("--traffic") + 1]
-    ek = [v for k, v in avg.items() if k.startswith("scann::edge_kernel") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+    # the plain g_update kernel on 64-row tiles (not the first layer's launch with the basis MLP fused in: `<true, 2, true>`)
+    ek = [v for k, v in avg.items() if k in ("scann::edge_kernel<true, 2>", "scann::edge_kernel<true, 2, false>") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
     if ek:
         path = os.path.join(root, "profiles", "edge_kernel.json")
         j = json.load(open(path))
