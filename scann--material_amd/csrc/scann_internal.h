@@ -202,12 +202,14 @@ struct ReadoutArgs {
 void launch_readout(const ReadoutArgs& a, hipStream_t s);
 
 // Host-side edge-tile plan of a packed batch (scann_pack.cpp): whole atoms per tile, <= tile_rows edges and <= tile_atoms
-// atoms; atoms with more than TE_MAX neighbours become chunk tiles when allow_chunks.  Fills edge_row (centre atom of each
-// edge) and validates the CSR arrays.  Returns SCANN_OK or a negative status with `err` set.
+// atoms; atoms with more than TE_MAX neighbours become chunk tiles when allow_chunks.  Validates the CSR arrays and, with
+// fill_edge_row, fills edge_row (centre atom of each edge).  Returns SCANN_OK or a negative status with `err` set.
 int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset, const int32_t* edge_col, int32_t A, int32_t E,
                int tile_rows_req, int tile_atoms, bool allow_chunks, std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part,
                std::vector<int32_t>& big_tab, std::vector<int32_t>& edge_row, int* tile_rows_out, int32_t* max_degree,
-               int32_t* n_slot, std::string& err);
+               int32_t* n_slot, std::string& err, bool fill_edge_row = true);
+// edge_row[e] = centre atom of edge e from the CSR offsets, on the device (scann_batch_upload: behind the input copy)
+void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, hipStream_t s);
 
 // Host-side permutation of a row-major [128,128] (in,out) kernel into MFMA fragment order.
 void pack_weight(const float* W, int ld, float* Wp);

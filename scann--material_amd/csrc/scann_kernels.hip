@@ -918,6 +918,16 @@ void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf,
     hipLaunchKernelGGL(edge_merge_kernel, dim3(n_big), dim3(128), 0, s, big_tab, part_buf, q, ln_g, ln_b, ctx, range_flag, layer);
 }
 
+// centre atom of every edge: one thread per atom writes its CSR row's entries (a batch has ~8 edges per atom)
+__global__ void edge_row_kernel(const int32_t* __restrict__ edge_offset, int n_atom, int32_t* __restrict__ edge_row) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_atom) return;
+  for (int e = edge_offset[a]; e < edge_offset[a + 1]; ++e) edge_row[e] = a;
+}
+void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, hipStream_t s) {
+  if (n_atom > 0) hipLaunchKernelGGL(edge_row_kernel, dim3((n_atom + 255) / 256), dim3(256), 0, s, edge_offset, n_atom, edge_row);
+}
+
 void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
   const dim3 grid(a.n_tile), block(256);

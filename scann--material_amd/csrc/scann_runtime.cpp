@@ -105,7 +105,9 @@ struct scann_handle {
   int device = 0;
   std::string err;
   hipStream_t streams[MAX_STREAM]{};
-  int nstream = 4;  // HIP streams batches are spread over (env SCANN_STREAMS, 1..16)
+  int nstream = 2;  // HIP streams batches are spread over (env SCANN_STREAMS, 1..16).  Two launch groups in flight fill each other's
+                    // latency-bound launches; with the upload off the launching thread more only split the caches (1.83 M vs 1.71 M
+                    // molecules/s host-inclusive at 4, tools/e2e_size.py)
   std::vector<WeightSpec> specs;
   bool loaded = false;
   bool debug = false;
@@ -158,6 +160,13 @@ struct scann_handle {
   hipEvent_t step_ev[2] = {nullptr, nullptr};         // recorded at the end of the step in that slot
   int64_t step_begun = 0, step_ended = 0;
   bool grads_zeroed = false;             // the gradient vector is known to be all zeros (Adam of scann_train_step leaves it so)
+  // scann_batch_upload: pinned staging buffers (a ring, grow-only) copied to the device on a stream of their own -- the call returns
+  // when the copy is ENQUEUED; the batch's first launches wait for it through the batch's event
+  struct Stage { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+  static constexpr int N_STAGE = 8;
+  Stage stage[N_STAGE];
+  int stage_next = 0;
+  hipStream_t copy_stream = nullptr;
   hipStream_t train_aux2 = nullptr;      // second side stream: the basis-MLP gradients beside the embedding chain
   bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
   hipStream_t train_aux = nullptr;       // side stream of the backward pass: weight-gradient GEMMs run beside the data-gradient chain
@@ -186,6 +195,8 @@ struct scann_dbatch {
   hipEvent_t busy_ev = nullptr;  // end of the last scann_train_step that used the batch (scann_batch_release)
   bool idle = false;             // nothing enqueued on the batch since its last scann_batch_download returned (scann_batch_release)
   int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
+  bool has_rev = false;          // in_off / in_edge are filled (uploads of a handle in training mode; else built on first backward)
+  hipEvent_t upload_ev = nullptr;  // end of the asynchronous input copy (scann_batch_upload); null: the copy was synchronous
   int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
   float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
@@ -445,6 +456,11 @@ void scann_destroy(scann_handle_t* h) {
     if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
   if (h->d_weights) (void)hipFree(h->d_weights);
   if (h->sp_c) (void)hipFree(h->sp_c);
+  for (scann_handle::Stage& st : h->stage) {
+    if (st.p) (void)hipHostFree(st.p);
+    if (st.ev) (void)hipEventDestroy(st.ev);
+  }
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (void* q : {(void*)h->t_master, (void*)h->t_grad, (void*)h->t_m, (void*)h->t_v, (void*)h->t_l2, (void*)h->t_descs})
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
@@ -746,6 +762,7 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   cached_free(db->dbg_g);
   cached_free(db->dbg_ctx);
   if (db->stamps) (void)hipFree(db->stamps);
+  if (db->upload_ev) (void)hipEventDestroy(db->upload_ev);
   free_train_ws(db);
   delete db;
 }
@@ -766,6 +783,7 @@ void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db) {
   cached_free(db->dbg_g);
   cached_free(db->dbg_ctx);
   if (db->stamps) (void)hipFree(db->stamps);
+  if (db->upload_ev) (void)hipEventDestroy(db->upload_ev);
   free_train_ws(db);
   delete db;
 }
@@ -804,13 +822,13 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   {
     std::string err;
     int r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles,
-                       tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err);
+                       tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err, false);
     if (r) return fail(h, r, "scann_batch_upload: " + err);
     // A launch that fits ONE round of workgroups is the latency chain of a tile: 32-row tiles (four workgroups per CU = 1,024 slots)
     // make that chain shorter.  Only when no atom needs chunking at 32 rows.
     if (E > 0 && E <= 32 * 1024 && max_degree <= 32) {
       r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, 32, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
-                     &tile_rows, &max_degree, &n_slot, err);
+                     &tile_rows, &max_degree, &n_slot, err, false);
       if (r) return fail(h, r, "scann_batch_upload: " + err);
     }
   }
@@ -849,7 +867,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
   const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4);
   hipError_t e = hipSuccess;
-  std::vector<char> img_vec;
+  scann_handle::Stage* stage = nullptr;
   char* img_ptr = nullptr;
   if (scratch) {
     if (off > h->sc_cap) {  // grow-only (dynamic M, N: SURVEY 8b "workspace sized on first call and grown monotonically")
@@ -868,8 +886,20 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     img_ptr = h->sc_host;
   } else {
     e = cached_malloc((void**)&db->arena, off);
-    img_vec.assign(in_bytes, 0);
-    img_ptr = img_vec.data();
+    if (e == hipSuccess && !h->copy_stream) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {  // next pinned staging buffer of the ring: free once its previous copy has completed (normally long ago)
+      stage = &h->stage[h->stage_next++ % scann_handle::N_STAGE];
+      if (stage->used) (void)hipEventSynchronize(stage->ev);
+      if (!stage->ev) e = hipEventCreateWithFlags(&stage->ev, hipEventDisableTiming);
+      if (e == hipSuccess && in_bytes > stage->cap) {
+        if (stage->p) (void)hipHostFree(stage->p);
+        stage->p = nullptr; stage->cap = 0;
+        const size_t want = in_bytes + in_bytes / 4;
+        e = hipHostMalloc((void**)&stage->p, want, hipHostMallocDefault);
+        if (e == hipSuccess) stage->cap = want;
+      }
+      img_ptr = stage->p;
+    }
   }
   if (e != hipSuccess) {
     if (!scratch) delete db;
@@ -883,12 +913,15 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   memcpy(img.data() + o_eoff, b->edge_offset, (size_t)(A + 1) * 4);
   if (E > 0) {
     memcpy(img.data() + o_col, b->edge_col, (size_t)E * 4);
-    memcpy(img.data() + o_row, edge_row.data(), (size_t)E * 4);
     memcpy(img.data() + o_dist, b->edge_dist, (size_t)E * 4);
     memcpy(img.data() + o_wgt, b->edge_weight, (size_t)E * 4);
   }
   memcpy(img.data() + o_tiles, tiles.data(), tiles.size() * sizeof(EdgeTile));
-  {  // reverse adjacency (counting sort of the edges by neighbour atom, stable): the backward pass sums per neighbour without atomics
+  // reverse adjacency (counting sort of the edges by neighbour atom, stable): the backward pass sums per neighbour without atomics.
+  // Only a handle in training mode (scann_train_begin) pays for it at upload; ensure_reverse builds it for a batch that was
+  // uploaded before, on its first backward pass.
+  const bool want_rev = h->t_master != nullptr;
+  if (want_rev) {
     int32_t* in_off = reinterpret_cast<int32_t*>(img.data() + o_inoff);
     int32_t* in_edge = reinterpret_cast<int32_t*>(img.data() + o_inedge);
     memset(in_off, 0, (size_t)(A + 1) * 4);
@@ -901,13 +934,24 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     memcpy(img.data() + o_tpart, tile_part.data(), tiles.size() * 4);
     memcpy(img.data() + o_big, big_tab.data(), (size_t)n_big * 3 * 4);
   }
+  // (the centre atom of every edge is derived from the offsets on the device, behind the copy: no host loop, no bytes over the bus)
+  int32_t* const d_eoff = (int32_t*)(db->arena + o_eoff);
+  int32_t* const d_erow = (int32_t*)(db->arena + o_row);
   if (scratch) {  // pinned staging, ordered before the kernels on stream 0
     e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->streams[0]);
+    if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->streams[0]);
   } else {
-    e = hipMemcpy(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice);
+    e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->copy_stream);
+    if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(stage->ev, h->copy_stream);
+    if (e == hipSuccess) stage->used = true;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&db->upload_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(db->upload_ev, h->copy_stream);
   }
   if (e != hipSuccess) {
     if (!scratch) {
+      (void)hipStreamSynchronize(h->copy_stream);
+      if (db->upload_ev) (void)hipEventDestroy(db->upload_ev);
       cached_free(db->arena);
       delete db;
     }
@@ -918,6 +962,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->edge_col = (int32_t*)(a0 + o_col); db->edge_row = (int32_t*)(a0 + o_row);
   db->dist = (float*)(a0 + o_dist); db->weight = (float*)(a0 + o_wgt); db->tiles = (EdgeTile*)(a0 + o_tiles);
   db->in_off = (int32_t*)(a0 + o_inoff); db->in_edge = (int32_t*)(a0 + o_inedge);
+  db->has_rev = want_rev;
   db->ring = (float*)(a0 + o_ring); db->cgcnn = (float*)(a0 + o_cg); db->c0 = (float*)(a0 + o_c0);
   db->geom = (float*)(a0 + o_geom); db->gd = (float*)(a0 + o_gd);
   db->c = (float*)(a0 + o_c); db->ctx = (float*)(a0 + o_ctx); db->P1 = (float*)(a0 + o_P1); db->P3 = (float*)(a0 + o_P3);
@@ -966,6 +1011,7 @@ int ensure_debug(scann_handle* h, scann_dbatch* db) {
 int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   db->idle = false;  // work is being enqueued on the batch (scann_batch_release)
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
+  if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention;
   const size_t rowA = (size_t)db->n_atom * D * 4, rowE = (size_t)db->n_edge * D * 4;
@@ -1557,8 +1603,30 @@ int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_globa
   return backward_impl(h, db, *wp, scale, nullptr, false);
 }
 
+// Reverse adjacency of a batch that was uploaded while the handle was not in training mode (scann_batch_upload skips it then):
+// the neighbour indices come back from the device, the counting sort runs on the host as in upload_impl.  Synchronous; once per batch.
+static int ensure_reverse(scann_handle_t* h, scann_dbatch_t* db) {
+  if (db->has_rev) return SCANN_OK;
+  const int A = db->n_atom, E = db->n_edge;
+  hipStream_t s = h->streams[0];
+  if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));
+  std::vector<int32_t> col((size_t)std::max(E, 1)), in_off((size_t)A + 1, 0), in_edge((size_t)std::max(E, 1));
+  if (E > 0) HIPCHK(h, hipMemcpyAsync(col.data(), db->edge_col, (size_t)E * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  for (int e = 0; e < E; ++e) ++in_off[(size_t)col[(size_t)e] + 1];
+  for (int a = 0; a < A; ++a) in_off[(size_t)a + 1] += in_off[(size_t)a];
+  std::vector<int32_t> fill(in_off.begin(), in_off.begin() + A);
+  for (int e = 0; e < E; ++e) in_edge[(size_t)fill[(size_t)col[(size_t)e]]++] = e;
+  HIPCHK(h, hipMemcpyAsync(db->in_off, in_off.data(), (size_t)(A + 1) * 4, hipMemcpyHostToDevice, s));
+  if (E > 0) HIPCHK(h, hipMemcpyAsync(db->in_edge, in_edge.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  db->has_rev = true;
+  return SCANN_OK;
+}
+
 // d_stat (device, {global sse, global count}) non-null: the loss scale is formed on the device (scann_train_step: no host round trip)
 static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat, bool dy_done) {
+  if (const int r = ensure_reverse(h, db)) return r;
   hipStream_t s = h->streams[0];
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;

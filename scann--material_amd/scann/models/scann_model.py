@@ -143,15 +143,22 @@ class HipModel:
         """Pipelined inference over a whole ``PackedDataset`` (or any sequence of ``(PackedBatch | inputs dict, target)``):
         batches are fused ``group`` at a time into one launch sequence, spread over the handle's streams, and fetched at
         the end -- the throughput path behind ``SCANN.evaluate`` / ``predict_model.py``.  Returns ``(y [N], ga list | None,
-        targets [N])`` in dataset order."""
+        targets [N])`` in dataset order.
+
+        Two host threads: a producer slices and uploads group k+1, k+2, ... (native calls, outside the GIL; the upload returns when
+        its copy is enqueued) while this thread enqueues the launches of group k and fetches the oldest group in flight -- slicing +
+        upload cost about as much host time per group as the device needs for it, so one thread doing both left the device idle a
+        fifth of the time (tools/e2e_breakdown.py)."""
+        import queue
+        import threading
+
         eng = self.engine
         ns = eng.num_streams()
         pending, ys, gas, ts = [], [], [], []
 
         def fetch_oldest():
             # a rolling window of `ns` groups in flight (one per stream): only the OLDEST is waited for, and its batch is released
-            # without a device-wide synchronisation, so the device keeps running the younger groups while the host slices and
-            # uploads the next one
+            # without a device-wide synchronisation, so the device keeps running the younger groups
             rb = pending.pop(0)
             y, ga = eng.download(rb, want_ga=want_ga)
             ys.append(y)
@@ -161,26 +168,77 @@ class HipModel:
 
         n = len(dataset)
         grouped = getattr(dataset, "batches", None)  # PackedDataset: a whole group with one native slice call
-        k = 0
-        for g0 in range(0, n, group):
+
+        def make(g0):
             if grouped is not None:
                 pk, tgt = grouped(g0, min(n, g0 + group))
-                ts.append(np.asarray(tgt, dtype=np.float32))
-            else:
-                parts = []
-                for i in range(g0, min(n, g0 + group)):
-                    item, tgt = dataset[i]
-                    parts.append(item if isinstance(item, _hip.PackedBatch) else _hip.pack_inputs(item))
-                    ts.append(np.asarray(tgt, dtype=np.float32))
-                pk = _hip.concat_packed(parts) if len(parts) > 1 else parts[0]
-            rb = eng.upload(pk)
-            if len(pending) >= ns:
-                fetch_oldest()  # frees the stream slot the new group is about to use
-            eng.forward_resident(rb, k)
-            k += 1
-            pending.append(rb)
-        while pending:
-            fetch_oldest()
+                return pk, [np.asarray(tgt, dtype=np.float32)]
+            parts, tg = [], []
+            for i in range(g0, min(n, g0 + group)):
+                item, tgt = dataset[i]
+                parts.append(item if isinstance(item, _hip.PackedBatch) else _hip.pack_inputs(item))
+                tg.append(np.asarray(tgt, dtype=np.float32))
+            return (_hip.concat_packed(parts) if len(parts) > 1 else parts[0]), tg
+
+        ready = queue.Queue(maxsize=max(2, ns))  # uploaded groups waiting for their launches
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def producer():
+            try:
+                for g0 in range(0, n, group):
+                    if stop.is_set():
+                        return
+                    pk, tg = make(g0)
+                    rb = eng.upload(pk)
+                    if not put((rb, tg)):
+                        rb.free()
+                        return
+                put(None)
+            except BaseException as e:  # noqa: BLE001 -- handed to the consumer, which re-raises it
+                put(e)
+
+        worker = threading.Thread(target=producer, name="scann-upload", daemon=True)
+        worker.start()
+        k = 0
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                rb, tg = item
+                ts.extend(tg)
+                if len(pending) >= ns:
+                    fetch_oldest()  # frees the stream slot the new group is about to use
+                eng.forward_resident(rb, k)
+                k += 1
+                pending.append(rb)
+            while pending:
+                fetch_oldest()
+        finally:
+            stop.set()
+            worker.join()
+            while True:  # groups uploaded but never launched (an error on either side)
+                try:
+                    item = ready.get_nowait()
+                except queue.Empty:
+                    break
+                if isinstance(item, tuple):
+                    item[0].free()
+            for rb in pending:
+                rb.free()
+        if not ys:
+            return np.zeros(0, np.float32), (np.zeros(0, np.float32) if want_ga else None), np.zeros(0, np.float32)
         return np.concatenate(ys), (np.concatenate(gas) if want_ga else None), np.concatenate(ts)
 
     def summary(self):

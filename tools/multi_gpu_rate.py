@@ -16,7 +16,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), ROOT]
-os.environ.setdefault("SCANN_STREAMS", "4")
+os.environ.setdefault("SCANN_STREAMS", "2")
 import bench  # noqa: E402
 from scann import _hip  # noqa: E402
 from scann.models.scann_model import normalize_config  # noqa: E402
