@@ -125,7 +125,11 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
                          const uint8_t* atom_mask, const int32_t* neighbors, const uint8_t* neighbor_mask,
                          const float* neighbor_weight, const float* neighbor_distance, float* y_out, float* ga_out);
 
-/* Resident-batch path (inputs already in HBM; used for pipelined inference and by bench.py). */
+/* Resident-batch path (inputs already in HBM; used for pipelined inference and by bench.py).  scann_batch_upload validates the
+ * CSR arrays, plans the edge tiles, copies the inputs into a pinned staging buffer of the handle and returns when the copy to the
+ * device is ENQUEUED on a stream of its own: the caller's arrays may be reused at once, and whatever is launched on the batch
+ * afterwards waits for the copy through the batch's event.  May be called from a second thread while the handle's owner thread
+ * launches and fetches other batches (HipModel.predict_dataset, trainer.fit do). */
 int scann_batch_upload(scann_handle_t* h, const scann_batch_t* batch, scann_dbatch_t** out);
 void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);
 void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db); /* see scann_train_step_begin */
@@ -189,7 +193,7 @@ int scann_train_step(scann_handle_t* h, scann_dbatch_t* db, const float* targets
                      float beta2, float eps, float l2, double* sse_out, int64_t* count_out);
 /* The same step in two halves: _begin enqueues everything and returns; _end waits for the OLDEST step in flight and returns its
  * {sse, count, sum |y - target|} (global over the communicator).  Up to TWO steps may be in flight: the host assembles, uploads
- * (scann_batch_upload copies on the null stream, which the handle's streams do not wait for) and begins step k + 1 while the
+ * (scann_batch_upload copies on a stream of its own; the step waits for the batch's copy event) and begins step k + 1 while the
  * device still runs step k, so the device never waits for the host.  A batch must not be freed or downloaded before the _end of
  * its step; scann_batch_release then frees it without the device-wide synchronisation of scann_batch_free.  The gradient vector
  * is left zeroed. */
