@@ -1034,7 +1034,20 @@ __global__ void embed_lut_kernel(const float* __restrict__ emb, const float* __r
                                  const float* __restrict__ b, int emb_dim, float* __restrict__ lut) {
   const int sp = blockIdx.x, col = threadIdx.x;
   float acc = 0.f;
-  for (int k = 0; k < emb_dim; ++k) acc += emb[sp * emb_dim + k] * W[k * D + col];
+  // the same sum in the same order, its operands requested sixteen at a time (the one-by-one loop was emb_dim dependent round trips:
+  // 13 us at the head of every training step)
+  for (int k0 = 0; k0 < emb_dim; k0 += 16) {
+    float e[16], w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = min(k0 + u, emb_dim - 1);
+      e[u] = emb[sp * emb_dim + k];
+      w[u] = W[k * D + col];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + u < emb_dim) acc += e[u] * w[u];
+  }
   lut[sp * D + col] = swishf(acc + b[col]);
 }
 

@@ -1818,8 +1818,9 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     pend.W[0] = pt.W1T; pend.W[1] = pt.W3T; pend.W[2] = pt.WqT;
     dG_in = dGnext;
   }
-  flush_pend();
   // ---- basis MLP and embedding (scann_model.py:362-389) ----
+  // (the basis leaf first: it needs only the geometry gradient the last edge_bwd_kernel left, and at 43 us on its own stream it is
+  // the longest thing between here and the optimiser -- started behind the embedding chain it ended 30 us after it)
   hipEvent_t ev_basis = nullptr;
   if (dG_in) {  // a leaf (parameter gradients only): on a stream of its own beside the embedding chain and the last weight gradients
     hipStream_t bs = s;
@@ -1836,8 +1837,9 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
       (void)hipEventRecord(ev_basis, bs);
     }
   }
-  launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, s);
+  flush_pend();
   if (c.use_ring || c.feature_cgcnn) {
+    launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, s);
     EmbedArgs e = h->embed;
     e.n_atom = A; e.atomic = db->atomic; e.c0 = db->c0;
     e.ring = c.use_ring ? db->ring : nullptr;
@@ -1849,7 +1851,8 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   } else {
     HIPCHK(h, hipMemsetAsync(w.dlut, 0, (size_t)c.n_atoms * D * 4, s));
     launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
-                     c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), s);
+                     c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), w.seed,
+                     DROP_TAG_EMBED, w.drop_p, s);
   }
   if (wg.off > w.wpart_floats)
     return fail(h, SCANN_ERR_HIP, "scann_train_backward: weight-gradient partial arena overrun");

@@ -114,7 +114,8 @@ void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weig
 void launch_base_geom_bwd(const float* gd, const float* Wf, const float* bf, const float* wgt, const float* dgeomL, int n_edge,
                           float* dWf, float* dbf, hipStream_t s);
 void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const float* emb, const float* W, const float* b,
-                      float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, hipStream_t s);
+                      float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, unsigned long long drop_seed,
+                      unsigned drop_tag, float drop_p, hipStream_t s);
 void launch_embed_general_bwd(const EmbedArgs& a, const float* dc0, float* dEmb, float* dWe, float* dbe, float* dWr, float* dbr,
                               float* dWde, float* dbde, hipStream_t s);
 void launch_sse(const float* y, const float* t, int n, double* out, float* t_dev, float* dy, double* host_stat, hipStream_t s);

@@ -1205,11 +1205,16 @@ void launch_base_geom_bwd(const float* gd, const float* Wf, const float* bf, con
 // the only writer of column `col`): the global table has only n_species x 128 addresses and every atomic on them is serialised
 // behind all the others of the launch, so each workgroup adds its totals once.
 __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restrict__ dc0, const int* __restrict__ atomic,
-                                                            float* __restrict__ dlut, int n_atom, int run, int n_species) {
+                                                            float* __restrict__ dlut, int n_atom, int run, int n_species,
+                                                            unsigned long long drop_seed, unsigned drop_tag, float drop_p) {
   extern __shared__ float sTab[];  // [n_species][D]
   const int col = threadIdx.x, a0 = blockIdx.x * run, a1 = min(n_atom, a0 + run);
   for (int sp = 0; sp < n_species; ++sp) sTab[sp * D + col] = 0.f;
-  for (int a = a0; a < a1; ++a) sTab[atomic[a] * D + col] += dc0[(size_t)a * D + col];
+  // (the Dropout(0.1) mask of the embedding rows, scann_model.py:374, is applied on the way in: no dropout launch before this one)
+  for (int a = a0; a < a1; ++a) {
+    const size_t i = (size_t)a * D + col;
+    sTab[atomic[a] * D + col] += drop_p > 0.f ? dc0[i] * drop_scale(drop_seed, drop_tag, i, drop_p) : dc0[i];
+  }
   for (int sp = 0; sp < n_species; ++sp) {
     const float v = sTab[sp * D + col];
     if (v != 0.f) atomicAdd(&dlut[(size_t)sp * D + col], v);
@@ -1221,12 +1226,29 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict_
   // one workgroup per species; thread = output column
   extern __shared__ float sdp[];  // [128] dpre
   const int sp = blockIdx.x, col = threadIdx.x;
+  const float dl = dlut[sp * D + col];
+  // a species absent from the batch has a zero row: nothing to add anywhere (QM9: 5 of the table's species occur; their workgroups'
+  // atomics on the shared dW / db addresses were queueing behind ~20 x as many adds of zero)
+  if (!__syncthreads_or(dl != 0.f)) return;
   float pre = b[col];
-  for (int k = 0; k < emb_dim; ++k) pre += emb[sp * emb_dim + k] * W[k * D + col];
-  const float dpre = dlut[sp * D + col] * dswish_(pre);
+  for (int k0 = 0; k0 < emb_dim; k0 += 16) {  // the same sum in the same order, operands requested sixteen at a time
+    float e[16], w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = min(k0 + u, emb_dim - 1);
+      e[u] = emb[sp * emb_dim + k];
+      w[u] = W[k * D + col];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + u < emb_dim) pre += e[u] * w[u];
+  }
+  const float dpre = dl * dswish_(pre);
   sdp[col] = dpre;
-  atomicAdd(&db[col], dpre);
-  for (int k = 0; k < emb_dim; ++k) atomicAdd(&dW[k * D + col], emb[sp * emb_dim + k] * dpre);
+  if (dpre != 0.f) {
+    atomicAdd(&db[col], dpre);
+    for (int k = 0; k < emb_dim; ++k) atomicAdd(&dW[k * D + col], emb[sp * emb_dim + k] * dpre);
+  }
   __syncthreads();
   for (int k = col; k < emb_dim; k += 128) {
     float acc = 0.f;
@@ -1235,11 +1257,12 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict_
   }
 }
 void launch_embed_bwd(const float* dc0, const int* atomic, int n_atom, const float* emb, const float* W, const float* b,
-                      float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, hipStream_t s) {
+                      float* dlut, int n_species, int emb_dim, float* dEmb, float* dW, float* db, unsigned long long drop_seed,
+                      unsigned drop_tag, float drop_p, hipStream_t s) {
   if (n_atom <= 0) return;
   const int run = std::max(32, (n_atom + 127) / 128);  // <= 128 workgroups
   hipLaunchKernelGGL(embed_scatter_kernel, dim3((n_atom + run - 1) / run), dim3(128), (size_t)n_species * D * sizeof(float), s, dc0,
-                     atomic, dlut, n_atom, run, n_species);
+                     atomic, dlut, n_atom, run, n_species, drop_seed, drop_tag, drop_p);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_species), dim3(128), D * sizeof(float), s, emb, W, b, dlut, n_species, emb_dim,
                      dEmb, dW, db);
 }
