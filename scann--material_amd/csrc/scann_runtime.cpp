@@ -1713,6 +1713,26 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   pend.n = 1;
   pend.X[0] = dpreA; pend.Wh[0] = h->WaTh; pend.W[0] = h->WaT;
   pend.fresh = true;
+  // basis MLP (scann_model.py:378-389): a leaf (parameter gradients only) on a stream of its own, started as soon as the geometry
+  // gradient entering layer 0 exists -- at 45 us it is the longest thing between there and the optimiser
+  hipEvent_t ev_basis = nullptr;
+  bool basis_done = false;
+  auto basis_leaf = [&](const float* dG) {
+    hipStream_t bs = s;
+    if (side && h->train_aux2) {
+      hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
+      (void)hipEventRecord(e, s);
+      (void)hipStreamWaitEvent(h->train_aux2, e, 0);
+      bs = h->train_aux2;
+    }
+    launch_basis_bwd(h->basis, db->dist, db->weight, dG, E, g("neighbor_d/kernel"), g("neighbor_d/bias"),
+                     g("neighbor_w/kernel"), g("neighbor_w/bias"), bs);
+    if (bs != s) {
+      ev_basis = h->train_ev[ev_i++ % h->train_ev.size()];
+      (void)hipEventRecord(ev_basis, bs);
+    }
+    basis_done = true;
+  };
   for (int l = L - 1; l >= 0; --l) {
     t3 = setA(l, 0); t4 = setA(l, 1); dQ = setA(l, 2); dP1 = setA(l, 3); dP3 = setA(l, 4);
     edK = setE(l, 0); eU = setE(l, 1);
@@ -1789,6 +1809,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
       ea.dK = edK; ea.c = c_in; ea.dG_in = dG_in; ea.T = TL; ea.V = VL; ea.gamma = p.lng_g; ea.nb = db->edge_col;
       ea.WkTh = pt.WkTh; ea.W2Th = pt.W2Th; ea.dang = edAng; ea.dV = eU; ea.dG = dGnext; ea.n_edge = E;
       launch_edge_bwd(wg, ea, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), s);
+      if (l == 0) basis_leaf(dGnext);  // (before the atom sums below: they do not touch the geometry gradient)
       // dC[j] = sum over the edges that point at j of dang * G' (gate), dP3[j] = the same sum of dV, dP1[i] = sum of dV over i's own edges
       launch_atom_gather3(edAng, Gout, eU, db->edge_offset, db->in_off, db->in_edge, dC, dP1, dP3, A, s);
     } else {
@@ -1821,22 +1842,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   // ---- basis MLP and embedding (scann_model.py:362-389) ----
   // (the basis leaf first: it needs only the geometry gradient the last edge_bwd_kernel left, and at 43 us on its own stream it is
   // the longest thing between here and the optimiser -- started behind the embedding chain it ended 30 us after it)
-  hipEvent_t ev_basis = nullptr;
-  if (dG_in) {  // a leaf (parameter gradients only): on a stream of its own beside the embedding chain and the last weight gradients
-    hipStream_t bs = s;
-    if (side && h->train_aux2) {
-      hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
-      (void)hipEventRecord(e, s);
-      (void)hipStreamWaitEvent(h->train_aux2, e, 0);
-      bs = h->train_aux2;
-    }
-    launch_basis_bwd(h->basis, db->dist, db->weight, dG_in, E, g("neighbor_d/kernel"), g("neighbor_d/bias"),
-                     g("neighbor_w/kernel"), g("neighbor_w/bias"), bs);
-    if (bs != s) {
-      ev_basis = h->train_ev[ev_i++ % h->train_ev.size()];
-      (void)hipEventRecord(ev_basis, bs);
-    }
-  }
+  if (dG_in && !basis_done) basis_leaf(dG_in);
   flush_pend();
   if (c.use_ring || c.feature_cgcnn) {
     launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, s);
