@@ -1383,7 +1383,8 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
                    // LayerNorm gamma / beta partials: per layer ln_bwd over edges and atoms, attention backward over atoms
                    (size_t)2 * D * Lc * ((size_t)std::max(ln_bwd_slots(std::max(db->n_edge, 1)), tile_slots(std::max(db->n_edge, 1))) +
                                          (size_t)std::max(ln_bwd_slots(db->n_atom), tile_slots(db->n_atom)) +
-                                         (size_t)attn_bwd_slots(db->n_atom, db->max_degree));
+                                         (size_t)attn_bwd_slots(db->n_atom, db->max_degree)) +
+                   (size_t)D * db->n_struct;  // predict_property/kernel: one slot per structure (readout_bwd_kernel)
   // the operands of a layer's weight gradients live until the end of the step (sets of their own per layer): the gradient launches on
   // the side stream never have to be waited for before a buffer is reused
   const size_t nTA = 5 + 5 * (Lc + 1), nTE = 4 + 2 * (Lc + 1);
@@ -1680,7 +1681,9 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   ra.gq = db->gq; ra.gk = db->gk; ra.ga = db->ga; ra.dy = w.dy;
   ra.Wb = h->head.Wb; ra.bb = h->head.bb; ra.wo = h->head.wo;
   ra.dgq = t2; ra.dgk = rdgk; ra.rep_out = w.rep; ra.dpre_out = w.dpre;
-  ra.dwo = g("predict_property/kernel"); ra.dbo = g("predict_property/bias");
+  // (one slot per structure, summed in structure order with the layer's other vectors: 128 workgroups adding to the same 128
+  // addresses was a queue of 16 k atomics)
+  ra.dwo = reserve_vec(wg, g("predict_property/kernel"), B); ra.dbo = g("predict_property/bias");
   launch_readout_bwd(ra, s);
   // the readout's four weight gradients ride with the first layer's launch on the side stream (their operands -- rep, dpre, z = t1,
   // dgq = t2, dgk and dpreA in the readout's operand set -- are not written again before the end of the step): no fork of their own,

@@ -14,7 +14,7 @@ struct ReadoutBwdArgs {
   const float *Wb, *bb, *wo;   // bf_property (row-major), predict_property
   float *dgq, *dgk;            // [n_atom,128] out
   float *rep_out, *dpre_out;   // [n_struct,128] out (inputs of the bf_property weight gradient)
-  float *dwo, *dbo;            // gradients (atomic)
+  float *dwo, *dbo;            // dwo: [n_struct,128] slots (reserve_vec); dbo: the scalar bias gradient (atomic)
 };
 
 // One region of the device weight arena, regenerated from the flat master parameters after each optimiser step.

@@ -1014,10 +1014,24 @@ __global__ __launch_bounds__(128) void readout_bwd_kernel(ReadoutBwdArgs a) {
   float* sDa = sd + 2 * n;
   const float dy = a.dy[mol];
   // rep, S = sum_j gq_j
+  // (every per-atom / per-feature sum of this kernel keeps its order and requests its operands eight or sixteen at a time: one
+  // workgroup per structure is a chain of such sums, and a load per iteration made each of them n or 128 memory round trips)
   float rep = 0.f, S = 0.f;
-  for (int i = 0; i < n; ++i) {
-    rep += a.ga[a0 + i] * a.gk[(size_t)(a0 + i) * D + tid];
-    S += a.gq[(size_t)(a0 + i) * D + tid];
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    float g[8], k[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + u, n - 1);
+      g[u] = a.ga[a0 + i];
+      k[u] = a.gk[(size_t)(a0 + i) * D + tid];
+      q[u] = a.gq[(size_t)(a0 + i) * D + tid];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < n) {
+        rep += g[u] * k[u];
+        S += q[u];
+      }
   }
   sRep[tid] = rep;
   sS[tid] = S;
@@ -1025,11 +1039,17 @@ __global__ __launch_bounds__(128) void readout_bwd_kernel(ReadoutBwdArgs a) {
   __syncthreads();
   // head: pre_j, h_j
   float pre = a.bb[tid];
-  for (int k = 0; k < D; ++k) pre += sRep[k] * a.Wb[k * D + tid];
+  for (int k0 = 0; k0 < D; k0 += 16) {
+    float w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = a.Wb[(k0 + u) * D + tid];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) pre += sRep[k0 + u] * w[u];
+  }
   const float hj = swish_(pre);
   const float dh = dy * a.wo[tid];
   const float dpre = dh * dswish_(pre);
-  atomicAdd(&a.dwo[tid], dy * hj);
+  a.dwo[(size_t)mol * D + tid] = dy * hj;  // this structure's slot (vec_reduce_kernel adds the slots in order)
   if (tid == 0) atomicAdd(a.dbo, dy);
   a.rep_out[(size_t)mol * D + tid] = rep;
   a.dpre_out[(size_t)mol * D + tid] = dpre;
@@ -1037,7 +1057,18 @@ __global__ __launch_bounds__(128) void readout_bwd_kernel(ReadoutBwdArgs a) {
   __syncthreads();
   // drep_k = sum_j dpre_j Wb[k][j]
   float drep = 0.f;
-  for (int j = 0; j < D; ++j) drep += sV[j] * a.Wb[tid * D + j];
+  for (int j0 = 0; j0 < D; j0 += 16) {  // this thread's ROW of Wb: four 16-byte loads per step
+    float4 w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(a.Wb + (size_t)tid * D + j0 + 4 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      drep += sV[j0 + 4 * u] * w[u].x;
+      drep += sV[j0 + 4 * u + 1] * w[u].y;
+      drep += sV[j0 + 4 * u + 2] * w[u].z;
+      drep += sV[j0 + 4 * u + 3] * w[u].w;
+    }
+  }
   __syncthreads();
   sV[tid] = drep;  // now drep
   __syncthreads();
@@ -1077,13 +1108,30 @@ __global__ __launch_bounds__(128) void readout_bwd_kernel(ReadoutBwdArgs a) {
   __syncthreads();
   // W = sum_i da_i gk_i ; dgk_i = at_i*drep + da_i (S - gq_i) ; dgq_j = W - da_j gk_j
   float Wacc = 0.f;
-  for (int i = 0; i < n; ++i) Wacc += sDa[i] * a.gk[(size_t)(a0 + i) * D + tid];
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    float k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) k[u] = a.gk[(size_t)(a0 + min(i0 + u, n - 1)) * D + tid];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < n) Wacc += sDa[i0 + u] * k[u];
+  }
   sW[tid] = Wacc;
-  for (int i = 0; i < n; ++i) {
-    const size_t o = (size_t)(a0 + i) * D + tid;
-    const float gk = a.gk[o], gq = a.gq[o];
-    a.dgk[o] = sAt[i] * sV[tid] + sDa[i] * (sS[tid] - gq);
-    a.dgq[o] = Wacc - sDa[i] * gk;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    float k[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t o = (size_t)(a0 + min(i0 + u, n - 1)) * D + tid;
+      k[u] = a.gk[o];
+      q[u] = a.gq[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < n) {
+        const size_t o = (size_t)(a0 + i0 + u) * D + tid;
+        a.dgk[o] = sAt[i0 + u] * sV[tid] + sDa[i0 + u] * (sS[tid] - q[u]);
+        a.dgq[o] = Wacc - sDa[i0 + u] * k[u];
+      }
   }
 }
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s) {
