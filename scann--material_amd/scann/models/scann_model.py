@@ -209,6 +209,7 @@ class HipModel:
         worker = threading.Thread(target=producer, name="scann-upload", daemon=True)
         worker.start()
         k = 0
+        taken = None  # a group taken off the queue and not yet in flight
         try:
             while True:
                 item = ready.get()
@@ -216,18 +217,21 @@ class HipModel:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                rb, tg = item
+                taken, tg = item
                 ts.extend(tg)
                 if len(pending) >= ns:
                     fetch_oldest()  # frees the stream slot the new group is about to use
-                eng.forward_resident(rb, k)
+                eng.forward_resident(taken, k)
                 k += 1
-                pending.append(rb)
+                pending.append(taken)
+                taken = None
             while pending:
                 fetch_oldest()
         finally:
             stop.set()
             worker.join()
+            if taken is not None:
+                taken.free()
             while True:  # groups uploaded but never launched (an error on either side)
                 try:
                     item = ready.get_nowait()

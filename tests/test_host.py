@@ -939,3 +939,91 @@ def test_train_cli_flags_and_overrides(tmp_path, monkeypatch):
     x = np.random.rand()
     cli.seed_everything(7)
     assert np.random.rand() == x
+
+
+def test_predict_dataset_pipeline_with_a_stub_engine():
+    """HipModel.predict_dataset's two-thread pipeline without a GPU: a producer thread uploads groups ahead, the caller launches and
+    fetches them in order; results come back in dataset order, an error raised by the engine on either thread reaches the caller, and
+    every uploaded batch is freed or released exactly once."""
+    import threading
+
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    rng = np.random.default_rng(3)
+
+    def batch(n_struct):
+        mol = np.concatenate([[0], np.cumsum(rng.integers(2, 5, n_struct))]).astype(np.int32)
+        deg = rng.integers(1, 3, mol[-1])
+        eoff = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        base = np.repeat(np.repeat(mol[:-1], np.diff(mol)), deg)
+        return _hip.PackedBatch(rng.integers(1, 9, mol[-1]).astype(np.int32), mol, eoff, base.astype(np.int32),
+                                rng.random(eoff[-1]).astype(np.float32), rng.random(eoff[-1]).astype(np.float32))
+
+    class Rb:
+        def __init__(self, eng, pk):
+            self.eng, self.packed, self.state = eng, pk, "uploaded"
+            eng.live.add(self)
+
+        def _end(self, how):
+            assert self.state != "gone", "freed twice"
+            self.state = "gone"
+            self.eng.live.discard(self)
+            self.eng.ended.append(how)
+
+        def free(self):
+            self._end("free")
+
+        def release(self):
+            self._end("release")
+
+    class Eng:
+        def __init__(self, fail_upload_at=None, fail_download_at=None):
+            self.live, self.ended, self.n_up, self.n_down = set(), [], 0, 0
+            self.fail_upload_at, self.fail_download_at = fail_upload_at, fail_download_at
+            self.upload_threads = set()
+
+        def num_streams(self):
+            return 2
+
+        def upload(self, pk):
+            self.upload_threads.add(threading.get_ident())
+            self.n_up += 1
+            if self.n_up == self.fail_upload_at:
+                raise RuntimeError("upload failed")
+            return Rb(self, pk)
+
+        def forward_resident(self, rb, slot):
+            assert rb.state == "uploaded"
+            rb.state = "launched"
+
+        def download(self, rb, want_ga=True):
+            assert rb.state == "launched"
+            self.n_down += 1
+            if self.n_down == self.fail_download_at:
+                raise RuntimeError("download failed")
+            y = np.diff(rb.packed.mol_offset).astype(np.float32)           # "prediction" = atoms per structure: order is checkable
+            return y, (np.arange(rb.packed.n_atom, dtype=np.float32) if want_ga else None)
+
+    data = [(batch(int(rng.integers(1, 6))), rng.random(1)) for _ in range(23)]
+    data = [(pk, np.full(pk.n_struct, i, np.float32)) for i, (pk, _) in enumerate(data)]
+    expect_y = np.concatenate([np.diff(pk.mol_offset) for pk, _ in data]).astype(np.float32)
+    expect_t = np.concatenate([t for _, t in data])
+
+    def model(eng):
+        m = HipModel.__new__(HipModel)
+        m.engine = eng
+        return m
+
+    for group in (1, 4, 50):
+        eng = Eng()
+        y, ga, t = model(eng).predict_dataset(data, group=group, want_ga=True)
+        assert np.array_equal(y, expect_y) and np.array_equal(t, expect_t) and len(ga) == sum(pk.n_atom for pk, _ in data)
+        assert not eng.live and eng.ended.count("release") == eng.n_up and threading.get_ident() not in eng.upload_threads
+    for kw in (dict(fail_upload_at=3), dict(fail_download_at=2)):
+        eng = Eng(**kw)
+        with pytest.raises(RuntimeError):
+            model(eng).predict_dataset(data, group=2)
+        assert not [rb for rb in eng.live if rb.state == "uploaded"]  # nothing uploaded is left waiting for a launch
+    y, ga, t = model(Eng()).predict_dataset([], group=4)
+    assert len(y) == 0 and ga is None and len(t) == 0
