@@ -160,7 +160,11 @@ class HipModel:
             # a rolling window of `ns` groups in flight (one per stream): only the OLDEST is waited for, and its batch is released
             # without a device-wide synchronisation, so the device keeps running the younger groups
             rb = pending.pop(0)
-            y, ga = eng.download(rb, want_ga=want_ga)
+            try:
+                y, ga = eng.download(rb, want_ga=want_ga)
+            except BaseException:
+                rb.free()
+                raise
             ys.append(y)
             if want_ga:
                 gas.append(ga)

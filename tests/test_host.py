@@ -1024,6 +1024,6 @@ def test_predict_dataset_pipeline_with_a_stub_engine():
         eng = Eng(**kw)
         with pytest.raises(RuntimeError):
             model(eng).predict_dataset(data, group=2)
-        assert not [rb for rb in eng.live if rb.state == "uploaded"]  # nothing uploaded is left waiting for a launch
+        assert not eng.live  # nothing uploaded is left behind, launched or not
     y, ga, t = model(Eng()).predict_dataset([], group=4)
     assert len(y) == 0 and ga is None and len(t) == 0
