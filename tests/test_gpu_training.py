@@ -693,3 +693,27 @@ def test_weight_pushed_out_of_range_by_the_optimiser_is_an_error(hip_lib):
         eng.train_step(rb, targets, 1.0e3, dropout=0.0, seed=2)  # Adam moves every weight by ~lr: far past 255.9
     assert ei.value.code == -7 and "weight" in str(ei.value), str(ei.value)
     rb.free()
+
+
+def test_batch_uploaded_before_training_mode_trains_the_same(hip_lib):
+    """scann_batch_upload builds the reverse adjacency (which only the backward pass reads) for handles in training mode; a batch
+    that was uploaded before scann_train_begin gets it on its first backward.  Same gradients either way."""
+    from scann.models.scann_model import HipModel
+
+    cfg, w, pk, targets, _ = setup(n=24, L=3, seed=31)
+    eng = HipModel(cfg, w, device=0).engine
+    early = eng.upload(pk)          # inference-mode upload: no reverse adjacency
+    y0, _ = eng.forward(pk)         # (and the handle can predict before it trains)
+    eng.train_begin()
+    late = eng.upload(pk)
+    grads = []
+    for rb in (late, early):
+        sse = eng.train_forward(rb, targets, dropout=0.0, seed=5)
+        eng.zero_grads()
+        eng.train_backward(rb, sse, pk.n_struct)
+        grads.append(eng.get_grads())
+    assert np.isfinite(y0).all()
+    for k in grads[0]:
+        assert np.array_equal(grads[0][k], grads[1][k]) or np.allclose(grads[0][k], grads[1][k], rtol=1e-5, atol=1e-8), k
+    late.free()
+    early.free()
