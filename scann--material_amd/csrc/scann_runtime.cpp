@@ -118,6 +118,7 @@ struct scann_handle {
   std::vector<hipEvent_t> time_ev;  // pairs (start, stop)
   std::vector<int> time_edges;
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
+  int fuse_attn = 1;   // env SCANN_TRAIN_FUSE_ATTN=0: attn_bwd16_kernel as a launch of its own before edge_bwd_kernel
   int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
   int species_tables = 1;  // env SCANN_SPECIES_TABLES=0: the first layer's atom rows come from an atom launch, not from per-species tables
   float* d_weights = nullptr;  // one arena with every device-side weight image
@@ -425,6 +426,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->specs = build_specs(*cfg);
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* fb = getenv("SCANN_FUSE_BASIS")) h->fuse_basis = atoi(fb) != 0;
+  if (const char* fa = getenv("SCANN_TRAIN_FUSE_ATTN")) h->fuse_attn = atoi(fa) != 0;
   if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
   {
     hipDeviceProp_t prop;
@@ -1384,7 +1386,8 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
                    (size_t)2 * D * Lc * ((size_t)std::max(ln_bwd_slots(std::max(db->n_edge, 1)), tile_slots(std::max(db->n_edge, 1))) +
                                          (size_t)std::max(ln_bwd_slots(db->n_atom), tile_slots(db->n_atom)) +
                                          (size_t)attn_bwd_slots(db->n_atom, db->max_degree)) +
-                   (size_t)D * db->n_struct;  // predict_property/kernel: one slot per structure (readout_bwd_kernel)
+                   (size_t)D * db->n_struct +  // predict_property/kernel: one slot per structure (readout_bwd_kernel)
+                   (size_t)4 * D * Lc * (size_t)db->n_tile;  // attention + edge backward in one launch: four vectors, one slot per tile
   // the operands of a layer's weight gradients live until the end of the step (sets of their own per layer): the gradient launches on
   // the side stream never have to be waited for before a buffer is reused
   const size_t nTA = 5 + 5 * (Lc + 1), nTE = 4 + 2 * (Lc + 1);
@@ -1786,8 +1789,12 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     }
 
     // ---- LocalAttention backward (attention.py:118-216) ----
-    launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A, db->max_degree,
-                    w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
+    // On the forward's 32-row tile plan (whole atoms per tile, every degree <= 16) the softmax / LayerNorm backward of a tile's atoms
+    // runs at the head of the tile's edge_bwd workgroup: one launch less per layer.
+    const bool fuse_attn = fused && h->fuse_attn && c.g_update && db->tile_rows == 32 && db->n_big == 0 && db->max_degree <= 16 && E > 0;
+    if (!fuse_attn)
+      launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A,
+                      db->max_degree, w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
     wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
     wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
     if (!c.g_update) {
@@ -1811,7 +1818,15 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
       EdgeBwdArgs ea{};
       ea.dK = edK; ea.c = c_in; ea.dG_in = dG_in; ea.T = TL; ea.V = VL; ea.gamma = p.lng_g; ea.nb = db->edge_col;
       ea.WkTh = pt.WkTh; ea.W2Th = pt.W2Th; ea.dang = edAng; ea.dV = eU; ea.dG = dGnext; ea.n_edge = E;
-      launch_edge_bwd(wg, ea, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), s);
+      if (fuse_attn) {
+        AttnPart ab{};
+        ab.q = qL; ab.K = KL; ab.dctx = dCtx; ab.gamma = p.ln_g; ab.edge_offset = db->edge_offset; ab.tiles = db->tiles;
+        ab.dq = dQ; ab.dK = edK; ab.drop_p = w.attn_p; ab.drop_tag = DROP_TAG_ATTN + (unsigned)l; ab.drop_seed = w.seed;
+        launch_attn_edge_bwd(wg, ea, ab, db->n_tile, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), g(la + "layer_norm/gamma"),
+                             g(la + "layer_norm/beta"), s);
+      } else {
+        launch_edge_bwd(wg, ea, g(la + "layer_norm_g/gamma"), g(la + "layer_norm_g/beta"), s);
+      }
       if (l == 0) basis_leaf(dGnext);  // (before the atom sums below: they do not touch the geometry gradient)
       // dC[j] = sum over the edges that point at j of dang * G' (gate), dP3[j] = the same sum of dV, dP1[i] = sum of dV over i's own edges
       launch_atom_gather3(edAng, Gout, eU, db->edge_offset, db->in_off, db->in_edge, dC, dP1, dP3, A, s);

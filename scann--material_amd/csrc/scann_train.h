@@ -104,8 +104,23 @@ struct EdgeBwdArgs {
   float *dgamma, *dbeta;
   int32_t n_edge;
 };
+// the attention backward of the same layer (attn_bwd16_kernel's arithmetic), run by edge_bwd_kernel<1, true> on the tile's own atoms
+// ahead of its own chain: the forward's 32-row tile plan holds whole atoms, so the dK rows a tile needs are the ones its atoms produce
+struct AttnPart {
+  const float *q, *K, *dctx, *gamma;  // [n_atom,128], [n_edge,128], [n_atom,128], layer_norm gamma
+  const int32_t* edge_offset;
+  const EdgeTile* tiles;              // the batch's 32-row tile plan (whole atoms, contiguous edges)
+  float *dq, *dK;                     // out [n_atom,128], [n_edge,128] (dK still goes to memory: the key weight gradient reads it)
+  float *dgamma, *dbeta;              // layer_norm gamma / beta slots, one per workgroup
+  float drop_p;
+  uint32_t drop_tag;
+  unsigned long long drop_seed;
+};
 void launch_rn_bwd(WgradCtx& ctx, RnBwdArgs a, float* dgamma, float* dbeta, hipStream_t s);
 void launch_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, float* dgamma, float* dbeta, hipStream_t s);
+// attention backward + edge_bwd in one launch over the n_tile tiles of the plan (32-row tiles, every degree <= 16)
+void launch_attn_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, AttnPart b, int n_tile, float* dgamma_g, float* dbeta_g, float* dgamma_ln,
+                          float* dbeta_ln, hipStream_t s);
 void launch_atom_gather3(const float* dang, const float* G, const float* dV, const int* edge_offset, const int* in_off, const int* in_edge,
                          float* dC, float* dP1, float* dP3, int n_atom, hipStream_t s);
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);

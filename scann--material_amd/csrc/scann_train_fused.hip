@@ -319,8 +319,27 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void rn_bwd_kernel(RnBwdArgs 
 // ---- key / gate / geometry-update backward of one layer's edges (attention.py:141-163) -------------------------------------
 // in : dK, centres c (gate ang = c[j] * G'), dG' of the layer below (null for the last layer), T (LayerNorm_g input), V
 // out: dang = dK Wk^T, dV = dT * swish'(V), dG = dT + dV W2^T, gamma / beta slots      (dT = LN_g backward of dang * c[j] + dG')
-template <int RT>
-__global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void edge_bwd_kernel(EdgeBwdArgs a) {
+// ATT (32-row tiles of the forward's plan: whole atoms, every degree <= 16): the tile's dK rows do not come from memory -- the waves
+// first run attn_bwd16_kernel's arithmetic on the tile's atoms (softmax / LayerNorm backward per atom, one atom per wave at a time),
+// leaving dq and dK in memory for the weight gradients and dK in a staging buffer for the chain below.  One launch less per layer.
+#define SCANN_DPP_(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float red8_(float v) {
+  v += SCANN_DPP_(v, 0xB1);   // lane ^ 1
+  v += SCANN_DPP_(v, 0x4E);   // lane ^ 2
+  v += SCANN_DPP_(v, 0x141);  // the other quad of the group of 8
+  return v;
+}
+__device__ __forceinline__ float red64_(float v) {
+  v = red8_(v);
+  v += SCANN_DPP_(v, 0x128);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int RT, bool ATT = false>
+__global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void edge_bwd_kernel(EdgeBwdArgs a, AttnPart b) {
+  static_assert(!ATT || RT == 1, "the fused attention backward runs on the 32-row tile plan");
   constexpr int TR = 32 * RT;  // rows per tile
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * 64 * PLANE_STRIDE * 2];
   __shared__ __attribute__((aligned(16))) float sStat[TR * 8], sSum[TR * 8];
@@ -331,8 +350,90 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void edge_bwd_kernel(EdgeBwdA
   float* const stage = reinterpret_cast<float*>(sTile);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
-  const int row0 = blockIdx.x * TR;
-  const int nrows = min(TR, a.n_edge - row0);
+  EdgeTile tile = {0, 0, 0, 0};
+  if (ATT) tile = b.tiles[blockIdx.x];
+  const int row0 = ATT ? tile.edge_begin : blockIdx.x * TR;
+  const int nrows = ATT ? tile.edge_end - tile.edge_begin : min(TR, a.n_edge - row0);
+  float* const stageK = reinterpret_cast<float*>(sTile + 2 * 64 * PLANE_STRIDE);  // ATT: [32][STAGE_STRIDE] dK rows (upper half of the buffer)
+
+  if (ATT) {
+    __shared__ float sred[4][4 * 64];
+    const float2 g = reinterpret_cast<const float2*>(b.gamma)[lane];
+    float2 dg = make_float2(0.f, 0.f), dbt = dg;
+    for (int at = tile.atom_begin + wave; at < tile.atom_end; at += 4) {  // attn_bwd16_kernel's body, atom by atom
+      const int e0 = b.edge_offset[at], deg = b.edge_offset[at + 1] - e0;
+      const float2 q2 = reinterpret_cast<const float2*>(b.q)[(size_t)at * 64 + lane];
+      const float2 dyv = reinterpret_cast<const float2*>(b.dctx)[(size_t)at * 64 + lane];
+      const float qx = q2.x * 0.25f, qy = q2.y * 0.25f;
+      float2 k2[16];
+      float ev[16];
+      float m = -INFINITY;
+      if (deg > 0) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) k2[n] = reinterpret_cast<const float2*>(b.K)[(size_t)(e0 + min(n, deg - 1)) * 64 + lane];
+      }
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        if (n >= deg) k2[n] = make_float2(0.f, 0.f);
+        float e = qx * k2[n].x + qy * k2[n].y;
+        e = red8_(e);
+        ev[n] = n < deg ? e : -INFINITY;
+        m = fmaxf(m, ev[n]);
+      }
+      float ssum = 0.f;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        ev[n] = n < deg ? __builtin_amdgcn_exp2f((ev[n] - m) * 1.44269504088896340736f) : 0.f;
+        ssum += ev[n];
+      }
+      const float rsum = deg > 0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+      float px = q2.x, py = q2.y;
+      float keep[16];
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        ev[n] = ev[n] * rsum;
+        keep[n] = (b.drop_p > 0.f && n < deg) ? drop_scale(b.drop_seed, b.drop_tag, (size_t)(e0 + n) * NHEAD + (lane >> 3), b.drop_p) : 1.0f;
+        px += ev[n] * keep[n] * k2[n].x;
+        py += ev[n] * keep[n] * k2[n].y;
+      }
+      const float sm = red64_(px + py);
+      const float mean = sm * (1.0f / D);
+      const float cx = px - mean, cy = py - mean;
+      const float v = red64_(cx * cx + cy * cy);
+      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
+      const float hx = cx * rstd, hy = cy * rstd;
+      const float ax = dyv.x * g.x, ay = dyv.y * g.y;
+      const float m1 = red64_(ax + ay) * (1.0f / D), m2 = red64_(ax * hx + ay * hy) * (1.0f / D);
+      const float dpx = rstd * (ax - m1 - hx * m2), dpy = rstd * (ay - m1 - hy * m2);
+      dg.x += dyv.x * hx; dg.y += dyv.y * hy; dbt.x += dyv.x; dbt.y += dyv.y;
+      float da[16];
+      float dot = 0.f;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        float d = dpx * k2[n].x + dpy * k2[n].y;
+        d = red8_(d);
+        da[n] = d * keep[n];
+        dot += ev[n] * da[n];
+      }
+      float dqx = dpx, dqy = dpy;
+#pragma unroll
+      for (int n = 0; n < 16; ++n)
+        if (n < deg) {
+          const float de = ev[n] * (da[n] - dot);
+          const float2 dk = make_float2(ev[n] * keep[n] * dpx + 0.25f * de * q2.x, ev[n] * keep[n] * dpy + 0.25f * de * q2.y);
+          reinterpret_cast<float2*>(b.dK)[(size_t)(e0 + n) * 64 + lane] = dk;
+          *reinterpret_cast<float2*>(&stageK[(e0 + n - row0) * STAGE_STRIDE + 2 * lane]) = dk;
+          dqx += 0.25f * de * k2[n].x;
+          dqy += 0.25f * de * k2[n].y;
+        }
+      reinterpret_cast<float2*>(b.dq)[(size_t)at * 64 + lane] = make_float2(dqx, dqy);
+    }
+    sred[wave][lane] = dg.x; sred[wave][64 + lane] = dg.y; sred[wave][128 + lane] = dbt.x; sred[wave][192 + lane] = dbt.y;
+    __syncthreads();  // (also: every dK row of the tile is in the staging buffer)
+    const float tot = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+    const int ln = tid & 63, which = tid >> 6;
+    (which < 2 ? b.dgamma : b.dbeta)[(size_t)blockIdx.x * D + 2 * ln + (which & 1)] = tot;  // this workgroup's slot
+  }
 
   f16x8 whA[4], wlA[4], whB[4], wlB[4];
   load_wsplit<4, 8>(a.WkTh, wave, lane, whA, wlA, 0);
@@ -343,12 +444,15 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void edge_bwd_kernel(EdgeBwdA
   float4 x[RT][4], dy[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int rc = row0 + min(lrow + 32 * rt, nrows - 1);
+    // (ATT: a tile of atoms without edges has no rows -- every load below reads a valid row and is ignored)
+    const int rc = min(row0 + min(lrow + 32 * rt, max(nrows - 1, 0)), a.n_edge - 1);
     off[rt] = ((unsigned)rc * D + cbase) * 4;
     noff[rt] = ((unsigned)a.nb[rc] * D + cbase) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      dy[rt][j] = lrow + 32 * rt < nrows ? ld4(a.dK, off[rt] + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dy[rt][j] = lrow + 32 * rt >= nrows ? make_float4(0.f, 0.f, 0.f, 0.f)
+                  : ATT ? *reinterpret_cast<const float4*>(&stageK[(lrow + 32 * rt) * STAGE_STRIDE + cbase + 8 * j])
+                        : ld4(a.dK, off[rt] + 32 * j);
       x[rt][j] = ld4(a.T, off[rt] + 32 * j);
     }
   }
@@ -494,8 +598,17 @@ void launch_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, float* dgamma, float* dbeta, 
   const int n = tile_slots(a.n_edge);
   a.dgamma = reserve_vec(ctx, dgamma, n);
   a.dbeta = reserve_vec(ctx, dbeta, n);
-  if (fused_tile_rows(a.n_edge) == 32) hipLaunchKernelGGL(edge_bwd_kernel<1>, dim3(n), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(edge_bwd_kernel<2>, dim3(n), dim3(256), 0, s, a);
+  if (fused_tile_rows(a.n_edge) == 32) hipLaunchKernelGGL((edge_bwd_kernel<1, false>), dim3(n), dim3(256), 0, s, a, AttnPart{});
+  else hipLaunchKernelGGL((edge_bwd_kernel<2, false>), dim3(n), dim3(256), 0, s, a, AttnPart{});
+}
+void launch_attn_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, AttnPart b, int n_tile, float* dgamma_g, float* dbeta_g, float* dgamma_ln,
+                          float* dbeta_ln, hipStream_t s) {
+  if (a.n_edge <= 0 || n_tile <= 0) return;
+  a.dgamma = reserve_vec(ctx, dgamma_g, n_tile);
+  a.dbeta = reserve_vec(ctx, dbeta_g, n_tile);
+  b.dgamma = reserve_vec(ctx, dgamma_ln, n_tile);
+  b.dbeta = reserve_vec(ctx, dbeta_ln, n_tile);
+  hipLaunchKernelGGL((edge_bwd_kernel<1, true>), dim3(n_tile), dim3(256), 0, s, a, b);
 }
 void launch_atom_gather3(const float* dang, const float* G, const float* dV, const int* edge_offset, const int* in_off, const int* in_edge,
                          float* dC, float* dP1, float* dP3, int n_atom, hipStream_t s) {
