@@ -359,6 +359,62 @@ def two_stream_leg(cfg, batches, batch_size, seconds=0.8, group=8, streams=2):
             "launch_sequences": n}
 
 
+def one_batch_leg(cfg, batches, batch_size, seconds=0.5):
+    """The same engine with exactly ONE 128-molecule batch per launch sequence (no fusing of batches), one stream."""
+    from scann.models.scann_model import HipModel
+
+    os.environ["SCANN_STREAMS"] = "1"
+    eng = HipModel(cfg, device=int(os.environ.get("LOCAL_RANK", "0")), seed=1234).engine
+    singles = [eng.upload(b) for b in batches[:32]]
+    for i in range(64):
+        eng.forward_resident(singles[i % len(singles)], 0)
+    eng.sync()
+    n1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < seconds:
+        for i in range(64):
+            eng.forward_resident(singles[i % len(singles)], 0)
+        eng.sync()
+        n1 += 64
+    dt = time.perf_counter() - t1
+    for rb in singles:
+        rb.free()
+    eng.close()
+    return {"value": n1 * batch_size / dt, "unit": "molecules/s", "steps": n1, "streams": 1}
+
+
+LEGS = {"two_streams": two_stream_leg, "one_batch_per_launch": one_batch_leg, "end_to_end": end_to_end, "training_step": training_leg}
+
+
+def run_leg_here(name, batch_size, config_name):
+    """`bench.py --leg NAME`: one extra leg in a process of its own, its dict on stdout."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.models.scann_model import normalize_config
+
+    model_cfg = dict(QM9_MODEL)
+    cfg = normalize_config({"model": model_cfg, "hyper": {"target": "homo"}})
+    rng = np.random.default_rng(1000)
+    batches = [synth_packed_batch(rng, batch_size) for _ in range(128)]
+    print(json.dumps(LEGS[name](cfg, batches, batch_size)), flush=True)
+
+
+def leg_in_subprocess(name, batch_size):
+    """The extra legs run in fresh processes: HIP deals a process's streams onto a few hardware queues in an order that depends on
+    every stream the process has ever made, and a leg run after the headline's engine read 4-14 % low (two of its "concurrent"
+    streams on one queue) -- an artefact of sharing the process, not of the leg."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.pop("SCANN_STREAMS", None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name, "--batch", str(batch_size)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "leg %s failed (rc %d): %s" % (name, r.returncode, (r.stderr or "")[-300:])}
+    return json.loads(lines[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,7 +447,10 @@ def main():
                     help="rehearsal only: allow more ranks than visible devices (rank r runs on device r %% n_devices); the line "
                          "is then marked \"oversubscribed\" and is not a scaling measurement")
     ap.add_argument("--profile-reps", type=int, default=12)
+    ap.add_argument("--leg", default=None, choices=sorted(LEGS), help="internal: run one extra leg in this process and print its dict")
     args = ap.parse_args()
+    if args.leg:
+        return run_leg_here(args.leg, args.batch, args.config)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: THIS process becomes the launcher.  It spawns one fresh process per GPU before anything here has
@@ -566,25 +625,10 @@ def main():
             rb.free()
     if rank == 0:
         if not args.no_extras and world == 1 and args.config == "qm9" and not args.worst:
-            # (a) the same engine with exactly ONE 128-molecule batch per launch sequence, (b) the host-inclusive dataset path
-            singles = [eng.upload(b) for b in batches[:32]]
-            for i in range(64):
-                eng.forward_resident(singles[i % len(singles)], i % nstream)
-            eng.sync()
-            n1, t1 = 0, time.perf_counter()
-            while time.perf_counter() - t1 < 0.5:
-                for i in range(64):
-                    eng.forward_resident(singles[i % len(singles)], i % nstream)
-                eng.sync()
-                n1 += 64
-            out["one_batch_per_launch"] = {"value": n1 * args.batch / (time.perf_counter() - t1), "unit": "molecules/s",
-                                           "steps": n1, "streams": nstream}
-            for rb in singles:
-                rb.free()
-            out["two_streams"] = two_stream_leg(cfg, batches, args.batch)
-            out["end_to_end"] = end_to_end(cfg, batches, args.batch)
-            if args.config == "qm9" and not args.worst:
-                out["training_step"] = training_leg(cfg, batches, args.batch)
+            # each in a process of its own (leg_in_subprocess); this process's engine goes first, so that the legs have the device
+            eng.close()
+            for name in ("two_streams", "one_batch_per_launch", "end_to_end", "training_step"):
+                out[name] = leg_in_subprocess(name, args.batch)
         if not args.no_cpu_baseline and not args.no_extras and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

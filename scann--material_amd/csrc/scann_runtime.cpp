@@ -414,8 +414,6 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
     return fail(nullptr, SCANN_ERR_UNSUPPORTED, "scann_create: embedding_dim (+10 ring features) must be <= 160");
   if (cfg->n_atoms <= 0 || cfg->embedding_dim <= 0 || cfg->n_attention < 0 || !(cfg->gaussian_d > 0))
     return fail(nullptr, SCANN_ERR_INVALID, "scann_create: bad hyper-parameter");
-  // (hardware queues behind the streams: see scann/_hip.py load_library; effective when this is the process's first HIP call)
-  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, SCANN_ERR_NO_DEVICE, "scann_create: no HIP device visible (this library has no CPU fallback)");

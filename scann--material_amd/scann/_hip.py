@@ -119,10 +119,6 @@ def load_library(path=None):
         # i.e. at the first HIP call of the process -- so it is set HERE, before the library is even loaded.  spawn_ranks sets
         # it for its children; ranks made by torch.distributed.run get it this way.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # HIP streams share a small pool of hardware queues (4 by default) round-robin; a process with two handles (or a handle plus its
-    # copy and side streams) ends up with two "concurrent" streams on ONE queue, which serialises them: the second engine of bench.py
-    # ran 9-14 % slower than the same engine in a fresh process until the pool was widened.  Read when HIP starts: set before the load.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(p)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)
