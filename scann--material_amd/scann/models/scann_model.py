@@ -139,7 +139,14 @@ class HipModel:
 
     __call__ = predict
 
-    def predict_dataset(self, dataset, group=4, want_ga=False):
+    @staticmethod
+    def default_group(dataset):
+        """Batches fused per launch sequence when the caller does not say: about 1,024 structures (8 batches of 128) -- two such groups
+        in flight on the handle's two streams measured best (tools/e2e_size.py: 1.78 M molecules/s; 1.64 M at 4, 1.69 M at 12)."""
+        bs = int(getattr(dataset, "batch_size", 0) or 0)
+        return max(1, 1024 // bs) if bs > 0 else 8
+
+    def predict_dataset(self, dataset, group=None, want_ga=False):
         """Pipelined inference over a whole ``PackedDataset`` (or any sequence of ``(PackedBatch | inputs dict, target)``):
         batches are fused ``group`` at a time into one launch sequence, spread over the handle's streams, and fetched at
         the end -- the throughput path behind ``SCANN.evaluate`` / ``predict_model.py``.  Returns ``(y [N], ga list | None,
@@ -155,6 +162,7 @@ class HipModel:
         eng = self.engine
         ns = eng.num_streams()
         pending, ys, gas, ts = [], [], [], []
+        group = int(group) if group else self.default_group(dataset)
 
         def fetch_oldest():
             # a rolling window of `ns` groups in flight (one per stream): only the OLDEST is waited for, and its batch is released

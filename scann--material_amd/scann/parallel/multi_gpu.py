@@ -17,6 +17,7 @@ class _Run:
 
     def __init__(self, ds, lo, hi):
         self.ds, self.lo, self.hi = ds, lo, hi
+        self.batch_size = getattr(ds, "batch_size", 0)  # (HipModel.default_group sizes the launch groups from it)
 
     def __len__(self):
         return self.hi - self.lo
@@ -64,7 +65,7 @@ class MultiGpuPredictor:
         cuts.append(len(costs))
         return list(zip(cuts[:-1], cuts[1:]))
 
-    def predict_dataset(self, dataset, group=4, want_ga=False):
+    def predict_dataset(self, dataset, group=None, want_ga=False):
         """-> (y [N], ga | None, targets [N]) in dataset order, like ``HipModel.predict_dataset``."""
         n = len(dataset)
         if n == 0:

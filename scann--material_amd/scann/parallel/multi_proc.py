@@ -113,7 +113,7 @@ class MultiProcessPredictor:
                 shm.close()
                 shm.unlink()
 
-    def predict_dataset(self, dataset, group=8, want_ga=False):
+    def predict_dataset(self, dataset, group=None, want_ga=False):
         from .multi_gpu import MultiGpuPredictor
 
         if not (hasattr(dataset, "batches") and hasattr(dataset, "edge_offset")):

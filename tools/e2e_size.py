@@ -8,6 +8,7 @@ from scann.utils import PackedDataset
 cfg = normalize_config({"model": dict(bench.QM9_MODEL), "hyper": {"target": "homo"}})
 rng = np.random.default_rng(0)
 base = [bench.synth_packed_batch(rng, 128) for _ in range(64)]
+GROUPS = [int(a) for a in sys.argv[1:]] or [8]
 for mult in (8, 32):
     batches = base * mult
     mol, eoff, atomic, local, dist, wgt = [0], [0], [], [], [], []
@@ -21,10 +22,11 @@ for mult in (8, 32):
     for streams in (2, 4):
         os.environ["SCANN_STREAMS"] = str(streams)
         model = HipModel(cfg, device=0, seed=1234)
-        model.predict_dataset(ds, group=8)
-        best = 0
-        for rep in range(3):
-            t0 = time.perf_counter(); model.predict_dataset(ds, group=8); dt = time.perf_counter() - t0
-            best = max(best, n / dt)
-        print("molecules", n, "streams", streams, "best %.0f molecules/s" % best, flush=True)
+        for group in GROUPS:
+            model.predict_dataset(ds, group=group)
+            best = 0
+            for rep in range(3):
+                t0 = time.perf_counter(); model.predict_dataset(ds, group=group); dt = time.perf_counter() - t0
+                best = max(best, n / dt)
+            print("molecules", n, "streams", streams, "group", group, "best %.0f molecules/s" % best, flush=True)
         model.engine.close()
