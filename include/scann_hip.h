@@ -135,6 +135,15 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);
 void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db); /* see scann_train_step_begin */
 int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot); /* async */
 int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out); /* syncs that batch */
+/* Structure-resident forward (csrc/scann_struct.hip): an inference forward of a SCANN+ (g_update) handle runs every group of whole
+ * structures that fits `max_tiles` edge tiles (<= 64 edges of whole atoms each; 1..6, default 6) as ONE workgroup that keeps the
+ * group's geometry rows on chip across all n_attention iterations (the loop of create_model, scann_model.py:413-421); structures
+ * beyond the limit (and every structure when it is 0) take the layer-streamed kernels.  Same results either way, byte for byte.
+ * The plan is made by scann_batch_upload: the limit applies to batches uploaded afterwards.  Env SCANN_RESIDENT sets the default. */
+int scann_set_resident_limit(scann_handle_t* h, int max_tiles);
+/* out8 = { resident groups of <= 3 tiles, resident groups of 4..6 tiles, structures left to the streamed kernels, resident edge
+ * tiles, edges and atoms of the <= 3-tile groups, edge tiles and rows per tile (32 | 64) of the whole-batch streamed plan }. */
+int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8);
 int scann_sync(scann_handle_t* h); /* all streams of the handle */
 int scann_num_streams(const scann_handle_t* h);
 
@@ -243,6 +252,14 @@ int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offse
  * edge_end.  Returns the planned edge rows per tile (32 | 64) or a negative status (text: scann_pack_last_error). */
 int scann_plan_tiles(const scann_batch_t* batch, int32_t tile_rows, int32_t tile_atoms, int32_t allow_chunks, int32_t cap,
                      int32_t* tiles_out, int32_t* part_out, int32_t* n_tiles, int32_t* n_slots);
+/* The structure-resident plan scann_batch_upload builds (host only): structures in batch order; one whose own greedy tile plan
+ * needs <= min(3, max_tiles) tiles joins the open group while the JOINT plan still fits, one that needs <= min(6, max_tiles) is a
+ * group of its own, the rest are listed in streamed_out.  groups_out[cap_groups][4] = atom_begin, atom_end, tile_begin, n_tile
+ * (the n_small groups of <= 3 tiles first, then the n_big others; each list by falling edge count); tiles_out[cap_tiles][4] as
+ * scann_plan_tiles.  With null outputs only the counts are returned. */
+int scann_plan_groups(const scann_batch_t* batch, int32_t tile_atoms, int32_t max_tiles, int32_t cap_groups, int32_t cap_tiles,
+                      int32_t* groups_out, int32_t* tiles_out, int32_t* streamed_out, int32_t* n_small, int32_t* n_big,
+                      int32_t* n_tiles, int32_t* n_streamed);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,10 @@ struct AtomArgs {
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS, env SCANN_STAMP_ATOM=1) only: [n_tiles,16] phase clocks
   int32_t* range_flag;         // host-pinned range-guard word (flag_range) or null
   int32_t layer;               // layer whose projections this launch computes (for the range-guard message)
+  // a batch whose other structures run on the structure-resident path: {first row, rows (<= 64)} of every atom tile, n_row_tab of
+  // them (64-row tiles); null: tiles of consecutive rows over [0, n_atom)
+  const int32_t* row_tab;
+  int32_t n_row_tab;
 };
 void launch_atom(const AtomArgs& a, hipStream_t s);
 
@@ -188,6 +192,50 @@ void launch_edge(const EdgeArgs& a, hipStream_t s);
 // softmax merge of the chunk tiles of every big atom (+ unscaled-query residual + LayerNorm, attention.py:189-214)
 void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,
                        const float* ln_b, float* ctx, int32_t* range_flag, int layer, hipStream_t s);
+
+// ---- structure-resident forward (scann_struct.hip) -------------------------------------------------------------------------------
+// One workgroup per GROUP: a run of whole structures whose edges fit <= 3 (two workgroups per CU) or <= 6 (one) edge tiles; the
+// group's geometry rows live in registers across all layers.
+struct SrGroup {
+  int32_t atom_begin, atom_end;  // the group's atoms (whole structures)
+  int32_t tile_begin, n_tile;    // its edge tiles in SrArgs::tiles: whole atoms, <= TE_MAX edges and <= TQ atoms each
+};
+constexpr int SR_NT_SMALL = 3, SR_NT_BIG = 6;
+constexpr int SR_ATOMS_SMALL = 40, SR_ATOMS_BIG = 72;  // atoms per group: rows of the kernel's atom-row cache in LDS
+
+struct SrArgs {
+  const SrGroup* groups;
+  const EdgeTile* tiles;
+  int32_t n_group, n_layer, use_attn_norm, reserved;
+  const int32_t *edge_offset, *edge_col, *edge_row;
+  const float *dist, *edge_weight;
+  const float* x0;           // layer-0 input rows: the embedding LUT [n_species,128] (x0_index = atomic numbers) or c0 [n_atom,128]
+  const int32_t* x0_index;
+  BasisParams basis;
+  const LayerParams* layers;  // DEVICE array [n_layer]
+  HeadParams head;
+  float *c, *P1, *P3, *q, *ctx;  // [n_atom,128] scratch rows, private to the workgroup that owns the atoms
+  float *gq, *gk;                // out: GlobalAttention query / key rows for readout_kernel
+  int32_t* range_flag;
+};
+void launch_struct(const SrArgs& a, int nt_max, hipStream_t s);
+
+// Host-side plan of the structure-resident forward (scann_pack.cpp): structures in order; a structure whose own greedy tile plan
+// (whole atoms, <= TE_MAX edges and <= tile_atoms atoms per tile) needs <= SR_NT_SMALL tiles joins the open small group while the
+// JOINT plan of the group still fits, one that needs <= SR_NT_BIG tiles is a group of its own in the big list, anything else (more
+// tiles, an atom with more than TE_MAX neighbours) is listed in `streamed`.  Groups are ordered by falling edge count (the
+// longest workgroups start first); tiles of a group are contiguous in `tiles`.
+struct SrPlan {
+  std::vector<SrGroup> small, big;
+  std::vector<EdgeTile> tiles;
+  std::vector<int32_t> streamed;  // structure ids the resident kernels cannot take
+};
+void plan_groups(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset, int tile_atoms, int max_tiles, SrPlan& plan);
+// The streamed kernels' plan for the structures plan_groups left over (a batch with both kinds): 64-row edge tiles (chunk tiles for
+// atoms with more than 64 neighbours) and 64-row atom tiles {first row, rows}, per run of consecutive structures.
+void plan_streamed_subset(const int32_t* mol_offset, const int32_t* edge_offset, const std::vector<int32_t>& streamed, int tile_atoms,
+                          std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part, std::vector<int32_t>& big_tab, int32_t* n_slot_out,
+                          std::vector<int32_t>& atom_tab);
 
 struct ReadoutArgs {
   const int32_t* mol_offset;  // [n_struct+1]

@@ -55,22 +55,6 @@ namespace scann {
 #define STAMP_REAL(buf, slot) do {} while (0)
 #endif
 
-// swish(x) = x * sigmoid(x) on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each.
-// Measured effect on the end-to-end parity error: DESIGN.md "numerics".
-__device__ __forceinline__ float swishf(float x) {
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
-}
-
-__device__ __forceinline__ float swish_exact(float x) { return x * (1.0f / (1.0f + expf(-x))); }
-
-// e^x through v_exp_f32 (2^x, 1 ulp); used where the argument is <= 0 (softmax numerators).
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 f4swish(float4 a) { return make_float4(swishf(a.x), swishf(a.y), swishf(a.z), swishf(a.w)); }
-__device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
-
 // ---- atom-tile kernel ------------------------------------------------------------------------------
 //
 // One workgroup (4 waves) per tile of 64 (or, for small launches, 32: launch_atom) atom rows, three (four) workgroups per CU; every projection is a split-fp16 MFMA GEMM
@@ -94,8 +78,9 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
   _Float16* const sL = sH + TAR * PLANE_STRIDE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
-  const int row0 = blockIdx.x * TAR;
-  const int nrows = min(TAR, a.n_atom - row0);
+  // (row_tab: the atom tiles of the structures that stay on this path in a batch shared with the structure-resident kernel)
+  const int row0 = a.row_tab ? a.row_tab[2 * blockIdx.x] : blockIdx.x * TAR;
+  const int nrows = a.row_tab ? a.row_tab[2 * blockIdx.x + 1] : min(TAR, a.n_atom - row0);
   constexpr float WINV = 1.0f / WSCALE;
   // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
   const _Float16* const firstW = MODE == 1 ? a.WCh : a.WAh;
@@ -340,8 +325,9 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
   // 32-row tiles (<= 128 VGPRs, 22 KB of LDS: four workgroups per CU = 1,024 slots) while they all fit ONE round of workgroups: the
   // launch is then the latency chain of a tile, and a 32-row tile's chain is shorter (one batch per launch: 490 k -> 568 k
   // molecules/s, training step 1.14 -> 1.09 ms).  Beyond that 64-row tiles (half the weight traffic per row).
-  const int rows = a.n_atom <= 32 * 1024 ? 32 : 64;
-  const dim3 grid((a.n_atom + rows - 1) / rows), block(256);
+  const int rows = a.row_tab ? TA : a.n_atom <= 32 * 1024 ? 32 : 64;
+  if (a.row_tab && a.n_row_tab <= 0) return;
+  const dim3 grid(a.row_tab ? a.n_row_tab : (a.n_atom + rows - 1) / rows), block(256);
 #define SCANN_ATOM_CASE(F, M)                                                                  \
   do {                                                                                         \
     if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1>), grid, block, 0, s, a);          \
@@ -385,19 +371,6 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 //
 // FB (g_update, 64-row tiles, first layer of an inference forward): the geometry rows come out of basis_kernel's arithmetic, done
 // here on the tile's rows (Gaussian expansions -> planes -> two K = 20 products -> bias, swish, product), not out of memory.
-constexpr int BASIS_STRIDE = 72;  // halfs per staged basis row: 64 + 8 pad = 144 B (conflict-free b128 fragment reads)
-// exp(-(x - c)^2 / 0.25)  (custom_layers.py:63-65, width 0.5 squared at :51)
-__device__ __forceinline__ float gauss(float x, float c) {
-  const float d = x - c;
-  return expf(-(d * d) / 0.25f);
-}
-// v_exp_f32 form for the fused basis MLP: |abs error| <= ~2e-8 (value * |arg| * 6e-8 peaks at arg = -1)
-__device__ __forceinline__ float gauss_fast(float x, float c) {
-  const float d = x - c;
-  return fast_exp(-(d * d) * 4.0f);
-}
-
-
 template <bool GUPD, int RT, bool FB = false>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) {
 #pragma clang fp contract(off)  // fusions are written out (fmaf): both unrolled row-tile copies of a formula must round alike,

@@ -92,6 +92,36 @@ __device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off,
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// ---- elementwise helpers shared by the forward kernels (scann_kernels.hip, scann_struct.hip) ----
+
+// swish(x) = x * sigmoid(x) on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each.
+// Measured effect on the end-to-end parity error: DESIGN.md "numerics".
+__device__ __forceinline__ float swishf(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
+__device__ __forceinline__ float swish_exact(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+
+// e^x through v_exp_f32 (2^x, 1 ulp); used where the argument is <= 0 (softmax numerators).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4swish(float4 a) { return make_float4(swishf(a.x), swishf(a.y), swishf(a.z), swishf(a.w)); }
+__device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+constexpr int BASIS_STRIDE = 72;  // halfs per staged basis row: 64 + 8 pad = 144 B (conflict-free b128 fragment reads)
+// exp(-(x - c)^2 / 0.25)  (custom_layers.py:63-65, width 0.5 squared at :51)
+__device__ __forceinline__ float gauss(float x, float c) {
+  const float d = x - c;
+  return expf(-(d * d) / 0.25f);
+}
+// v_exp_f32 form for the fused basis MLP: |abs error| <= ~2e-8 (value * |arg| * 6e-8 peaks at arg = -1)
+__device__ __forceinline__ float gauss_fast(float x, float c) {
+  const float d = x - c;
+  return fast_exp(-(d * d) * 4.0f);
+}
+
 // acc = X . W for the tile staged in (sH, sL), W's halves already in (whA, wlA) / (whB, wlB); when NEXT, the halves of the
 // following weight are requested into the same registers as soon as the MFMAs that read them have been issued.
 template <bool NEXT, int RT = 2>

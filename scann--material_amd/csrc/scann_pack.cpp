@@ -26,6 +26,45 @@ int pack_fail(const char* msg) {
 
 namespace scann {
 
+// Greedy tiling of atoms [a0, a1): whole atoms, <= want edges and <= tile_atoms atoms per tile; with allow_chunks an atom with more
+// than `want` neighbours closes the open tile and becomes ceil(deg / want) single-atom chunk tiles (tile_part = softmax-merge slot).
+static void tile_range(const int32_t* edge_offset, int32_t a0, int32_t a1, int want, int tile_atoms, bool allow_chunks,
+                       std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part, std::vector<int32_t>& big_tab, int32_t& n_slot) {
+  EdgeTile cur{a0, a0, edge_offset[a0], edge_offset[a0]};
+  for (int a = a0; a < a1; ++a) {
+    const int32_t e0 = edge_offset[a], e1 = edge_offset[a + 1];
+    if (allow_chunks && e1 - e0 > want) {  // big atom: close the open tile, then one chunk tile per <= tile_rows of its edges
+      if (a > cur.atom_begin) {
+        cur.atom_end = a;
+        cur.edge_end = e0;
+        tiles.push_back(cur);
+        tile_part.push_back(-1);
+      }
+      big_tab.push_back(a); big_tab.push_back(n_slot); big_tab.push_back((e1 - e0 + want - 1) / want);
+      for (int c0 = e0; c0 < e1; c0 += want) {
+        tiles.push_back(EdgeTile{a, a + 1, c0, std::min(c0 + want, e1)});
+        tile_part.push_back(n_slot++);
+      }
+      cur = EdgeTile{a + 1, a + 1, e1, e1};
+      continue;
+    }
+    // greedy tiling: whole atoms, <= tile_rows edges and <= tile_atoms atoms per tile
+    if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= tile_atoms) {
+      cur.atom_end = a;
+      cur.edge_end = e0;
+      tiles.push_back(cur);
+      tile_part.push_back(-1);
+      cur = EdgeTile{a, a, e0, e0};
+    }
+  }
+  if (cur.atom_begin < a1) {
+    cur.atom_end = a1;
+    cur.edge_end = edge_offset[a1];
+    tiles.push_back(cur);
+    tile_part.push_back(-1);
+  }
+}
+
 int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset, const int32_t* edge_col, int32_t A, int32_t E,
                int tile_rows_req, int tile_atoms, bool allow_chunks, std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part,
                std::vector<int32_t>& big_tab, std::vector<int32_t>& edge_row, int* tile_rows_out, int32_t* max_degree,
@@ -61,47 +100,104 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
   }
   int tile_rows = tile_rows_req;
   if (maxdeg > tile_rows && !allow_chunks) tile_rows = TE_MAX;  // a 32-row tile cannot hold the largest atom: 64-row tiles
-  {
-    const int want = tile_rows;
-    tiles.clear(); tile_part.clear(); big_tab.clear(); n_slot = 0;
-    EdgeTile cur{0, 0, 0, 0};
-    for (int a = 0; a < A; ++a) {
-      const int32_t e0 = edge_offset[a], e1 = edge_offset[a + 1];
-      if (allow_chunks && e1 - e0 > want) {  // big atom: close the open tile, then one chunk tile per <= tile_rows of its edges
-        if (a > cur.atom_begin) {
-          cur.atom_end = a;
-          cur.edge_end = e0;
-          tiles.push_back(cur);
-          tile_part.push_back(-1);
-        }
-        big_tab.push_back(a); big_tab.push_back(n_slot); big_tab.push_back((e1 - e0 + want - 1) / want);
-        for (int c0 = e0; c0 < e1; c0 += want) {
-          tiles.push_back(EdgeTile{a, a + 1, c0, std::min(c0 + want, e1)});
-          tile_part.push_back(n_slot++);
-        }
-        cur = EdgeTile{a + 1, a + 1, e1, e1};
-        continue;
-      }
-      // greedy tiling: whole atoms, <= tile_rows edges and <= tile_atoms atoms per tile
-      if ((e1 - cur.edge_begin) > want || (a - cur.atom_begin) >= tile_atoms) {
-        cur.atom_end = a;
-        cur.edge_end = e0;
-        tiles.push_back(cur);
-        tile_part.push_back(-1);
-        cur = EdgeTile{a, a, e0, e0};
-      }
-    }
-    if (cur.atom_begin < A || tiles.empty()) {
-      cur.atom_end = A;
-      cur.edge_end = E;
-      tiles.push_back(cur);
-      tile_part.push_back(-1);
-    }
+  tiles.clear(); tile_part.clear(); big_tab.clear(); n_slot = 0;
+  tile_range(edge_offset, 0, A, tile_rows, tile_atoms, allow_chunks, tiles, tile_part, big_tab, n_slot);
+  if (tiles.empty()) {
+    tiles.push_back(EdgeTile{0, A, 0, E});
+    tile_part.push_back(-1);
   }
   *tile_rows_out = tile_rows;
   *max_degree = maxdeg;
   *n_slot_out = n_slot;
   return SCANN_OK;
+}
+
+
+namespace {
+// Greedy tiling of atoms [a0, a1) by plan_tiles's rule (whole atoms, <= TE_MAX edges and <= tile_atoms atoms per tile); appends the
+// tiles to `out` when given.  Returns the number of tiles, or -1 when an atom has more than TE_MAX neighbours.
+int tile_run(const int32_t* eo, int32_t a0, int32_t a1, int tile_atoms, std::vector<EdgeTile>* out) {
+  int n = 0;
+  EdgeTile cur{a0, a0, eo[a0], eo[a0]};
+  for (int32_t a = a0; a < a1; ++a) {
+    const int32_t e0 = eo[a], e1 = eo[a + 1];
+    if (e1 - e0 > TE_MAX) return -1;
+    if ((e1 - cur.edge_begin) > TE_MAX || (a - cur.atom_begin) >= tile_atoms) {
+      cur.atom_end = a;
+      cur.edge_end = e0;
+      if (out) out->push_back(cur);
+      ++n;
+      cur = EdgeTile{a, a, e0, e0};
+    }
+  }
+  cur.atom_end = a1;
+  cur.edge_end = eo[a1];
+  if (out) out->push_back(cur);
+  return n + 1;
+}
+}  // namespace
+
+void plan_groups(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset, int tile_atoms, int max_tiles, SrPlan& plan) {
+  const int nt_small = std::min(SR_NT_SMALL, max_tiles), nt_big = std::min(SR_NT_BIG, max_tiles);
+  plan.small.clear(); plan.big.clear(); plan.tiles.clear(); plan.streamed.clear();
+  struct Run { int32_t a0, a1; };
+  std::vector<Run> small, big;
+  Run open{-1, -1};
+  auto close_open = [&]() {
+    if (open.a0 >= 0) small.push_back(open);
+    open = Run{-1, -1};
+  };
+  for (int32_t s = 0; s < B; ++s) {
+    const int32_t a0 = mol_offset[s], a1 = mol_offset[s + 1];
+    int own = tile_run(edge_offset, a0, a1, tile_atoms, nullptr);
+    if (a1 - a0 > SR_ATOMS_BIG) own = -1;
+    else if (a1 - a0 > SR_ATOMS_SMALL && own >= 0) own = std::max(own, nt_small + 1);  // too many atoms for the small kernel's cache
+    if (own < 0 || own > nt_big) {
+      close_open();
+      plan.streamed.push_back(s);
+    } else if (own > nt_small) {
+      close_open();
+      big.push_back(Run{a0, a1});
+    } else if (open.a0 >= 0 && a1 - open.a0 <= SR_ATOMS_SMALL && tile_run(edge_offset, open.a0, a1, tile_atoms, nullptr) <= nt_small) {
+      open.a1 = a1;  // the joint plan of the open group and this structure still fits
+    } else {
+      close_open();
+      open = Run{a0, a1};
+    }
+  }
+  close_open();
+  // the longest workgroups first: a launch ends with its short ones
+  auto by_edges = [&](const Run& x, const Run& y) {
+    return edge_offset[x.a1] - edge_offset[x.a0] > edge_offset[y.a1] - edge_offset[y.a0];
+  };
+  std::stable_sort(small.begin(), small.end(), by_edges);
+  std::stable_sort(big.begin(), big.end(), by_edges);
+  for (int pass = 0; pass < 2; ++pass)
+    for (const Run& r : pass ? big : small) {
+      const int32_t t0 = (int32_t)plan.tiles.size();
+      const int n = tile_run(edge_offset, r.a0, r.a1, tile_atoms, &plan.tiles);
+      (pass ? plan.big : plan.small).push_back(SrGroup{r.a0, r.a1, t0, n});
+    }
+}
+
+
+void plan_streamed_subset(const int32_t* mol_offset, const int32_t* edge_offset, const std::vector<int32_t>& streamed, int tile_atoms,
+                          std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part, std::vector<int32_t>& big_tab, int32_t* n_slot_out,
+                          std::vector<int32_t>& atom_tab) {
+  tiles.clear(); tile_part.clear(); big_tab.clear(); atom_tab.clear();
+  int32_t n_slot = 0;
+  for (size_t i = 0; i < streamed.size();) {
+    size_t j = i + 1;
+    while (j < streamed.size() && streamed[j] == streamed[j - 1] + 1) ++j;  // a run of consecutive structures
+    const int32_t a0 = mol_offset[streamed[i]], a1 = mol_offset[streamed[j - 1] + 1];
+    tile_range(edge_offset, a0, a1, TE_MAX, tile_atoms, true, tiles, tile_part, big_tab, n_slot);
+    for (int32_t r = a0; r < a1; r += TA) {
+      atom_tab.push_back(r);
+      atom_tab.push_back(std::min<int32_t>(TA, a1 - r));
+    }
+    i = j;
+  }
+  *n_slot_out = n_slot;
 }
 
 }  // namespace scann
@@ -248,6 +344,40 @@ int scann_plan_tiles(const scann_batch_t* b, int32_t tile_rows, int32_t tile_ato
     part_out[i] = part[i];
   }
   return rows;  // 32 or 64: the edge rows per tile actually planned
+}
+
+int scann_plan_groups(const scann_batch_t* b, int32_t tile_atoms, int32_t max_tiles, int32_t cap_groups, int32_t cap_tiles, int32_t* groups_out,
+                      int32_t* tiles_out, int32_t* streamed_out, int32_t* n_small, int32_t* n_big, int32_t* n_tiles,
+                      int32_t* n_streamed) {
+  if (!b || !n_small || !n_big || !n_tiles || !n_streamed || !b->mol_offset || !b->edge_offset || b->n_struct <= 0 || b->n_atom <= 0 ||
+      b->n_edge < 0 || tile_atoms <= 0 || tile_atoms > scann::TQ || max_tiles < 1)
+    return pack_fail("scann_plan_groups: bad argument");
+  if (b->mol_offset[0] != 0 || b->mol_offset[b->n_struct] != b->n_atom || b->edge_offset[0] != 0 || b->edge_offset[b->n_atom] != b->n_edge)
+    return pack_fail("scann_plan_groups: offsets do not cover the batch");
+  for (int s = 0; s < b->n_struct; ++s)
+    if (b->mol_offset[s + 1] <= b->mol_offset[s]) return pack_fail("scann_plan_groups: structure without atoms");
+  for (int a = 0; a < b->n_atom; ++a)
+    if (b->edge_offset[a + 1] < b->edge_offset[a]) return pack_fail("scann_plan_groups: edge_offset not monotone");
+  scann::SrPlan plan;
+  scann::plan_groups(b->mol_offset, b->n_struct, b->edge_offset, tile_atoms, max_tiles, plan);
+  *n_small = (int32_t)plan.small.size();
+  *n_big = (int32_t)plan.big.size();
+  *n_tiles = (int32_t)plan.tiles.size();
+  *n_streamed = (int32_t)plan.streamed.size();
+  if (!groups_out || !tiles_out || !streamed_out) return SCANN_OK;
+  if (*n_small + *n_big > cap_groups || *n_tiles > cap_tiles) return pack_fail("scann_plan_groups: output capacity too small");
+  int i = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (const scann::SrGroup& g : pass ? plan.big : plan.small) {
+      groups_out[4 * i] = g.atom_begin; groups_out[4 * i + 1] = g.atom_end; groups_out[4 * i + 2] = g.tile_begin; groups_out[4 * i + 3] = g.n_tile;
+      ++i;
+    }
+  for (size_t t = 0; t < plan.tiles.size(); ++t) {
+    tiles_out[4 * t] = plan.tiles[t].atom_begin; tiles_out[4 * t + 1] = plan.tiles[t].atom_end;
+    tiles_out[4 * t + 2] = plan.tiles[t].edge_begin; tiles_out[4 * t + 3] = plan.tiles[t].edge_end;
+  }
+  for (size_t k = 0; k < plan.streamed.size(); ++k) streamed_out[k] = plan.streamed[k];
+  return SCANN_OK;
 }
 
 }  // extern "C"

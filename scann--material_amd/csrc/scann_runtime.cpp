@@ -121,6 +121,10 @@ struct scann_handle {
   int fuse_attn = 1;   // env SCANN_TRAIN_FUSE_ATTN=0: attn_bwd16_kernel as a launch of its own before edge_bwd_kernel
   int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
   int species_tables = 1;  // env SCANN_SPECIES_TABLES=0: the first layer's atom rows come from an atom launch, not from per-species tables
+  // structure-resident forward (scann_struct.hip): the largest group, in edge tiles, that scann_batch_upload plans for it; 0: every
+  // structure stays on the layer-streamed kernels (env SCANN_RESIDENT, scann_set_resident_limit)
+  int sr_max_tiles = SR_NT_BIG;
+  LayerParams* d_layers = nullptr;  // device copy of `layers` (the resident kernel walks the layers itself)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -202,6 +206,16 @@ struct scann_dbatch {
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
   float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
   int32_t n_big = 0, n_slot = 0;
+  // structure-resident plan (plan_groups): groups of <= 3 tiles first, then the groups of 4..6; tiles of their own
+  SrGroup* sr_groups = nullptr;
+  EdgeTile* sr_tiles = nullptr;
+  int32_t n_sr_small = 0, n_sr_big = 0, n_sr_tile = 0, n_streamed = 0;
+  int32_t sr_small_edges = 0, sr_small_atoms = 0;  // edges / atoms of the groups of <= 3 tiles (what one sr_kernel<3> launch processes)
+  // ... and, when the batch also holds structures the resident kernels cannot take, the streamed kernels' plan for THOSE
+  EdgeTile* s2_tiles = nullptr;
+  int32_t *s2_tile_part = nullptr, *s2_big_tab = nullptr, *s2_row_tab = nullptr;
+  float* s2_part_buf = nullptr;
+  int32_t s2_n_tile = 0, s2_n_big = 0, s2_n_slot = 0, s2_n_row = 0;
   // workspace
   float *geom = nullptr, *gd = nullptr, *c = nullptr, *ctx = nullptr, *P1 = nullptr, *P3 = nullptr, *q = nullptr;
   float *gq = nullptr, *gk = nullptr, *ga = nullptr, *y = nullptr;
@@ -426,6 +440,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* fb = getenv("SCANN_FUSE_BASIS")) h->fuse_basis = atoi(fb) != 0;
   if (const char* fa = getenv("SCANN_TRAIN_FUSE_ATTN")) h->fuse_attn = atoi(fa) != 0;
   if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
+  if (const char* sr = getenv("SCANN_RESIDENT")) h->sr_max_tiles = std::min((int)SR_NT_BIG, std::max(0, atoi(sr)));
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -458,6 +473,7 @@ void scann_destroy(scann_handle_t* h) {
     if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
   if (h->d_weights) (void)hipFree(h->d_weights);
   if (h->sp_c) (void)hipFree(h->sp_c);
+  if (h->d_layers) (void)hipFree(h->d_layers);
   for (scann_handle::Stage& st : h->stage) {
     if (st.p) (void)hipHostFree(st.p);
     if (st.ev) (void)hipEventDestroy(st.ev);
@@ -732,6 +748,10 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   h->embed.emb = P(oemb); h->embed.We = P(oWc); h->embed.be = P(obc); h->embed.Wr = P(oWr); h->embed.br = P(obr);
   h->embed.Wde = P(oWe); h->embed.bde = P(obe);
   h->sp_dirty = true;
+  if (L > 0) {  // the structure-resident kernel reads the per-layer pointer table from the device
+    if (!h->d_layers) HIPCHK(h, hipMalloc((void**)&h->d_layers, (size_t)L * sizeof(LayerParams)));
+    HIPCHK(h, hipMemcpy(h->d_layers, h->layers.data(), (size_t)L * sizeof(LayerParams), hipMemcpyHostToDevice));
+  }
   if (!general_embed && !h->sp_c && c.g_update) {  // c | P1 | P3 | q tables of the first layer, one allocation
     const size_t tab = (size_t)c.n_atoms * D;
     HIPCHK(h, hipMalloc((void**)&h->sp_c, 4 * tab * sizeof(float)));
@@ -835,6 +855,20 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     }
   }
   const int32_t n_big = (int32_t)big_tab.size() / 3;
+  // structure-resident plan (inference handles, SCANN+ only) and, for a batch with structures beyond it, the streamed kernels' plan
+  // for exactly those
+  SrPlan sr;
+  std::vector<EdgeTile> tiles2;
+  std::vector<int32_t> tile_part2, big_tab2, row_tab2;
+  int32_t n_slot2 = 0;
+  if (h->sr_max_tiles > 0 && h->cfg.g_update && E > 0 && !h->t_master) {
+    plan_groups(b->mol_offset, B, b->edge_offset, h->tile_atoms, h->sr_max_tiles, sr);
+    if (sr.small.empty() && sr.big.empty()) sr.streamed.clear();  // nothing resident: the whole-batch plan above serves
+    else if (!sr.streamed.empty())
+      plan_streamed_subset(b->mol_offset, b->edge_offset, sr.streamed, h->tile_atoms, tiles2, tile_part2, big_tab2, &n_slot2, row_tab2);
+  }
+  const int32_t n_big2 = (int32_t)big_tab2.size() / 3;
+  const size_t n_srg = sr.small.size() + sr.big.size();
   HIPCHK(h, hipSetDevice(h->device));
   scann_dbatch* db = nullptr;
   if (scratch) {
@@ -861,13 +895,16 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_tpart = take(n_big ? tiles.size() * 4 : 0), o_big = take((size_t)n_big * 3 * 4);
   const size_t o_inoff = take((size_t)(A + 1) * 4), o_inedge = take((size_t)E * 4);
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
+  const size_t o_srg = take(n_srg * sizeof(SrGroup)), o_srt = take(sr.tiles.size() * sizeof(EdgeTile));
+  const size_t o_t2 = take(tiles2.size() * sizeof(EdgeTile)), o_tp2 = take(n_big2 ? tiles2.size() * 4 : 0), o_big2 = take((size_t)n_big2 * 3 * 4);
+  const size_t o_row2 = take(row_tab2.size() * 4);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
   const size_t o_geom = take(h->cfg.g_update ? rowE : 0), o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
   const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
-  const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4);
+  const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4), o_pbuf2 = take((size_t)n_slot2 * 3 * D * 4);
   hipError_t e = hipSuccess;
   scann_handle::Stage* stage = nullptr;
   char* img_ptr = nullptr;
@@ -904,7 +941,10 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     }
   }
   if (e != hipSuccess) {
-    if (!scratch) delete db;
+    if (!scratch) {
+      if (db->arena) cached_free(db->arena);
+      delete db;
+    }
     return fail(h, e == hipErrorOutOfMemory ? SCANN_ERR_OOM : SCANN_ERR_HIP, std::string("hipMalloc(batch arena): ") + hipGetErrorString(e));
   }
   struct ImgView { char* p; char* data() const { return p; } } img{img_ptr};
@@ -935,6 +975,17 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   if (n_big) {
     memcpy(img.data() + o_tpart, tile_part.data(), tiles.size() * 4);
     memcpy(img.data() + o_big, big_tab.data(), (size_t)n_big * 3 * 4);
+  }
+  if (n_srg) {
+    memcpy(img.data() + o_srg, sr.small.data(), sr.small.size() * sizeof(SrGroup));
+    memcpy(img.data() + o_srg + sr.small.size() * sizeof(SrGroup), sr.big.data(), sr.big.size() * sizeof(SrGroup));
+    memcpy(img.data() + o_srt, sr.tiles.data(), sr.tiles.size() * sizeof(EdgeTile));
+    if (!tiles2.empty()) memcpy(img.data() + o_t2, tiles2.data(), tiles2.size() * sizeof(EdgeTile));
+    if (!row_tab2.empty()) memcpy(img.data() + o_row2, row_tab2.data(), row_tab2.size() * 4);
+    if (n_big2) {
+      memcpy(img.data() + o_tp2, tile_part2.data(), tiles2.size() * 4);
+      memcpy(img.data() + o_big2, big_tab2.data(), (size_t)n_big2 * 3 * 4);
+    }
   }
   // (the centre atom of every edge is derived from the offsets on the device, behind the copy: no host loop, no bytes over the bus)
   int32_t* const d_eoff = (int32_t*)(db->arena + o_eoff);
@@ -972,6 +1023,21 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->ga = (float*)(a0 + o_ga); db->y = (float*)(a0 + o_y);
   if (n_big) {
     db->tile_part = (int32_t*)(a0 + o_tpart); db->big_tab = (int32_t*)(a0 + o_big); db->part_buf = (float*)(a0 + o_pbuf);
+  }
+  if (n_srg) {
+    db->sr_groups = (SrGroup*)(a0 + o_srg); db->sr_tiles = (EdgeTile*)(a0 + o_srt);
+    db->n_sr_small = (int32_t)sr.small.size(); db->n_sr_big = (int32_t)sr.big.size(); db->n_sr_tile = (int32_t)sr.tiles.size();
+    db->n_streamed = (int32_t)sr.streamed.size();
+    for (const SrGroup& g : sr.small) {
+      db->sr_small_edges += b->edge_offset[g.atom_end] - b->edge_offset[g.atom_begin];
+      db->sr_small_atoms += g.atom_end - g.atom_begin;
+    }
+    db->s2_tiles = (EdgeTile*)(a0 + o_t2); db->s2_n_tile = (int32_t)tiles2.size();
+    db->s2_row_tab = (int32_t*)(a0 + o_row2); db->s2_n_row = (int32_t)row_tab2.size() / 2;
+    db->s2_n_big = n_big2; db->s2_n_slot = n_slot2;
+    if (n_big2) {
+      db->s2_tile_part = (int32_t*)(a0 + o_tp2); db->s2_big_tab = (int32_t*)(a0 + o_big2); db->s2_part_buf = (float*)(a0 + o_pbuf2);
+    }
   }
   *out = db;
   return SCANN_OK;
@@ -1029,10 +1095,20 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
   auto g_of = [&](int l) { return direct && c.g_update ? db->dbg_g + (size_t)l * nE_ : db->geom; };
   if (tm) tm->mark(-1);
+  // Structure-resident path (scann_struct.hip) for the groups scann_batch_upload planned; the layer-streamed launches below then
+  // cover only the structures beyond it (none in a QM9-shaped batch), through the plan made for exactly those.
+  const bool resident = db->n_sr_small + db->n_sr_big > 0 && L > 0 && !h->debug && !h->in_train_forward && h->train_drop_p == 0.f && h->d_layers;
+  const bool streamed_any = !resident || db->n_streamed > 0;
+  const EdgeTile* const v_tiles = resident ? db->s2_tiles : db->tiles;
+  const int v_n_tile = resident ? db->s2_n_tile : db->n_tile, v_n_big = resident ? db->s2_n_big : db->n_big;
+  const int32_t* const v_tile_part = resident ? db->s2_tile_part : db->tile_part;
+  const int32_t* const v_big_tab = resident ? db->s2_big_tab : db->big_tab;
+  float* const v_part_buf = resident ? db->s2_part_buf : db->part_buf;
+  const int v_tile_rows = resident ? TE_MAX : db->tile_rows;
   // inference: the first layer's edge kernel computes its geometry rows from (dist, weight) itself -- geom0 is never written by a
   // basis launch and read back (282 MB of the 16-batch forward's traffic and one launch)
   const bool fuse_basis = h->fuse_basis && c.g_update && L > 0 && !h->debug && !h->in_train_forward && db->n_edge > 0;
-  if (fuse_basis) {}
+  if (fuse_basis || !streamed_any) {}
   else if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
   else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
   if (tm) tm->mark(0);
@@ -1049,7 +1125,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   }
   // first layer from per-species tables: no atom launch at all (see EdgeArgs::species)
   // (not with chunked atoms: edge_merge_kernel reads the query rows per atom)
-  const bool species0 = fuse_basis && h->species_tables && !general_embed && h->train_drop_p == 0.f && h->sp_c && db->n_big == 0;
+  const bool species0 = streamed_any && fuse_basis && h->species_tables && !general_embed && h->train_drop_p == 0.f && h->sp_c && v_n_big == 0;
   if (species0 && h->sp_dirty) {
     AtomArgs a{};
     a.n_atom = c.n_atoms; a.x = h->lut; a.ffn = 0; a.c = h->sp_c;
@@ -1062,12 +1138,13 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     HIPCHK(h, hipStreamSynchronize(s));  // once per weight change: forwards on the handle's other streams read the tables too
     h->sp_dirty = false;
   }
-  for (int l = 0; l <= L; ++l) {
+  for (int l = 0; l <= L && streamed_any; ++l) {
     // training forward through edge_kernel_lean: q, V, T, ang, K of every layer are kept for the backward
     const bool keep = direct && h->in_train_forward && db->keep_K && l < L;
     // atom kernel at the head of layer l: ResidualNorm of layer l-1, centres, projections of layer l
     AtomArgs a{};
     a.n_atom = db->n_atom;
+    if (resident) { a.row_tab = db->s2_row_tab; a.n_row_tab = db->s2_n_row; }
     if (l == 0) {
       a.x = general_embed ? db->c0 : h->lut;
       a.x_index = general_embed ? nullptr : db->atomic;
@@ -1114,7 +1191,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     if (h->debug && !direct) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
     if (l == L) break;
     EdgeArgs ea{};
-    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update; ea.tile_rows = db->tile_rows;
+    ea.tiles = v_tiles; ea.n_tile = v_n_tile; ea.g_update = c.g_update; ea.tile_rows = v_tile_rows;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = g_of(l); ea.geom_out = direct && c.g_update ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
     if (fuse_basis && l == 0) { ea.fuse_basis = 1; ea.dist = db->dist; ea.basis = h->basis; }
@@ -1129,14 +1206,14 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     ea.p = h->layers[l];
     ea.range_flag = h->range_flag; ea.layer = l;
     // (the first layer's launch with the basis MLP fused in is a different kernel: not part of edge_kernel's sampled average)
-    const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
+    const bool sample = !resident && !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) {
       (void)hipEventCreate(&ev0);
       (void)hipEventCreate(&ev1);
       (void)hipEventRecord(ev0, s);
     }
-    ea.tile_part = db->tile_part; ea.part_buf = db->part_buf;
+    ea.tile_part = v_tile_part; ea.part_buf = v_part_buf;
     ea.xcd_remap = h->xcd_remap;
     if (h->in_train_forward && h->attn_drop_p > 0.f) {  // validation passes run with scann_set_attention_dropout(h, 0): trainer.fit
       ea.attn_drop_p = h->attn_drop_p;
@@ -1151,7 +1228,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
 #endif
     launch_edge(ea, s);
-    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, h->range_flag, l, s);
+    launch_edge_merge(v_big_tab, v_n_big, v_part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, h->range_flag, l, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);
@@ -1164,6 +1241,36 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       if (c.g_update && db->n_edge)
         HIPCHK(h, hipMemcpyAsync(db->dbg_g + (size_t)(l + 1) * db->n_edge * D, db->geom, rowE, hipMemcpyDeviceToDevice, s));
     }
+  }
+  if (resident) {
+    SrArgs sa{};
+    sa.groups = db->sr_groups; sa.tiles = db->sr_tiles; sa.n_group = db->n_sr_small; sa.n_layer = L; sa.use_attn_norm = c.use_attn_norm;
+    sa.edge_offset = db->edge_offset; sa.edge_col = db->edge_col; sa.edge_row = db->edge_row;
+    sa.dist = db->dist; sa.edge_weight = db->weight;
+    sa.x0 = general_embed ? db->c0 : h->lut; sa.x0_index = general_embed ? nullptr : db->atomic;
+    sa.basis = h->basis; sa.layers = h->d_layers; sa.head = h->head;
+    sa.c = db->c; sa.P1 = db->P1; sa.P3 = db->P3; sa.q = db->q; sa.ctx = db->ctx; sa.gq = db->gq; sa.gk = db->gk;
+    sa.range_flag = h->range_flag;
+    // (scann_edge_timing: with this path the sampled kernel is sr_kernel<3>, the whole forward of the groups of <= 3 tiles)
+    const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && sa.n_group > 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (sample) {
+      (void)hipEventCreate(&ev0);
+      (void)hipEventCreate(&ev1);
+      (void)hipEventRecord(ev0, s);
+    }
+    launch_struct(sa, SR_NT_SMALL, s);
+    if (sample) {
+      (void)hipEventRecord(ev1, s);
+      h->time_ev.push_back(ev0);
+      h->time_ev.push_back(ev1);
+      h->time_edges.push_back(db->sr_small_edges);
+    }
+    if (db->n_sr_big) {
+      sa.groups = db->sr_groups + db->n_sr_small; sa.n_group = db->n_sr_big;
+      launch_struct(sa, SR_NT_BIG, s);
+    }
+    if (tm) tm->mark(2);
   }
   if (!tm) h->time_count++;
   ReadoutArgs r{};
@@ -1186,6 +1293,19 @@ int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slo
   const int slot = ((stream_slot % h->nstream) + h->nstream) % h->nstream;
   db->last_slot = slot;
   return run_forward(h, db, h->streams[slot], nullptr);
+}
+
+int scann_set_resident_limit(scann_handle_t* h, int max_tiles) {
+  if (!h || max_tiles < 0) return fail(h, SCANN_ERR_INVALID, "scann_set_resident_limit: bad argument");
+  h->sr_max_tiles = std::min((int)SR_NT_BIG, max_tiles);
+  return SCANN_OK;
+}
+
+int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8) {
+  if (!h || !db || !out8) return fail(h, SCANN_ERR_INVALID, "scann_batch_info: null argument");
+  out8[0] = db->n_sr_small; out8[1] = db->n_sr_big; out8[2] = db->n_streamed; out8[3] = db->n_sr_tile;
+  out8[4] = db->sr_small_edges; out8[5] = db->sr_small_atoms; out8[6] = db->n_tile; out8[7] = db->tile_rows;
+  return SCANN_OK;
 }
 
 int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out) {

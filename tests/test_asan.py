@@ -44,6 +44,10 @@ for n, seed in ((1, 0), (7, 1), (33, 2)):
         assert pk.n_struct == n and pk.edge_offset[-1] == pk.n_edge == int(inputs["neighbor_mask"].sum())
         for tr in (32, 64):
             _hip.plan_tiles(pk, tile_rows=tr) if hasattr(_hip, "plan_tiles") else None
+        for mt in (1, 2, 3, 6):
+            pl = _hip.plan_groups(pk, max_tiles=mt)
+            assert sum(g[1] - g[0] for g in list(pl["small"]) + list(pl["big"])) + sum(
+                pk.mol_offset[s + 1] - pk.mol_offset[s] for s in pl["streamed"]) == pk.n_atom
     ds = PackedDataset(data_energy=de, data_neighbor=dn, batch_size=5, use_ring=False, feature="atomic", g_update=True,
                        atomic_features=None, shuffle=False)
     it = DataIterator(de, dn, batch_size=5, g_update=True)
@@ -78,13 +82,14 @@ print("ASAN_OK")
 
 
 def test_host_native_code_under_asan_and_ubsan(tmp_path):
-    rt_file = os.path.join(ASAN_DIR, "runtime.txt")
-    if not os.path.exists(rt_file):
-        r = subprocess.run(["make", "-C", os.path.join(ROOT, "scann--material_amd", "csrc"), "asan"], capture_output=True, text=True)
-        if r.returncode != 0 or not os.path.exists(rt_file):
-            pytest.skip("sanitizer build unavailable: " + r.stderr[-300:])
-    runtime = open(rt_file).read().strip()
-    if not os.path.exists(runtime):
+    # the make target is idempotent (file targets): a fresh checkout builds, a stale build is refreshed, nothing else happens
+    csrc = os.path.join(ROOT, "scann--material_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True)
+    libs = [os.path.join(ASAN_DIR, n) for n in ("libscann_pack_asan.so", "_listwalk.so", "libscann_oracle_c_asan.so")]
+    if r.returncode != 0 or not all(os.path.exists(p) for p in libs):
+        pytest.skip("sanitizer build unavailable: " + r.stderr[-300:])
+    runtime = subprocess.run(["make", "-s", "--no-print-directory", "-C", csrc, "asan-runtime"], capture_output=True, text=True).stdout.strip()
+    if not runtime or not os.path.exists(runtime):
         pytest.skip("sanitizer runtime not found: " + runtime)
     script = tmp_path / "asan_child.py"
     script.write_text(_CHILD)

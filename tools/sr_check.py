@@ -1,0 +1,85 @@
+"""GPU check of the structure-resident forward (csrc/scann_struct.hip) against the layer-streamed kernels on ONE box:
+same bytes?  error against the fp32 NumPy oracle?  resident-input rate of both paths at 1 / 10 / 16 batches per launch.
+
+    python tools/sr_check.py [n_batches_per_launch ...]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "scann--material_amd"), os.path.join(ROOT, "oracle")]
+import scann_oracle as so  # noqa: E402  (checker only)
+from scann import _hip  # noqa: E402
+from scann.models.scann_model import HipModel  # noqa: E402
+
+
+def batches(n_batch, bs, seed):
+    out = []
+    for i in range(n_batch):
+        de, dn = so.synth_dataset(bs, seed + i)
+        inputs, _ = so.pad_batch(de, dn, g_update=True)
+        out.append(_hip.pack_inputs(inputs))
+    return out
+
+
+def main():
+    cfg = so.default_config("qm9")
+    w = so.init_weights(cfg, 1234, perturb=True)
+    streamed = HipModel(cfg, w, device=0, infer=True)
+    streamed.engine.set_resident_limit(0)
+    resident = HipModel(cfg, w, device=0, infer=True)
+    mixed = HipModel(cfg, w, device=0, infer=True)
+    mixed.engine.set_resident_limit(2)
+
+    # ---- parity: one batch of 96 QM9-shaped molecules + the worst case (29 atoms x 12 neighbours) + tiny ones
+    de, dn = so.synth_dataset(96, 5)
+    inputs, _ = so.pad_batch(de, dn, g_update=True)
+    pk = _hip.pack_inputs(inputs)
+    res = {}
+    for name, m in (("streamed", streamed), ("resident", resident), ("mixed", mixed)):
+        rb = m.engine.upload(pk)
+        info = m.engine.batch_info(rb)
+        m.engine.forward_resident(rb)
+        res[name] = m.engine.download(rb)
+        print(name, info)
+        rb.free()
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    for name in ("resident", "mixed"):
+        y, ga = res[name]
+        same_y = np.array_equal(y, res["streamed"][0])
+        same_ga = np.array_equal(ga, res["streamed"][1])
+        print("%s vs streamed: y bytes equal %s, ga bytes equal %s, max |dy| %.3e" % (name, same_y, same_ga, float(np.max(np.abs(y - res["streamed"][0])))))
+    y = res["resident"][0]
+    err = float(np.max(np.abs(y - y_ref[:, 0]) / np.maximum(np.abs(y_ref[:, 0]), 1e-6)))
+    print("resident vs fp32 oracle: strict max rel err %.3e" % err)
+
+    # ---- rate, inputs resident
+    sizes = [int(a) for a in sys.argv[1:]] or [1, 10, 16]
+    pool = batches(32, 128, 100)
+    for g in sizes:
+        groups = [_hip.concat_packed(pool[i:i + g]) if g > 1 else pool[i] for i in range(0, len(pool) - g + 1, g)][:8]
+        for name, m in (("streamed", streamed), ("resident", resident)):
+            eng = m.engine
+            rbs = [eng.upload(p) for p in groups]
+            for rb in rbs:
+                eng.forward_resident(rb, 0)
+            eng.sync()
+            t0 = time.perf_counter()
+            n_mol, reps = 0, 0
+            while time.perf_counter() - t0 < 1.0:
+                for rb in rbs:
+                    eng.forward_resident(rb, 0)
+                    n_mol += rb.packed.n_struct
+                eng.sync()
+                reps += 1
+            dt = time.perf_counter() - t0
+            print("%2d batches/launch %-9s %8.0f molecules/s  (%.1f us per forward)" % (g, name, n_mol / dt, dt / (reps * len(rbs)) * 1e6))
+            for rb in rbs:
+                rb.free()
+
+
+if __name__ == "__main__":
+    main()
