@@ -135,10 +135,12 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);
 void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db); /* see scann_train_step_begin */
 int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot); /* async */
 int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out); /* syncs that batch */
-/* Structure-resident forward (csrc/scann_struct.hip): an inference forward of a SCANN+ (g_update) handle runs every group of whole
- * structures that fits `max_tiles` edge tiles (<= 64 edges of whole atoms each; 1..6, default 6) as ONE workgroup that keeps the
- * group's geometry rows on chip across all n_attention iterations (the loop of create_model, scann_model.py:413-421); structures
- * beyond the limit (and every structure when it is 0) take the layer-streamed kernels.  Same results either way, byte for byte.
+/* Structure-resident forward (csrc/scann_struct.hip), EXPERIMENTAL and off by default (limit 0): an inference forward of a SCANN+
+ * (g_update) handle runs every group of whole structures that fits `max_tiles` edge tiles (<= 64 edges of whole atoms each; 1..6)
+ * as ONE workgroup that keeps the group's geometry rows in registers and its atom rows in LDS across all n_attention iterations
+ * (the loop of create_model, scann_model.py:413-421); structures beyond the limit (and every structure when it is 0) take the
+ * layer-streamed kernels.  Same results either way (to 1 ulp-level differences, tests/test_gpu_parity.py).  Measured 0.45-0.55 x the
+ * streamed path's rate on MI355X (profiles/r04_notes.md): kept for the measurements and as a base, not as the product path.
  * The plan is made by scann_batch_upload: the limit applies to batches uploaded afterwards.  Env SCANN_RESIDENT sets the default. */
 int scann_set_resident_limit(scann_handle_t* h, int max_tiles);
 /* out8 = { resident groups of <= 3 tiles, resident groups of 4..6 tiles, structures left to the streamed kernels, resident edge

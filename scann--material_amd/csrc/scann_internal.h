@@ -201,7 +201,7 @@ struct SrGroup {
   int32_t tile_begin, n_tile;    // its edge tiles in SrArgs::tiles: whole atoms, <= TE_MAX edges and <= TQ atoms each
 };
 constexpr int SR_NT_SMALL = 3, SR_NT_BIG = 6;
-constexpr int SR_ATOMS_SMALL = 40, SR_ATOMS_BIG = 72;  // atoms per group: rows of the kernel's atom-row cache in LDS
+constexpr int SR_ATOMS_SMALL = 36, SR_ATOMS_BIG = 72;  // atoms per group: rows of the kernel's atom-row cache in LDS
 
 struct SrArgs {
   const SrGroup* groups;
@@ -217,6 +217,11 @@ struct SrArgs {
   float *c, *P1, *P3, *q, *ctx;  // [n_atom,128] scratch rows, private to the workgroup that owns the atoms
   float *gq, *gk;                // out: GlobalAttention query / key rows for readout_kernel
   int32_t* range_flag;
+  unsigned long long* stamps;    // diagnostic build (-DSCANN_STAMPS) only: [n_group,64] phase clocks of layer 2, else null
+  // test hook (env SCANN_SR_DEBUG=1): per-layer copies for scann_debug_read -- centres [L+1][n_atom,128], context [L][n_atom,128],
+  // geometry [L+1][n_edge,128] (slice 0, the basis MLP's output, is not written) -- else null
+  float *dbg_c, *dbg_ctx, *dbg_g;
+  int32_t n_atom_total, n_edge_total;
 };
 void launch_struct(const SrArgs& a, int nt_max, hipStream_t s);
 

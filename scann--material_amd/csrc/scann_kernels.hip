@@ -200,9 +200,15 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
       }
       m2[rt] = xor32(v2);
     }
-    if (lh == 0) {
+    {
+      // (the lane id is re-derived HERE, from the hardware (v_mbcnt): the address and the predicate of this store were otherwise
+      // computed at the top of the kernel and carried -- at 168 VGPRs, spilled -- across both products)
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      if ((ln >> 5) == 0) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float2*>(&sRed[((lrow + 32 * rt) * 4 + wave) * 2]) = make_float2(mean32[rt], m2[rt]);
+        for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float2*>(&sRed[(((ln & 31) + 32 * rt) * 4 + wave) * 2]) = make_float2(mean32[rt], m2[rt]);
+      }
     }
     __syncthreads();  // statistics complete; every wave is done reading the hidden planes
     STAMP(a.stamps, 5);
@@ -458,11 +464,14 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
         load_wsplit<2>(a.basis.Wwh, wave, lane, bwh, bwl);
         {
           const float xd = ne > 0 ? a.dist[eb + rs] : 0.f, xw = ne > 0 ? a.edge_weight[eb + rs] : 0.f;
+          // the 20 + 20 Gaussian centres: ONE coalesced load per wave and table, handed to the lanes by ds_bpermute (the sixteen
+          // per-lane table loads of basis_kernel were a fifth of this kernel's vector-memory instructions); the same values
+          const float cd_l = a.basis.cd[min(lane, NG - 1)], cw_l = a.basis.cw[min(lane, NG - 1)];
           f16x8 gh[2], gl[2];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int k = 8 * sub + i;
-            const float cdk = a.basis.cd[min(k, NG - 1)], cwk = a.basis.cw[min(k, NG - 1)];
+            const float cdk = __shfl(cd_l, k), cwk = __shfl(cw_l, k);
             const float vd = (k < NG && r < ne) ? gauss_fast(xd, cdk) : 0.f, vw = (k < NG && r < ne) ? gauss_fast(xw, cwk) : 0.f;
             gh[0][i] = (_Float16)vd; gl[0][i] = (_Float16)(vd - (float)gh[0][i]);
             gh[1][i] = (_Float16)vw; gl[1][i] = (_Float16)(vw - (float)gh[1][i]);
@@ -474,15 +483,22 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
             *reinterpret_cast<f16x8*>(bL + r * BASIS_STRIDE + 32 + 8 * sub) = gl[1];
           }
         }
+        // the P1 rows (requested before the Gaussians) go to their LDS rows NOW: twelve registers less across the basis products
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int idx = tid + 256 * i;
+          *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         f32x16 accd[RT], accw[RT];
         mma_split<2, true, BASIS_STRIDE, RT>(bH, bL, bdh, bdl, lane, accd);
         mma_split<2, true, BASIS_STRIDE, RT>(bH + 32, bL + 32, bwh, bwl, lane, accw);
-        load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
-        load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // W2 in halves, each requested once a row tile's accumulators are free (all of it at once: 28 B of scratch per lane)
         constexpr float WINV0 = 1.0f / WSCALE;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float4 bd = *reinterpret_cast<const float4*>(a.basis.bd + cbase + 8 * j);
@@ -493,6 +509,11 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
                                                   fmaf(accw[rt][4 * j + 2], WINV0, bw.z), fmaf(accw[rt][4 * j + 3], WINV0, bw.w)));
             greg[rt][j] = f4mul(sd, sw);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if (rt == 0) load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
+          if (rt == RT - 1) load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();  // every wave is done reading the basis planes: the geometry planes may overwrite them
       } else {
         const float* gsrc = ne > 0 ? a.geom : a.P1;
@@ -503,10 +524,12 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
           for (int j = 0; j < 4; ++j) greg[rt][j] = ld4(gsrc, goff + 32 * j);
         }
       }
+      if (!FB) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int idx = tid + 256 * i;
-        *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
+        for (int i = 0; i < 3; ++i) {
+          const int idx = tid + 256 * i;
+          *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
@@ -597,7 +620,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
         v.y = fmaf(acc[rt][4 * j + 1], WINV, p1v.y) + p3r[rt][j].y;
         v.z = fmaf(acc[rt][4 * j + 2], WINV, p1v.z) + p3r[rt][j].z;
         v.w = fmaf(acc[rt][4 * j + 3], WINV, p1v.w) + p3r[rt][j].w;
-        const float4 t = f4add(f4swish(v), g);
+        const float4 t = f4swish_plus(v, g);
         acc[rt][4 * j] = t.x; acc[rt][4 * j + 1] = t.y; acc[rt][4 * j + 2] = t.z; acc[rt][4 * j + 3] = t.w;
         s += f4sum(t);
         if (a.keep_V && row < ne) {  // training forward: the backward reads these instead of recomputing them
@@ -746,7 +769,9 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int row = lrow + 32 * rt;
-    sE[row * NHEAD + 2 * wave + lh] = lh ? lg[rt][1] : lg[rt][0];
+    // (two predicated stores, not `lh ? lg[rt][1] : lg[rt][0]`: hipcc makes a private array of lg for the select in the base kernel)
+    if (lh == 0) sE[row * NHEAD + 2 * wave] = lg[rt][0];
+    else sE[row * NHEAD + 2 * wave + 1] = lg[rt][1];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 k4 = make_float4(acc[rt][4 * j], acc[rt][4 * j + 1], acc[rt][4 * j + 2], acc[rt][4 * j + 3]);

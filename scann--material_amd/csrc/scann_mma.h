@@ -100,6 +100,17 @@ __device__ __forceinline__ float swishf(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
 }
 
+// swish(x) + g with ONE rounding of the product-sum: x * sigmoid(x) + g as an fma.  This is what hipcc made of
+// `f4add(f4swish(v), g)` in edge_kernel all along (the helpers' multiply and add carry the default contraction flags, and the
+// kernel's `fp contract(off)` pragma does not reach into them), silently and only while both sat in one basic block; written out so
+// that edge_kernel and the structure-resident kernel (where they do not) round alike.
+__device__ __forceinline__ float swish_plus(float x, float g) {
+  return fmaf(x, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)), g);
+}
+__device__ __forceinline__ float4 f4swish_plus(float4 v, float4 g) {
+  return make_float4(swish_plus(v.x, g.x), swish_plus(v.y, g.y), swish_plus(v.z, g.z), swish_plus(v.w, g.w));
+}
+
 __device__ __forceinline__ float swish_exact(float x) { return x * (1.0f / (1.0f + expf(-x))); }
 
 // e^x through v_exp_f32 (2^x, 1 ulp); used where the argument is <= 0 (softmax numerators).

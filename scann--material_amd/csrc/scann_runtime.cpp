@@ -121,9 +121,10 @@ struct scann_handle {
   int fuse_attn = 1;   // env SCANN_TRAIN_FUSE_ATTN=0: attn_bwd16_kernel as a launch of its own before edge_bwd_kernel
   int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
   int species_tables = 1;  // env SCANN_SPECIES_TABLES=0: the first layer's atom rows come from an atom launch, not from per-species tables
-  // structure-resident forward (scann_struct.hip): the largest group, in edge tiles, that scann_batch_upload plans for it; 0: every
-  // structure stays on the layer-streamed kernels (env SCANN_RESIDENT, scann_set_resident_limit)
-  int sr_max_tiles = SR_NT_BIG;
+  // structure-resident forward (scann_struct.hip): the largest group, in edge tiles, that scann_batch_upload plans for it; 0 (the
+  // default: measured slower than the layer-streamed kernels, profiles/r04_notes.md): every structure stays on the layer-streamed
+  // kernels (env SCANN_RESIDENT, scann_set_resident_limit)
+  int sr_max_tiles = 0;
   LayerParams* d_layers = nullptr;  // device copy of `layers` (the resident kernel walks the layers itself)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
@@ -1251,6 +1252,20 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     sa.basis = h->basis; sa.layers = h->d_layers; sa.head = h->head;
     sa.c = db->c; sa.P1 = db->P1; sa.P3 = db->P3; sa.q = db->q; sa.ctx = db->ctx; sa.gq = db->gq; sa.gk = db->gk;
     sa.range_flag = h->range_flag;
+    if (getenv("SCANN_SR_DEBUG")) {  // test hook: per-layer intermediates of the resident kernels for scann_debug_read
+      const int r = ensure_debug(h, db);
+      if (r) return r;
+      sa.dbg_c = db->dbg_c; sa.dbg_ctx = db->dbg_ctx; sa.dbg_g = db->dbg_g;
+      sa.n_atom_total = db->n_atom; sa.n_edge_total = db->n_edge;
+    }
+#ifdef SCANN_STAMPS
+    if (!db->stamps && db->n_sr_small > 0) {
+      HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_sr_small * 64 * sizeof(unsigned long long)));
+      HIPCHK(h, hipMemsetAsync(db->stamps, 0, (size_t)db->n_sr_small * 64 * sizeof(unsigned long long), s));
+    }
+    sa.stamps = db->stamps;
+    db->n_stamp = 4 * db->n_sr_small;  // scann_debug_stamps copies 16-word records
+#endif
     // (scann_edge_timing: with this path the sampled kernel is sr_kernel<3>, the whole forward of the groups of <= 3 tiles)
     const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && sa.n_group > 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1268,6 +1283,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
     if (db->n_sr_big) {
       sa.groups = db->sr_groups + db->n_sr_small; sa.n_group = db->n_sr_big;
+      sa.stamps = nullptr;
       launch_struct(sa, SR_NT_BIG, s);
     }
     if (tm) tm->mark(2);

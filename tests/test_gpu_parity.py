@@ -633,3 +633,59 @@ def test_first_layer_computes_its_geometry_rows_itself(hip_lib, monkeypatch):
     sub = {k: v[:48] for k, v in inputs.items()}
     y_ref, _ = so.forward(cfg, w, sub, np.float32)
     assert rel_err(out["1"][0][:48], y_ref) <= RTOL
+
+
+@pytest.mark.parametrize("variant", ["qm9", "ring", "no_attn_norm", "L1"])
+def test_resident_and_streamed_structures_mixed(hip_lib, variant):
+    """The structure-resident forward (csrc/scann_struct.hip; opt-in, scann_set_resident_limit) against the layer-streamed
+    kernels: one batch of QM9-shaped molecules, worst-case molecules (29 atoms x 12 neighbours: 6 tiles, the one-workgroup-per-CU
+    kernel), tiny ones and MP2018-shaped crystals (beyond both resident kernels), run (a) streamed, (b) with every structure that
+    fits resident, (c) with a limit of 2 tiles, which leaves most molecules to the streamed kernels in the SAME batch.  Every
+    formula of the resident kernel is the streamed kernels' instruction sequence on the same rows, so the three give the same
+    BYTES (attention.py:118-216, :37-40; scann_model.py:413-421)."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    ring = variant == "ring"
+    if ring:
+        cfg["model"]["use_ring"] = True
+    if variant == "no_attn_norm":
+        cfg["model"]["use_attn_norm"] = False
+    if variant == "L1":
+        cfg["model"]["n_attention"] = 1
+    cfg["model"]["n_atoms"] = 100  # room for the crystals' species
+    w = so.init_weights(cfg, 77, perturb=True)
+    parts = []
+    for n, seed, kind in ((40, 11, "qm9"), (3, 12, "worst"), (5, 13, "mp2018"), (30, 14, "qm9")):
+        de, dn = so.synth_dataset(n, seed, kind, use_ring=ring)
+        parts.append(_hip.pack_inputs(so.pad_batch(de, dn, True, use_ring=ring)[0]))
+    tiny = so.synth_dataset(6, 15, "qm9", use_ring=ring)
+    for i in range(6):  # 3- and 4-atom molecules: several share one group
+        keep = 3 + (i & 1)
+        tiny[0][i][0] = tiny[0][i][0][:keep]
+        if ring:
+            tiny[0][i][2] = tiny[0][i][2][:keep]
+        tiny[1][i] = [[e for e in atom if e[1] < keep] or [[atom[0][0], (a + 1) % keep, 1.0, 1.0, 1.5]] for a, atom in enumerate(tiny[1][i][:keep])]
+    parts.append(_hip.pack_inputs(so.pad_batch(tiny[0], tiny[1], True, use_ring=ring)[0]))
+    pk = _hip.concat_packed(parts)
+    out, infos = {}, {}
+    for name, limit in (("streamed", 0), ("resident", 6), ("mixed", 2)):
+        m = HipModel(cfg, w, device=0, infer=True)
+        m.engine.set_resident_limit(limit)
+        rb = m.engine.upload(pk)
+        infos[name] = m.engine.batch_info(rb)
+        m.engine.forward_resident(rb, 0)
+        out[name] = m.engine.download(rb)
+        m.engine.forward_resident(rb, 1)  # a second forward of the same resident batch: no state left behind
+        again = m.engine.download(rb)
+        assert np.array_equal(out[name][0], again[0], equal_nan=True) and np.array_equal(out[name][1], again[1], equal_nan=True)
+        rb.free()
+    assert infos["streamed"]["resident_small"] == infos["streamed"]["resident_big"] == 0
+    assert infos["resident"]["resident_small"] > 0 and infos["resident"]["resident_big"] >= 3 and infos["resident"]["streamed_structs"] >= 1
+    assert infos["mixed"]["resident_small"] > 0 and infos["mixed"]["streamed_structs"] > infos["resident"]["streamed_structs"]
+    for name in ("resident", "mixed"):
+        assert np.array_equal(out[name][0], out["streamed"][0]), (name, float(np.max(np.abs(out[name][0] - out["streamed"][0]))))
+        assert np.array_equal(out[name][1], out["streamed"][1]), name
+    # (the oracle comparison of these shapes is the other tests' job; here: the two paths against each other)
+    assert np.all(np.isfinite(out["streamed"][0]))

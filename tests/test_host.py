@@ -417,6 +417,58 @@ def test_listwalk_matches_python_walk_of_the_nested_lists():
     assert len(PackedDataset([], [], batch_size=2)) == 0
 
 
+def test_structure_resident_group_plan(hip_lib):
+    """scann_plan_groups (host only): the plan scann_batch_upload makes for the structure-resident forward (csrc/scann_struct.hip).
+    Every structure lands in exactly one place -- a group of <= 3 tiles, a group of 4..6 tiles, or the streamed list -- groups hold
+    whole structures and their tiles whole atoms within the kernel's limits (64 edges, 24 atoms per tile; 36 / 72 atoms per group:
+    the LDS atom-row caches), small structures share a group, the lists are ordered by falling edge count, and anything the
+    kernels cannot hold (more tiles, more atoms, an atom with more than 64 neighbours) is left to the streamed path."""
+    from scann import _hip
+
+    parts = []
+    for n, seed, kind in ((60, 21, "qm9"), (4, 22, "worst"), (12, 23, "mp2018")):
+        de, dn = so.synth_dataset(n, seed, kind)
+        parts.append(_hip.pack_inputs(so.pad_batch(de, dn, True)[0]))
+    # five 4-atom rings (share a group), one 80-atom chain (too many atoms), one star whose centre has 70 neighbours
+    ring4 = _hip.PackedBatch(np.full(20, 6), np.arange(0, 21, 4), np.arange(21), np.arange(20) // 4 * 4 + (np.arange(20) + 1) % 4, np.ones(20), np.ones(20))
+    chain = _hip.PackedBatch(np.full(80, 6), [0, 80], np.arange(81), (np.arange(80) + 1) % 80, np.ones(80), np.ones(80))
+    deg = np.array([70] + [1] * 70)
+    star = _hip.PackedBatch(np.full(71, 6), [0, 71], np.concatenate([[0], np.cumsum(deg)]), np.concatenate([np.arange(1, 71), np.zeros(70, dtype=np.int64)]),
+                            np.ones(140), np.ones(140))
+    pk = _hip.concat_packed(parts + [ring4, chain, star])
+    B = pk.n_struct
+    for limit in (6, 3, 2, 1):
+        pl = _hip.plan_groups(pk, tile_atoms=24, max_tiles=limit)
+        small, big, tiles, streamed = pl["small"], pl["big"], pl["tiles"], pl["streamed"]
+        owner = np.zeros(pk.n_atom, dtype=np.int64)
+        for g in list(small) + list(big):
+            owner[g[0]:g[1]] += 1
+            assert g[0] in pk.mol_offset and g[1] in pk.mol_offset  # whole structures
+            t = tiles[g[2]:g[2] + g[3]]
+            assert t[0, 0] == g[0] and t[-1, 1] == g[1] and np.array_equal(t[1:, 0], t[:-1, 1])  # its tiles partition its atoms in order
+            assert np.array_equal(t[:, 2], pk.edge_offset[t[:, 0]]) and np.array_equal(t[:, 3], pk.edge_offset[t[:, 1]])
+            assert ((t[:, 3] - t[:, 2]) <= 64).all() and ((t[:, 1] - t[:, 0]) <= 24).all() and ((t[:, 1] - t[:, 0]) >= 1).all()
+        for s in streamed:
+            owner[pk.mol_offset[s]:pk.mol_offset[s + 1]] += 1
+        assert (owner == 1).all()  # every atom exactly once
+        assert (small[:, 3] <= min(3, limit)).all() and ((small[:, 1] - small[:, 0]) <= 36).all()
+        assert len(big) == 0 or ((big[:, 3] <= limit).all() and (big[:, 3] > 3).all() and ((big[:, 1] - big[:, 0]) <= 72).all())
+        if limit <= 3:
+            assert len(big) == 0
+        for lst in (small, big):
+            e = pk.edge_offset[lst[:, 1]] - pk.edge_offset[lst[:, 0]]
+            assert (np.diff(e) <= 0).all()  # the longest workgroups first
+        assert B - 2 in streamed and B - 1 in streamed  # the 80-atom chain (atom cache) and the 70-neighbour star (tile rows)
+        ring_groups = [g for g in small if g[0] >= pk.mol_offset[B - 7] and g[1] <= pk.mol_offset[B - 2]]
+        assert len(ring_groups) == 1 and ring_groups[0][1] - ring_groups[0][0] == 20  # the five rings share one group
+    full = _hip.plan_groups(pk, max_tiles=6)
+    assert len(full["big"]) >= 4  # the 29 x 12 molecules need six tiles each
+    none = _hip.plan_groups(_hip.concat_packed([chain, star]))
+    assert len(none["small"]) == len(none["big"]) == 0 and list(none["streamed"]) == [0, 1]
+    with pytest.raises(_hip.ScannHipError):
+        _hip.plan_groups(pk, max_tiles=0)
+
+
 def test_edge_tile_plan_invariants(hip_lib):
     """scann_plan_tiles (host only): the tile table scann_batch_upload builds.  Tiles partition atoms and edges in order,
     hold whole atoms within the edge / atom limits, atoms with more than 64 neighbours become single-atom chunk tiles with

@@ -31,6 +31,7 @@ def main():
     streamed = HipModel(cfg, w, device=0, infer=True)
     streamed.engine.set_resident_limit(0)
     resident = HipModel(cfg, w, device=0, infer=True)
+    resident.engine.set_resident_limit(6)
     mixed = HipModel(cfg, w, device=0, infer=True)
     mixed.engine.set_resident_limit(2)
 
