@@ -184,7 +184,8 @@ struct scann_handle {
   size_t sc_host_cap = 0;
   struct scann_dbatch* sc_db = nullptr;
   int comm_world = 1;
-  int32_t* range_flag = nullptr;  // host-pinned, written by the kernels' range guard (flag_range), read after a synchronisation
+  int32_t* range_flag = nullptr;  // host-pinned [MAX_STREAM], one word per stream slot (training: slot 0), written by the kernels'
+                                  // range guard (flag_range), read after that stream's synchronisation
 };
 
 struct scann_dbatch {
@@ -241,11 +242,13 @@ int fail(scann_handle* h, int code, const std::string& msg) {
 
 // After a synchronisation: did a kernel of the finished work trip the range guard (flag_range)?  The word is cleared, so the handle
 // stays usable once the caller has dealt with the cause.
-int check_range(scann_handle* h, const char* where) {
+// One word per stream slot: with two launch groups in flight, the download of the group on stream A must not consume (and clear) a
+// report raised by the kernels of the group on stream B.
+int check_range(scann_handle* h, const char* where, int slot = 0) {
   if (!h->range_flag) return SCANN_OK;
-  const int32_t code = *reinterpret_cast<volatile int32_t*>(h->range_flag);
+  const int32_t code = *reinterpret_cast<volatile int32_t*>(h->range_flag + slot);
   if (!code) return SCANN_OK;
-  *h->range_flag = 0;
+  h->range_flag[slot] = 0;
   const int site = code >> 8, layer = (code & 0xff) - 1;
   static const char* const names[] = {"?", "layer_norm_g statistics (geometry update)", "layer_norm statistics (attention context)",
                                       "ResidualNorm statistics", "after_Lc activation", "a weight after the optimiser step"};
@@ -455,7 +458,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
     delete h;
     return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipHostMalloc failed");
   }
-  *h->range_flag = 0;
+  for (int i = 0; i < MAX_STREAM; ++i) h->range_flag[i] = 0;  // 64 bytes: one word per stream slot
   for (int i = 0; i < h->nstream; ++i) {
     if (hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking) != hipSuccess) {
       delete h;
@@ -849,7 +852,8 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (r) return fail(h, r, "scann_batch_upload: " + err);
     // A launch that fits ONE round of workgroups is the latency chain of a tile: 32-row tiles (four workgroups per CU = 1,024 slots)
     // make that chain shorter.  Only when no atom needs chunking at 32 rows.
-    if (E > 0 && E <= 32 * 1024 && max_degree <= 32) {
+    static const int force_rows = getenv("SCANN_TILE_ROWS") ? atoi(getenv("SCANN_TILE_ROWS")) : 0;  // A/B switch (32 | 64)
+    if (E > 0 && max_degree <= 32 && (force_rows ? force_rows == 32 : E <= 32 * 1024)) {
       r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, 32, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
                      &tile_rows, &max_degree, &n_slot, err, false);
       if (r) return fail(h, r, "scann_batch_upload: " + err);
@@ -1095,6 +1099,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   auto c_of = [&](int l) { return direct ? db->dbg_c + (size_t)l * nA_ : db->c; };
   auto ctx_of = [&](int l) { return direct ? db->dbg_ctx + (size_t)l * nA_ : db->ctx; };
   auto g_of = [&](int l) { return direct && c.g_update ? db->dbg_g + (size_t)l * nE_ : db->geom; };
+  int32_t* const rflag = h->range_flag ? h->range_flag + db->last_slot : nullptr;  // this stream's range-guard word
   if (tm) tm->mark(-1);
   // Structure-resident path (scann_struct.hip) for the groups scann_batch_upload planned; the layer-streamed launches below then
   // cover only the structures beyond it (none in a QM9-shaped batch), through the plan made for exactly those.
@@ -1130,7 +1135,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   if (species0 && h->sp_dirty) {
     AtomArgs a{};
     a.n_atom = c.n_atoms; a.x = h->lut; a.ffn = 0; a.c = h->sp_c;
-    a.range_flag = h->range_flag; a.layer = 0;
+    a.range_flag = rflag; a.layer = 0;
     const LayerParams& p = h->layers[0];
     a.mode = 0;
     a.WAh = p.W1h; a.bA = p.bg; a.WBh = p.W3h; a.WCh = p.Wqh; a.bC = p.bq;
@@ -1162,7 +1167,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       }
     }
     a.c = c_of(l);
-    a.range_flag = h->range_flag; a.layer = l;
+    a.range_flag = rflag; a.layer = l;
     if (h->train_drop_p > 0.f) {  // training-mode Dropout(0.1) layers (scann_model.py:374, attention.py:29)
       a.drop_p = (l == 0 || c.use_attn_norm) ? h->train_drop_p : 0.f;
       a.drop_seed = h->train_seed;
@@ -1205,7 +1210,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       db->kept = true;
     }
     ea.p = h->layers[l];
-    ea.range_flag = h->range_flag; ea.layer = l;
+    ea.range_flag = rflag; ea.layer = l;
     // (the first layer's launch with the basis MLP fused in is a different kernel: not part of edge_kernel's sampled average)
     const bool sample = !resident && !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1229,7 +1234,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     }
 #endif
     launch_edge(ea, s);
-    launch_edge_merge(v_big_tab, v_n_big, v_part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, h->range_flag, l, s);
+    launch_edge_merge(v_big_tab, v_n_big, v_part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, rflag, l, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);
@@ -1251,7 +1256,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
     sa.x0 = general_embed ? db->c0 : h->lut; sa.x0_index = general_embed ? nullptr : db->atomic;
     sa.basis = h->basis; sa.layers = h->d_layers; sa.head = h->head;
     sa.c = db->c; sa.P1 = db->P1; sa.P3 = db->P3; sa.q = db->q; sa.ctx = db->ctx; sa.gq = db->gq; sa.gk = db->gk;
-    sa.range_flag = h->range_flag;
+    sa.range_flag = rflag;
     if (getenv("SCANN_SR_DEBUG")) {  // test hook: per-layer intermediates of the resident kernels for scann_debug_read
       const int r = ensure_debug(h, db);
       if (r) return r;
@@ -1332,7 +1337,7 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
   if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   db->idle = true;
-  return check_range(h, "scann_batch_download");
+  return check_range(h, "scann_batch_download", db->last_slot);
 }
 
 int scann_sync(scann_handle_t* h) {
@@ -1685,6 +1690,7 @@ static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float
   h->train_seed = seed;
   h->in_train_forward = true;
   w->attn_p = h->attn_drop_p;
+  db->last_slot = 0;  // training runs on stream 0 (its range-guard word is slot 0's)
   r = run_forward(h, db, s, nullptr);
   h->in_train_forward = false;
   h->train_drop_p = 0.f;

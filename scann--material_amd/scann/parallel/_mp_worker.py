@@ -53,21 +53,22 @@ def _worker(conn):
                     s.close()
                 conn.send(("ok", None))
                 continue
-            _, token, desc, batch_size, lo, hi, group, want_ga, out_desc = msg
+            _, token, desc, batch_size, indexes, lo, hi, group, want_ga, out_desc = msg
             if token not in cache:
                 arrays, keep = attach(desc, True)
                 ds = PackedDataset.from_arrays(arrays["mol_offset"], arrays["atomic"], arrays["edge_offset"], arrays["edge_local"],
                                                arrays["edge_dist"], arrays["edge_weight"], arrays["target"], batch_size=batch_size,
                                                ring=arrays["ring"])
-                ds.indexes = np.array(arrays["indexes"])
                 cache[token] = (ds, keep)
             ds = cache[token][0]
+            # the order and the batch size of THIS call (the parent's dataset may have been reshuffled or re-batched since the last)
+            ds.indexes, ds.batch_size = np.asarray(indexes, dtype=np.int64), int(batch_size)
             outs, keep_out = attach(out_desc, True)
             y, ga, _ = model.predict_dataset(_Run(ds, lo, hi), group=group, want_ga=want_ga)
             s0 = lo * batch_size
             outs["y"][s0:s0 + len(y)] = y
             if want_ga:
-                a0 = int(ds.mol_offset[ds.indexes[s0]]) if not ds.shuffle else None
+                a0 = int(ds.mol_offset[ds.indexes[s0]])  # (want_ga: the parent checked that the order is the natural one)
                 outs["ga"][a0:a0 + len(ga)] = ga
             del outs
             for s in keep_out:
@@ -83,4 +84,7 @@ def _worker(conn):
 
 
 if __name__ == "__main__":
-    _worker(Client(sys.argv[1], family="AF_UNIX", authkey=bytes.fromhex(os.environ.pop("SCANN_MP_KEY"))))
+    _key = os.environ.pop("SCANN_MP_KEY", None)
+    if _key is None:
+        sys.exit("scann.parallel._mp_worker: SCANN_MP_KEY is not set (this module is started by MultiProcessPredictor)")
+    _worker(Client(sys.argv[1], family="AF_UNIX", authkey=bytes.fromhex(_key)))

@@ -15,17 +15,25 @@ which connects back over an authenticated local socket, builds its model once an
 """
 from __future__ import annotations
 
+import itertools
 import os
 import secrets
 import subprocess
 import sys
 import tempfile
+import threading
+import time
+import weakref
 from multiprocessing import shared_memory
 from multiprocessing.connection import Listener
 
 import numpy as np
 
-_FIELDS = ("mol_offset", "edge_offset", "atomic", "edge_local", "edge_dist", "edge_weight", "target", "ring", "indexes")
+# the dataset's immutable flat arrays: shared once.  `indexes` (reshuffled by on_epoch_end) and `batch_size` (an attribute the caller
+# may change) travel with every predict message instead -- the workers never slice with a stale copy.
+_FIELDS = ("mol_offset", "edge_offset", "atomic", "edge_local", "edge_dist", "edge_weight", "target", "ring")
+_tokens = itertools.count(1)  # dataset tokens: never reused (id() can be, once a dataset is collected)
+START_TIMEOUT = float(os.environ.get("SCANN_MP_START_TIMEOUT", "300"))  # seconds for all workers to connect and load their model
 
 
 
@@ -48,6 +56,7 @@ class MultiProcessPredictor:
         pkg_dir = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
         self._procs, self._conns, self._shared = [], [], {}
+        self._collected = []  # tokens of datasets that were garbage-collected: dropped at the next call
         self._dir = tempfile.mkdtemp(prefix="scann_mp_")
         key = secrets.token_bytes(32)
         listener = Listener(os.path.join(self._dir, "sock"), family="AF_UNIX", authkey=key)
@@ -56,17 +65,58 @@ class MultiProcessPredictor:
         try:
             for d in self.devices:
                 self._procs.append(subprocess.Popen([sys.executable, "-m", "scann.parallel._mp_worker", listener.address], env=env))
-            for d in self.devices:
-                c = listener.accept()
+            # accept() has no timeout of its own: do it on a thread and watch the children meanwhile -- a worker that dies before
+            # it connects (import error, missing libscann_hip.so, bad PYTHONPATH) must not hang the parent
+            accepted, failure = [], []
+
+            def _accept_all():
+                try:
+                    for _ in self.devices:
+                        accepted.append(listener.accept())
+                except BaseException as e:  # listener closed under us, authentication failure
+                    failure.append(e)
+
+            t = threading.Thread(target=_accept_all, daemon=True)
+            t.start()
+            deadline = time.monotonic() + START_TIMEOUT
+            while t.is_alive():
+                t.join(0.05)
+                dead = [(i, p.poll()) for i, p in enumerate(self._procs) if p.poll() is not None]
+                if dead and len(accepted) < len(self.devices):
+                    i, code = dead[0]
+                    raise RuntimeError("MultiProcessPredictor: the worker for device %s exited with code %s before it connected "
+                                       "(its stderr has the reason)" % (self.devices[i], code))
+                if time.monotonic() > deadline:
+                    raise RuntimeError("MultiProcessPredictor: %d of %d workers connected within %.0f s (SCANN_MP_START_TIMEOUT)"
+                                       % (len(accepted), len(self.devices), START_TIMEOUT))
+            if failure:
+                raise RuntimeError("MultiProcessPredictor: accepting the workers failed: %r" % (failure[0],))
+            for d, c in zip(self.devices, accepted):
                 c.send((d, config, w, infer))
                 self._conns.append(c)
-            for c in self._conns:
+            for i, c in enumerate(self._conns):
+                while not c.poll(0.05):  # the model is being built: keep watching the process
+                    code = self._procs[i].poll() if i < len(self._procs) else None
+                    if code is not None and not c.poll(0):
+                        raise RuntimeError("MultiProcessPredictor: a worker exited with code %s while loading its model" % code)
+                    if time.monotonic() > deadline:
+                        raise RuntimeError("MultiProcessPredictor: a worker did not report ready within %.0f s" % START_TIMEOUT)
                 self._expect(c, "ready")
         except BaseException:
+            try:
+                listener.close()  # unblocks the accept thread
+            except Exception:
+                pass
+            for p in self._procs:
+                if p.poll() is None:
+                    p.kill()
             self.close()
             raise
         finally:
-            listener.close()
+            try:
+                listener.close()
+            except Exception:
+                pass
 
     @staticmethod
     def _expect(conn, what):
@@ -85,11 +135,14 @@ class MultiProcessPredictor:
         return shm, (shm.name, arr.shape, arr.dtype.str)
 
     def share(self, dataset):
-        """Place the dataset's flat arrays in shared memory (once); later calls with the same object reuse them."""
-        key = id(dataset)
-        if key not in self._shared:
+        """Place the dataset's flat arrays in shared memory (once); later calls with the same object reuse them.  The token is
+        kept ON the dataset object and never reused; when the dataset is collected its segments are dropped (here and in the
+        workers) at the next call."""
+        key = getattr(dataset, "_scann_mp_token", None)
+        if key is None or key not in self._shared:
             if getattr(dataset, "cgcnn_table", None) is not None:
                 raise ValueError("MultiProcessPredictor: feature='cgcnn' datasets are not supported (use MultiGpuPredictor)")
+            key = next(_tokens)
             desc, keep = {}, []
             for f in _FIELDS:
                 a = getattr(dataset, f)
@@ -100,10 +153,11 @@ class MultiProcessPredictor:
                     keep.append(shm)
                     desc[f] = d
             self._shared[key] = (desc, keep)
+            dataset._scann_mp_token = key
+            weakref.finalize(dataset, self._collected.append, key)
         return key
 
-    def forget(self, dataset):
-        key = id(dataset)
+    def _drop(self, key):
         if key in self._shared:
             for c in self._conns:
                 c.send(("forget", key))
@@ -111,7 +165,15 @@ class MultiProcessPredictor:
                 self._expect(c, "ok")
             for shm in self._shared.pop(key)[1]:
                 shm.close()
-                shm.unlink()
+                try:
+                    shm.unlink()
+                except FileNotFoundError:
+                    pass
+
+    def forget(self, dataset):
+        key = getattr(dataset, "_scann_mp_token", None)
+        if key is not None:
+            self._drop(key)
 
     def predict_dataset(self, dataset, group=None, want_ga=False):
         from .multi_gpu import MultiGpuPredictor
@@ -122,8 +184,11 @@ class MultiProcessPredictor:
         n_struct = len(dataset.indexes)
         if want_ga and not np.array_equal(dataset.indexes, np.arange(n_struct)):
             raise ValueError("want_ga needs the dataset in its natural order (shuffle=False)")
+        while self._collected:
+            self._drop(self._collected.pop())
         key = self.share(dataset)
         desc = self._shared[key][0]
+        indexes = np.ascontiguousarray(dataset.indexes, dtype=np.int64)  # as of THIS call (on_epoch_end reshuffles)
         mol, eoff = dataset.mol_offset, dataset.edge_offset
         per_struct = (eoff[mol[1:]] - eoff[mol[:-1]]) + 8 * np.diff(mol)
         sel_cost = per_struct[dataset.indexes].astype(np.float64)
@@ -137,7 +202,7 @@ class MultiProcessPredictor:
             keep.append(ga_shm)
         try:
             for c, (lo, hi) in zip(self._conns, runs):
-                c.send(("predict", key, desc, dataset.batch_size, lo, hi, group, want_ga, out_desc))
+                c.send(("predict", key, desc, int(dataset.batch_size), indexes, lo, hi, group, want_ga, out_desc))
             for c, _ in zip(self._conns, runs):
                 self._expect(c, "done")
             y = np.array(np.ndarray(y_desc[1], dtype=np.float32, buffer=y_shm.buf))
@@ -146,7 +211,7 @@ class MultiProcessPredictor:
             for shm in keep:
                 shm.close()
                 shm.unlink()
-        return y, ga, np.asarray(dataset.target[dataset.indexes], dtype=np.float32)
+        return y, ga, np.asarray(dataset.target[indexes], dtype=np.float32)
 
     def close(self):
         for key in list(self._shared):

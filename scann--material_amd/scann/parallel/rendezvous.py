@@ -4,7 +4,11 @@ The ranks of a data-parallel job (one process per GPU) need three host-side exch
 ``ncclUniqueId`` from rank 0 to everybody before ``scann_comm_init``, a barrier, and small reductions of Python numbers
 (the max of a wall time in ``bench.py``).  Everything on the data path goes over RCCL inside ``libscann_hip.so``.
 
-Rank 0 listens on LOOPBACK (``SCANN_RDZV_BIND`` overrides the address) on the first free port of a fixed candidate list
+Rank 0 listens on ``MASTER_ADDR`` when that is a loopback address (the ranks of one node: the normal case) -- otherwise on that
+address too, so that a multi-node ``torch.distributed.run`` job meets as well (``SCANN_RDZV_BIND`` overrides where rank 0 binds;
+the other ranks always CONNECT to ``MASTER_ADDR``), and then the per-job secret must come from the environment
+(``SCANN_RDZV_SECRET``, identical on every node): the 0600 key file of the single-node case lives in one host's /tmp.  The port is
+the first free one of a fixed candidate list
 derived from ``MASTER_PORT`` (the port itself belongs to the launcher: ``torch.distributed.run`` keeps its own store there);
 the other ranks walk the same list until a server answers the handshake token of THIS job.  The token is a hash over the
 job's coordinates AND a random per-job secret: ``SCANN_RDZV_SECRET`` when the launcher provides one
@@ -16,6 +20,7 @@ MASTER_PORT in the environment) and under ``spawn_ranks`` (same variables, set b
 from __future__ import annotations
 
 import hashlib
+import hmac
 import json
 import os
 import secrets
@@ -130,8 +135,16 @@ class Rendezvous:
         self._secret_file = None
         if self.world <= 1:
             return
-        bind = os.environ.get("SCANN_RDZV_BIND", "127.0.0.1")  # the ranks of one node: loopback unless told otherwise
+        loop = self.addr in ("localhost", "ip6-localhost") or self.addr.startswith("127.") or self.addr == "::1"
+        # rank 0 binds where the others will look for it: MASTER_ADDR (loopback for the ranks of one node)
+        bind = os.environ.get("SCANN_RDZV_BIND", "127.0.0.1" if loop else self.addr)
+        connect = "127.0.0.1" if loop else self.addr
         env_secret = os.environ.get("SCANN_RDZV_SECRET")
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)) or self.world)
+        if not env_secret and (self.world > local_world or not loop):
+            raise RuntimeError("rendezvous: a job that spans nodes (WORLD_SIZE %d > LOCAL_WORLD_SIZE %d, or MASTER_ADDR %s is not "
+                               "loopback) needs SCANN_RDZV_SECRET exported identically on every node -- the fallback key file is "
+                               "local to one host" % (self.world, local_world, self.addr))
         spath = _secret_path(self.addr, self.port, self.world)
         deadline = time.time() + timeout
         if self.rank == 0:
@@ -164,7 +177,7 @@ class Rendezvous:
                     c.close()
                     continue
                 r = struct.unpack("<i", hello[-4:])[0]
-                if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):-4] != tok or not 0 < r < self.world or r in peers:
+                if hello[:len(_MAGIC)] != _MAGIC or not hmac.compare_digest(hello[len(_MAGIC):-4], tok) or not 0 < r < self.world or r in peers:
                     c.close()  # not a rank of this job
                     continue
                 c.sendall(b"OK")
@@ -184,7 +197,7 @@ class Rendezvous:
                 hello = _MAGIC + _token(self.addr, self.port, self.world, secret) + struct.pack("<i", self.rank)
                 for p in _candidates(self.port):
                     try:
-                        s = socket.create_connection((bind, p), timeout=2.0)
+                        s = socket.create_connection((connect, p), timeout=2.0)
                         s.sendall(hello)
                         if _recv_exact(s, 2) == b"OK":
                             s.settimeout(None)

@@ -23,6 +23,14 @@ def rel_err(got, ref):
     return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), scale)))
 
 
+def strict_rel_err(got, ref):
+    """SURVEY.md 8(d) "Parity measurement": max_i |y_gpu - y_oracle32| / max(|y_oracle32|, 1e-6) -- every prediction against its
+    OWN magnitude, however small (rel_err above judges values near zero against the tensor's RMS)."""
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)))
+
+
 def make(cfg_name="qm9", n=24, seed=0, kind="qm9", perturb=True, **over):
     from scann.models.scann_model import HipModel
 
@@ -43,6 +51,7 @@ def test_forward_matches_oracle_qm9(hip_lib):
     assert y.shape == y_ref.shape and ga.shape == ga_ref.shape
     assert rel_err(y, y_ref) <= RTOL
     assert rel_err(ga, ga_ref) <= RTOL
+    assert strict_rel_err(y, y_ref) <= RTOL, strict_rel_err(y, y_ref)  # the north-star bound in SURVEY 8(d)'s own form
 
 
 def test_every_layer_intermediate(hip_lib):
@@ -84,14 +93,14 @@ def test_every_layer_intermediate(hip_lib):
 ], ids=["base", "no_attn_norm", "no_ga_norm", "e_b", "base_plain", "L1", "L0"])
 def test_branches(hip_lib, over):
     """Every architecture switch.  Some variants are ill-conditioned in fp32 (use_ga_norm False feeds raw pair
-    sums, |a| >> 1, into a softmax), so the bound is max(1e-4, 3 x the fp32 oracle's own error) against the
+    sums, |a| >> 1, into a softmax), so the bound is max(1e-4, 2 x the fp32 oracle's own error) against the
     fp64 oracle -- the GPU must not be worse than the reference precision by more than that."""
     cfg, w, inputs, model = make(n=10, seed=3, **{k: dict(v) for k, v in over.items()})
     y, ga = model.predict(inputs)
     y32, ga32 = so.forward(cfg, w, inputs, np.float32)
     y64, ga64 = so.forward(cfg, w, inputs, np.float64)
-    assert rel_err(y, y64) <= max(RTOL, 3 * rel_err(y32, y64))
-    assert rel_err(ga, ga64) <= max(RTOL, 3 * rel_err(ga32, ga64))
+    assert rel_err(y, y64) <= max(RTOL, 2 * rel_err(y32, y64))
+    assert rel_err(ga, ga64) <= max(RTOL, 2 * rel_err(ga32, ga64))
 
 
 @pytest.mark.parametrize("ring,cgcnn", [(True, False), (False, True), (True, True)], ids=["ring", "cgcnn", "ring+cgcnn"])
@@ -261,8 +270,8 @@ def test_golden_vectors(hip_lib, name):
     inputs = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
     model = HipModel(cfg, w, device=0, infer=True)
     y, ga = model.predict(inputs)
-    tol_y = max(RTOL, 3 * rel_err(z["y32"], z["y64"]))
-    tol_g = max(RTOL, 3 * rel_err(z["ga32"], z["ga64"]))
+    tol_y = max(RTOL, 2 * rel_err(z["y32"], z["y64"]))
+    tol_g = max(RTOL, 2 * rel_err(z["ga32"], z["ga64"]))
     assert rel_err(y, z["y64"]) <= tol_y and rel_err(ga, z["ga64"]) <= tol_g
 
 
@@ -423,7 +432,7 @@ def test_split_fp16_projections_reach_fp32_accuracy(hip_lib):
             got = eng.debug_read(rb, what, l)
             e_gpu = rel_err(got, t64[key][mask])
             e_f32 = rel_err(t32[key][mask], t64[key][mask])
-            assert e_gpu <= max(3.0 * e_f32, 2e-6), (key, e_gpu, e_f32)
+            assert e_gpu <= max(2.0 * e_f32, 2e-6), (key, e_gpu, e_f32)
     rb.free()
 
 
@@ -498,6 +507,7 @@ def test_s134k_sampled_batches_match_c_oracle(hip_lib):
     ga_ref = np.concatenate([r[1][..., 0][it[0]["atom_mask"][..., 0]] for r, it in zip(refs, items)])
     assert y.shape == y_ref.shape == (7 * B + 15,) and np.array_equal(t, np.concatenate([it[1] for it in items]))
     assert rel_err(y, y_ref) <= RTOL, rel_err(y, y_ref)
+    assert strict_rel_err(y, y_ref) <= RTOL, strict_rel_err(y, y_ref)  # |dy| / max(|y|, 1e-6), all 911 predictions
     assert float(np.max(np.abs(ga - ga_ref))) <= 1e-5
     # the MAE SCANN.evaluate() would print (scann_model.py:273-280) agrees to the same bound
     mae_gpu, mae_ref = float(np.mean(np.abs(y - t))), float(np.mean(np.abs(y_ref - t)))
@@ -603,7 +613,31 @@ def test_process_per_gpu_predictor_equals_single_handle(hip_lib):
         y2, _, _ = mp.predict_dataset(ds, group=3)  # the shared dataset is reused
         assert np.array_equal(y, ref_y) and np.array_equal(ga, ref_ga) and np.array_equal(t, ref_t)
         assert np.array_equal(y2, ref_y)
+        # the caller reshuffles (on_epoch_end) and re-batches between two calls: the workers must slice with the order and the
+        # batch size of THIS call, not with the copy they saw first
+        ds.shuffle = True
+        np.random.seed(4)
+        ds.on_epoch_end()
+        ds.batch_size = 7
+        assert not np.array_equal(ds.indexes, np.arange(37))
+        single = HipModel(cfg, w, device=0, infer=True)
+        sy, _, st = single.predict_dataset(ds, group=2)
+        y3, _, t3 = mp.predict_dataset(ds, group=2)
+        assert np.array_equal(t3, st) and np.array_equal(t3, ds.target[ds.indexes])
+        assert np.array_equal(y3, sy)
+        assert np.array_equal(np.sort(y3), np.sort(ref_y))  # the same structures, another order
         mp.forget(ds)
+        # a second dataset object gets a token of its own (never reused), and a collected one is dropped at the next call
+        ds_b = PackedDataset(data_energy=de[:9], data_neighbor=dn[:9], batch_size=4, use_ring=False, feature="atomic", g_update=True,
+                             atomic_features=None, shuffle=False)
+        yb, _, _ = mp.predict_dataset(ds_b)
+        assert np.array_equal(yb, ref_y[:9]) and ds_b._scann_mp_token != ds._scann_mp_token
+        tok = ds_b._scann_mp_token
+        del ds_b
+        import gc
+        gc.collect()
+        mp.predict_dataset(ds)
+        assert tok not in mp._shared
 
 
 

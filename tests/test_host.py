@@ -417,6 +417,36 @@ def test_listwalk_matches_python_walk_of_the_nested_lists():
     assert len(PackedDataset([], [], batch_size=2)) == 0
 
 
+def test_process_per_gpu_predictor_does_not_hang_on_a_dead_worker(monkeypatch):
+    """A worker process that dies before it connects back (import error, missing library, bad PYTHONPATH) used to leave the
+    parent in listener.accept() for ever; now the parent watches its children and names the failure."""
+    import time
+
+    from scann.parallel import multi_proc
+
+    real = multi_proc.subprocess.Popen
+
+    def dead_on_arrival(args, **kw):
+        return real([sys.executable, "-c", "import sys; sys.exit(3)"], **kw)
+
+    monkeypatch.setattr(multi_proc.subprocess, "Popen", dead_on_arrival)
+    cfg = so.default_config("qm9")
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError, match="exited with code 3 before it connected"):
+        multi_proc.MultiProcessPredictor(cfg, so.init_weights(cfg, 1), devices=[0])
+    assert time.monotonic() - t0 < 30
+
+    def never_connects(args, **kw):
+        return real([sys.executable, "-c", "import time; time.sleep(60)"], **kw)
+
+    monkeypatch.setattr(multi_proc.subprocess, "Popen", never_connects)
+    monkeypatch.setattr(multi_proc, "START_TIMEOUT", 1.0)
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError, match="0 of 1 workers connected"):
+        multi_proc.MultiProcessPredictor(cfg, so.init_weights(cfg, 1), devices=[0])
+    assert time.monotonic() - t0 < 30
+
+
 def test_structure_resident_group_plan(hip_lib):
     """scann_plan_groups (host only): the plan scann_batch_upload makes for the structure-resident forward (csrc/scann_struct.hip).
     Every structure lands in exactly one place -- a group of <= 3 tiles, a group of 4..6 tiles, or the streamed list -- groups hold
@@ -592,6 +622,19 @@ def test_rendezvous_three_ranks_without_torch(tmp_path):
     script = tmp_path / "rdzv_worker.py"
     script.write_text("ROOT = %r\n" % ROOT + _RDZV_WORKER)
     assert spawn_ranks([str(script)], 3, timeout=120) == 0
+
+
+def test_rendezvous_across_nodes_needs_a_shared_secret(monkeypatch):
+    """Ranks connect to MASTER_ADDR; when that is not loopback (or the world is larger than the local world) the per-job secret cannot
+    be the 0600 file in one host's /tmp: a clear error instead of a rendezvous that times out."""
+    from scann.parallel.rendezvous import Rendezvous
+
+    monkeypatch.delenv("SCANN_RDZV_SECRET", raising=False)
+    with pytest.raises(RuntimeError, match="SCANN_RDZV_SECRET"):
+        Rendezvous(rank=1, world=2, addr="10.11.12.13", port=29511, timeout=1.0)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="spans nodes"):
+        Rendezvous(rank=1, world=4, addr="127.0.0.1", port=29511, timeout=1.0)
 
 
 def test_rendezvous_file_secret_and_no_pickle(tmp_path):
