@@ -147,6 +147,11 @@ int scann_set_resident_limit(scann_handle_t* h, int max_tiles);
  * tiles, edges and atoms of the <= 3-tile groups, edge tiles and rows per tile (32 | 64) of the whole-batch streamed plan }. */
 int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8);
 int scann_sync(scann_handle_t* h); /* all streams of the handle */
+/* Inference forwards whose range guard fired -- an activation left the range of the split-fp16 projections (|x| < 65504) -- are run
+ * again by scann_batch_download / scann_forward on exact-fp32 matrix instructions (v_mfma_f32_32x32x2_f32, the arithmetic of the
+ * reference's fp32 Dense layers, attention.py:95-113) instead of returning SCANN_ERR_RANGE; this counts them.  Env
+ * SCANN_STRICT_RANGE=1 turns the re-run off (the error is returned).  Training entry points always return the error. */
+int64_t scann_exact_reruns(const scann_handle_t* h);
 int scann_num_streams(const scann_handle_t* h);
 
 /* Timed forward of a resident batch: HIP events around every kernel on its stream. */

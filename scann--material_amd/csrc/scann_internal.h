@@ -69,6 +69,8 @@ struct LayerParams {
   const float *Wfg, *bfg;       // base branch (g_update False): filter_geo [20,128] raw + bias (backward of the basis filter)
   // ResidualNorm that follows this LocalAttention (applied at the head of the next atom kernel)
   const float *bf1, *bf2, *lnr_g, *lnr_b;
+  // fp32 fragment-order images (pack_weight) of the seven 128x128 kernels: the exact-fp32 fallback of the forward (EX kernels)
+  const float *W1p, *W2p, *W3p, *Wqp, *Wkp, *Wf1p, *Wf2p;
 };
 
 struct HeadParams {
@@ -143,6 +145,8 @@ struct AtomArgs {
   // them (64-row tiles); null: tiles of consecutive rows over [0, n_atom)
   const int32_t* row_tab;
   int32_t n_row_tab;
+  // exact-fp32 projections (EX instantiation): Wf1h, Wf2h, WAh .. WDh then point at fp32 fragment-order images (pack_weight)
+  int32_t exact;
 };
 void launch_atom(const AtomArgs& a, hipStream_t s);
 
@@ -186,6 +190,7 @@ struct EdgeArgs {
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS) only: [n_tile,16] phase clocks, else null
   int32_t* range_flag;         // host-pinned range-guard word (flag_range) or null
   int32_t layer;
+  int32_t exact;               // exact-fp32 projections (EX instantiation): p.W2h, p.Wkh then point at fp32 fragment-order images
   LayerParams p;
 };
 void launch_edge(const EdgeArgs& a, hipStream_t s);

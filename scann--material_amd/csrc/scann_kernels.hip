@@ -67,28 +67,27 @@ namespace scann {
 //   MODE 0: P1 = c W1 + bg, P3 = c W3, q = c Wq + bq                        centre / neighbour thirds of filter_geo :142-151, query :160
 //   MODE 1: q only (base branch)           MODE 2: z = swish(c Wa + ba); gq = z Wgq + b, gk = z Wgk + b   (scann_model.py:424, attention.py:269-272)
 
-template <bool FFN, int MODE, int RT>
+// EX: exact-fp32 projections (scann_mma.h: the fallback run_forward takes when the split-fp16 range guard fired)
+template <bool FFN, int MODE, int RT, bool EX = false>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) {
 #pragma clang fp contract(off)  // fusions are written out: both row-tile copies of a formula round alike (see edge_kernel)
   constexpr int TAR = 32 * RT;  // atom rows per tile
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TAR * PLANE_STRIDE * 2];  // hi / lo planes of the current GEMM input
   __shared__ __attribute__((aligned(16))) float sRed[TAR * 8];  // LayerNorm partial statistics [row][wave][mean, m2]
   __shared__ __attribute__((aligned(16))) float sPar[7 * D];   // bf1 | bf2 | lnr_g | lnr_b | bA | bC | bD
-  _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
-  _Float16* const sL = sH + TAR * PLANE_STRIDE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
   // (row_tab: the atom tiles of the structures that stay on this path in a batch shared with the structure-resident kernel)
   const int row0 = a.row_tab ? a.row_tab[2 * blockIdx.x] : blockIdx.x * TAR;
   const int nrows = a.row_tab ? a.row_tab[2 * blockIdx.x + 1] : min(TAR, a.n_atom - row0);
-  constexpr float WINV = 1.0f / WSCALE;
+  constexpr float WINV = EX ? 1.0f : 1.0f / WSCALE;  // (exact images are unscaled)
   // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
   const _Float16* const firstW = MODE == 1 ? a.WCh : a.WAh;
 
   STAMP(a.stamps, 0);
-  f16x8 whA[4], wlA[4], whB[4], wlB[4];
-  load_wsplit<4, 8>(FFN ? a.Wf1h : firstW, wave, lane, whA, wlA, 0);
-  load_wsplit<4, 8>(FFN ? a.Wf1h : firstW, wave, lane, whB, wlB, 4);
+  WRegs<EX> wr;
+  load_whalf<EX>(wr, FFN ? a.Wf1h : firstW, wave, lane, 0);
+  load_whalf<EX>(wr, FFN ? a.Wf1h : firstW, wave, lane, 1);
   {  // bias / LayerNorm rows -> sPar (absent ones read a valid dummy row and are never used)
     const float* const tab[7] = {FFN ? a.bf1 : a.bC, FFN ? a.bf2 : a.bC, FFN ? a.lnr_g : a.bC, FFN ? a.lnr_b : a.bC,
                                  MODE != 1 ? a.bA : a.bC, a.bC, MODE == 2 ? a.bD : a.bC};
@@ -129,10 +128,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
         st4(a.c, ooff[rt] + 32 * j, v);  // centres = staged rows (layer 0 / no ResidualNorm)
       }
       xr[rt][j] = v;
-      f16x4 h, l;
-      split4(v, h, l);
-      *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
-      *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+      tile_store<EX, TAR>(sTile, row, cbase + 8 * j, v);
     }
   }
   __syncthreads();
@@ -141,7 +137,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
   f32x16 acc[RT];
   if (FFN) {
     // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
-    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.Wf2h, wave, lane, acc);
+    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.Wf2h, wave, lane, acc);
     STAMP(a.stamps, 2);
     __syncthreads();  // every wave is done reading the x planes
 #pragma unroll
@@ -157,16 +153,13 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
           st4(a.keep_pre1, ooff[rt] + 32 * j, pre);
           st4(a.keep_H1, ooff[rt] + 32 * j, hh);
         }
-        f16x4 h, l;
-        split4(hh, h, l);
-        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
-        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+        tile_store<EX, TAR>(sTile, row, cbase + 8 * j, hh);
       }
     }
     __syncthreads();
     STAMP(a.stamps, 3);
     // y = h W2 + b2 ; t = x + drop(y)
-    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, firstW, wave, lane, acc);
+    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, firstW, wave, lane, acc);
     STAMP(a.stamps, 4);
     float mean32[RT], m2[RT];
 #pragma unroll
@@ -220,7 +213,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
       const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
       const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
       const float rstd = 1.0f / sqrtf(var + 1e-6f);
-      if (!(var < RANGE_FINITE) && row < nrows) flag_range(a.range_flag, 3, a.layer - 1);  // an operand of the ResidualNorm overflowed fp16
+      if (!EX && !(var < RANGE_FINITE) && row < nrows) flag_range(a.range_flag, 3, a.layer - 1);  // an operand of the ResidualNorm overflowed fp16
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + cbase + 8 * j]);
@@ -232,10 +225,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
         inv = rstd * g.z; y.z = fmaf(acc[rt][4 * j + 2], inv, be.z - mean * inv);
         inv = rstd * g.w; y.w = fmaf(acc[rt][4 * j + 3], inv, be.w - mean * inv);
         if (row < nrows) st4(a.c, ooff[rt] + 32 * j, y);
-        f16x4 h, l;
-        split4(y, h, l);
-        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
-        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+        tile_store<EX, TAR>(sTile, row, cbase + 8 * j, y);
       }
     }
     __syncthreads();
@@ -243,7 +233,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
   }
 
   if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
-    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WBh, wave, lane, acc);
+    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WBh, wave, lane, acc);
     STAMP(a.stamps, 7);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -254,7 +244,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
           st4(a.oA, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bg.x), fmaf(acc[rt][4 * j + 1], WINV, bg.y),
                                                    fmaf(acc[rt][4 * j + 2], WINV, bg.z), fmaf(acc[rt][4 * j + 3], WINV, bg.w)));
       }
-    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
+    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WCh, wave, lane, acc);
     STAMP(a.stamps, 9);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -265,7 +255,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
   }
   if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
     STAMP(a.stamps, 10);
-    gemm_tile<false, RT>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
+    gemm_tile_x<EX, false, TAR, RT>(sTile, wr, nullptr, wave, lane, acc);
     STAMP(a.stamps, 11);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -279,7 +269,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
     STAMP(a.stamps, 12);
   }
   if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
-    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WCh, wave, lane, acc);
+    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WCh, wave, lane, acc);
     __syncthreads();  // every wave is done reading the centre planes
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -291,19 +281,16 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
                                        fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
         const float4 z = f4swish(pre);
         // no LayerNorm follows this activation: test it directly (its hi part feeds the GlobalAttention projections)
-        if (!(fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))) < 65504.f) && row < nrows) flag_range(a.range_flag, 4, a.layer);
+        if (!EX && !(fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))) < 65504.f) && row < nrows) flag_range(a.range_flag, 4, a.layer);
         if (a.keep_preA && row < nrows) {  // training forward: after_Lc pre-activation and output, kept for the backward
           st4(a.keep_preA, ooff[rt] + 32 * j, pre);
           st4(a.keep_z, ooff[rt] + 32 * j, z);
         }
-        f16x4 h, l;
-        split4(z, h, l);
-        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
-        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+        tile_store<EX, TAR>(sTile, row, cbase + 8 * j, z);
       }
     }
     __syncthreads();
-    gemm_tile<true, RT>(sH, sL, whA, wlA, whB, wlB, a.WDh, wave, lane, acc);
+    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WDh, wave, lane, acc);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -313,7 +300,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
           st4(a.oC, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bq.x), fmaf(acc[rt][4 * j + 1], WINV, bq.y),
                                                    fmaf(acc[rt][4 * j + 2], WINV, bq.z), fmaf(acc[rt][4 * j + 3], WINV, bq.w)));
       }
-    gemm_tile<false, RT>(sH, sL, whA, wlA, whB, wlB, nullptr, wave, lane, acc);
+    gemm_tile_x<EX, false, TAR, RT>(sTile, wr, nullptr, wave, lane, acc);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -336,7 +323,10 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
   const dim3 grid(a.row_tab ? a.n_row_tab : (a.n_atom + rows - 1) / rows), block(256);
 #define SCANN_ATOM_CASE(F, M)                                                                  \
   do {                                                                                         \
-    if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1>), grid, block, 0, s, a);          \
+    if (a.exact) {                                                                             \
+      if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1, true>), grid, block, 0, s, a);  \
+      else hipLaunchKernelGGL((atom_kernel<F, M, 2, true>), grid, block, 0, s, a);             \
+    } else if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1>), grid, block, 0, s, a);   \
     else hipLaunchKernelGGL((atom_kernel<F, M, 2>), grid, block, 0, s, a);                     \
   } while (0)
   if (a.ffn) {
@@ -377,11 +367,14 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 //
 // FB (g_update, 64-row tiles, first layer of an inference forward): the geometry rows come out of basis_kernel's arithmetic, done
 // here on the tile's rows (Gaussian expansions -> planes -> two K = 20 products -> bias, swish, product), not out of memory.
-template <bool GUPD, int RT, bool FB = false>
+// EX: exact-fp32 projections for the 128x128 kernels (scann_mma.h; the K = 20 filters keep the split form: their inputs are Gaussians
+// in [0, 1]) -- the fallback run_forward takes when the split-fp16 range guard fired.  Never with FB.
+template <bool GUPD, int RT, bool FB = false, bool EX = false>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) {
 #pragma clang fp contract(off)  // fusions are written out (fmaf): both unrolled row-tile copies of a formula must round alike,
                                 // so that a row's result does not depend on where in a tile it lands (batch-composition invariance)
   static_assert(!FB || GUPD, "the fused basis exists for the g_update kernel only");
+  static_assert(!(FB && EX), "the exact fallback runs the plain first layer");
   constexpr int TEK = 32 * RT;  // edge rows per tile: 64 (three workgroups per CU) or, for launches of one round, 32 (four)
   // hi / lo planes of the A operand (G or the basis, then ang): 2 x 64 x 272 B; afterwards K as fp32 [64][LDS_STRIDE]
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TEK * PLANE_STRIDE * 2];
@@ -412,16 +405,15 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
   // ---- prologue: every load is issued UNCONDITIONALLY from clamped rows and selected afterwards (a load under a per-thread
   // guard compiles to branch + load + s_waitcnt vmcnt(0): one full memory round trip per guard) -------------------------------
   // one weight slab at a time, in two halves of 4 k-steps (A: k < 64, B: k >= 64): W2 (base branch: Wf, 2 k-steps in A), later Wk
-  f16x8 whA[4], wlA[4], whB[4], wlB[4];
+  WRegs<EX> wr;
+  f16x8 fth[2], ftl[2];  // base branch: the K = 20 filter (split form in every instantiation)
   if (GUPD) {
     if (!FB) {  // (FB: requested after the basis products, whose operands and accumulators need the registers first)
-      load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
-      load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+      load_whalf<EX>(wr, a.p.W2h, wave, lane, 0);
+      load_whalf<EX>(wr, a.p.W2h, wave, lane, 1);
     }
   } else {
-    f16x8 th[2], tl[2];
-    load_wsplit<2>(a.p.Wfh, wave, lane, th, tl);
-    whA[0] = th[0]; whA[1] = th[1]; wlA[0] = tl[0]; wlA[1] = tl[1];
+    load_wsplit<2>(a.p.Wfh, wave, lane, fth, ftl);
   }
   unsigned nboff[RT];  // byte offset of (neighbour atom row, this lane's first column) in an [n_atom,128] tensor
   int ctr[RT];         // tile-local centre atom of this lane's two edge rows
@@ -510,8 +502,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
             greg[rt][j] = f4mul(sd, sw);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (rt == 0) load_wsplit<4, 8>(a.p.W2h, wave, lane, whA, wlA, 0);
-          if (rt == RT - 1) load_wsplit<4, 8>(a.p.W2h, wave, lane, whB, wlB, 4);
+          if (rt == 0) load_whalf<EX>(wr, a.p.W2h, wave, lane, 0);
+          if (rt == RT - 1) load_whalf<EX>(wr, a.p.W2h, wave, lane, 1);
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // every wave is done reading the basis planes: the geometry planes may overwrite them
@@ -537,10 +529,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (row >= ne) greg[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          f16x4 h, l;
-          split4(greg[rt][j], h, l);
-          *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
-          *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+          tile_store<EX, TEK>(sTile, row, cbase + 8 * j, greg[rt][j]);
         }
       }
     } else {
@@ -574,7 +563,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
   float4 p3r[RT][4];
   f32x16 acc[RT];
   if (GUPD) {
-    mma_split<4, true, PLANE_STRIDE, RT>(sH, sL, whA, wlA, lane, acc);
+    mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 0);
     __builtin_amdgcn_sched_barrier(0);
     // gathered neighbour thirds P3[j] = c_j W3 (into the registers the first weight half leaves): in flight over the second half
 #pragma unroll
@@ -582,15 +571,15 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) p3r[rt][j] = ld4(a.P3, nboff[rt] + 32 * j);
     __builtin_amdgcn_sched_barrier(0);
-    mma_split<4, false, PLANE_STRIDE, RT>(sH + 64, sL + 64, whB, wlB, lane, acc);
+    mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 1);
   } else {
-    f16x8 th[2] = {whA[0], whA[1]}, tl[2] = {wlA[0], wlA[1]};
-    mma_split<2, true, PLANE_STRIDE, RT>(sH, sL, th, tl, lane, acc);
+    mma_split<2, true, PLANE_STRIDE, RT>(sH, sL, fth, ftl, lane, acc);
   }
   STAMP(a.stamps, 2);
   __builtin_amdgcn_sched_barrier(0);
 
-  constexpr float WINV = 1.0f / WSCALE;
+  constexpr float WINV = EX ? 1.0f : 1.0f / WSCALE;     // the 128x128 kernels (exact images are unscaled)
+  constexpr float WINVF = 1.0f / WSCALE;                // the base branch's K = 20 filter: always the split form
   const int qa = tid >> 5;  // query rows qa, qa + 8, qa + 16 of the tile go through this thread
   const unsigned qoff = (tid & 31) * 16;
   // byte offset of the row of tile-local atom la (clamped by the caller) in an [n_atom,128] tensor / the per-species table
@@ -650,7 +639,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
-    load_wsplit<4, 8>(a.p.Wkh, wave, lane, whA, wlA, 0);  // first half of the key weights; the second half is requested at the GEMM
+    load_whalf<EX>(wr, a.p.Wkh, wave, lane, 0);  // first half of the key weights; the second half is requested at the GEMM
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // statistics complete; every wave is done with the G planes and the P1 rows
     STAMP(a.stamps, 3);
@@ -667,7 +656,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
       const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
       const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
       const float rstd = 1.0f / sqrtf(var + 1e-6f);
-      if (!(var < RANGE_FINITE) && row < ne) flag_range(a.range_flag, 1, a.layer);  // an operand of the geometry update overflowed fp16
+      if (!EX && !(var < RANGE_FINITE) && row < ne) flag_range(a.range_flag, 1, a.layer);  // an operand of the geometry update overflowed fp16
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 g = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
@@ -685,10 +674,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
         } else {
           ang = make_float4(0.f, 0.f, 0.f, 0.f);  // ragged tail rows stay defined (and zero) for the MFMA
         }
-        f16x4 h, l;
-        split4(ang, h, l);
-        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
-        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+        tile_store<EX, TEK>(sTile, row, cbase + 8 * j, ang);
       }
       __builtin_amdgcn_sched_barrier(0);  // one row tile at a time (register pressure)
     }
@@ -698,7 +684,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
-    load_wsplit<4, 8>(a.p.Wkh, wave, lane, whA, wlA, 0);
+    load_whalf<EX>(wr, a.p.Wkh, wave, lane, 0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave is done reading the basis planes
     STAMP(a.stamps, 3);
@@ -714,8 +700,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 bf = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
-        float4 y = f4swish(make_float4(fmaf(acc[rt][4 * j], WINV, bf.x), fmaf(acc[rt][4 * j + 1], WINV, bf.y),
-                                       fmaf(acc[rt][4 * j + 2], WINV, bf.z), fmaf(acc[rt][4 * j + 3], WINV, bf.w)));
+        float4 y = f4swish(make_float4(fmaf(acc[rt][4 * j], WINVF, bf.x), fmaf(acc[rt][4 * j + 1], WINVF, bf.y),
+                                       fmaf(acc[rt][4 * j + 2], WINVF, bf.z), fmaf(acc[rt][4 * j + 3], WINVF, bf.w)));
         y.x *= ewgt[rt]; y.y *= ewgt[rt]; y.z *= ewgt[rt]; y.w *= ewgt[rt];
         float4 ang = f4mul(cn[rt][j], y);
         if (row >= ne) ang = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -723,10 +709,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
           st4(a.keep_V, eoff[rt] + 32 * j, y);
           st4(a.keep_ang, eoff[rt] + 32 * j, ang);
         }
-        f16x4 h, l;
-        split4(ang, h, l);
-        *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + cbase + 8 * j) = h;
-        *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + cbase + 8 * j) = l;
+        tile_store<EX, TEK>(sTile, row, cbase + 8 * j, ang);
       }
     }
   }
@@ -738,10 +721,10 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
   STAMP(a.stamps, 4);
 
   // K = ang . Wk + bk (attention.py:163); the second half of Wk arrives under the first half's MFMAs
-  load_wsplit<4, 8>(a.p.Wkh, wave, lane, whB, wlB, 4);
+  load_whalf<EX>(wr, a.p.Wkh, wave, lane, 1);
   __builtin_amdgcn_sched_barrier(0);
-  mma_split<4, true, PLANE_STRIDE, RT>(sH, sL, whA, wlA, lane, acc);
-  mma_split<4, false, PLANE_STRIDE, RT>(sH + 64, sL + 64, whB, wlB, lane, acc);
+  mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 0);
+  mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 1);
   STAMP(a.stamps, 5);
   // logits e[n, h] = (q[i, h, :] * 16^-0.5) . K[n, h, :] (attention.py:180-183) from the accumulators: this lane holds 8 of the
   // 16 columns of heads 2 wave (j = 0, 1) and 2 wave + 1 (j = 2, 3) of its rows; its partner lane (^32) holds the other 8
@@ -852,7 +835,7 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
       v += __shfl_xor(v, 1);
       v += __shfl_xor(v, 2);
       v += __shfl_xor(v, 4);
-      if (!(v < RANGE_FINITE)) flag_range(a.range_flag, 2, a.layer);  // the gated rows or the keys overflowed fp16
+      if (!EX && !(v < RANGE_FINITE)) flag_range(a.range_flag, 2, a.layer);  // the gated rows or the keys overflowed fp16
       const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -930,7 +913,15 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
   const dim3 grid(a.n_tile), block(256);
   // tile_rows is the height the batch's tile plan was made for (scann_batch_upload: 32 for launches of one round of workgroups)
-  if (a.fuse_basis && a.g_update) {
+  if (a.exact) {  // exact-fp32 fallback: never with the fused first layer
+    if (a.tile_rows == 32) {
+      if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 1, false, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((edge_kernel<false, 1, false, true>), grid, block, 0, s, a);
+    } else {
+      if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 2, false, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((edge_kernel<false, 2, false, true>), grid, block, 0, s, a);
+    }
+  } else if (a.fuse_basis && a.g_update) {
     if (a.tile_rows == 32) hipLaunchKernelGGL((edge_kernel<true, 1, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((edge_kernel<true, 2, true>), grid, block, 0, s, a);
   } else if (a.tile_rows == 32) {

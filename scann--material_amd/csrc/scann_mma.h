@@ -149,4 +149,89 @@ __device__ __forceinline__ void gemm_tile(const _Float16* __restrict__ sH, const
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- exact-fp32 projections: the fallback for operands outside the split-fp16 range (EX instantiations of atom_kernel / edge_kernel,
+// run by run_forward when a forward's range guard fired) -- v_mfma_f32_32x32x2_f32 on fp32 rows staged in the SAME tile buffer
+// ([rows][LDS_STRIDE] fp32 = the bytes of the two fp16 planes) against the fp32 fragment-order image of the kernel (pack_weight:
+// [wave 4][t 16][lane 64] float4 = W[8 t + 4 (lane >> 5) + 0..3][32 wave + (lane & 31)]), unscaled.  1/16 of the f16 pipe's rate.
+template <int NTT>
+__device__ __forceinline__ void load_wexact(const float* __restrict__ Wp, int wave, int lane, float4 (&w)[NTT], int t0) {
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(Wp) + (size_t)wave * (16 * 64) + lane;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) w[t] = src[(t0 + t) * 64];
+}
+// acc[rt] (+)= X[rows][8 t0 .. 8 (t0 + NTT)) . W[same k][32 wave .. +32); sX points at the tile's first row, column 8 t0
+template <int NTT, bool FIRST, int RT>
+__device__ __forceinline__ void mma_exact(const float* __restrict__ sX, const float4 (&w)[NTT], int lane, f32x16 (&acc)[RT]) {
+  const float* xrow = sX + (lane & 31) * LDS_STRIDE + 4 * (lane >> 5);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NTT; ++t)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float4 x = *reinterpret_cast<const float4*>(xrow + rt * 32 * LDS_STRIDE + 8 * t);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].x, x.x, FIRST && t == 0 ? zero : acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].y, x.y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].z, x.z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t].w, x.w, acc[rt], 0, 0, 0);
+    }
+}
+
+// One 128x128 kernel's operand registers of a wave, in two halves (A: k < 64, B: k >= 64): a split-fp16 slab or, EX, fp32 fragments.
+// Same 64 VGPRs either way.
+template <bool EX> struct WRegs;
+template <> struct WRegs<false> { f16x8 hA[4], lA[4], hB[4], lB[4]; };
+template <> struct WRegs<true> { float4 A[8], B[8]; };
+template <bool EX>
+__device__ __forceinline__ void load_whalf(WRegs<EX>& w, const _Float16* __restrict__ W, int wave, int lane, int half) {
+  if constexpr (EX) {
+    if (half == 0) load_wexact<8>(reinterpret_cast<const float*>(W), wave, lane, w.A, 0);
+    else load_wexact<8>(reinterpret_cast<const float*>(W), wave, lane, w.B, 8);
+  } else {
+    if (half == 0) load_wsplit<4, 8>(W, wave, lane, w.hA, w.lA, 0);
+    else load_wsplit<4, 8>(W, wave, lane, w.hB, w.lB, 4);
+  }
+}
+// half 0 starts the accumulators (FIRST), half 1 adds to them; tile = the staged rows (TR of them: planes at TR * PLANE_STRIDE halfs)
+template <bool EX, int TR, int RT>
+__device__ __forceinline__ void mma_half(const unsigned char* tile, const WRegs<EX>& w, int lane, f32x16 (&acc)[RT], int half) {
+  if constexpr (EX) {
+    const float* sX = reinterpret_cast<const float*>(tile);
+    if (half == 0) mma_exact<8, true, RT>(sX, w.A, lane, acc);
+    else mma_exact<8, false, RT>(sX + 64, w.B, lane, acc);
+  } else {
+    const _Float16* sH = reinterpret_cast<const _Float16*>(tile);
+    const _Float16* sL = sH + TR * PLANE_STRIDE;
+    if (half == 0) mma_split<4, true, PLANE_STRIDE, RT>(sH, sL, w.hA, w.lA, lane, acc);
+    else mma_split<4, false, PLANE_STRIDE, RT>(sH + 64, sL + 64, w.hB, w.lB, lane, acc);
+  }
+}
+// four consecutive columns of one staged row: hi / lo fp16 parts into the planes, or (EX) the fp32 values themselves
+template <bool EX, int TR>
+__device__ __forceinline__ void tile_store(unsigned char* tile, int row, int col, const float4 v) {
+  if constexpr (EX) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(tile) + row * LDS_STRIDE + col) = v;
+  } else {
+    _Float16* sH = reinterpret_cast<_Float16*>(tile);
+    _Float16* sL = sH + TR * PLANE_STRIDE;
+    f16x4 h, l;
+    split4(v, h, l);
+    *reinterpret_cast<f16x4*>(sH + row * PLANE_STRIDE + col) = h;
+    *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + col) = l;
+  }
+}
+// acc = X . W for the staged tile with W in `w`; when NEXT, the halves of the following kernel are requested into the same registers
+// as soon as the products that read them have been issued (gemm_tile's schedule)
+template <bool EX, bool NEXT, int TR, int RT>
+__device__ __forceinline__ void gemm_tile_x(const unsigned char* tile, WRegs<EX>& w, const _Float16* __restrict__ next, int wave, int lane,
+                                            f32x16 (&acc)[RT]) {
+  mma_half<EX, TR, RT>(tile, w, lane, acc, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (NEXT) load_whalf<EX>(w, next, wave, lane, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma_half<EX, TR, RT>(tile, w, lane, acc, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  if (NEXT) load_whalf<EX>(w, next, wave, lane, 1);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 }  // namespace scann

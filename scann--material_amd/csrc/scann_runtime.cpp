@@ -125,6 +125,10 @@ struct scann_handle {
   // default: measured slower than the layer-streamed kernels, profiles/r04_notes.md): every structure stays on the layer-streamed
   // kernels (env SCANN_RESIDENT, scann_set_resident_limit)
   int sr_max_tiles = 0;
+  bool weights_exact = false;  // a loaded 128x128 kernel has |w| >= 255.9: the split-fp16 images cannot hold it, inference runs exact
+  bool force_exact = false;    // env SCANN_EXACT=1: every inference forward on the exact-fp32 kernels (test / diagnosis switch)
+  bool strict_range = false;   // env SCANN_STRICT_RANGE=1: SCANN_ERR_RANGE instead of the exact-fp32 re-run of an inference forward
+  int64_t exact_reruns = 0;    // forwards re-run on the exact-fp32 kernels so far (scann_exact_reruns)
   LayerParams* d_layers = nullptr;  // device copy of `layers` (the resident kernel walks the layers itself)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
@@ -444,6 +448,8 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* fb = getenv("SCANN_FUSE_BASIS")) h->fuse_basis = atoi(fb) != 0;
   if (const char* fa = getenv("SCANN_TRAIN_FUSE_ATTN")) h->fuse_attn = atoi(fa) != 0;
   if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
+  if (const char* sg = getenv("SCANN_STRICT_RANGE")) h->strict_range = atoi(sg) != 0;
+  if (const char* fe = getenv("SCANN_EXACT")) h->force_exact = atoi(fe) != 0;
   if (const char* sr = getenv("SCANN_RESIDENT")) h->sr_max_tiles = std::min((int)SR_NT_BIG, std::max(0, atoi(sr)));
   {
     hipDeviceProp_t prop;
@@ -599,19 +605,36 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     h->descs.push_back(RepackDesc{(int64_t)(W - mbase), (int64_t)off, 1, -1});
     return off;
   };
-  for (const WeightSpec& sp : h->specs)  // the fp16 hi part of a split weight holds |w| * 2^8 < 65504
+  // The fp16 hi part of a split weight holds |w| * 2^8 < 65504.  A 128x128 kernel beyond that (the reference loads any fp32
+  // checkpoint, scann_model.py:79) sends every inference forward of the handle to the exact-fp32 kernels; the K = 20 filters exist
+  // in the split form only, and nothing can be done with a value that is not finite.
+  h->weights_exact = false;
+  for (const WeightSpec& sp : h->specs)
     if (sp.cols) {
       const float* wp = src[sp.name];
+      const bool split_only = sp.name == "neighbor_d/kernel" || sp.name == "neighbor_w/kernel" ||
+                              (!c.g_update && sp.name.size() > 17 && sp.name.compare(sp.name.size() - 17, 17, "filter_geo/kernel") == 0);
+      const bool projection = sp.rows == D * (sp.name.find("filter_geo") != std::string::npos ? 3 : 1) && sp.cols == D &&
+                              sp.name != "bf_property/kernel" && sp.name != "dense_embed/kernel";
       for (int64_t i = 0; i < sp.numel(); ++i)
-        if (!(std::fabs(wp[i]) < WMAX))
-          return fail(h, SCANN_ERR_UNSUPPORTED, "scann_load_weights: |" + sp.name + "| reaches " + std::to_string(std::fabs(wp[i])) +
-                                                    "; the split-fp16 projections need |w| < 255.9 (or the value is not finite)");
+        if (!(std::fabs(wp[i]) < WMAX)) {
+          if (std::isfinite(wp[i]) && projection && !split_only) {
+            h->weights_exact = true;
+            break;
+          }
+          if (!std::isfinite(wp[i]) || split_only)
+            return fail(h, SCANN_ERR_UNSUPPORTED, "scann_load_weights: |" + sp.name + "| reaches " + std::to_string(std::fabs(wp[i])) +
+                                                      (split_only ? "; this kernel is multiplied in split-fp16 form only, which needs |w| < 255.9"
+                                                                  : "; the value is not finite"));
+          break;  // an fp32-only tensor (embedding, dense_embed, bf_property, head): any finite value
+        }
     }
   struct LTOff { size_t W1T, W2T, W3T, WqT, WkT, Wf1T, Wf2T, W1Th, W2Th, W3Th, WqTh, WkTh, Wf1Th, Wf2Th; };
   std::vector<LTOff> lto(L);
   struct LOff {
     size_t bg, bq, bk, lng_g, lng_b, ln_g, ln_b, Wfg, bfg, bf1, bf2, lnr_g, lnr_b;
     size_t W2h, Wkh, Wfh, W1h, W3h, Wqh, Wf1h, Wf2h;
+    size_t W1p, W2p, W3p, Wqp, Wkp, Wf1p, Wf2p;  // fp32 fragment-order images: the exact-fp32 fallback of the forward
   };
   std::vector<LOff> lo(L);
   const size_t NONE = (size_t)-1;
@@ -619,13 +642,16 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     const std::string p = "local_attention_" + std::to_string(i) + "/";
     LOff& o = lo[i];
     o = LOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE,
-             NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
+             NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     const float* fg = src[p + "filter_geo/kernel"];
     lto[i] = LTOff{NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE};
     if (c.g_update) {  // concat order [centre, geometry, neighbour] (attention.py:143-149)
       o.W1h = put_f16(fg, D, 8);
       o.W3h = put_f16(fg + (size_t)2 * D * D, D, 8);
       o.W2h = put_f16(fg + (size_t)D * D, D, 8);
+      o.W1p = put_packed(fg);
+      o.W2p = put_packed(fg + (size_t)D * D);
+      o.W3p = put_packed(fg + (size_t)2 * D * D);
       lto[i].W1T = put_packedT(fg);
       lto[i].W2T = put_packedT(fg + (size_t)D * D);
       lto[i].W3T = put_packedT(fg + (size_t)2 * D * D);
@@ -641,6 +667,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       o.bfg = put_raw(src[p + "filter_geo/bias"], D);
     }
     o.Wqh = put_f16(src[p + "query/kernel"], D, 8);
+    o.Wqp = put_packed(src[p + "query/kernel"]);
+    o.Wkp = put_packed(src[p + "key/kernel"]);
     lto[i].WqT = put_packedT(src[p + "query/kernel"]);
     lto[i].WkT = put_packedT(src[p + "key/kernel"]);
     lto[i].WqTh = put_f16T(src[p + "query/kernel"]);
@@ -658,6 +686,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       lto[i].Wf2Th = put_f16T(src[r + "dense_2/kernel"]);
       o.Wf1h = put_f16(src[r + "dense_1/kernel"], D, 8);
       o.Wf2h = put_f16(src[r + "dense_2/kernel"], D, 8);
+      o.Wf1p = put_packed(src[r + "dense_1/kernel"]);
+      o.Wf2p = put_packed(src[r + "dense_2/kernel"]);
       o.bf1 = put_raw(src[r + "dense_1/bias"], D);
       o.bf2 = put_raw(src[r + "dense_2/bias"], D);
       o.lnr_g = put_raw(src[r + "layer_norm/gamma"], D);
@@ -729,6 +759,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
     lp.Wf2h = reinterpret_cast<const _Float16*>(P(o.Wf2h));
     lp.bf1 = P(o.bf1); lp.bf2 = P(o.bf2);
     lp.lnr_g = P(o.lnr_g); lp.lnr_b = P(o.lnr_b);
+    lp.W1p = P(o.W1p); lp.W2p = P(o.W2p); lp.W3p = P(o.W3p); lp.Wqp = P(o.Wqp); lp.Wkp = P(o.Wkp); lp.Wf1p = P(o.Wf1p); lp.Wf2p = P(o.Wf2p);
   }
   h->layersT.assign(L, scann_handle::LayerT{});
   for (int i = 0; i < L; ++i) {
@@ -1081,7 +1112,8 @@ int ensure_debug(scann_handle* h, scann_dbatch* db) {
 
 // The forward graph of create_model (scann_model.py:362-447) as a launch schedule on one stream.
 // kind codes for the timer: 0 basis, 1 atom, 2 edge, 3 readout.
-int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
+int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, bool exact = false) {
+  if ((h->force_exact || h->weights_exact) && !h->debug && !h->in_train_forward) exact = true;
   db->idle = false;  // work is being enqueued on the batch (scann_batch_release)
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
   if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
@@ -1103,7 +1135,9 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   if (tm) tm->mark(-1);
   // Structure-resident path (scann_struct.hip) for the groups scann_batch_upload planned; the layer-streamed launches below then
   // cover only the structures beyond it (none in a QM9-shaped batch), through the plan made for exactly those.
-  const bool resident = db->n_sr_small + db->n_sr_big > 0 && L > 0 && !h->debug && !h->in_train_forward && h->train_drop_p == 0.f && h->d_layers;
+  // exact: the forward's range guard fired (an operand outside the split-fp16 range): the same launches on the EX instantiations of
+  // the atom / edge kernels -- exact-fp32 projections -- with the plain first layer (basis_kernel, no per-species tables)
+  const bool resident = !exact && db->n_sr_small + db->n_sr_big > 0 && L > 0 && !h->debug && !h->in_train_forward && h->train_drop_p == 0.f && h->d_layers;
   const bool streamed_any = !resident || db->n_streamed > 0;
   const EdgeTile* const v_tiles = resident ? db->s2_tiles : db->tiles;
   const int v_n_tile = resident ? db->s2_n_tile : db->n_tile, v_n_big = resident ? db->s2_n_big : db->n_big;
@@ -1113,7 +1147,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
   const int v_tile_rows = resident ? TE_MAX : db->tile_rows;
   // inference: the first layer's edge kernel computes its geometry rows from (dist, weight) itself -- geom0 is never written by a
   // basis launch and read back (282 MB of the 16-batch forward's traffic and one launch)
-  const bool fuse_basis = h->fuse_basis && c.g_update && L > 0 && !h->debug && !h->in_train_forward && db->n_edge > 0;
+  const bool fuse_basis = !exact && h->fuse_basis && c.g_update && L > 0 && !h->debug && !h->in_train_forward && db->n_edge > 0;
   if (fuse_basis || !streamed_any) {}
   else if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
   else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
@@ -1192,6 +1226,21 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       db->n_stamp = nt;
     }
 #endif
+    if (exact) {  // fp32 fragment-order images in place of the split-fp16 ones
+      a.exact = 1;
+      if (l > 0 && a.ffn) {
+        const LayerParams& pp = h->layers[l - 1];
+        a.Wf1h = reinterpret_cast<const _Float16*>(pp.Wf1p); a.Wf2h = reinterpret_cast<const _Float16*>(pp.Wf2p);
+      }
+      if (l < L) {
+        const LayerParams& p = h->layers[l];
+        a.WAh = reinterpret_cast<const _Float16*>(p.W1p); a.WBh = reinterpret_cast<const _Float16*>(p.W3p);
+        a.WCh = reinterpret_cast<const _Float16*>(p.Wqp);
+      } else {
+        a.WAh = reinterpret_cast<const _Float16*>(h->head.Wap); a.WCh = reinterpret_cast<const _Float16*>(h->head.Wgqp);
+        a.WDh = reinterpret_cast<const _Float16*>(h->head.Wgkp);
+      }
+    }
     if (!(species0 && l == 0)) launch_atom(a, s);
     if (tm) tm->mark(l < L ? 1 : 3);
     if (h->debug && !direct) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
@@ -1210,6 +1259,10 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm) {
       db->kept = true;
     }
     ea.p = h->layers[l];
+    if (exact) {
+      ea.exact = 1;
+      ea.p.W2h = reinterpret_cast<const _Float16*>(ea.p.W2p); ea.p.Wkh = reinterpret_cast<const _Float16*>(ea.p.Wkp);
+    }
     ea.range_flag = rflag; ea.layer = l;
     // (the first layer's launch with the basis MLP fused in is a different kernel: not part of edge_kernel's sampled average)
     const bool sample = !resident && !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
@@ -1336,9 +1389,27 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
   HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
   if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
+  // The forward's range guard fired: an activation left the range of the split-fp16 projections (sites 1-4).  The reference runs any
+  // fp32 values (attention.py:95-113), so the forward is run again on the exact-fp32 instantiations (1/16 of the matrix rate, this
+  // batch only) instead of handing an error back -- unless SCANN_STRICT_RANGE=1 asks for the error.
+  if (h->range_flag && !h->strict_range && !db->kept) {
+    const int32_t code = *reinterpret_cast<volatile int32_t*>(h->range_flag + db->last_slot);
+    const int site = code >> 8;
+    if (code && site >= 1 && site <= 4) {
+      h->range_flag[db->last_slot] = 0;
+      const int r = run_forward(h, db, s, nullptr, true);
+      if (r) return r;
+      h->exact_reruns++;
+      HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
+      if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(h, hipStreamSynchronize(s));
+    }
+  }
   db->idle = true;
   return check_range(h, "scann_batch_download", db->last_slot);
 }
+
+int64_t scann_exact_reruns(const scann_handle_t* h) { return h ? h->exact_reruns : -1; }
 
 int scann_sync(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;
@@ -1592,6 +1663,9 @@ int64_t scann_param_count(const scann_handle_t* h) {
 int scann_train_begin(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "scann_train_begin: weights not loaded");
+  if (h->weights_exact)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: a 128x128 kernel has |w| >= 255.9; the training kernels multiply in split-fp16 "
+                                          "form only (inference of such a checkpoint runs on the exact-fp32 kernels)");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t n = h->host_master.size();
   if (!h->t_master) {

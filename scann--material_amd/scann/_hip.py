@@ -100,6 +100,7 @@ SYMBOLS = [
     ("scann_plan_tiles", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("scann_plan_groups", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P] + [C.POINTER(C.c_int32)] * 4),
     ("scann_set_resident_limit", C.c_int, [_P, C.c_int]),
+    ("scann_exact_reruns", C.c_int64, [_P]),
     ("scann_batch_info", C.c_int, [_P, _P, _P]),
 ]
 
@@ -431,6 +432,10 @@ class Engine:
         """largest group (in edge tiles, 0..6) the structure-resident forward takes; 0 = layer-streamed kernels only.
         Applies to batches uploaded afterwards."""
         self._check(self.lib.scann_set_resident_limit(self._h, int(max_tiles)))
+
+    def exact_reruns(self):
+        """forwards this handle has re-run on the exact-fp32 kernels because an activation left the split-fp16 range"""
+        return int(self.lib.scann_exact_reruns(self._h))
 
     def batch_info(self, rb):
         out = np.zeros(8, dtype=np.int32)

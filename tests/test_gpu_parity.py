@@ -564,10 +564,12 @@ def test_keras_h5_checkpoint_loads_and_predicts(hip_lib, tmp_path):
     assert scann.model.config["model"]["n_attention"] == cfg["model"]["n_attention"]
 
 
-def test_activation_outside_the_split_fp16_range_is_an_error_not_a_nan(hip_lib):
+def test_activation_outside_the_split_fp16_range_is_rerun_in_exact_fp32(hip_lib, monkeypatch):
     """The projections carry every operand as fp16 hi + lo parts: an activation beyond 65504 would become inf, then NaN.  The
-    kernels test every LayerNorm variance downstream of a split (and the one activation no LayerNorm follows); the call that
-    returns the results fails with SCANN_ERR_RANGE and names the layer -- it does not hand back NaNs.  The handle stays usable."""
+    kernels test every LayerNorm variance downstream of a split (and the one activation no LayerNorm follows).  When that guard
+    fires, the call that returns the results runs the forward AGAIN on exact-fp32 matrix instructions -- the reference evaluates
+    any fp32 checkpoint (attention.py:95-113) -- and returns the oracle's numbers; with SCANN_STRICT_RANGE=1 it fails with
+    SCANN_ERR_RANGE and names the layer instead.  Never NaNs, and the handle stays usable."""
     from scann import _hip
     from scann.models.scann_model import HipModel
 
@@ -577,20 +579,101 @@ def test_activation_outside_the_split_fp16_range_is_an_error_not_a_nan(hip_lib):
     inputs, _ = so.pad_batch(de, dn, True)
     y_ok = HipModel(cfg, w, device=0).predict(inputs)
     assert np.isfinite(y_ok).all()
+    cases = []
     bad = dict(w)
     bad["local_attention_1/layer_norm_g/gamma"] = (w["local_attention_1/layer_norm_g/gamma"] * 3.0e5).astype(np.float32)  # geom' ~ 3e5
-    model = HipModel(cfg, bad, device=0)
-    with pytest.raises(_hip.ScannHipError) as ei:
-        model.predict(inputs)
-    assert ei.value.code == -7 and "local_attention_" in str(ei.value) and "65504" in str(ei.value), str(ei.value)
-    model.set_weights(w)  # same handle, sane weights again: the flag was cleared by the failed call
-    assert np.array_equal(model.predict(inputs), y_ok)
-    # the activation with no LayerNorm behind it: after_Lc
+    cases.append((bad, "local_attention_"))
     bad = dict(w)
-    bad["after_Lc/bias"] = (w["after_Lc/bias"] + 1.0e5).astype(np.float32)
+    bad["after_Lc/bias"] = (w["after_Lc/bias"] + 1.0e5).astype(np.float32)  # the activation with no LayerNorm behind it
+    cases.append((bad, "after_Lc"))
+    for bad, where in cases:
+        model = HipModel(cfg, bad, device=0, infer=True)
+        assert model.engine.exact_reruns() == 0
+        y, ga = model.predict(inputs)
+        assert model.engine.exact_reruns() == 1
+        y32, ga32 = so.forward(cfg, bad, inputs, np.float32)
+        y64, ga64 = so.forward(cfg, bad, inputs, np.float64)
+        assert np.isfinite(y).all() and np.isfinite(ga).all()
+        assert rel_err(y, y64) <= max(RTOL, 2 * rel_err(y32, y64)), (where, rel_err(y, y64), rel_err(y32, y64))
+        assert rel_err(ga, ga64) <= max(RTOL, 2 * rel_err(ga32, ga64)), (where, rel_err(ga, ga64), rel_err(ga32, ga64))
+        model.set_weights(w)  # same handle, sane weights again: the fast path, the same bytes as before, no further re-run
+        assert np.array_equal(model.predict(inputs)[0], y_ok) and model.engine.exact_reruns() == 1
+        # the resident-batch pipeline: the batch whose guard fired is re-run at its download, its neighbour on the other stream is not
+        model.set_weights(bad)
+        pk = _hip.pack_inputs(inputs)
+        rb1, rb2 = model.engine.upload(pk), model.engine.upload(pk)
+        model.engine.forward_resident(rb1, 0)
+        model.engine.forward_resident(rb2, 1)
+        y1, _ = model.engine.download(rb1)
+        y2, _ = model.engine.download(rb2)
+        assert np.array_equal(y1, y[:, 0]) and np.array_equal(y2, y[:, 0]) and model.engine.exact_reruns() == 3
+        rb1.free()
+        rb2.free()
+    # the exact kernels on an ordinary model: the fp32 oracle's numbers (they ARE the reference's arithmetic)
+    monkeypatch.setenv("SCANN_STRICT_RANGE", "1")
+    for bad, where in cases:
+        model = HipModel(cfg, bad, device=0)
+        with pytest.raises(_hip.ScannHipError) as ei:
+            model.predict(inputs)
+        assert ei.value.code == -7 and where in str(ei.value) and "65504" in str(ei.value), str(ei.value)
+        model.set_weights(w)  # the flag was cleared by the failed call
+        assert np.array_equal(model.predict(inputs), y_ok)
+
+
+@pytest.mark.parametrize("name,kind,n,over", [
+    ("qm9", "qm9", 40, {}), ("qm9", "qm9", 12, dict(g_update=False)), ("qm9", "qm9", 12, dict(use_attn_norm=False)),
+    ("mp2018", "mp2018", 6, {}), ("qm9", "worst", 4, {}),
+], ids=["qm9", "base", "no_attn_norm", "mp2018", "worst"])
+def test_exact_fp32_kernels_match_the_oracle(hip_lib, monkeypatch, name, kind, n, over):
+    """SCANN_EXACT=1 runs every inference forward on the EX instantiations of the atom / edge kernels (exact-fp32 MFMA: the re-run
+    path of a forward whose split-fp16 range guard fired), here on ordinary models: the oracle's numbers on every branch, 32- and
+    64-row tiles, and the fast path's to the split scheme's accuracy."""
+    from scann.models.scann_model import HipModel
+
+    cfg, w, inputs, fast = make(name, n=n, seed=9, kind=kind, model=dict(over))
+    y_fast, ga_fast = fast.predict(inputs)
+    monkeypatch.setenv("SCANN_EXACT", "1")
+    y, ga = HipModel(cfg, w, device=0, infer=True).predict(inputs)
+    y32, ga32 = so.forward(cfg, w, inputs, np.float32)
+    y64, ga64 = so.forward(cfg, w, inputs, np.float64)
+    assert rel_err(y, y64) <= max(RTOL, 2 * rel_err(y32, y64)) and rel_err(ga, ga64) <= max(RTOL, 2 * rel_err(ga32, ga64))
+    assert rel_err(y, y_fast) <= RTOL and rel_err(ga, ga_fast) <= RTOL
+
+
+def test_weights_beyond_the_split_fp16_range_run_on_the_exact_kernels(hip_lib):
+    """A 128x128 kernel with |w| >= 255.9 cannot be held as fp16 hi / lo parts of w * 2^8.  The reference loads any fp32 checkpoint
+    (scann_model.py:79): such a handle runs its inference forwards on the exact-fp32 kernels (the oracle's numbers), refuses to
+    train, and a K = 20 filter -- multiplied in split form only -- or a value that is not finite is still refused at load."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    w = so.init_weights(cfg, 1234, perturb=True)
+    de, dn = so.synth_dataset(9, 3)
+    inputs, _ = so.pad_batch(de, dn, True)
+    big = dict(w)
+    big["local_attention_0/key/kernel"] = (w["local_attention_0/key/kernel"] * 4000.0).astype(np.float32)
+    big["residual_norm_2/dense_1/kernel"] = (w["residual_norm_2/dense_1/kernel"] * 3000.0).astype(np.float32)
+    assert np.abs(big["local_attention_0/key/kernel"]).max() > 255.9
+    model = HipModel(cfg, big, device=0, infer=True)
+    y, ga = model.predict(inputs)
+    y32, ga32 = so.forward(cfg, big, inputs, np.float32)
+    y64, ga64 = so.forward(cfg, big, inputs, np.float64)
+    assert np.isfinite(y).all()
+    assert rel_err(y, y64) <= max(RTOL, 2 * rel_err(y32, y64)), (rel_err(y, y64), rel_err(y32, y64))
+    assert rel_err(ga, ga64) <= max(RTOL, 2 * rel_err(ga32, ga64))
     with pytest.raises(_hip.ScannHipError) as ei:
-        HipModel(cfg, bad, device=0).predict(inputs)
-    assert ei.value.code == -7 and "after_Lc" in str(ei.value), str(ei.value)
+        model.engine.train_begin()
+    assert ei.value.code == -2 and "255.9" in str(ei.value)
+    for name, factor in (("neighbor_d/kernel", 4000.0), ("after_Lc/kernel", np.inf)):
+        bad = dict(w)
+        bad[name] = (w[name] * factor).astype(np.float32)
+        with pytest.raises(_hip.ScannHipError) as ei:
+            HipModel(cfg, bad, device=0)
+        assert ei.value.code == -2 and name in str(ei.value), str(ei.value)
+    model.set_weights(w)  # back inside the range: the fast path again
+    assert np.array_equal(model.predict(inputs)[0], HipModel(cfg, w, device=0, infer=True).predict(inputs)[0])
+    model.engine.train_begin()
 
 
 def test_process_per_gpu_predictor_equals_single_handle(hip_lib):
