@@ -107,6 +107,28 @@ SYMBOLS = [
 _lib = None
 
 
+def _check_hw_queues():
+    """``GPU_MAX_HW_QUEUES`` above ROCm's default of 4 makes a stream that waits for an event of a later-created stream (the upload
+    copy stream, the basis-gradient stream of the training step) stall ~2 ms per wait: two queues time-sliced on one hardware pipe,
+    the waiter holding it.  Measured (profiles/r03_notes.md, tools/queue_matrix.sh): ``trainer.fit`` 0.93 -> 2.85 ms per step with
+    6-16 queues and 2-3 streams per handle; inference is unaffected.  The HIP runtime reads the variable at its first call, which is
+    after this point: a value above 4 is therefore put back to 4, loudly.  ``SCANN_KEEP_HW_QUEUES=1`` leaves it alone."""
+    v = os.environ.get("GPU_MAX_HW_QUEUES")
+    if not v or os.environ.get("SCANN_KEEP_HW_QUEUES") == "1":
+        return
+    try:
+        n = int(v)
+    except ValueError:
+        return
+    if n > 4:
+        import warnings
+
+        warnings.warn("GPU_MAX_HW_QUEUES=%d: with more than 4 hardware queues a stream waiting on a later-created stream stalls ~2 ms "
+                      "per wait (trainer.fit: 3x slower, profiles/r03_notes.md); using 4 for this process -- set SCANN_KEEP_HW_QUEUES=1 "
+                      "to keep your value" % n, RuntimeWarning, stacklevel=3)
+        os.environ["GPU_MAX_HW_QUEUES"] = "4"
+
+
 def load_library(path=None):
     """dlopen the in-tree library and type every entry point.  Raises if it is not built."""
     global _lib
@@ -123,6 +145,12 @@ def load_library(path=None):
         # i.e. at the first HIP call of the process -- so it is set HERE, before the library is even loaded.  spawn_ranks sets
         # it for its children; ranks made by torch.distributed.run get it this way.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # ... and one rank per GPU means one rank per NUMA neighbourhood: pin this process to the cores next to its device before
+        # the first GPU call (scann/parallel/affinity.py; SCANN_NO_AFFINITY=1 leaves the affinity alone)
+        from .parallel.affinity import pin_to_device
+
+        pin_to_device(int(os.environ.get("LOCAL_RANK", "0") or 0))
+    _check_hw_queues()
     lib = C.CDLL(p)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)

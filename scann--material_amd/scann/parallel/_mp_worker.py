@@ -35,6 +35,9 @@ def _worker(conn):
     """Worker process: one model on one device, then a loop of predict requests."""
     try:
         device, config, weights, infer = conn.recv()
+        from scann.parallel.affinity import pin_to_device
+
+        pin_to_device(device)  # the cores of this device's NUMA node, before the first GPU call and the producer thread
         from scann.models.scann_model import HipModel
         from scann.parallel.multi_gpu import _Run
         from scann.utils.packed_dataset import PackedDataset

@@ -417,6 +417,90 @@ def test_listwalk_matches_python_walk_of_the_nested_lists():
     assert len(PackedDataset([], [], batch_size=2)) == 0
 
 
+def test_more_than_four_hardware_queues_are_put_back_with_a_warning(monkeypatch):
+    """GPU_MAX_HW_QUEUES > 4 triples trainer.fit's step time (a waiter and its signaller time-sliced on one hardware pipe,
+    profiles/r03_notes.md): the package resets it to ROCm's default before the HIP runtime reads it, with a warning; an explicit
+    SCANN_KEEP_HW_QUEUES=1 keeps the caller's value."""
+    import warnings
+
+    from scann import _hip
+
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    monkeypatch.delenv("SCANN_KEEP_HW_QUEUES", raising=False)
+    with pytest.warns(RuntimeWarning, match="GPU_MAX_HW_QUEUES=8"):
+        _hip._check_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    for value, keep in (("4", None), ("2", None), ("16", "1"), ("junk", None)):
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", value)
+        if keep:
+            monkeypatch.setenv("SCANN_KEEP_HW_QUEUES", keep)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            _hip._check_hw_queues()
+        assert os.environ["GPU_MAX_HW_QUEUES"] == value
+
+
+def test_rank_affinity_follows_the_gpu_numa_node(tmp_path, monkeypatch):
+    """scann.parallel.affinity on a fake sysfs tree: eight AMD devices on two NUMA nodes (plus a non-AMD card and connector
+    entries), 16 cores per node.  Every rank gets a quarter of ITS device's node, visible-device lists are honoured, unknown
+    topologies and SCANN_NO_AFFINITY leave the affinity alone."""
+    from scann.parallel import affinity
+
+    sysfs = tmp_path / "sys"
+    pci = sysfs / "devices" / "pci0000:00"
+    (sysfs / "class" / "drm").mkdir(parents=True)
+    for i in range(8):
+        d = pci / ("0000:%02x:00.0" % (0x10 + i))
+        d.mkdir(parents=True)
+        (d / "vendor").write_text("0x1002\n")
+        (d / "numa_node").write_text("%d\n" % (i // 4))
+        card = sysfs / "class" / "drm" / ("card%d" % (7 - i))  # card numbers do NOT follow the PCI order
+        card.mkdir()
+        os.symlink(d, card / "device")
+        conn = sysfs / "class" / "drm" / ("card%d-DP-1" % (7 - i))
+        conn.mkdir()
+        os.symlink(d, conn / "device")
+    other = pci / "0000:05:00.0"
+    other.mkdir()
+    (other / "vendor").write_text("0x1a03\n")
+    (other / "numa_node").write_text("0\n")
+    (sysfs / "class" / "drm" / "card8").mkdir()
+    os.symlink(other, sysfs / "class" / "drm" / "card8" / "device")
+    for n in range(2):
+        nd = sysfs / "devices" / "system" / "node" / ("node%d" % n)
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text("%d-%d,%d-%d\n" % (8 * n, 8 * n + 7, 16 + 8 * n, 16 + 8 * n + 7))
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "SCANN_NO_AFFINITY"):
+        monkeypatch.delenv(v, raising=False)
+    assert affinity.parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    gpus = affinity.amd_gpus(str(sysfs))
+    assert [n for _, n in gpus] == [0, 0, 0, 0, 1, 1, 1, 1] and len(gpus) == 8
+    sets = [affinity.cpus_for_device(d, str(sysfs)) for d in range(8)]
+    node0, node1 = {0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23}, {8, 9, 10, 11, 12, 13, 14, 15, 24, 25, 26, 27, 28, 29, 30, 31}
+    assert all(len(s) == 4 for s in sets)
+    assert set().union(*sets[:4]) == node0 and set().union(*sets[4:]) == node1  # a partition of each node
+    assert sum(len(s) for s in sets) == 32
+    assert affinity.cpus_for_device(8, str(sysfs)) is None
+    # the cores the process may use at all bound the answer
+    assert affinity.cpus_for_device(5, str(sysfs), allowed=range(0, 12)) == {8, 9, 10, 11}  # too few to split: shared by the node's four
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6,1")
+    assert affinity.cpus_for_device(0, str(sysfs)) == node1 and affinity.cpus_for_device(1, str(sysfs)) == node0  # alone on their nodes
+    assert affinity.cpus_for_device(2, str(sysfs)) is None
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    (pci / "0000:10:00.0" / "numa_node").write_text("-1\n")  # single-socket hosts report -1
+    assert affinity.cpus_for_device(0, str(sysfs)) is None
+    # pin_to_device really sets the affinity (in a child: this process keeps its own), and SCANN_NO_AFFINITY leaves it alone
+    allowed = sorted(os.sched_getaffinity(0))
+    nd = sysfs / "devices" / "system" / "node" / "node1"
+    (nd / "cpulist").write_text(",".join(str(c) for c in allowed[:2]) + "\n")
+    code = ("import os, sys; sys.path.insert(0, %r); from scann.parallel.affinity import pin_to_device; "
+            "print(sorted(pin_to_device(7, %r) or []), sorted(os.sched_getaffinity(0)))" % (os.path.join(ROOT, "scann--material_amd"), str(sysfs)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SCANN_NO_AFFINITY="0"))
+    assert out.returncode == 0 and out.stdout.strip() == "%s %s" % (allowed[:2], allowed[:2]), (out.stdout, out.stderr)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SCANN_NO_AFFINITY="1"))
+    assert out.returncode == 0 and out.stdout.strip() == "[] %s" % allowed, (out.stdout, out.stderr)
+
+
 def test_process_per_gpu_predictor_does_not_hang_on_a_dead_worker(monkeypatch):
     """A worker process that dies before it connects back (import error, missing library, bad PYTHONPATH) used to leave the
     parent in listener.accept() for ever; now the parent watches its children and names the failure."""
@@ -916,6 +1000,33 @@ def test_two_rank_fit_with_a_short_final_batch(tmp_path):
     script.write_text("ROOT = %r\n" % ROOT + _DP_FIT_WORKER)
     env = dict(os.environ, DP_OUT=str(tmp_path / "run"))
     assert spawn_ranks([str(script)], 2, env=env, timeout=180) == 0
+
+
+def test_two_rank_rccl_worker_script_on_the_cpu_stand_in(tmp_path):
+    """The worker of tests/test_gpu_training.py::test_two_rank_rccl_gradients_match_single_rank needs two GPUs and is skipped on
+    the one-GPU boxes.  Here the SAME script runs on two CPU ranks with HipModel replaced by tests/cpu_engine.py (the torch graph,
+    collectives over the rendezvous): Communicator's start-up (unique id, comm_init, weight broadcast from different initialiser
+    draws), the sharding, the global-RMSE rule, summed shard gradients = full-batch gradients, replicas identical after a step."""
+    pytest.importorskip("torch")
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.parallel.launch import spawn_ranks
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_training import _RCCL_WORKER
+
+    prelude = ("import os, sys\nROOT = %r\n"
+               "sys.path[:0] = [os.path.join(ROOT, 'scann--material_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')]\n"
+               "import cpu_engine\ncpu_engine.install()\n" % ROOT)
+    script = tmp_path / "rccl_worker_cpu.py"
+    script.write_text(prelude + _RCCL_WORKER)
+    log = tmp_path / "out.txt"
+    env = dict(os.environ, OMP_NUM_THREADS="2", SCANN_NO_AFFINITY="1")
+    with open(log, "w") as f:
+        import contextlib
+
+        with contextlib.redirect_stdout(f):
+            rc = spawn_ranks([str(script)], 2, env=env, timeout=600)
+    assert rc == 0
 
 
 def test_checkpoint_replace_is_atomic(tmp_path):

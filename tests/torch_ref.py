@@ -4,6 +4,9 @@ neither the layout nor the hand-written LayerNorm/softmax/swish of oracle/scann_
 import math
 
 import numpy as np
+import pytest
+
+pytest.importorskip("torch")  # test infrastructure only: a box without torch SKIPS the tests that cross-check against it
 
 
 REGULARIZED = ("query/kernel", "key/kernel", "filter_geo/kernel", "dense_1/kernel", "dense_2/kernel",
