@@ -3,9 +3,9 @@ a Keras full-model checkpoint (``ModelCheckpoint(save_weights_only=False)``, sca
 
 * superblock version 0 / 1, version-1 object headers (+ continuation blocks), old-style groups (symbol table message ->
   version-1 B-tree -> symbol-table nodes -> local heap);
-* datasets with contiguous or compact layout (what ``create_dataset(name, shape, dtype)`` gives without chunking or
-  compression; a chunked or filtered dataset raises), little- or big-endian fixed-point and floating-point types, fixed-length
-  strings;
+* datasets with contiguous, compact or CHUNKED layout (version-1 chunk B-tree) without filters -- what
+  ``create_dataset(name, shape, dtype[, chunks=...])`` gives without compression; a filtered (compressed / shuffled) dataset
+  raises -- little- or big-endian fixed-point and floating-point types, fixed-length strings;
 * attributes (message versions 1-3) of those types, of variable-length strings (global heap), scalar or array.
 
 File-format reference: "HDF5 File Format Specification Version 2.0" (sections III.A superblock, III.B/III.D B-trees and
@@ -22,8 +22,16 @@ _SIG = b"\x89HDF\r\n\x1a\n"
 _UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
+#: what to do with a file this reader refuses: libhdf5's own tool rewrites it in the subset handled here
+REPACK = ("re-write it with libhdf5's `h5repack --low=0 --high=0 -l CONTI -f NONE in.h5 out.h5` (oldest format, contiguous datasets, no "
+          "filters), or on a machine with h5py: `python tools/keras_h5_to_container.py` reads the result")
+
+
 class Hdf5Error(ValueError):
-    pass
+    """An HDF5 feature outside the subset above; the message names the feature and ``REPACK``, the way out."""
+
+    def __init__(self, msg):
+        super().__init__(msg + " -- " + REPACK if "h5repack" not in msg else msg)
 
 
 class Dataset:
@@ -85,7 +93,8 @@ class File(Group):
             raise Hdf5Error("%s: not an HDF5 file (or a user block precedes the superblock: not supported)" % path)
         ver = b[8]
         if ver not in (0, 1):
-            raise Hdf5Error("%s: superblock version %d (written with libver='latest'); this reader handles versions 0 and 1" % (path, ver))
+            raise Hdf5Error("%s: superblock version %d (a file written with libver='latest': version-2 object headers, link-message "
+                            "groups, fractal heaps); this reader handles superblock versions 0 and 1" % (path, ver))
         self.O, self.L = b[13], b[14]  # size of offsets / lengths
         if self.O not in (4, 8) or self.L not in (4, 8):
             raise Hdf5Error("unsupported offset / length size")
@@ -110,7 +119,8 @@ class File(Group):
         b = self.buf
         a = self.base + addr
         if b[a] != 1:
-            raise Hdf5Error("object header version %d at %d: only version-1 headers (libver='earliest', the h5py default) are handled" % (b[a], addr))
+            what = "version-2 object header ('OHDR')" if b[a:a + 4] == b"OHDR" else "object header version %d" % b[a]
+            raise Hdf5Error("%s at %d: only version-1 headers (libver='earliest', the h5py / Keras default) are handled" % (what, addr))
         n_msg = struct.unpack_from("<H", b, a + 2)[0]
         size = struct.unpack_from("<I", b, a + 8)[0]
         blocks = [(a + 16, size)]
@@ -134,7 +144,7 @@ class File(Group):
             if mtype == 0x11:  # symbol table -> old-style group
                 links = self._group_links(self._off(body), self._off(body + self.O))
             elif mtype == 0x02 or mtype == 0x06:
-                raise Hdf5Error("%s: new-style (link-message) group; re-save with h5py defaults" % name)
+                raise Hdf5Error("%s: new-style group (link / link-info messages, libver='latest' or track_order=True)" % name)
             elif mtype == 0x01:
                 space = self._dataspace(body)
             elif mtype == 0x03:
@@ -142,7 +152,7 @@ class File(Group):
             elif mtype == 0x08:
                 layout = (body, size)
             elif mtype == 0x0B:
-                raise Hdf5Error("%s: filtered (compressed) dataset: not supported" % name)
+                raise Hdf5Error("%s: dataset with a filter pipeline (%s): not supported" % (name, self._filter_names(body)))
             elif mtype == 0x0C:
                 k, v = self._attribute(body)
                 attrs[k] = v
@@ -298,7 +308,22 @@ class File(Group):
                 if addr == _UNDEF >> (64 - 8 * self.O):
                     return np.zeros(shape, dtype=dt[0])  # never written: fill value
                 return self._decode(b[self.base + addr:self.base + addr + n], dt, shape)
-            raise Hdf5Error("chunked dataset: not supported (Keras writes its weights contiguous)")
+            if cls == 2:  # chunked: version-1 B-tree (node type 1) over the chunks
+                ndim = b[p + 2]  # rank + 1: the last "dimension" is the element size
+                btree = self._off(p + 3)
+                q = p + 3 + self.O
+                cdims = struct.unpack_from("<%dI" % ndim, b, q)
+                if ndim - 1 != len(shape) or cdims[-1] != dt[1]:
+                    raise Hdf5Error("chunked dataset: layout message disagrees with the dataspace / datatype")
+                if dt[0] == "vlen_str":
+                    raise Hdf5Error("chunked dataset of variable-length strings: not supported")
+                out = np.zeros(shape, dtype=dt[0])
+                if btree != _UNDEF >> (64 - 8 * self.O):
+                    self._read_chunks(btree, cdims[:-1], dt, out)
+                if out.dtype.byteorder == ">":
+                    out = out.astype(out.dtype.newbyteorder("<"))
+                return out
+            raise Hdf5Error("data layout class %d (virtual dataset?): not supported" % cls)
         if ver in (1, 2):
             rank, cls = b[p + 1], b[p + 2]
             if cls == 1:
@@ -309,3 +334,51 @@ class File(Group):
                 sz = struct.unpack_from("<I", b, q)[0]
                 return self._decode(b[q + 4:q + 4 + sz], dt, shape)
         raise Hdf5Error("data layout version %d / class not supported" % ver)
+
+    def _read_chunks(self, node, cdims, dt, out):
+        """Walk a version-1 chunk B-tree (III.A.1, node type 1): key = chunk size, filter mask, offsets (rank + 1 x 8 bytes)."""
+        b = self.buf
+        a = self.base + node
+        if b[a:a + 4] != b"TREE" or b[a + 4] != 1:
+            raise Hdf5Error("bad chunk B-tree node")
+        level, used = b[a + 5], struct.unpack_from("<H", b, a + 6)[0]
+        rank = len(cdims)
+        key = 8 + 8 * (rank + 1)
+        p = a + 8 + 2 * self.O
+        n_chunk = int(np.prod(cdims))
+        for _ in range(used):
+            size, mask = struct.unpack_from("<II", b, p)
+            offs = struct.unpack_from("<%dQ" % rank, b, p + 8)
+            child = self._off(p + key)
+            p += key + self.O
+            if level > 0:
+                self._read_chunks(child, cdims, dt, out)
+                continue
+            if mask or size != n_chunk * dt[1]:
+                raise Hdf5Error("filtered chunk (mask %#x, %d bytes for %d elements)" % (mask, size, n_chunk))
+            chunk = np.frombuffer(b, dtype=dt[0], count=n_chunk, offset=self.base + child).reshape(cdims)
+            sel = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, out.shape))
+            out[sel] = chunk[tuple(slice(0, x.stop - x.start) for x in sel)]
+
+    def _filter_names(self, p):
+        """Names of the filters of a pipeline message (IV.A.2.l), for the error text."""
+        known = {1: "deflate / gzip", 2: "shuffle", 3: "fletcher32", 4: "szip", 5: "nbit", 6: "scaleoffset", 32000: "lzf"}
+        b = self.buf
+        try:
+            ver, n = b[p], b[p + 1]
+            q = p + (8 if ver == 1 else 2)
+            ids = []
+            for _ in range(n):
+                fid = struct.unpack_from("<H", b, q)[0]
+                ids.append(known.get(fid, "filter %d" % fid))
+                if ver == 1 or fid >= 256:
+                    nlen = struct.unpack_from("<H", b, q + 2)[0]
+                    nvals = struct.unpack_from("<H", b, q + 6)[0]
+                    q += 8 + (nlen + 7) // 8 * 8 if ver == 1 else 8 + nlen
+                else:
+                    nvals = struct.unpack_from("<H", b, q + 4)[0]
+                    q += 6
+                q += 4 * nvals + (4 if ver == 1 and nvals % 2 else 0)
+            return ", ".join(ids) or "unknown"
+        except Exception:
+            return "unknown"

@@ -55,6 +55,28 @@ def test_hdf5_lite_reads_a_file_written_by_libhdf5():
         f["model_weights/nope"]
 
 
+def test_hdf5_lite_chunked_datasets_and_named_refusals():
+    """Second libhdf5-written pin (tests/golden/make_h5_fixture2.py): chunked datasets without filters are READ (chunk B-tree with
+    several leaves, ragged edge chunks, big-endian elements, a dataset never written); what stays outside the reader -- a filter
+    pipeline, a libver='latest' file -- is refused with a message that names the feature and the way out (h5repack)."""
+    from scann.utils.hdf5_lite import File, Hdf5Error
+
+    rng = np.random.default_rng(7)
+    c = {"a": rng.normal(size=(37, 128)).astype(np.float32), "b": np.arange(1000, dtype=np.int64).reshape(10, 100) * 3 - 7,
+         "c": rng.normal(size=(5, 3, 9)), "d": rng.normal(size=(300,)).astype(">f4")}
+    f = File(os.path.join(ROOT, "tests", "golden", "hdf5_lite_chunked.h5"))
+    for k, ref in c.items():
+        got = f[k].read()
+        assert got.shape == ref.shape and got.dtype.byteorder in "<=|" and np.array_equal(got, ref.astype(ref.dtype.newbyteorder("<"))), k
+    assert np.array_equal(f["never_written"].read(), np.zeros((6, 4), np.float32))
+    with pytest.raises(Hdf5Error, match=r"gz: dataset with a filter pipeline \(shuffle, deflate / gzip\).*h5repack"):
+        f["gz"]
+    with pytest.raises(Hdf5Error, match=r"superblock version 3 .*libver='latest'.*h5repack --low=0 --high=0 -l CONTI -f NONE"):
+        File(os.path.join(ROOT, "tests", "golden", "hdf5_lite_latest.h5"))
+    with pytest.raises(Hdf5Error, match="not an HDF5 file"):
+        File(os.path.join(ROOT, "tests", "golden", "make_h5_fixture2.py"))
+
+
 def _keras_nested(cfg, w):
     """The container `w` as the nested structure Keras' model_weights group has (layer -> [(weight name, array)]), with the
     auto-generated names a create_model build produces: global LayerNormalization / Dense counters, weightless layers."""

@@ -106,3 +106,46 @@ def test_dataset_records_xyz_and_the_parallel_driver(tmp_path):
     ext.write_text('2\nLattice="5.64 0 0 0 5.64 0 0 0 5.64"\nNa 0 0 0\nCl 2.82 2.82 2.82\n')
     c2 = vn.read_xyz(str(ext))
     assert isinstance(c2, vn.Structure) and len(vn.compute_voronoi_neighbor(c2, d_thresh=5.0)[0]) == 8
+
+
+def test_pathological_unbounded_cells_keep_their_bounded_facets():
+    """``allow_pathological=True`` (voronoi_neighbor.py:27): an atom whose Voronoi cell inside the cut-off sphere is UNBOUNDED keeps
+    the facets that are bounded and loses the others, no error.  A methane-like cluster alone in a 40 A box (no periodic image within
+    the 7 A cut-off): the centre's cell is a regular tetrahedron (four facets of pi each); every outer atom's cell runs to infinity,
+    its only bounded facet is the one it shares with the centre -- the same triangle seen from the mirror point, pi again."""
+    from scann.utils.voronoi_neighbor import Structure, compute_voronoi_neighbor, voronoi_polyhedron
+
+    t = np.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], dtype=np.float64) / np.sqrt(3.0)
+    coords = np.vstack([np.zeros(3), t]) + 20.0
+    s = Structure(np.eye(3) * 40.0, ["C", "H", "H", "H", "H"], coords)
+    facets = voronoi_polyhedron(s.lattice, s.cart_coords, 0, 7.0)
+    assert sorted(j for j, _, _ in facets) == [1, 2, 3, 4] and np.allclose([w for _, w, _ in facets], np.pi, atol=1e-9)
+    for i in range(1, 5):
+        f = voronoi_polyhedron(s.lattice, s.cart_coords, i, 7.0)
+        assert [j for j, _, _ in f] == [0], (i, f)  # the H-H facets have a vertex at infinity: skipped
+        assert abs(f[0][1] - np.pi) < 1e-9 and abs(f[0][2] - 1.0) < 1e-12
+    nb = compute_voronoi_neighbor(s, cutoff=7, d_thresh=4.0, w_thresh=0.4)
+    assert len(nb) == 5 and [len(a) for a in nb] == [4, 1, 1, 1, 1]
+    assert all(e[0] == "H" and abs(e[3] - 1.0) < 1e-9 for e in nb[0]) and all(a[0][0] == "C" and a[0][1] == 0 for a in nb[1:])
+
+
+def test_cutoff_widening_retry_fires_and_gives_up_like_the_reference(capsys):
+    """voronoi_neighbor.py:33-60: a tessellation that fails (here: fewer than five sites inside the cut-off sphere) widens the
+    cut-off by 5 A and tries again -- the widened value STAYS for the following atoms, as in the reference -- and beyond
+    ``max_cutoff`` the atom is given up: its entry is missing from the result (the reference's ``break`` does the same)."""
+    from scann.utils.voronoi_neighbor import Structure, compute_voronoi_neighbor
+
+    # simple cubic, a = 3: inside 2.5 A there is only the atom itself; at 7.5 A the classical cell (6 facets of 2 pi / 3)
+    s = Structure(np.eye(3) * 3.0, ["Po"], [[0.0, 0.0, 0.0]])
+    out = compute_voronoi_neighbor(s, cutoff=2.5, d_thresh=4.0, w_thresh=0.4)
+    printed = capsys.readouterr().out
+    assert printed.count("Error Voronoi, increase cutoff to") == 1 and "7.5" in printed
+    ref = compute_voronoi_neighbor(s, cutoff=7.5, d_thresh=4.0, w_thresh=0.4)
+    assert capsys.readouterr().out == ""
+    assert len(out) == 1 and len(out[0]) == 6 and sorted(map(tuple, out[0])) == sorted(map(tuple, ref[0]))
+    assert np.allclose([e[2] for e in out[0]], 2.0 * np.pi / 3.0, atol=1e-9) and np.allclose([e[4] for e in out[0]], 3.0)
+    # one atom alone in a 200 A box: never five sites -- 7, 12, ..., 32 > max_cutoff: given up, no entry, no exception
+    lone = Structure(np.eye(3) * 200.0, ["He"], [[100.0, 100.0, 100.0]])
+    out = compute_voronoi_neighbor(lone, cutoff=7, d_thresh=4.0, w_thresh=0.4)
+    printed = capsys.readouterr().out
+    assert out == [] and printed.count("increase cutoff") == 5 and "32.0" in printed and "Error Voronoi, max cutoff" in printed
