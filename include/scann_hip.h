@@ -152,6 +152,17 @@ int scann_sync(scann_handle_t* h); /* all streams of the handle */
  * reference's fp32 Dense layers, attention.py:95-113) instead of returning SCANN_ERR_RANGE; this counts them.  Env
  * SCANN_STRICT_RANGE=1 turns the re-run off (the error is returned).  Training entry points always return the error. */
 int64_t scann_exact_reruns(const scann_handle_t* h);
+/* Layer launches (csrc/scann_layer.hip; an experiment, OFF by default): on inference handles the atom tiles that turn the contexts
+ * of LocalAttention iteration l into the centres and projections of iteration l + 1 (attention.py:148-160 -> scann_model.py:413-421)
+ * run inside iteration l's edge launch, each behind a counter its feeding edge tiles bump -- one launch per iteration instead of two,
+ * the same bytes, measured no faster (profiles/r04_notes.md).  Needs g_update, 64-row tiles and no chunked atoms in the batch's plan;
+ * env SCANN_FUSE_LAYERS=1 or scann_set_layer_fusion(h, 1) turns it on for batches uploaded afterwards (SCANN_LF_DELAY: how many
+ * workgroups behind its last feeding edge tile an atom tile is placed, default 400).  scann_layer_fusion_state: 1 on, 0 off, < 0: a
+ * launch reported a fault (-1 a dependency wait ran out, -2 an atom tile ran on another XCD than its edge tiles); the handle then
+ * re-ran the batch through separate launches and keeps doing so. */
+int scann_set_layer_fusion(scann_handle_t* h, int on);
+int scann_layer_fusion_state(const scann_handle_t* h);
+int64_t scann_fused_forwards(const scann_handle_t* h); /* forwards of this handle that ran as layer launches */
 int scann_num_streams(const scann_handle_t* h);
 
 /* Timed forward of a resident batch: HIP events around every kernel on its stream. */
@@ -264,6 +275,14 @@ int scann_plan_tiles(const scann_batch_t* batch, int32_t tile_rows, int32_t tile
  * group of its own, the rest are listed in streamed_out.  groups_out[cap_groups][4] = atom_begin, atom_end, tile_begin, n_tile
  * (the n_small groups of <= 3 tiles first, then the n_big others; each list by falling edge count); tiles_out[cap_tiles][4] as
  * scann_plan_tiles.  With null outputs only the counts are returned. */
+/* The work list of a LAYER LAUNCH (csrc/scann_layer.hip; host only): the 64-edge tiles of scann_plan_tiles dealt to the 8 XCDs in
+ * contiguous runs, per XCD the 64-row atom tiles covering exactly its tiles' atoms (row_tab_out[cap_atiles][2] = first row, rows),
+ * and the interleaved dispatch order work_out[cap_blocks][2] = {kind: 0 edge tile | 1 atom tile | -1 nothing, index} -- block b is
+ * item b >> 3 of XCD b & 7; an atom tile comes `delay` items behind the last edge tile that feeds it.  e_atile_out[n_etiles][2] =
+ * first atom tile an edge tile's atoms fall into and how many (1 | 2); a_need_out[n_atiles] = edge tiles feeding an atom tile. */
+int scann_plan_layer(const scann_batch_t* batch, int32_t tile_atoms, int32_t delay, int32_t cap_blocks, int32_t cap_atiles,
+                     int32_t* work_out, int32_t* row_tab_out, int32_t* e_atile_out, int32_t* a_need_out, int32_t* n_blocks,
+                     int32_t* n_atiles, int32_t* n_etiles);
 int scann_plan_groups(const scann_batch_t* batch, int32_t tile_atoms, int32_t max_tiles, int32_t cap_groups, int32_t cap_tiles,
                       int32_t* groups_out, int32_t* tiles_out, int32_t* streamed_out, int32_t* n_small, int32_t* n_big,
                       int32_t* n_tiles, int32_t* n_streamed);

@@ -247,6 +247,27 @@ void plan_streamed_subset(const int32_t* mol_offset, const int32_t* edge_offset,
                           std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part, std::vector<int32_t>& big_tab, int32_t* n_slot_out,
                           std::vector<int32_t>& atom_tab);
 
+// ---- layer launch (scann_layer.hip): edge tiles of layer l + atom tiles of layer l + 1 in one grid --------------------------------
+struct LayerFuse {
+  const int2* work;        // [n_block] {kind, index}: 0 edge tile, 1 atom tile (row_tab entry), -1 nothing; block b is item b >> 3 of XCD b & 7
+  int32_t n_block;
+  const int32_t* e_atile;  // [n_edge_tile][2]: first atom tile the edge tile's atoms fall into, how many (1 | 2)
+  const int32_t* a_need;   // [n_atom_tile]: edge tiles feeding the atom tile
+  unsigned long long* a_count;  // [n_atom_tile], this layer's (zeroed at the start of every forward): bits 0-7 arrivals, then 7 bits per
+                                // dispatch offset (XCC_ID - block) mod 8: the arrivals that ran with it
+  int32_t* fault;          // host-pinned word: 1 = a wait ran out, 2 | ... = an atom tile and one of its edge tiles ran on different XCDs
+};
+void launch_layer(const EdgeArgs& ea, const AtomArgs& aa, const LayerFuse& f, hipStream_t s);
+// Host side (scann_pack.cpp): per XCD a contiguous run of edge tiles, the 64-row atom tiles covering exactly their atoms, and the
+// interleaved work list (an atom tile `delay` items behind the last edge tile that feeds it).
+struct LayerPlan {
+  std::vector<int32_t> work;     // [n_block][2]
+  std::vector<int32_t> row_tab;  // [n_atom_tile][2] first row, rows
+  std::vector<int32_t> e_atile;  // [n_edge_tile][2]
+  std::vector<int32_t> a_need;   // [n_atom_tile]
+};
+void plan_layer_fusion(const std::vector<EdgeTile>& tiles, int delay, LayerPlan& plan);
+
 struct ReadoutArgs {
   const int32_t* mol_offset;  // [n_struct+1]
   int32_t n_struct;

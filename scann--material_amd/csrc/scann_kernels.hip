@@ -23,38 +23,6 @@
 
 namespace scann {
 
-// Diagnostic build only (-DSCANN_STAMPS): per-workgroup phase timestamps, written to a buffer nothing else reads.
-#ifdef SCANN_STAMPS
-#define STAMP(buf, slot)                                                                      \
-  do {                                                                                        \
-    if ((buf) && threadIdx.x == 0) {                                                          \
-      unsigned long long t_;                                                                  \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
-    }                                                                                         \
-  } while (0)
-#define STAMP_IF(buf, slot, cond)                                                             \
-  do {                                                                                        \
-    if ((buf) && (cond)) {                                                                    \
-      unsigned long long t_;                                                                  \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
-    }                                                                                         \
-  } while (0)
-#define STAMP_REAL(buf, slot)                                                                 \
-  do {                                                                                        \
-    if ((buf) && threadIdx.x == 0) {                                                          \
-      unsigned long long t_;                                                                  \
-      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
-    }                                                                                         \
-  } while (0)
-#else
-#define STAMP(buf, slot) do {} while (0)
-#define STAMP_IF(buf, slot, cond) do {} while (0)
-#define STAMP_REAL(buf, slot) do {} while (0)
-#endif
-
 // ---- atom-tile kernel ------------------------------------------------------------------------------
 //
 // One workgroup (4 waves) per tile of 64 (or, for small launches, 32: launch_atom) atom rows, three (four) workgroups per CU; every projection is a split-fp16 MFMA GEMM
@@ -75,242 +43,9 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) 
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TAR * PLANE_STRIDE * 2];  // hi / lo planes of the current GEMM input
   __shared__ __attribute__((aligned(16))) float sRed[TAR * 8];  // LayerNorm partial statistics [row][wave][mean, m2]
   __shared__ __attribute__((aligned(16))) float sPar[7 * D];   // bf1 | bf2 | lnr_g | lnr_b | bA | bC | bD
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lrow = lane & 31, lh = lane >> 5, cbase = 32 * wave + 4 * lh;
-  // (row_tab: the atom tiles of the structures that stay on this path in a batch shared with the structure-resident kernel)
-  const int row0 = a.row_tab ? a.row_tab[2 * blockIdx.x] : blockIdx.x * TAR;
-  const int nrows = a.row_tab ? a.row_tab[2 * blockIdx.x + 1] : min(TAR, a.n_atom - row0);
-  constexpr float WINV = EX ? 1.0f : 1.0f / WSCALE;  // (exact images are unscaled)
-  // first projection after the (optional) ResidualNorm: W1 (mode 0), Wq (mode 1), after_Lc (mode 2)
-  const _Float16* const firstW = MODE == 1 ? a.WCh : a.WAh;
-
-  STAMP(a.stamps, 0);
-  WRegs<EX> wr;
-  load_whalf<EX>(wr, FFN ? a.Wf1h : firstW, wave, lane, 0);
-  load_whalf<EX>(wr, FFN ? a.Wf1h : firstW, wave, lane, 1);
-  {  // bias / LayerNorm rows -> sPar (absent ones read a valid dummy row and are never used)
-    const float* const tab[7] = {FFN ? a.bf1 : a.bC, FFN ? a.bf2 : a.bC, FFN ? a.lnr_g : a.bC, FFN ? a.lnr_b : a.bC,
-                                 MODE != 1 ? a.bA : a.bC, a.bC, MODE == 2 ? a.bD : a.bC};
-    float pv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pv[i] = (tid < D ? tab[2 * i] : tab[2 * i + 1 < 7 ? 2 * i + 1 : 6])[tid & (D - 1)];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (256 * i + tid < 7 * D) sPar[256 * i + tid] = pv[i];
-  }
-  // x rows of the tile in the accumulator layout, straight into registers (they stay there for the residual); rows clamped,
-  // never guarded, and zero-filled afterwards so that the MFMAs see defined data
-  float4 xr[RT][4];
-  unsigned ooff[RT];  // byte offset of (output row, this lane's first column) in an [n_atom,128] tensor
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int rc = row0 + min(lrow + 32 * rt, nrows - 1);
-    const int src = a.x_index ? a.x_index[rc] : rc;
-    ooff[rt] = ((unsigned)(row0 + lrow + 32 * rt) * D + cbase) * 4;
-    const unsigned soff = ((unsigned)src * D + cbase) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xr[rt][j] = ld4(a.x, soff + 32 * j);
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int row = lrow + 32 * rt;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 v = row < nrows ? xr[rt][j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!FFN && row < nrows) {
-        if (a.drop_p > 0.f) {  // training: Dropout after dense_embed (scann_model.py:374)
-          const size_t e = (size_t)(row0 + row) * D + cbase + 8 * j;
-          v.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
-          v.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
-          v.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
-          v.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
-        }
-        st4(a.c, ooff[rt] + 32 * j, v);  // centres = staged rows (layer 0 / no ResidualNorm)
-      }
-      xr[rt][j] = v;
-      tile_store<EX, TAR>(sTile, row, cbase + 8 * j, v);
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 1);
-
-  f32x16 acc[RT];
-  if (FFN) {
-    // ResidualNorm (attention.py:37-40): h = swish(x W1 + b1)
-    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.Wf2h, wave, lane, acc);
-    STAMP(a.stamps, 2);
-    __syncthreads();  // every wave is done reading the x planes
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int row = lrow + 32 * rt;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bv = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
-        const float4 pre = make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
-                                       fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
-        const float4 hh = f4swish(pre);
-        if (a.keep_pre1 && row < nrows) {  // training forward: kept for the backward
-          st4(a.keep_pre1, ooff[rt] + 32 * j, pre);
-          st4(a.keep_H1, ooff[rt] + 32 * j, hh);
-        }
-        tile_store<EX, TAR>(sTile, row, cbase + 8 * j, hh);
-      }
-    }
-    __syncthreads();
-    STAMP(a.stamps, 3);
-    // y = h W2 + b2 ; t = x + drop(y)
-    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, firstW, wave, lane, acc);
-    STAMP(a.stamps, 4);
-    float mean32[RT], m2[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int row = lrow + 32 * rt;
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bv = *reinterpret_cast<const float4*>(&sPar[D + cbase + 8 * j]);
-        float4 y = make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
-                               fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
-        if (a.drop_p > 0.f) {  // attention.py:29 (training)
-          const size_t e = (size_t)(row0 + row) * D + cbase + 8 * j;
-          y.x *= drop_scale(a.drop_seed, a.drop_tag, e, a.drop_p);
-          y.y *= drop_scale(a.drop_seed, a.drop_tag, e + 1, a.drop_p);
-          y.z *= drop_scale(a.drop_seed, a.drop_tag, e + 2, a.drop_p);
-          y.w *= drop_scale(a.drop_seed, a.drop_tag, e + 3, a.drop_p);
-        }
-        const float4 t2 = f4add(xr[rt][j], y);
-        acc[rt][4 * j] = t2.x; acc[rt][4 * j + 1] = t2.y; acc[rt][4 * j + 2] = t2.z; acc[rt][4 * j + 3] = t2.w;
-        s += f4sum(t2);
-        if (a.keep_T2 && row < nrows) st4(a.keep_T2, ooff[rt] + 32 * j, t2);
-      }
-      // LayerNorm statistics: pairwise combination of the eight 16-column pieces of the row (see edge_kernel)
-      mean32[rt] = xor32(s) * (1.0f / 32.0f);
-      float v2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float d = acc[rt][i] - mean32[rt];
-        v2 = fmaf(d, d, v2);
-      }
-      m2[rt] = xor32(v2);
-    }
-    {
-      // (the lane id is re-derived HERE, from the hardware (v_mbcnt): the address and the predicate of this store were otherwise
-      // computed at the top of the kernel and carried -- at 168 VGPRs, spilled -- across both products)
-      int ln;
-      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-      if ((ln >> 5) == 0) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float2*>(&sRed[(((ln & 31) + 32 * rt) * 4 + wave) * 2]) = make_float2(mean32[rt], m2[rt]);
-      }
-    }
-    __syncthreads();  // statistics complete; every wave is done reading the hidden planes
-    STAMP(a.stamps, 5);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int row = lrow + 32 * rt;
-      const float4 sa = *reinterpret_cast<const float4*>(&sRed[row * 8]), sb = *reinterpret_cast<const float4*>(&sRed[row * 8 + 4]);
-      const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * 0.25f;
-      const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
-      const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
-      const float rstd = 1.0f / sqrtf(var + 1e-6f);
-      if (!EX && !(var < RANGE_FINITE) && row < nrows) flag_range(a.range_flag, 3, a.layer - 1);  // an operand of the ResidualNorm overflowed fp16
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + cbase + 8 * j]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + cbase + 8 * j]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = fmaf(acc[rt][4 * j], inv, be.x - mean * inv);
-        inv = rstd * g.y; y.y = fmaf(acc[rt][4 * j + 1], inv, be.y - mean * inv);
-        inv = rstd * g.z; y.z = fmaf(acc[rt][4 * j + 2], inv, be.z - mean * inv);
-        inv = rstd * g.w; y.w = fmaf(acc[rt][4 * j + 3], inv, be.w - mean * inv);
-        if (row < nrows) st4(a.c, ooff[rt] + 32 * j, y);
-        tile_store<EX, TAR>(sTile, row, cbase + 8 * j, y);
-      }
-    }
-    __syncthreads();
-    STAMP(a.stamps, 6);
-  }
-
-  if (MODE == 0) {  // P1 = c W1 + bg ; P3 = c W3 ; q = c Wq + bq (attention.py:142-151 thirds, :160)
-    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WBh, wave, lane, acc);
-    STAMP(a.stamps, 7);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bg = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
-        if (lrow + 32 * rt < nrows)
-          st4(a.oA, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bg.x), fmaf(acc[rt][4 * j + 1], WINV, bg.y),
-                                                   fmaf(acc[rt][4 * j + 2], WINV, bg.z), fmaf(acc[rt][4 * j + 3], WINV, bg.w)));
-      }
-    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WCh, wave, lane, acc);
-    STAMP(a.stamps, 9);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (lrow + 32 * rt < nrows)
-          st4(a.oB, ooff[rt] + 32 * j, make_float4(acc[rt][4 * j] * WINV, acc[rt][4 * j + 1] * WINV, acc[rt][4 * j + 2] * WINV, acc[rt][4 * j + 3] * WINV));
-  }
-  if (MODE == 0 || MODE == 1) {  // q = c Wq + bq (attention.py:160)
-    STAMP(a.stamps, 10);
-    gemm_tile_x<EX, false, TAR, RT>(sTile, wr, nullptr, wave, lane, acc);
-    STAMP(a.stamps, 11);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bq = *reinterpret_cast<const float4*>(&sPar[5 * D + cbase + 8 * j]);
-        if (lrow + 32 * rt < nrows)
-          st4(a.oC, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bq.x), fmaf(acc[rt][4 * j + 1], WINV, bq.y),
-                                                   fmaf(acc[rt][4 * j + 2], WINV, bq.z), fmaf(acc[rt][4 * j + 3], WINV, bq.w)));
-      }
-    STAMP(a.stamps, 12);
-  }
-  if (MODE == 2) {  // z = swish(c Wa + ba) (scann_model.py:424); gq = z Wgq + b ; gk = z Wgk + b (attention.py:269-272)
-    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WCh, wave, lane, acc);
-    __syncthreads();  // every wave is done reading the centre planes
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int row = lrow + 32 * rt;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bv = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
-        const float4 pre = make_float4(fmaf(acc[rt][4 * j], WINV, bv.x), fmaf(acc[rt][4 * j + 1], WINV, bv.y),
-                                       fmaf(acc[rt][4 * j + 2], WINV, bv.z), fmaf(acc[rt][4 * j + 3], WINV, bv.w));
-        const float4 z = f4swish(pre);
-        // no LayerNorm follows this activation: test it directly (its hi part feeds the GlobalAttention projections)
-        if (!EX && !(fmaxf(fmaxf(fabsf(z.x), fabsf(z.y)), fmaxf(fabsf(z.z), fabsf(z.w))) < 65504.f) && row < nrows) flag_range(a.range_flag, 4, a.layer);
-        if (a.keep_preA && row < nrows) {  // training forward: after_Lc pre-activation and output, kept for the backward
-          st4(a.keep_preA, ooff[rt] + 32 * j, pre);
-          st4(a.keep_z, ooff[rt] + 32 * j, z);
-        }
-        tile_store<EX, TAR>(sTile, row, cbase + 8 * j, z);
-      }
-    }
-    __syncthreads();
-    gemm_tile_x<EX, true, TAR, RT>(sTile, wr, a.WDh, wave, lane, acc);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bq = *reinterpret_cast<const float4*>(&sPar[5 * D + cbase + 8 * j]);
-        if (lrow + 32 * rt < nrows)
-          st4(a.oC, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bq.x), fmaf(acc[rt][4 * j + 1], WINV, bq.y),
-                                                   fmaf(acc[rt][4 * j + 2], WINV, bq.z), fmaf(acc[rt][4 * j + 3], WINV, bq.w)));
-      }
-    gemm_tile_x<EX, false, TAR, RT>(sTile, wr, nullptr, wave, lane, acc);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bk = *reinterpret_cast<const float4*>(&sPar[6 * D + cbase + 8 * j]);
-        if (lrow + 32 * rt < nrows)
-          st4(a.oB, ooff[rt] + 32 * j, make_float4(fmaf(acc[rt][4 * j], WINV, bk.x), fmaf(acc[rt][4 * j + 1], WINV, bk.y),
-                                                   fmaf(acc[rt][4 * j + 2], WINV, bk.z), fmaf(acc[rt][4 * j + 3], WINV, bk.w)));
-      }
-  }
+#define SCANN_ATOM_BIX blockIdx.x
+#include "scann_atom_body.inc"
+#undef SCANN_ATOM_BIX
 }
 
 void launch_atom(const AtomArgs& a, hipStream_t s) {
@@ -386,474 +121,14 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
   __shared__ float sDummy[7 * 1024];
   if (a.n_tile < 0) sDummy[threadIdx.x] = 1.f;
 #endif
-  static_assert(sizeof(sTile) >= TEK * LDS_STRIDE * sizeof(float), "K tile must fit the plane buffer");
-  _Float16* const sH = reinterpret_cast<_Float16*>(sTile);
-  _Float16* const sL = sH + TEK * PLANE_STRIDE;
-  float* const sK = reinterpret_cast<float*>(sTile);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tix = a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
-  const EdgeTile tile = a.tiles[tix];
-  const int part = a.tile_part ? a.tile_part[tix] : -1;  // >= 0: one <= 64-edge chunk of an atom with more than 64 neighbours
-  const int eb = tile.edge_begin, ne = tile.edge_end - eb, natom = tile.atom_end - tile.atom_begin;
-  const int nem1 = ne > 0 ? ne - 1 : 0;
-  const int lrow = lane & 31, lh = lane >> 5;  // accumulator layout: this lane's rows lrow, lrow + 32; column runs 32 wave + 8 j + 4 lh
-  const int cbase = 32 * wave + 4 * lh;
-
-  STAMP(a.stamps, 0);
-  STAMP_REAL(a.stamps, 12);  // 100 MHz reference clock at entry and exit: shader clock = cycles / ticks * 100 MHz
-  // ---- prologue: every load is issued UNCONDITIONALLY from clamped rows and selected afterwards (a load under a per-thread
-  // guard compiles to branch + load + s_waitcnt vmcnt(0): one full memory round trip per guard) -------------------------------
-  // one weight slab at a time, in two halves of 4 k-steps (A: k < 64, B: k >= 64): W2 (base branch: Wf, 2 k-steps in A), later Wk
-  WRegs<EX> wr;
-  f16x8 fth[2], ftl[2];  // base branch: the K = 20 filter (split form in every instantiation)
-  if (GUPD) {
-    if (!FB) {  // (FB: requested after the basis products, whose operands and accumulators need the registers first)
-      load_whalf<EX>(wr, a.p.W2h, wave, lane, 0);
-      load_whalf<EX>(wr, a.p.W2h, wave, lane, 1);
-    }
-  } else {
-    load_wsplit<2>(a.p.Wfh, wave, lane, fth, ftl);
-  }
-  unsigned nboff[RT];  // byte offset of (neighbour atom row, this lane's first column) in an [n_atom,128] tensor
-  int ctr[RT];         // tile-local centre atom of this lane's two edge rows
-  float ewgt[RT] = {};
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int e = ne > 0 ? eb + min(lrow + 32 * rt, nem1) : 0;
-    int nb = ne > 0 ? a.edge_col[e] : 0;
-    if (FB && a.species) nb = a.species[nb];  // row of the per-species tables
-    nboff[rt] = ((unsigned)nb * D + cbase) * 4;
-    ctr[rt] = ne > 0 ? a.edge_row[e] - tile.atom_begin : 0;
-    if (!GUPD) ewgt[rt] = ne > 0 ? a.edge_weight[e] : 0.f;
-  }
-  const int voff = a.edge_offset[tile.atom_begin + min(tid, natom)];
-  const float bkc = a.p.bk[tid & (D - 1)];
-  const float par0 = GUPD ? (tid < D ? a.p.lng_g : a.p.lng_b)[tid & (D - 1)] : a.p.bfg[tid & (D - 1)];
-  const float par1 = (tid < D ? a.p.ln_g : a.p.ln_b)[tid & (D - 1)];
-  float4 greg[RT][4];
-  {
-    const int r = tid >> 2, sub = tid & 3;  // staging map of the base branch: 4 threads per edge row
-    const int rs = r < ne ? r : nem1;
-    if (GUPD) {
-      float4 p1reg[3];  // centre thirds P1 = c_i W1 + bg of the tile's atoms
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int idx = tid + 256 * i, la = min(idx >> 5, natom - 1), c4 = idx & 31;
-        const int arow = FB && a.species ? a.species[tile.atom_begin + la] : tile.atom_begin + la;
-        p1reg[i] = ld4(a.P1, ((unsigned)arow * 32 + c4) * 16);
-      }
-      // geometry rows G of the tile's edges in the ACCUMULATOR layout, straight into registers: they stay there, exact fp32,
-      // for the residual (attention.py:153); a tile without edges reads (and ignores) a valid row
-      if (FB) {
-        // geom0 rows of the tile = swish(Gauss(dist) Wd + bd) * swish(Gauss(weight) Ww + bw) (scann_model.py:378-389): basis_kernel's
-        // instruction sequence on this tile's rows (a row's result does not depend on where in a tile it sits), the basis planes
-        // staged in the plane buffer the geometry rows take over afterwards
-        _Float16* const bH = reinterpret_cast<_Float16*>(sTile);
-        _Float16* const bL = bH + TEK * BASIS_STRIDE;
-        f16x8 bdh[2], bdl[2], bwh[2], bwl[2];
-        load_wsplit<2>(a.basis.Wdh, wave, lane, bdh, bdl);
-        load_wsplit<2>(a.basis.Wwh, wave, lane, bwh, bwl);
-        {
-          const float xd = ne > 0 ? a.dist[eb + rs] : 0.f, xw = ne > 0 ? a.edge_weight[eb + rs] : 0.f;
-          // the 20 + 20 Gaussian centres: ONE coalesced load per wave and table, handed to the lanes by ds_bpermute (the sixteen
-          // per-lane table loads of basis_kernel were a fifth of this kernel's vector-memory instructions); the same values
-          const float cd_l = a.basis.cd[min(lane, NG - 1)], cw_l = a.basis.cw[min(lane, NG - 1)];
-          f16x8 gh[2], gl[2];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int k = 8 * sub + i;
-            const float cdk = __shfl(cd_l, k), cwk = __shfl(cw_l, k);
-            const float vd = (k < NG && r < ne) ? gauss_fast(xd, cdk) : 0.f, vw = (k < NG && r < ne) ? gauss_fast(xw, cwk) : 0.f;
-            gh[0][i] = (_Float16)vd; gl[0][i] = (_Float16)(vd - (float)gh[0][i]);
-            gh[1][i] = (_Float16)vw; gl[1][i] = (_Float16)(vw - (float)gh[1][i]);
-          }
-          if (RT == 2 || r < TEK) {  // (32-row tiles: the upper half of the staging threads has no row)
-            *reinterpret_cast<f16x8*>(bH + r * BASIS_STRIDE + 8 * sub) = gh[0];
-            *reinterpret_cast<f16x8*>(bL + r * BASIS_STRIDE + 8 * sub) = gl[0];
-            *reinterpret_cast<f16x8*>(bH + r * BASIS_STRIDE + 32 + 8 * sub) = gh[1];
-            *reinterpret_cast<f16x8*>(bL + r * BASIS_STRIDE + 32 + 8 * sub) = gl[1];
-          }
-        }
-        // the P1 rows (requested before the Gaussians) go to their LDS rows NOW: twelve registers less across the basis products
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int idx = tid + 256 * i;
-          *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        f32x16 accd[RT], accw[RT];
-        mma_split<2, true, BASIS_STRIDE, RT>(bH, bL, bdh, bdl, lane, accd);
-        mma_split<2, true, BASIS_STRIDE, RT>(bH + 32, bL + 32, bwh, bwl, lane, accw);
-        __builtin_amdgcn_sched_barrier(0);
-        // W2 in halves, each requested once a row tile's accumulators are free (all of it at once: 28 B of scratch per lane)
-        constexpr float WINV0 = 1.0f / WSCALE;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 bd = *reinterpret_cast<const float4*>(a.basis.bd + cbase + 8 * j);
-            const float4 bw = *reinterpret_cast<const float4*>(a.basis.bw + cbase + 8 * j);
-            const float4 sd = f4swish(make_float4(fmaf(accd[rt][4 * j], WINV0, bd.x), fmaf(accd[rt][4 * j + 1], WINV0, bd.y),
-                                                  fmaf(accd[rt][4 * j + 2], WINV0, bd.z), fmaf(accd[rt][4 * j + 3], WINV0, bd.w)));
-            const float4 sw = f4swish(make_float4(fmaf(accw[rt][4 * j], WINV0, bw.x), fmaf(accw[rt][4 * j + 1], WINV0, bw.y),
-                                                  fmaf(accw[rt][4 * j + 2], WINV0, bw.z), fmaf(accw[rt][4 * j + 3], WINV0, bw.w)));
-            greg[rt][j] = f4mul(sd, sw);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (rt == 0) load_whalf<EX>(wr, a.p.W2h, wave, lane, 0);
-          if (rt == RT - 1) load_whalf<EX>(wr, a.p.W2h, wave, lane, 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();  // every wave is done reading the basis planes: the geometry planes may overwrite them
-      } else {
-        const float* gsrc = ne > 0 ? a.geom : a.P1;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const unsigned goff = ((ne > 0 ? (unsigned)(eb + min(lrow + 32 * rt, nem1)) : (unsigned)tile.atom_begin) * D + cbase) * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) greg[rt][j] = ld4(gsrc, goff + 32 * j);
-        }
-      }
-      if (!FB) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int idx = tid + 256 * i;
-          *reinterpret_cast<float4*>(&sQ[(idx >> 5) * LDS_STRIDE + 4 * (idx & 31)]) = p1reg[i];  // rows >= natom: unused copies
-        }
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int row = lrow + 32 * rt;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (row >= ne) greg[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          tile_store<EX, TEK>(sTile, row, cbase + 8 * j, greg[rt][j]);
-        }
-      }
-    } else {
-      // base SCANN (attention.py:155): the raw distance basis gd[e][0..20) of the tile's edges, zero-padded to K = 32
-      float4 gv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int c4 = sub + 4 * i;  // float4 piece 0..7 of the 32-wide row; pieces 5..7 are padding
-        gv[i] = ne > 0 ? ld4(a.gd, (unsigned)(eb + rs) * (NG * 4) + min(c4, 4) * 16) : ld4(a.q, (unsigned)tile.atom_begin * (D * 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int c4 = sub + 4 * i;
-        if (r >= ne || c4 > 4) gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        f16x4 h, l;
-        split4(gv[i], h, l);
-        if (r < TEK) {  // (32-row tiles: the upper half of the staging threads has no row)
-          *reinterpret_cast<f16x4*>(sH + r * PLANE_STRIDE + 4 * c4) = h;
-          *reinterpret_cast<f16x4*>(sL + r * PLANE_STRIDE + 4 * c4) = l;
-        }
-      }
-    }
-  }
-  if (tid <= natom) sOff[tid] = part >= 0 ? (tid == 0 ? 0 : ne) : voff - eb;  // a chunk tile holds edges [0, ne) of its single atom
-  sPar[tid] = par0;            // g_update: gamma | beta of layer_norm_g; base: filter bias (both halves)
-  sPar[2 * D + tid] = par1;    // gamma | beta of layer_norm
-  if (tid < D) sPar[4 * D + tid] = bkc;
+  static_assert(2 * TEK * PLANE_STRIDE * 2 >= TEK * LDS_STRIDE * (int)sizeof(float), "K tile must fit the plane buffer");
+#define SCANN_EDGE_TIX (a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x)
+#include "scann_edge_body.inc"
+#undef SCANN_EDGE_TIX
+#ifdef SCANN_DIAG_TAILWAIT  // diagnostic: what the layer launch's producer side costs an edge tile (its stores acknowledged before it ends)
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  STAMP(a.stamps, 1);
-
-  float4 p3r[RT][4];
-  f32x16 acc[RT];
-  if (GUPD) {
-    mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // gathered neighbour thirds P3[j] = c_j W3 (into the registers the first weight half leaves): in flight over the second half
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) p3r[rt][j] = ld4(a.P3, nboff[rt] + 32 * j);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 1);
-  } else {
-    mma_split<2, true, PLANE_STRIDE, RT>(sH, sL, fth, ftl, lane, acc);
-  }
-  STAMP(a.stamps, 2);
-  __builtin_amdgcn_sched_barrier(0);
-
-  constexpr float WINV = EX ? 1.0f : 1.0f / WSCALE;     // the 128x128 kernels (exact images are unscaled)
-  constexpr float WINVF = 1.0f / WSCALE;                // the base branch's K = 20 filter: always the split form
-  const int qa = tid >> 5;  // query rows qa, qa + 8, qa + 16 of the tile go through this thread
-  const unsigned qoff = (tid & 31) * 16;
-  // byte offset of the row of tile-local atom la (clamped by the caller) in an [n_atom,128] tensor / the per-species table
-  const auto arow_off = [&](int la) __attribute__((always_inline)) {
-    return qoff + (unsigned)(FB && a.species ? a.species[tile.atom_begin + la] : tile.atom_begin + la) * (D * 4);
-  };
-  float4 q0, q1, q2;
-  float4 cn[RT][4];
-  unsigned eoff[RT];  // (edge row, first column) bytes
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) eoff[rt] = ((unsigned)(eb + lrow + 32 * rt) * D + cbase) * 4;
-  float* const gout = a.geom_out ? a.geom_out : a.geom;
-  if (GUPD) {
-    // geometry update (attention.py:141-153) on the accumulators: T = swish(U + P1[i] + P3[j]) + G
-    float mean32[RT], m2[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int row = lrow + 32 * rt;
-      const float* p1 = sQ + ctr[rt] * LDS_STRIDE + cbase;
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 p1v = *reinterpret_cast<const float4*>(p1 + 8 * j);
-        const float4 g = greg[rt][j];
-        float4 v;
-        v.x = fmaf(acc[rt][4 * j], WINV, p1v.x) + p3r[rt][j].x;
-        v.y = fmaf(acc[rt][4 * j + 1], WINV, p1v.y) + p3r[rt][j].y;
-        v.z = fmaf(acc[rt][4 * j + 2], WINV, p1v.z) + p3r[rt][j].z;
-        v.w = fmaf(acc[rt][4 * j + 3], WINV, p1v.w) + p3r[rt][j].w;
-        const float4 t = f4swish_plus(v, g);
-        acc[rt][4 * j] = t.x; acc[rt][4 * j + 1] = t.y; acc[rt][4 * j + 2] = t.z; acc[rt][4 * j + 3] = t.w;
-        s += f4sum(t);
-        if (a.keep_V && row < ne) {  // training forward: the backward reads these instead of recomputing them
-          st4(a.keep_V, eoff[rt] + 32 * j, v);
-          st4(a.keep_T, eoff[rt] + 32 * j, t);
-        }
-      }
-      // LayerNorm_g statistics of the row: its 128 columns sit in 2 lanes x 4 waves.  Pairwise (Chan) combination of
-      // (mean, sum of squared deviations) of the eight 16-column pieces: as accurate as the two-pass form.
-      mean32[rt] = xor32(s) * (1.0f / 32.0f);
-      float v2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float d = acc[rt][i] - mean32[rt];
-        v2 = fmaf(d, d, v2);
-      }
-      m2[rt] = xor32(v2);
-      __builtin_amdgcn_sched_barrier(0);  // one row tile at a time: hoisting both tiles' LDS reads costs 40 VGPRs (spills)
-    }
-    if (lh == 0) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<float2*>(&sE[((lrow + 32 * rt) * 4 + wave) * 2]) = make_float2(mean32[rt], m2[rt]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the P3 registers are free: neighbour centre rows c[j] (attention.py:136) and the key weights land over the barrier
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
-    load_whalf<EX>(wr, a.p.Wkh, wave, lane, 0);  // first half of the key weights; the second half is requested at the GEMM
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // statistics complete; every wave is done with the G planes and the P1 rows
-    STAMP(a.stamps, 3);
-    // query rows of the tile's atoms: requested now, parked in sQ (the P1 rows are dead) before the key GEMM
-    q0 = ld4(a.q, arow_off(min(qa, natom - 1)));
-    q1 = ld4(a.q, arow_off(min(qa + 8, natom - 1)));
-    q2 = ld4(a.q, arow_off(min(qa + 16, natom - 1)));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int row = lrow + 32 * rt;
-      const float4 sa = *reinterpret_cast<const float4*>(&sE[row * 8]), sb = *reinterpret_cast<const float4*>(&sE[row * 8 + 4]);
-      const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * 0.25f;
-      const float d0 = sa.x - mean, d1 = sa.z - mean, d2 = sb.x - mean, d3 = sb.z - mean;
-      const float var = (((sa.y + sa.w) + (sb.y + sb.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / D);
-      const float rstd = 1.0f / sqrtf(var + 1e-6f);
-      if (!EX && !(var < RANGE_FINITE) && row < ne) flag_range(a.range_flag, 1, a.layer);  // an operand of the geometry update overflowed fp16
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[D + cbase + 8 * j]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = fmaf(acc[rt][4 * j], inv, be.x - mean * inv);
-        inv = rstd * g.y; y.y = fmaf(acc[rt][4 * j + 1], inv, be.y - mean * inv);
-        inv = rstd * g.z; y.z = fmaf(acc[rt][4 * j + 2], inv, be.z - mean * inv);
-        inv = rstd * g.w; y.w = fmaf(acc[rt][4 * j + 3], inv, be.w - mean * inv);
-        float4 ang = f4mul(cn[rt][j], y);  // attention.py:157
-        if (row < ne) {
-          if (!a.geom_dead) st4(gout, eoff[rt] + 32 * j, y);  // threaded to the next layer (scann_model.py:415)
-          if (a.keep_ang) st4(a.keep_ang, eoff[rt] + 32 * j, ang);
-        } else {
-          ang = make_float4(0.f, 0.f, 0.f, 0.f);  // ragged tail rows stay defined (and zero) for the MFMA
-        }
-        tile_store<EX, TEK>(sTile, row, cbase + 8 * j, ang);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // one row tile at a time (register pressure)
-    }
-  } else {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cn[rt][j] = ld4(a.c, nboff[rt] + 32 * j);
-    load_whalf<EX>(wr, a.p.Wkh, wave, lane, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // every wave is done reading the basis planes
-    STAMP(a.stamps, 3);
-    // query rows of the tile's atoms: requested now, parked in sQ (the P1 rows are dead) before the key GEMM
-    q0 = ld4(a.q, arow_off(min(qa, natom - 1)));
-    q1 = ld4(a.q, arow_off(min(qa + 8, natom - 1)));
-    q2 = ld4(a.q, arow_off(min(qa + 16, natom - 1)));
-    __builtin_amdgcn_sched_barrier(0);
-    // base SCANN: geomL = swish(gd Wf + bf) * weight (attention.py:155); ang = c[j] * geomL
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int row = lrow + 32 * rt;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 bf = *reinterpret_cast<const float4*>(&sPar[cbase + 8 * j]);
-        float4 y = f4swish(make_float4(fmaf(acc[rt][4 * j], WINVF, bf.x), fmaf(acc[rt][4 * j + 1], WINVF, bf.y),
-                                       fmaf(acc[rt][4 * j + 2], WINVF, bf.z), fmaf(acc[rt][4 * j + 3], WINVF, bf.w)));
-        y.x *= ewgt[rt]; y.y *= ewgt[rt]; y.z *= ewgt[rt]; y.w *= ewgt[rt];
-        float4 ang = f4mul(cn[rt][j], y);
-        if (row >= ne) ang = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.keep_ang && row < ne) {  // training forward: geomL (in the V slot) and the gated rows, kept for the backward
-          st4(a.keep_V, eoff[rt] + 32 * j, y);
-          st4(a.keep_ang, eoff[rt] + 32 * j, ang);
-        }
-        tile_store<EX, TEK>(sTile, row, cbase + 8 * j, ang);
-      }
-    }
-  }
-  // query rows: the P1 rows are dead (barrier above)
-  *reinterpret_cast<float4*>(&sQ[qa * LDS_STRIDE + 4 * (tid & 31)]) = q0;
-  *reinterpret_cast<float4*>(&sQ[(qa + 8) * LDS_STRIDE + 4 * (tid & 31)]) = q1;
-  *reinterpret_cast<float4*>(&sQ[(qa + 16) * LDS_STRIDE + 4 * (tid & 31)]) = q2;
-  __syncthreads();  // ang planes and query rows complete
-  STAMP(a.stamps, 4);
-
-  // K = ang . Wk + bk (attention.py:163); the second half of Wk arrives under the first half's MFMAs
-  load_whalf<EX>(wr, a.p.Wkh, wave, lane, 1);
-  __builtin_amdgcn_sched_barrier(0);
-  mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 0);
-  mma_half<EX, TEK, RT>(sTile, wr, lane, acc, 1);
-  STAMP(a.stamps, 5);
-  // logits e[n, h] = (q[i, h, :] * 16^-0.5) . K[n, h, :] (attention.py:180-183) from the accumulators: this lane holds 8 of the
-  // 16 columns of heads 2 wave (j = 0, 1) and 2 wave + 1 (j = 2, 3) of its rows; its partner lane (^32) holds the other 8
-  float lg[RT][2];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const float* qrow = sQ + ctr[rt] * LDS_STRIDE + cbase;
-#pragma unroll
-    for (int hp = 0; hp < 2; ++hp) {
-      float e = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * hp + jj;
-        const float4 bk = *reinterpret_cast<const float4*>(&sPar[4 * D + cbase + 8 * j]);
-        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * j);
-        const float k0 = fmaf(acc[rt][4 * j], WINV, bk.x), k1 = fmaf(acc[rt][4 * j + 1], WINV, bk.y);
-        const float k2 = fmaf(acc[rt][4 * j + 2], WINV, bk.z), k3 = fmaf(acc[rt][4 * j + 3], WINV, bk.w);
-        acc[rt][4 * j] = k0; acc[rt][4 * j + 1] = k1; acc[rt][4 * j + 2] = k2; acc[rt][4 * j + 3] = k3;
-        e = fmaf(q4.x * 0.25f, k0, e); e = fmaf(q4.y * 0.25f, k1, e); e = fmaf(q4.z * 0.25f, k2, e); e = fmaf(q4.w * 0.25f, k3, e);
-      }
-      lg[rt][hp] = xor32(e);
-    }
-  }
-  __syncthreads();  // every wave is done reading the ang planes: K may overwrite them
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int row = lrow + 32 * rt;
-    // (two predicated stores, not `lh ? lg[rt][1] : lg[rt][0]`: hipcc makes a private array of lg for the select in the base kernel)
-    if (lh == 0) sE[row * NHEAD + 2 * wave] = lg[rt][0];
-    else sE[row * NHEAD + 2 * wave + 1] = lg[rt][1];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 k4 = make_float4(acc[rt][4 * j], acc[rt][4 * j + 1], acc[rt][4 * j + 2], acc[rt][4 * j + 3]);
-      *reinterpret_cast<float4*>(&sK[row * LDS_STRIDE + cbase + 8 * j]) = k4;
-      if (a.keep_K && row < ne) st4(a.keep_K, eoff[rt] + 32 * j, k4);
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 8);
-  // softmax over each atom's edges + context + unscaled-query residual (attention.py:186-212).
-  // Packed edges are all unmasked: the additive -1e9 and the multiplicative mask are the identity; an atom without edges
-  // yields q (then LayerNorm), which is what the reference's fully-masked row gives.
-  {
-    const int lgp = tid >> 5, c4 = tid & 31, h = c4 >> 2;
-    for (int la = lgp; la < natom; la += 8) {
-      const int e0 = sOff[la], e1 = sOff[la + 1];
-      // row maximum first (logits only), then one exp per edge: no running-maximum rescaling in the accumulation loop
-      float m = -INFINITY;
-      for (int n = e0; n < e1; n += 4) {
-        const float v0 = sE[n * NHEAD + h], v1 = sE[min(n + 1, e1 - 1) * NHEAD + h];
-        const float v2 = sE[min(n + 2, e1 - 1) * NHEAD + h], v3 = sE[min(n + 3, e1 - 1) * NHEAD + h];
-        m = fmaxf(fmaxf(m, fmaxf(v0, v1)), fmaxf(v2, v3));
-      }
-      float ssum = 0.f;
-      float4 cx = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int n = e0; n < e1; n += 2) {
-        const bool two = n + 1 < e1;
-        const int n1 = two ? n + 1 : n;
-        const float4 ka = *reinterpret_cast<const float4*>(&sK[n * LDS_STRIDE + 4 * c4]);
-        const float4 kb = *reinterpret_cast<const float4*>(&sK[n1 * LDS_STRIDE + 4 * c4]);
-        float pa = fast_exp(sE[n * NHEAD + h] - m), pb = two ? fast_exp(sE[n1 * NHEAD + h] - m) : 0.f;
-        ssum += pa + pb;
-        if (a.attn_drop_p > 0.f) {  // training with use_drop: Dropout(0.05) on the attention weights (attention.py:116,191)
-          pa *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n) * NHEAD + h, a.attn_drop_p);
-          pb *= drop_scale(a.attn_drop_seed, a.attn_drop_tag, (size_t)(eb + n1) * NHEAD + h, a.attn_drop_p);
-        }
-        cx.x = fmaf(pa, ka.x, fmaf(pb, kb.x, cx.x));
-        cx.y = fmaf(pa, ka.y, fmaf(pb, kb.y, cx.y));
-        cx.z = fmaf(pa, ka.z, fmaf(pb, kb.z, cx.z));
-        cx.w = fmaf(pa, ka.w, fmaf(pb, kb.w, cx.w));
-      }
-      if (part >= 0) {  // chunk tile: leave the softmax state of this chunk for edge_merge_kernel
-        float* pb = a.part_buf + (size_t)part * 3 * D + 4 * c4;
-        *reinterpret_cast<float4*>(pb) = make_float4(m, m, m, m);
-        *reinterpret_cast<float4*>(pb + D) = make_float4(ssum, ssum, ssum, ssum);
-        *reinterpret_cast<float4*>(pb + 2 * D) = cx;
-      } else {
-        const float rs = e1 > e0 ? __builtin_amdgcn_rcpf(ssum) : 0.f;
-        float4* qp = reinterpret_cast<float4*>(&sQ[la * LDS_STRIDE + 4 * c4]);
-        const float4 q4 = *qp;
-        *qp = make_float4(fmaf(cx.x, rs, q4.x), fmaf(cx.y, rs, q4.y), fmaf(cx.z, rs, q4.z), fmaf(cx.w, rs, q4.w));
-      }
-    }
-  }
-  __syncthreads();
-  STAMP(a.stamps, 9);
-  // LayerNorm of the context rows (attention.py:214): 8 threads per atom row
-  {
-    const int rr = tid >> 3, sb = tid & 7;
-    if (rr < natom && part < 0) {
-      float4 t[4];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        t[i] = *reinterpret_cast<const float4*>(&sQ[rr * LDS_STRIDE + 4 * (sb + 8 * i)]);
-        s += f4sum(t[i]);
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      const float mean = s * (1.0f / D);
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float dx = t[i].x - mean, dy = t[i].y - mean, dz = t[i].z - mean, dw = t[i].w - mean;
-        v += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      if (!EX && !(v < RANGE_FINITE)) flag_range(a.range_flag, 2, a.layer);  // the gated rows or the keys overflowed fp16
-      const float rstd = 1.0f / sqrtf(v * (1.0f / D) + 1e-6f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c4 = sb + 8 * i;
-        const float4 g = *reinterpret_cast<const float4*>(&sPar[2 * D + 4 * c4]);
-        const float4 be = *reinterpret_cast<const float4*>(&sPar[3 * D + 4 * c4]);
-        float4 y;
-        float inv;
-        inv = rstd * g.x; y.x = t[i].x * inv + (be.x - mean * inv);
-        inv = rstd * g.y; y.y = t[i].y * inv + (be.y - mean * inv);
-        inv = rstd * g.z; y.z = t[i].z * inv + (be.z - mean * inv);
-        inv = rstd * g.w; y.w = t[i].w * inv + (be.w - mean * inv);
-        st4(a.ctx, ((unsigned)(tile.atom_begin + rr) * 32 + c4) * 16, y);
-      }
-    }
-  }
-  STAMP(a.stamps, 7);
-  STAMP_REAL(a.stamps, 13);
+#endif
 }
 
 // Atoms with more than 64 neighbours: combine the per-chunk softmax states (running max m, sum s, unnormalised context x per

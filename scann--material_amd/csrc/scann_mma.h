@@ -5,6 +5,38 @@
 
 namespace scann {
 
+// Diagnostic build only (-DSCANN_STAMPS): per-workgroup phase timestamps, written to a buffer nothing else reads.
+#ifdef SCANN_STAMPS
+#define STAMP(buf, slot)                                                                      \
+  do {                                                                                        \
+    if ((buf) && threadIdx.x == 0) {                                                          \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
+    }                                                                                         \
+  } while (0)
+#define STAMP_IF(buf, slot, cond)                                                             \
+  do {                                                                                        \
+    if ((buf) && (cond)) {                                                                    \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
+    }                                                                                         \
+  } while (0)
+#define STAMP_REAL(buf, slot)                                                                 \
+  do {                                                                                        \
+    if ((buf) && threadIdx.x == 0) {                                                          \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
+    }                                                                                         \
+  } while (0)
+#else
+#define STAMP(buf, slot) do {} while (0)
+#define STAMP_IF(buf, slot, cond) do {} while (0)
+#define STAMP_REAL(buf, slot) do {} while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // C/D map of the 32x32 MFMA: register i of lane l holds row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31.
@@ -49,11 +81,14 @@ __device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
 // one coalesced 1-KiB read.  KS = K / 16 k-steps.
 template <int KS, int KT = KS>
 __device__ __forceinline__ void load_wsplit(const _Float16* __restrict__ Wp, int wave, int lane, f16x8 (&wh)[KS], f16x8 (&wl)[KS], int s0 = 0) {
-  const f16x8* __restrict__ src = reinterpret_cast<const f16x8*>(Wp) + (size_t)wave * (KT * 2 * 64) + lane;
+  // (uniform base + 32-bit per-lane byte offset: the saddr form of global_load -- ONE offset VGPR for the whole slab instead of a
+  // 64-bit address pair per 4 KiB of it; the slab of a wave is KT x 2 KiB, far below 4 GiB)
+  const char* __restrict__ base = reinterpret_cast<const char*>(Wp);
+  const unsigned off = ((unsigned)wave * (KT * 2 * 64) + (unsigned)lane) * 16u;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    wh[s] = src[(2 * (s0 + s)) * 64];
-    wl[s] = src[(2 * (s0 + s) + 1) * 64];
+    wh[s] = *reinterpret_cast<const f16x8*>(base + (off + (unsigned)((2 * (s0 + s)) * 64 * 16)));
+    wl[s] = *reinterpret_cast<const f16x8*>(base + (off + (unsigned)((2 * (s0 + s) + 1) * 64 * 16)));
   }
 }
 
@@ -155,9 +190,10 @@ __device__ __forceinline__ void gemm_tile(const _Float16* __restrict__ sH, const
 // [wave 4][t 16][lane 64] float4 = W[8 t + 4 (lane >> 5) + 0..3][32 wave + (lane & 31)]), unscaled.  1/16 of the f16 pipe's rate.
 template <int NTT>
 __device__ __forceinline__ void load_wexact(const float* __restrict__ Wp, int wave, int lane, float4 (&w)[NTT], int t0) {
-  const float4* __restrict__ src = reinterpret_cast<const float4*>(Wp) + (size_t)wave * (16 * 64) + lane;
+  const char* __restrict__ base = reinterpret_cast<const char*>(Wp);
+  const unsigned off = ((unsigned)wave * (16 * 64) + (unsigned)lane) * 16u;
 #pragma unroll
-  for (int t = 0; t < NTT; ++t) w[t] = src[(t0 + t) * 64];
+  for (int t = 0; t < NTT; ++t) w[t] = *reinterpret_cast<const float4*>(base + (off + (unsigned)((t0 + t) * 64 * 16)));
 }
 // acc[rt] (+)= X[rows][8 t0 .. 8 (t0 + NTT)) . W[same k][32 wave .. +32); sX points at the tile's first row, column 8 t0
 template <int NTT, bool FIRST, int RT>
@@ -187,6 +223,13 @@ __device__ __forceinline__ void load_whalf(WRegs<EX>& w, const _Float16* __restr
     if (half == 0) load_wexact<8>(reinterpret_cast<const float*>(W), wave, lane, w.A, 0);
     else load_wexact<8>(reinterpret_cast<const float*>(W), wave, lane, w.B, 8);
   } else {
+#ifdef SCANN_DIAG_HALFW  // diagnostic (wrong results): half the weight bytes -- how much of the kernels' time is weight streaming?
+    if (half == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { w.hB[i] = w.hA[i]; w.lB[i] = w.lA[i]; }
+      return;
+    }
+#endif
     if (half == 0) load_wsplit<4, 8>(W, wave, lane, w.hA, w.lA, 0);
     else load_wsplit<4, 8>(W, wave, lane, w.hB, w.lB, 4);
   }

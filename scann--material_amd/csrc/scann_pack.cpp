@@ -200,6 +200,57 @@ void plan_streamed_subset(const int32_t* mol_offset, const int32_t* edge_offset,
   *n_slot_out = n_slot;
 }
 
+
+void plan_layer_fusion(const std::vector<EdgeTile>& tiles, int delay, LayerPlan& plan) {
+  plan.work.clear(); plan.row_tab.clear(); plan.e_atile.clear(); plan.a_need.clear();
+  const int n_e = (int)tiles.size();
+  if (n_e == 0) return;
+  plan.e_atile.assign((size_t)2 * n_e, 0);
+  const int q = n_e >> 3, r = n_e & 7;
+  std::vector<std::vector<int32_t>> seq(8);  // per XCD: items (kind << 30 | index), in dispatch order
+  for (int x = 0; x < 8; ++x) {
+    const int t0 = x * q + std::min(x, r), t1 = t0 + q + (x < r ? 1 : 0);  // this XCD's contiguous run of edge tiles
+    if (t1 <= t0) continue;
+    const int32_t a0 = tiles[t0].atom_begin, a1 = tiles[t1 - 1].atom_end;
+    // 64-row atom tiles over exactly these tiles' atoms; `last[j]` = the last edge tile (position in the run) that feeds atom tile j
+    const int j0 = (int)plan.a_need.size();
+    const int nj = (a1 - a0 + TA - 1) / TA;
+    for (int j = 0; j < nj; ++j) {
+      plan.row_tab.push_back(a0 + j * TA);
+      plan.row_tab.push_back(std::min<int32_t>(TA, a1 - (a0 + j * TA)));
+      plan.a_need.push_back(0);
+    }
+    std::vector<int> last(nj, -1);
+    for (int t = t0; t < t1; ++t) {
+      const EdgeTile& tl = tiles[t];
+      const int ja = (tl.atom_begin - a0) / TA, jb = tl.atom_end > tl.atom_begin ? (tl.atom_end - 1 - a0) / TA : ja;
+      plan.e_atile[2 * t] = j0 + ja;
+      plan.e_atile[2 * t + 1] = jb - ja + 1;
+      for (int j = ja; j <= jb; ++j) {
+        ++plan.a_need[j0 + j];
+        last[j] = t - t0;
+      }
+    }
+    // an atom tile goes `delay` items behind the last edge tile that feeds it (by then that tile has most likely finished), in atom
+    // order; what is left goes to the end of the list
+    int next = 0;
+    for (int i = 0; i < t1 - t0; ++i) {
+      seq[x].push_back(t0 + i);
+      while (next < nj && last[next] + delay <= i) seq[x].push_back((1 << 30) | (j0 + next++));
+    }
+    while (next < nj) seq[x].push_back((1 << 30) | (j0 + next++));
+  }
+  size_t longest = 0;
+  for (int x = 0; x < 8; ++x) longest = std::max(longest, seq[x].size());
+  plan.work.assign(longest * 8 * 2, -1);
+  for (int x = 0; x < 8; ++x)
+    for (size_t i = 0; i < seq[x].size(); ++i) {
+      const size_t b = i * 8 + x;
+      plan.work[2 * b] = seq[x][i] >> 30;
+      plan.work[2 * b + 1] = seq[x][i] & ((1 << 30) - 1);
+    }
+}
+
 }  // namespace scann
 
 extern "C" {
@@ -377,6 +428,37 @@ int scann_plan_groups(const scann_batch_t* b, int32_t tile_atoms, int32_t max_ti
     tiles_out[4 * t + 2] = plan.tiles[t].edge_begin; tiles_out[4 * t + 3] = plan.tiles[t].edge_end;
   }
   for (size_t k = 0; k < plan.streamed.size(); ++k) streamed_out[k] = plan.streamed[k];
+  return SCANN_OK;
+}
+
+int scann_plan_layer(const scann_batch_t* b, int32_t tile_atoms, int32_t delay, int32_t cap_blocks, int32_t cap_atiles, int32_t* work_out,
+                     int32_t* row_tab_out, int32_t* e_atile_out, int32_t* a_need_out, int32_t* n_blocks, int32_t* n_atiles, int32_t* n_etiles) {
+  if (!b || !n_blocks || !n_atiles || !n_etiles || !b->mol_offset || !b->edge_offset || (b->n_edge > 0 && !b->edge_col) || b->n_struct <= 0 ||
+      b->n_atom <= 0 || b->n_edge < 0 || tile_atoms <= 0 || tile_atoms > scann::TQ || delay < 0)
+    return pack_fail("scann_plan_layer: bad argument");
+  std::vector<scann::EdgeTile> tiles;
+  std::vector<int32_t> part, big, row;
+  int rows = 0;
+  int32_t maxdeg = 0, nslot = 0;
+  std::string err;
+  const int r = scann::plan_tiles(b->mol_offset, b->n_struct, b->edge_offset, b->edge_col, b->n_atom, b->n_edge, scann::TE_MAX, tile_atoms, true,
+                                  tiles, part, big, row, &rows, &maxdeg, &nslot, err, false);
+  if (r) {
+    t_pack_error = "scann_plan_layer: " + err;
+    return r;
+  }
+  if (!big.empty()) return pack_fail("scann_plan_layer: the batch has atoms with more than 64 neighbours (chunk tiles are merged by a launch of their own)");
+  scann::LayerPlan plan;
+  scann::plan_layer_fusion(tiles, delay, plan);
+  *n_blocks = (int32_t)plan.work.size() / 2;
+  *n_atiles = (int32_t)plan.a_need.size();
+  *n_etiles = (int32_t)tiles.size();
+  if (!work_out || !row_tab_out || !e_atile_out || !a_need_out) return SCANN_OK;
+  if (*n_blocks > cap_blocks || *n_atiles > cap_atiles) return pack_fail("scann_plan_layer: output capacity too small");
+  memcpy(work_out, plan.work.data(), plan.work.size() * 4);
+  memcpy(row_tab_out, plan.row_tab.data(), plan.row_tab.size() * 4);
+  memcpy(e_atile_out, plan.e_atile.data(), plan.e_atile.size() * 4);
+  memcpy(a_need_out, plan.a_need.data(), plan.a_need.size() * 4);
   return SCANN_OK;
 }
 

@@ -125,6 +125,11 @@ struct scann_handle {
   // default: measured slower than the layer-streamed kernels, profiles/r04_notes.md): every structure stays on the layer-streamed
   // kernels (env SCANN_RESIDENT, scann_set_resident_limit)
   int sr_max_tiles = 0;
+  int fuse_layers = 0;         // env SCANN_FUSE_LAYERS=1 / scann_set_layer_fusion: the next iteration's atom tiles inside each edge launch
+                               // (scann_layer.hip; measured no faster than separate launches, profiles/r04_notes.md: off by default);
+                               // cleared for good when a layer launch reports a fault
+  int64_t fused_forwards = 0;  // forwards that went through layer launches
+  int fuse_fault = 0;          // the fault code that switched layer launches off (0: none)
   bool weights_exact = false;  // a loaded 128x128 kernel has |w| >= 255.9: the split-fp16 images cannot hold it, inference runs exact
   bool force_exact = false;    // env SCANN_EXACT=1: every inference forward on the exact-fp32 kernels (test / diagnosis switch)
   bool strict_range = false;   // env SCANN_STRICT_RANGE=1: SCANN_ERR_RANGE instead of the exact-fp32 re-run of an inference forward
@@ -222,6 +227,13 @@ struct scann_dbatch {
   int32_t *s2_tile_part = nullptr, *s2_big_tab = nullptr, *s2_row_tab = nullptr;
   float* s2_part_buf = nullptr;
   int32_t s2_n_tile = 0, s2_n_big = 0, s2_n_slot = 0, s2_n_row = 0;
+  // layer launches (scann_layer.hip): work list, atom tiles, dependency tables (inputs) and counters + the second half of the
+  // double-buffered atom rows (workspace); lf_n_block == 0: no plan (32-row tiles, chunk tiles, training handle, base branch)
+  int32_t *lf_work = nullptr, *lf_row_tab = nullptr, *lf_e_atile = nullptr, *lf_a_need = nullptr;
+  unsigned long long* lf_a_count = nullptr;
+  int32_t lf_n_block = 0, lf_n_atile = 0;
+  bool fused_run = false;  // the last forward went through layer launches (scann_batch_download checks their fault word)
+  float *c_b = nullptr, *P1_b = nullptr, *P3_b = nullptr, *q_b = nullptr;
   // workspace
   float *geom = nullptr, *gd = nullptr, *c = nullptr, *ctx = nullptr, *P1 = nullptr, *P3 = nullptr, *q = nullptr;
   float *gq = nullptr, *gk = nullptr, *ga = nullptr, *y = nullptr;
@@ -449,6 +461,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* fa = getenv("SCANN_TRAIN_FUSE_ATTN")) h->fuse_attn = atoi(fa) != 0;
   if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
   if (const char* sg = getenv("SCANN_STRICT_RANGE")) h->strict_range = atoi(sg) != 0;
+  if (const char* fl = getenv("SCANN_FUSE_LAYERS")) h->fuse_layers = atoi(fl) != 0;
   if (const char* fe = getenv("SCANN_EXACT")) h->force_exact = atoi(fe) != 0;
   if (const char* sr = getenv("SCANN_RESIDENT")) h->sr_max_tiles = std::min((int)SR_NT_BIG, std::max(0, atoi(sr)));
   {
@@ -460,11 +473,11 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
     delete h;
     return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipSetDevice failed");
   }
-  if (hipHostMalloc((void**)&h->range_flag, 64, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&h->range_flag, 128, hipHostMallocDefault) != hipSuccess) {  // [0, 16): range guard per stream; [16]: layer-launch fault
     delete h;
     return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipHostMalloc failed");
   }
-  for (int i = 0; i < MAX_STREAM; ++i) h->range_flag[i] = 0;  // 64 bytes: one word per stream slot
+  for (int i = 0; i < 32; ++i) h->range_flag[i] = 0;  // one range-guard word per stream slot, then the layer-launch fault word
   for (int i = 0; i < h->nstream; ++i) {
     if (hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking) != hipSuccess) {
       delete h;
@@ -903,6 +916,9 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     else if (!sr.streamed.empty())
       plan_streamed_subset(b->mol_offset, b->edge_offset, sr.streamed, h->tile_atoms, tiles2, tile_part2, big_tab2, &n_slot2, row_tab2);
   }
+  LayerPlan lplan;  // edge tiles + the next layer's atom tiles in one launch (64-row plans without chunk tiles, inference handles)
+  if (h->fuse_layers && h->cfg.g_update && E > 0 && !h->t_master && tile_rows == TE_MAX && n_big == 0 && !h->cfg.use_ring && !h->cfg.feature_cgcnn)
+    plan_layer_fusion(tiles, getenv("SCANN_LF_DELAY") ? atoi(getenv("SCANN_LF_DELAY")) : 400, lplan);
   const int32_t n_big2 = (int32_t)big_tab2.size() / 3;
   const size_t n_srg = sr.small.size() + sr.big.size();
   HIPCHK(h, hipSetDevice(h->device));
@@ -934,6 +950,8 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_srg = take(n_srg * sizeof(SrGroup)), o_srt = take(sr.tiles.size() * sizeof(EdgeTile));
   const size_t o_t2 = take(tiles2.size() * sizeof(EdgeTile)), o_tp2 = take(n_big2 ? tiles2.size() * 4 : 0), o_big2 = take((size_t)n_big2 * 3 * 4);
   const size_t o_row2 = take(row_tab2.size() * 4);
+  const size_t o_lfw = take(lplan.work.size() * 4), o_lfr = take(lplan.row_tab.size() * 4), o_lfe = take(lplan.e_atile.size() * 4);
+  const size_t o_lfn = take(lplan.a_need.size() * 4);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
   const size_t o_geom = take(h->cfg.g_update ? rowE : 0), o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
@@ -941,6 +959,9 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
   const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4), o_pbuf2 = take((size_t)n_slot2 * 3 * D * 4);
+  const bool lf = !lplan.work.empty();
+  const size_t o_lfc = take(lplan.a_need.size() * 8 * (size_t)std::max(1, h->cfg.n_attention));
+  const size_t o_cb = take(lf ? rowA : 0), o_P1b = take(lf ? rowA : 0), o_P3b = take(lf ? rowA : 0), o_qb = take(lf ? rowA : 0);
   hipError_t e = hipSuccess;
   scann_handle::Stage* stage = nullptr;
   char* img_ptr = nullptr;
@@ -1012,6 +1033,12 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     memcpy(img.data() + o_tpart, tile_part.data(), tiles.size() * 4);
     memcpy(img.data() + o_big, big_tab.data(), (size_t)n_big * 3 * 4);
   }
+  if (lf) {
+    memcpy(img.data() + o_lfw, lplan.work.data(), lplan.work.size() * 4);
+    memcpy(img.data() + o_lfr, lplan.row_tab.data(), lplan.row_tab.size() * 4);
+    memcpy(img.data() + o_lfe, lplan.e_atile.data(), lplan.e_atile.size() * 4);
+    memcpy(img.data() + o_lfn, lplan.a_need.data(), lplan.a_need.size() * 4);
+  }
   if (n_srg) {
     memcpy(img.data() + o_srg, sr.small.data(), sr.small.size() * sizeof(SrGroup));
     memcpy(img.data() + o_srg + sr.small.size() * sizeof(SrGroup), sr.big.data(), sr.big.size() * sizeof(SrGroup));
@@ -1059,6 +1086,12 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->ga = (float*)(a0 + o_ga); db->y = (float*)(a0 + o_y);
   if (n_big) {
     db->tile_part = (int32_t*)(a0 + o_tpart); db->big_tab = (int32_t*)(a0 + o_big); db->part_buf = (float*)(a0 + o_pbuf);
+  }
+  if (lf) {
+    db->lf_work = (int32_t*)(a0 + o_lfw); db->lf_row_tab = (int32_t*)(a0 + o_lfr); db->lf_e_atile = (int32_t*)(a0 + o_lfe);
+    db->lf_a_need = (int32_t*)(a0 + o_lfn); db->lf_a_count = (unsigned long long*)(a0 + o_lfc);
+    db->lf_n_block = (int32_t)lplan.work.size() / 2; db->lf_n_atile = (int32_t)lplan.a_need.size();
+    db->c_b = (float*)(a0 + o_cb); db->P1_b = (float*)(a0 + o_P1b); db->P3_b = (float*)(a0 + o_P3b); db->q_b = (float*)(a0 + o_qb);
   }
   if (n_srg) {
     db->sr_groups = (SrGroup*)(a0 + o_srg); db->sr_tiles = (EdgeTile*)(a0 + o_srt);
@@ -1115,6 +1148,7 @@ int ensure_debug(scann_handle* h, scann_dbatch* db) {
 int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, bool exact = false) {
   if ((h->force_exact || h->weights_exact) && !h->debug && !h->in_train_forward) exact = true;
   db->idle = false;  // work is being enqueued on the batch (scann_batch_release)
+  db->fused_run = false;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
   if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
   const scann_config_t& c = h->cfg;
@@ -1178,7 +1212,73 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     HIPCHK(h, hipStreamSynchronize(s));  // once per weight change: forwards on the handle's other streams read the tables too
     h->sp_dirty = false;
   }
-  for (int l = 0; l <= L && streamed_any; ++l) {
+  // Layer launches (scann_layer.hip): the atom tiles of layer l + 1 ride in layer l's edge launch behind per-XCD counters; the atom
+  // rows are double-buffered because edge tiles of the launch still gather the current ones.  Same bytes as the schedule below.
+  const bool fused = species0 && !resident && h->fuse_layers && db->lf_n_block > 0 && v_tile_rows == TE_MAX && !h->in_train_forward;
+  if (fused) {
+    HIPCHK(h, hipMemsetAsync(db->lf_a_count, 0, (size_t)L * db->lf_n_atile * 8, s));  // one counter word per layer and atom tile
+    float* const cS[2] = {db->c, db->c_b};
+    float* const p1S[2] = {db->P1, db->P1_b};
+    float* const p3S[2] = {db->P3, db->P3_b};
+    float* const qS[2] = {db->q, db->q_b};
+    for (int l = 0; l < L; ++l) {
+      const int in = l & 1, out = in ^ 1;
+      EdgeArgs ea{};
+      ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = 1; ea.tile_rows = TE_MAX;
+      ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
+      ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
+      ea.geom_dead = l == L - 1 ? 1 : 0;
+      ea.ctx = db->ctx;
+      if (l == 0) {
+        ea.fuse_basis = 1; ea.dist = db->dist; ea.basis = h->basis;
+        ea.species = db->atomic; ea.c = h->sp_c; ea.P1 = h->sp_P1; ea.P3 = h->sp_P3; ea.q = h->sp_q;
+      } else {
+        ea.c = cS[in]; ea.P1 = p1S[in]; ea.P3 = p3S[in]; ea.q = qS[in];
+      }
+      ea.p = h->layers[l];
+      ea.range_flag = rflag; ea.layer = l;
+      AtomArgs a{};  // head of layer l + 1: ResidualNorm of layer l, centres, projections of layer l + 1 (or the readout's rows)
+      a.n_atom = db->n_atom;
+      a.row_tab = db->lf_row_tab; a.n_row_tab = db->lf_n_atile;
+      a.x = db->ctx; a.ffn = c.use_attn_norm ? 1 : 0;
+      const LayerParams& pp = h->layers[l];
+      a.Wf1h = pp.Wf1h; a.bf1 = pp.bf1; a.Wf2h = pp.Wf2h; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
+      a.c = cS[out];
+      a.range_flag = rflag; a.layer = l + 1;
+      if (l + 1 < L) {
+        const LayerParams& p = h->layers[l + 1];
+        a.mode = 0;
+        a.WAh = p.W1h; a.bA = p.bg; a.WBh = p.W3h; a.WCh = p.Wqh; a.bC = p.bq;
+        a.oA = p1S[out]; a.oB = p3S[out]; a.oC = qS[out];
+      } else {
+        a.mode = 2;
+        a.WAh = h->head.Wah; a.bA = h->head.ba; a.WCh = h->head.Wgqh; a.bC = h->head.bgq; a.WDh = h->head.Wgkh; a.bD = h->head.bgk;
+        a.oB = db->gk; a.oC = db->gq;
+      }
+      LayerFuse f{};
+      f.work = reinterpret_cast<const int2*>(db->lf_work); f.n_block = db->lf_n_block;
+      f.e_atile = db->lf_e_atile; f.a_need = db->lf_a_need; f.a_count = db->lf_a_count + (size_t)l * db->lf_n_atile; f.fault = h->range_flag + 16;
+      // (scann_edge_timing: the sampled kernel is layer_kernel<false, ..., 0>, the launches of layers 1 .. L-2)
+      const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && l > 0 && l + 1 < L;
+      hipEvent_t ev0 = nullptr, ev1 = nullptr;
+      if (sample) {
+        (void)hipEventCreate(&ev0);
+        (void)hipEventCreate(&ev1);
+        (void)hipEventRecord(ev0, s);
+      }
+      launch_layer(ea, a, f, s);
+      if (sample) {
+        (void)hipEventRecord(ev1, s);
+        h->time_ev.push_back(ev0);
+        h->time_ev.push_back(ev1);
+        h->time_edges.push_back(db->n_edge);
+      }
+      if (tm) tm->mark(2);
+    }
+    db->fused_run = true;
+    h->fused_forwards++;
+  }
+  for (int l = 0; l <= L && streamed_any && !fused; ++l) {
     // training forward through edge_kernel_lean: q, V, T, ang, K of every layer are kept for the backward
     const bool keep = direct && h->in_train_forward && db->keep_K && l < L;
     // atom kernel at the head of layer l: ResidualNorm of layer l-1, centres, projections of layer l
@@ -1392,6 +1492,22 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
   // The forward's range guard fired: an activation left the range of the split-fp16 projections (sites 1-4).  The reference runs any
   // fp32 values (attention.py:95-113), so the forward is run again on the exact-fp32 instantiations (1/16 of the matrix rate, this
   // batch only) instead of handing an error back -- unless SCANN_STRICT_RANGE=1 asks for the error.
+  // A layer launch reported that its hand-off assumptions did not hold (a wait ran out, or workgroups were not dealt round-robin over
+  // the XCDs): layer launches are switched off on the handle for good and this batch goes through the unfused schedule.
+  if (db->fused_run && h->range_flag && *reinterpret_cast<volatile int32_t*>(h->range_flag + 16) != 0) {
+    if (h->fuse_layers) {
+      h->fuse_fault = h->range_flag[16];
+      h->fuse_layers = 0;
+      fprintf(stderr, "scann_hip: layer launches disabled on device %d (fault 0x%x: %s); using one launch per kernel\n", h->device, h->fuse_fault,
+              h->fuse_fault & 2 ? "an atom tile ran on another XCD than its edge tiles" : "a dependency wait ran out");
+    }
+    h->range_flag[db->last_slot] = 0;  // whatever the discarded pass flagged
+    const int r = run_forward(h, db, s, nullptr);
+    if (r) return r;
+    HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
+    if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+  }
   if (h->range_flag && !h->strict_range && !db->kept) {
     const int32_t code = *reinterpret_cast<volatile int32_t*>(h->range_flag + db->last_slot);
     const int site = code >> 8;
@@ -1410,6 +1526,17 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
 }
 
 int64_t scann_exact_reruns(const scann_handle_t* h) { return h ? h->exact_reruns : -1; }
+
+int scann_set_layer_fusion(scann_handle_t* h, int on) {
+  if (!h) return SCANN_ERR_INVALID;
+  if (on && h->fuse_fault) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_set_layer_fusion: layer launches faulted on this device");
+  h->fuse_layers = on ? 1 : 0;  // batches uploaded while it was off carry no plan: they keep the unfused schedule
+  return SCANN_OK;
+}
+
+int64_t scann_fused_forwards(const scann_handle_t* h) { return h ? h->fused_forwards : -1; }
+
+int scann_layer_fusion_state(const scann_handle_t* h) { return !h ? SCANN_ERR_INVALID : h->fuse_fault ? -(h->fuse_fault & 3) : h->fuse_layers; }
 
 int scann_sync(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;

@@ -99,8 +99,12 @@ SYMBOLS = [
     ("scann_slice_batch", C.c_int, [_P] * 8 + [C.c_int32, C.c_int64] + [_P] * 7),
     ("scann_plan_tiles", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("scann_plan_groups", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P] + [C.POINTER(C.c_int32)] * 4),
+    ("scann_plan_layer", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P] + [C.POINTER(C.c_int32)] * 3),
     ("scann_set_resident_limit", C.c_int, [_P, C.c_int]),
     ("scann_exact_reruns", C.c_int64, [_P]),
+    ("scann_set_layer_fusion", C.c_int, [_P, C.c_int]),
+    ("scann_layer_fusion_state", C.c_int, [_P]),
+    ("scann_fused_forwards", C.c_int64, [_P]),
     ("scann_batch_info", C.c_int, [_P, _P, _P]),
 ]
 
@@ -297,6 +301,22 @@ def plan_tiles(packed, tile_rows=64, tile_atoms=24, allow_chunks=True):
     return rc, tiles[:nt.value].copy(), part[:nt.value].copy(), ns.value
 
 
+def plan_layer(packed, tile_atoms=24, delay=96):
+    """The work list of a layer launch (csrc/scann_layer.hip) for `packed` (host only): dict with `work` [n_block,2] = kind (0 edge
+    tile, 1 atom tile, -1 nothing) and index, `row_tab` [n_atile,2], `e_atile` [n_etile,2], `a_need` [n_atile]."""
+    lib = load_library()
+    cap_b, cap_a = packed.n_atom + packed.n_edge // 16 + 64, packed.n_atom // 32 + 16
+    work, rows = np.empty((cap_b, 2), np.int32), np.empty((cap_a, 2), np.int32)
+    eat, need = np.empty((cap_b, 2), np.int32), np.empty(cap_a, np.int32)
+    nb, na, ne = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    st = packed.as_struct()
+    rc = lib.scann_plan_layer(C.byref(st), tile_atoms, delay, cap_b, cap_a, _ptr(work), _ptr(rows), _ptr(eat), _ptr(need),
+                              C.byref(nb), C.byref(na), C.byref(ne))
+    if rc < 0:
+        raise ScannHipError(rc, (lib.scann_pack_last_error() or b"").decode())
+    return {"work": work[:nb.value].copy(), "row_tab": rows[:na.value].copy(), "e_atile": eat[:ne.value].copy(), "a_need": need[:na.value].copy()}
+
+
 def plan_groups(packed, tile_atoms=24, max_tiles=6):
     """The structure-resident plan scann_batch_upload would build for `packed` (host only): dict with `small` / `big` groups
     [n,4] = atom_begin, atom_end, tile_begin, n_tile (<= 3 tiles / 4..6 tiles), `tiles` [n,4] and the `streamed` structure ids."""
@@ -464,6 +484,17 @@ class Engine:
     def exact_reruns(self):
         """forwards this handle has re-run on the exact-fp32 kernels because an activation left the split-fp16 range"""
         return int(self.lib.scann_exact_reruns(self._h))
+
+    def set_layer_fusion(self, on):
+        """atom tiles of the next iteration inside each edge launch (scann_layer.hip); applies to batches uploaded afterwards"""
+        self._check(self.lib.scann_set_layer_fusion(self._h, int(bool(on))))
+
+    def layer_fusion_state(self):
+        """1 on, 0 off, < 0: a layer launch faulted and the handle fell back to separate launches (-1 a wait ran out, -2 tiles on different XCDs)"""
+        return int(self.lib.scann_layer_fusion_state(self._h))
+
+    def fused_forwards(self):
+        return int(self.lib.scann_fused_forwards(self._h))
 
     def batch_info(self, rb):
         out = np.zeros(8, dtype=np.int32)

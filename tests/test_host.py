@@ -583,6 +583,63 @@ def test_structure_resident_group_plan(hip_lib):
         _hip.plan_groups(pk, max_tiles=0)
 
 
+def test_layer_launch_plan(hip_lib):
+    """scann_plan_layer (host only): the work list of a layer launch (csrc/scann_layer.hip).  Every edge tile and every atom tile is
+    there exactly once; workgroup b is item b >> 3 of XCD b & 7; an XCD's edge tiles are one contiguous run and its atom tiles cover
+    exactly that run's atoms (so producer and consumer of a context row share an L2); an atom tile's `need` is the number of edge
+    tiles whose atoms fall into it and those tiles all sit EARLIER in the same XCD's list (the waits cannot deadlock: workgroups are
+    dispatched in order), at least `delay` items earlier unless the list ran out."""
+    from scann import _hip
+
+    parts = []
+    for n, seed, kind in ((300, 31, "qm9"), (5, 32, "worst"), (20, 33, "mp2018")):
+        de, dn = so.synth_dataset(n, seed, kind)
+        parts.append(_hip.pack_inputs(so.pad_batch(de, dn, True)[0]))
+    lone = _hip.PackedBatch(np.full(3, 6), [0, 3], np.zeros(4, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0), np.zeros(0))  # no edges at all
+    for pk, delay in ((_hip.concat_packed(parts), 96), (_hip.concat_packed(parts + [lone]), 7), (parts[1], 96), (parts[0], 0)):
+        _, tiles, part, _ = _hip.plan_tiles(pk, 64, 24, False)
+        assert (part < 0).all()
+        pl = _hip.plan_layer(pk, 24, delay)
+        work, rows, eat, need = pl["work"], pl["row_tab"], pl["e_atile"], pl["a_need"]
+        assert len(work) % 8 == 0 and len(eat) == len(tiles)
+        for kind, n in ((0, len(tiles)), (1, len(rows))):
+            assert np.array_equal(np.sort(work[work[:, 0] == kind, 1]), np.arange(n))  # exactly once
+        assert set(np.unique(work[:, 0])) <= {-1, 0, 1}
+        covered = np.zeros(pk.n_atom, dtype=np.int64)
+        for r0, n in rows:
+            assert 1 <= n <= 64
+            covered[r0:r0 + n] += 1
+        assert (covered == 1).all()
+        fed = np.zeros(len(rows), dtype=np.int64)
+        for x in range(8):
+            lst = work[x::8]
+            lst = lst[lst[:, 0] >= 0]
+            et = lst[lst[:, 0] == 0, 1]
+            if len(et) == 0:
+                assert len(lst) == 0
+                continue
+            assert np.array_equal(et, np.arange(et[0], et[0] + len(et)))  # contiguous run, in order
+            at = lst[lst[:, 0] == 1, 1]
+            assert np.array_equal(at, np.arange(at[0], at[0] + len(at)))
+            assert rows[at[0], 0] == tiles[et[0], 0] and rows[at[-1], 0] + rows[at[-1], 1] == tiles[et[-1], 1]  # the same atoms
+            pos_e = {int(t): i for i, (k, t) in enumerate(lst) if k == 0}
+            pos_a = {int(j): i for i, (k, j) in enumerate(lst) if k == 1}
+            for t in et:
+                j0, nj = eat[t]
+                assert 1 <= nj <= 2
+                lo, hi = tiles[t, 0], tiles[t, 1]
+                for j in range(j0, j0 + nj):
+                    assert j in pos_a  # same XCD
+                    assert rows[j, 0] < hi and rows[j, 0] + rows[j, 1] > lo  # the tile's atoms do fall into atom tile j
+                    assert pos_a[j] > pos_e[int(t)]
+                    assert pos_a[j] - pos_e[int(t)] > delay or pos_a[j] >= len(et)  # `delay` items behind, or in the tail
+                    fed[j] += 1
+                assert rows[j0, 0] <= lo and rows[j0 + nj - 1, 0] + rows[j0 + nj - 1, 1] >= hi  # ... and nowhere else
+        assert np.array_equal(fed, need) and (need >= 1).all()
+    with pytest.raises(_hip.ScannHipError):
+        _hip.plan_layer(_hip.concat_packed([parts[0], lone]), 24, -1)
+
+
 def test_edge_tile_plan_invariants(hip_lib):
     """scann_plan_tiles (host only): the tile table scann_batch_upload builds.  Tiles partition atoms and edges in order,
     hold whole atoms within the edge / atom limits, atoms with more than 64 neighbours become single-atom chunk tiles with
