@@ -125,6 +125,7 @@ struct scann_handle {
   // default: measured slower than the layer-streamed kernels, profiles/r04_notes.md): every structure stays on the layer-streamed
   // kernels (env SCANN_RESIDENT, scann_set_resident_limit)
   int sr_max_tiles = 0;
+  int train_fork_every = 1;    // env SCANN_TRAIN_FORK_EVERY: LocalAttention layers per weight-gradient launch on the side stream
   int fuse_layers = 0;         // env SCANN_FUSE_LAYERS=1 / scann_set_layer_fusion: the next iteration's atom tiles inside each edge launch
                                // (scann_layer.hip; measured no faster than separate launches, profiles/r04_notes.md: off by default);
                                // cleared for good when a layer launch reports a fault
@@ -462,6 +463,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
   if (const char* sg = getenv("SCANN_STRICT_RANGE")) h->strict_range = atoi(sg) != 0;
   if (const char* fl = getenv("SCANN_FUSE_LAYERS")) h->fuse_layers = atoi(fl) != 0;
+  if (const char* fk = getenv("SCANN_TRAIN_FORK_EVERY")) h->train_fork_every = std::max(1, atoi(fk));
   if (const char* fe = getenv("SCANN_EXACT")) h->force_exact = atoi(fe) != 0;
   if (const char* sr = getenv("SCANN_RESIDENT")) h->sr_max_tiles = std::min((int)SR_NT_BIG, std::max(0, atoi(sr)));
   {
@@ -1354,8 +1356,11 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
     if (species0 && l == 0) { ea.species = db->atomic; ea.c = h->sp_c; ea.P1 = h->sp_P1; ea.P3 = h->sp_P3; ea.q = h->sp_q; }
     if (keep) {
-      ea.keep_V = db->keep_V + (size_t)l * nE_; ea.keep_T = db->keep_T + (size_t)l * nE_;
-      ea.keep_ang = db->keep_ang + (size_t)l * nE_; ea.keep_K = db->keep_K + (size_t)l * nE_;
+      ea.keep_V = db->keep_V + (size_t)l * nE_; ea.keep_K = db->keep_K + (size_t)l * nE_;
+      // T = swish(V) + G and ang = c[j] * G' are formed again where the fused backward needs them (edge_bwd_kernel, the key weight
+      // gradient's operand load): two of the six [n_edge,128] streams of the training forward's edge launch
+      if (db->keep_T) ea.keep_T = db->keep_T + (size_t)l * nE_;
+      if (db->keep_ang) ea.keep_ang = db->keep_ang + (size_t)l * nE_;
       db->kept = true;
     }
     ea.p = h->layers[l];
@@ -1727,9 +1732,12 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
                    (size_t)4 * D * Lc * (size_t)db->n_tile;  // attention + edge backward in one launch: four vectors, one slot per tile
   // the operands of a layer's weight gradients live until the end of the step (sets of their own per layer): the gradient launches on
   // the side stream never have to be waited for before a buffer is reused
+  // the modular backward (SCANN_TRAIN_FUSED=0) reads T and ang as tensors; the fused chains form them again
+  const bool keep_all = !h->train_fused || (getenv("SCANN_TRAIN_KEEP_ALL") && atoi(getenv("SCANN_TRAIN_KEEP_ALL")));
+  const size_t n_keepE = keep_all ? 4 : h->cfg.g_update ? 2 : 3;
   const size_t nTA = 5 + 5 * (Lc + 1), nTE = 4 + 2 * (Lc + 1);
   const size_t total = nTA * rowA + nTE * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
-                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + 4 * rowE) + 2 * rowA + align_up(w.wpart_floats * 4);
+                       align_up((size_t)h->cfg.n_atoms * D * 4) + 256 + Lk * (4 * rowA + n_keepE * rowE) + 2 * rowA + align_up(w.wpart_floats * 4);
   HIPCHK(h, cached_malloc((void**)&w.arena, total));
   char* p = w.arena;
   w.tA.assign(nTA, nullptr);
@@ -1746,8 +1754,12 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   if (Lk) {  // slices are [rows,128] without padding between layers: size them from the un-aligned row counts
     w.keep_q = (float*)p; p += Lk * rowA;
     w.keep_V = (float*)p; p += Lk * rowE;
-    w.keep_T = (float*)p; p += Lk * rowE;
-    w.keep_ang = (float*)p; p += Lk * rowE;
+    if (keep_all) {
+      w.keep_T = (float*)p; p += Lk * rowE;
+      w.keep_ang = (float*)p; p += Lk * rowE;
+    } else if (!h->cfg.g_update) {  // base branch: the gated rows feed edge_dang_kernel as they are
+      w.keep_ang = (float*)p; p += Lk * rowE;
+    }
     w.keep_K = (float*)p; p += Lk * rowE;
     w.keep_pre1 = (float*)p; p += Lk * rowA;
     w.keep_H1 = (float*)p; p += Lk * rowA;
@@ -1820,6 +1832,7 @@ int scann_train_begin(scann_handle_t* h) {
   }
   HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
   if (!h->train_aux && !getenv("SCANN_TRAIN_ONE_STREAM")) {
+    // (side streams created with the lowest priority changed nothing: 0.895 vs 0.895 ms per step, profiles/r04_notes.md)
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux2, hipStreamNonBlocking));
     h->train_ev.resize(128);
@@ -2003,6 +2016,9 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   };
   WgradCtx wg;
   wg.arena = w.wpart;
+  // a fork costs the main stream ~7 us (tools/fork_probe.hip): the layers' gradient launches may share one (their operand sets live
+  // to the end of the step)
+  const int fork_every = std::max(1, h->train_fork_every);
 
   // named temporaries
   float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4];
@@ -2092,10 +2108,10 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     const float* Gout = c.g_update ? db->dbg_g + (size_t)(l + 1) * nE : nullptr;  // geometry leaving layer l (= layer_norm_g output)
     // tensors the training forward kept (nothing is recomputed): q [A,128]; K, ang, V (base branch: geomL), T [E,128]
     const float* qL = db->keep_q + (size_t)l * nA;
-    const float* angL = db->keep_ang + (size_t)l * nE;
+    const float* angL = db->keep_ang ? db->keep_ang + (size_t)l * nE : nullptr;  // null: formed again from c[j] and G
     const float* KL = db->keep_K + (size_t)l * nE;
     const float* VL = db->keep_V + (size_t)l * nE;
-    const float* TL = db->keep_T + (size_t)l * nE;
+    const float* TL = db->keep_T ? db->keep_T + (size_t)l * nE : nullptr;        // null: formed again from V and G
 
     if (pend.n && !(fused && c.use_attn_norm)) flush_pend();  // nobody below folds the projections of the layer above in
     // ---- ResidualNorm backward (attention.py:37-40): c_{l+1} = LN(x + drop(W2 swish(W1 x + b1) + b2)), x = ctx ----
@@ -2136,7 +2152,8 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     if (!fuse_attn)
       launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A,
                       db->max_degree, w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
-    wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
+    if (angL) wgrad_add(wg, angL, edK, g(la + "key/kernel"), g(la + "key/bias"), E);
+    else wgrad_add(wg, c_in, edK, g(la + "key/kernel"), g(la + "key/bias"), E, db->edge_col, Gout);  // ang = c[j] * G'
     wgrad_add(wg, c_in, dQ, g(la + "query/kernel"), g(la + "query/bias"), A);
     if (!c.g_update) {
       // base SCANN (attention.py:155): geomL = swish(gd.Wf + bf) * weight from the raw basis (kept in the V slices), no geometry threading
@@ -2157,7 +2174,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     if (fused) {
       // one kernel: dang = dK.Wk^T -> dG'tot = dang * c[j] + dG'(next layer) -> LayerNorm_g backward -> dV = dT * swish'(V) -> dG = dT + dV.W2^T
       EdgeBwdArgs ea{};
-      ea.dK = edK; ea.c = c_in; ea.dG_in = dG_in; ea.T = TL; ea.V = VL; ea.gamma = p.lng_g; ea.nb = db->edge_col;
+      ea.dK = edK; ea.c = c_in; ea.dG_in = dG_in; ea.T = TL; ea.G = Gin; ea.V = VL; ea.gamma = p.lng_g; ea.nb = db->edge_col;
       ea.WkTh = pt.WkTh; ea.W2Th = pt.W2Th; ea.dang = edAng; ea.dV = eU; ea.dG = dGnext; ea.n_edge = E;
       if (fuse_attn) {
         AttnPart ab{};
@@ -2185,8 +2202,9 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     wgrad_add(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E);  // dW2
     wgrad_add(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), A);
     wgrad_add(wg, c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A);
-    {  // every weight gradient of this layer (ResidualNorm 2, key, query, filter_geo 3) in ONE launch, then the fixed-order sum of its
-       // partial slots (and of the layer's LayerNorm gamma / beta slots): both beside the chains of the layers below
+    if ((L - 1 - l) % fork_every == fork_every - 1 || l == 0) {
+      // every weight gradient of this layer (ResidualNorm 2, key, query, filter_geo 3) in ONE launch, then the fixed-order sum of its
+      // partial slots (and of the layer's LayerNorm gamma / beta slots): both beside the chains of the layers below
       hipStream_t ws = fork();
       wgrad_launch(wg, ws);
       if (side) wgrad_flush(wg, ws);

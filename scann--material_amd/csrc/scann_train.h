@@ -41,6 +41,8 @@ struct WgradCtx {
     const float *X, *dY;
     float *part, *bpart;
     int32_t rows, chunks;
+    const int32_t* nb = nullptr;  // gated operand: row r of the X operand is X[nb[r]] * X2[r] (ang = c[j] * G', attention.py:157,
+    const float* X2 = nullptr;    // which the training forward then does not have to keep)
   };
   std::vector<Job> jobs;                  // queued by wgrad_add, launched together by wgrad_launch
   float* arena = nullptr;                 // partial slots (device)
@@ -48,7 +50,8 @@ struct WgradCtx {
   std::vector<WgradReduceEntry> entries;  // one per gradient tensor since the last wgrad_flush
 };
 int wgrad_slabs(int rows);
-void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows);
+void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, const int32_t* nb = nullptr,
+               const float* X2 = nullptr);
 void wgrad_launch(WgradCtx& ctx, hipStream_t s);
 void wgrad_flush(WgradCtx& ctx, hipStream_t s);
 
@@ -98,6 +101,7 @@ struct RnBwdArgs {
 };
 struct EdgeBwdArgs {
   const float *dK, *c, *dG_in, *T, *V, *gamma;  // [n_edge,128] (c: [n_atom,128]; dG_in may be null), layer_norm_g gamma
+  const float* G;                               // T == null: T is recomputed as swish(V) + G from the geometry entering the layer
   const int* nb;                                // [n_edge] neighbour atom row
   const _Float16 *WkTh, *W2Th;                  // split-fp16 images of key^T, filter_geo (geometry third)^T
   float *dang, *dV, *dG;                        // out [n_edge,128]

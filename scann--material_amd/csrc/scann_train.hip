@@ -213,6 +213,8 @@ struct WgradSet {  // up to WGRAD_MAX_JOBS independent gradients in one launch (
   float* part[WGRAD_MAX_JOBS];   // [n_slab][128*128] partial sums of the job
   float* bpart[WGRAD_MAX_JOBS];  // [n_slab][128] bias partials or null
   int32_t rows[WGRAD_MAX_JOBS], chunks[WGRAD_MAX_JOBS];
+  const int32_t* nb[WGRAD_MAX_JOBS];  // gated X operand (WgradCtx::Job) or null
+  const float* X2[WGRAD_MAX_JOBS];
 };
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
   // blockIdx.y selects the job: all weight gradients of one LocalAttention / ResidualNorm layer go out in ONE launch.
@@ -227,6 +229,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
   if (blockIdx.x * 64 * chunks >= rows) return;  // jobs over fewer rows than the largest one
   const float* __restrict__ X = set.X[blockIdx.y];
   const float* __restrict__ dY = set.dY[blockIdx.y];
+  const int32_t* __restrict__ nb = set.nb[blockIdx.y];
+  const float* __restrict__ X2 = set.X2[blockIdx.y];
   float* __restrict__ part = set.part[blockIdx.y] + (size_t)blockIdx.x * D * D;
   float* __restrict__ bpart = set.bpart[blockIdx.y];
   __shared__ f16x8 sA[4][4][2][64];  // [k-step][feature tile][hi | lo][lane]: the chunk's X^T fragments (32 KB)
@@ -245,6 +249,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
   float xa[4][8], db[4][8];
   const unsigned voff = ((unsigned)(8 * kh) * D + col) * 4;  // byte offset of (row 8 kh, this lane's column) inside a k-step's 16 rows
   auto fetch_full = [&](int row0) {  // uniform base + one offset register + immediates (saddr form): no per-load address registers
+    if (nb) {  // gated operand: X[nb[r]] * X2[r], the product the forward formed (one rounding, never contracted)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int r0 = row0 + 16 * s2 + 8 * kh;
+        const int4 i0 = *reinterpret_cast<const int4*>(nb + r0), i1 = *reinterpret_cast<const int4*>(nb + r0 + 4);
+        const int idx[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+        const char* gs = reinterpret_cast<const char*>(X2 + (size_t)(row0 + 16 * s2) * D);
+        const char* ds = reinterpret_cast<const char*>(dY + (size_t)(row0 + 16 * s2) * D);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xa[s2][j] = __fmul_rn(X[(size_t)idx[j] * D + col], *reinterpret_cast<const float*>(gs + voff + j * D * 4));
+          db[s2][j] = *reinterpret_cast<const float*>(ds + voff + j * D * 4);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
       const char* xs = reinterpret_cast<const char*>(X + (size_t)(row0 + 16 * s2) * D);
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const size_t o = (size_t)(row0 + min(16 * s2 + 8 * kh + j, rem - 1)) * D + col;
-        xa[s2][j] = X[o];
+        xa[s2][j] = nb ? __fmul_rn(X[(size_t)nb[o / D] * D + col], X2[o]) : X[o];
         db[s2][j] = dY[o];
       }
     consume(rem, false, 0);
@@ -470,10 +490,11 @@ void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
 }
 
 // queue one gradient dW += X^T dY (db += column sums of dY when db) for the next wgrad_launch
-void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows) {
+void wgrad_add(WgradCtx& ctx, const float* X, const float* dY, float* dW, float* db, int rows, const int32_t* nb, const float* X2) {
   if (rows <= 0) return;
   WgradCtx::Job j{};
   j.X = X; j.dY = dY; j.rows = rows; j.chunks = wgrad_chunks(rows);
+  j.nb = nb; j.X2 = X2;
   const int n_slab = wgrad_slabs(rows);
   j.part = ctx.arena + ctx.off;
   ctx.entries.push_back(WgradReduceEntry{dW, j.part, n_slab, D * D});
@@ -494,6 +515,7 @@ void wgrad_launch(WgradCtx& ctx, hipStream_t s) {
     for (int k = 0; k < n; ++k) {
       const WgradCtx::Job& j = ctx.jobs[j0 + k];
       set.X[k] = j.X; set.dY[k] = j.dY; set.part[k] = j.part; set.bpart[k] = j.bpart; set.rows[k] = j.rows; set.chunks[k] = j.chunks;
+      set.nb[k] = j.nb; set.X2[k] = j.X2;
       max_slab = std::max(max_slab, wgrad_slabs(j.rows));
     }
     hipLaunchKernelGGL(wgrad_kernel, dim3(max_slab, n), dim3(256), 0, s, set);

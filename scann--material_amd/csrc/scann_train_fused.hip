@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256, RT == 2 ? 2 : 3) void edge_bwd_kernel(EdgeBwdA
       dy[rt][j] = lrow + 32 * rt >= nrows ? make_float4(0.f, 0.f, 0.f, 0.f)
                   : ATT ? *reinterpret_cast<const float4*>(&stageK[(lrow + 32 * rt) * STAGE_STRIDE + cbase + 8 * j])
                         : ld4(a.dK, off[rt] + 32 * j);
-      x[rt][j] = ld4(a.T, off[rt] + 32 * j);
+      // T = swish(V) + G (attention.py:150-152): read back, or formed again from V and the geometry that entered the layer -- the
+      // forward's own instruction (swish_plus), the same bits -- so that the training forward need not write it
+      x[rt][j] = a.T ? ld4(a.T, off[rt] + 32 * j) : f4swish_plus(ld4(a.V, off[rt] + 32 * j), ld4(a.G, off[rt] + 32 * j));
     }
   }
   put_rowmax<RT>(sMax[0], dy, lrow, lh, wave);
