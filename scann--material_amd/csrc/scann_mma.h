@@ -31,7 +31,17 @@ namespace scann {
       (buf)[(size_t)blockIdx.x * 16 + (slot)] = t_;                                            \
     }                                                                                         \
   } while (0)
+#define STAMP_HWID(buf, slot) /* where the workgroup runs: HW_ID (wave / SIMD / CU / SE) in the low word, XCC_ID in the high */ \
+  do {                                                                                        \
+    if ((buf) && threadIdx.x == 0) {                                                          \
+      unsigned hw_, xcc_;                                                                     \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                       \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                     \
+      (buf)[(size_t)blockIdx.x * 16 + (slot)] = ((unsigned long long)xcc_ << 32) | hw_;        \
+    }                                                                                         \
+  } while (0)
 #else
+#define STAMP_HWID(buf, slot) do {} while (0)
 #define STAMP(buf, slot) do {} while (0)
 #define STAMP_IF(buf, slot, cond) do {} while (0)
 #define STAMP_REAL(buf, slot) do {} while (0)

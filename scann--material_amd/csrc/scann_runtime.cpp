@@ -1385,7 +1385,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
       ea.attn_drop_tag = DROP_TAG_ATTN + (unsigned)l;
     }
 #ifdef SCANN_STAMPS
-    if (!getenv("SCANN_STAMP_ATOM")) {
+    if (!getenv("SCANN_STAMP_ATOM") && l == (getenv("SCANN_STAMP_LAYER") ? atoi(getenv("SCANN_STAMP_LAYER")) : L - 1)) {  // one launch's picture
       if (!db->stamps) HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_tile * 16 * sizeof(unsigned long long)));
       ea.stamps = db->stamps;
       db->n_stamp = db->n_tile;
