@@ -18,6 +18,7 @@
 //                   scann_model.py:437-447), one workgroup per structure (pair energies: exact-fp32 MFMA)
 //   basis_kernel  : Gaussian expansion + neighbor_d/neighbor_w MLP (custom_layers.py:63-65,
 //                   scann_model.py:378-389)
+#include <cstdlib>
 #include "scann_internal.h"
 #include "scann_mma.h"
 
@@ -53,7 +54,8 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
   // 32-row tiles (<= 128 VGPRs, 22 KB of LDS: four workgroups per CU = 1,024 slots) while they all fit ONE round of workgroups: the
   // launch is then the latency chain of a tile, and a 32-row tile's chain is shorter (one batch per launch: 490 k -> 568 k
   // molecules/s, training step 1.14 -> 1.09 ms).  Beyond that 64-row tiles (half the weight traffic per row).
-  const int rows = a.row_tab ? TA : a.n_atom <= 32 * 1024 ? 32 : 64;
+  static const int force_rows = getenv("SCANN_ATOM_ROWS") ? atoi(getenv("SCANN_ATOM_ROWS")) : 0;  // A/B switch (32 | 64)
+  const int rows = a.row_tab ? TA : force_rows == 32 || force_rows == 64 ? force_rows : a.n_atom <= 32 * 1024 ? 32 : 64;
   if (a.row_tab && a.n_row_tab <= 0) return;
   const dim3 grid(a.row_tab ? a.n_row_tab : (a.n_atom + rows - 1) / rows), block(256);
 #define SCANN_ATOM_CASE(F, M)                                                                  \
