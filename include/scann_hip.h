@@ -100,7 +100,11 @@ typedef struct scann_profile {
 int scann_abi_version(void);
 int scann_device_count(void);
 
-/* Replaces create_model(config) (scann_model.py:329). */
+/* Replaces create_model(config) (scann_model.py:329).  local_dim = global_dim = dense_out = 128 with num_head = 8 (every shipped
+ * reference yaml) runs on the split-fp16 MFMA kernels; any other widths the reference accepts (scann_model.py:330-434; here: each
+ * <= 1024, local_dim a multiple of num_head) evaluate on the plain-fp32 kernels of csrc/scann_generic.hip -- same entry points, same
+ * packed batch, inference only (scann_train_begin returns SCANN_ERR_UNSUPPORTED), about ten times slower at equal width.  Env
+ * SCANN_GENERIC=1 forces that path for a 128 / 8 handle (the cross-check of tests/test_gpu_parity.py). */
 int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out);
 void scann_destroy(scann_handle_t* h);
 const char* scann_last_error(const scann_handle_t* h); /* h may be NULL: last create error */

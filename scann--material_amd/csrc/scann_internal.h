@@ -268,6 +268,33 @@ struct LayerPlan {
 };
 void plan_layer_fusion(const std::vector<EdgeTile>& tiles, int delay, LayerPlan& plan);
 
+// ---- generic-width forward (scann_generic.hip): plain fp32 kernels for local_dim / num_head / global_dim / dense_out other than 128 / 8 ----
+struct GenSeg {
+  const float* p;      // [*, w] rows
+  const int32_t* idx;  // row r of the operand reads p[idx[r]] (null: p[r])
+  int32_t w;
+};
+struct GenDenseArgs {
+  GenSeg seg[3];
+  int32_t n_seg;  // x = concat of the segments' rows ...
+  int32_t prod;   // ... or (prod) the elementwise product of segments 0 and 1, both K wide
+  const float* W;  // [K, N] row-major (the Keras kernel)
+  const float* b;  // [N] or null
+  int32_t K, N, rows;
+  int32_t act;  // 0 none, 1 swish
+  const float* res;        // added after the activation: res[(res_idx ? res_idx[r] : r)][o]
+  const int32_t* res_idx;
+  const float* row_scale;  // [rows] or null: multiplied last
+  float* Y;                // [rows, N]
+};
+void launch_gen_dense(const GenDenseArgs& a, hipStream_t s);
+void launch_gen_layernorm(const float* X, const float* res, const float* gamma, const float* beta, int rows, int N, float* Y, hipStream_t s);
+void launch_gen_gauss(const float* x, const float* centres, int n, float* out, hipStream_t s);
+void launch_gen_mul(const float* a, const float* b, size_t n, float* out, hipStream_t s);
+void launch_gen_attn(const float* q, const float* K, const int32_t* edge_offset, int n_atom, int d, int H, int max_degree, float* ctx, hipStream_t s);
+void launch_gen_readout(const int32_t* mol_offset, int n_struct, int max_atoms, const float* gq, const float* gk, int dg, int dout, int use_ga_norm,
+                        int relu_out, const float* Wb, const float* bb, const float* wo, const float* bo, float* ga_attn, float* y, hipStream_t s);
+
 struct ReadoutArgs {
   const int32_t* mol_offset;  // [n_struct+1]
   int32_t n_struct;

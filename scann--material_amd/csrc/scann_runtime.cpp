@@ -125,6 +125,9 @@ struct scann_handle {
   // default: measured slower than the layer-streamed kernels, profiles/r04_notes.md): every structure stays on the layer-streamed
   // kernels (env SCANN_RESIDENT, scann_set_resident_limit)
   int sr_max_tiles = 0;
+  bool generic = false;        // widths other than 128 / 8: the plain-fp32 forward of scann_generic.hip (inference only)
+  float* g_weights = nullptr;  // generic: the flat fp32 parameter vector on the device (spec order, spec_off offsets)
+  float* g_centres = nullptr;  // generic: 20 + 20 Gaussian centres (distance, Voronoi weight)
   int train_fork_every = 1;    // env SCANN_TRAIN_FORK_EVERY: LocalAttention layers per weight-gradient launch on the side stream
   int fuse_layers = 0;         // env SCANN_FUSE_LAYERS=1 / scann_set_layer_fusion: the next iteration's atom tiles inside each edge launch
                                // (scann_layer.hip; measured no faster than separate launches, profiles/r04_notes.md: off by default);
@@ -233,6 +236,8 @@ struct scann_dbatch {
   int32_t *lf_work = nullptr, *lf_row_tab = nullptr, *lf_e_atile = nullptr, *lf_a_need = nullptr;
   unsigned long long* lf_a_count = nullptr;
   int32_t lf_n_block = 0, lf_n_atile = 0;
+  size_t gen_ws_bytes = 0;
+  char* gen_ws = nullptr;  // generic-width forward: its per-batch workspace (sized by the handle's widths; cached_malloc)
   bool fused_run = false;  // the last forward went through layer launches (scann_batch_download checks their fault word)
   float *c_b = nullptr, *P1_b = nullptr, *P3_b = nullptr, *q_b = nullptr;
   // workspace
@@ -441,12 +446,19 @@ const char* scann_last_error(const scann_handle_t* h) { return h ? h->err.c_str(
 int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out) {
   if (!cfg || !out) return fail(nullptr, SCANN_ERR_INVALID, "scann_create: null argument");
   *out = nullptr;
-  if (cfg->local_dim != D || cfg->global_dim != D || cfg->dense_out != D || cfg->num_head != NHEAD || cfg->n_gauss != NG)
-    return fail(nullptr, SCANN_ERR_UNSUPPORTED,
-                "scann_create: kernels implement local_dim = global_dim = dense_out = 128, num_head = 8, 20 Gaussians "
-                "(every shipped reference config)");
-  if (cfg->embedding_dim + (cfg->use_ring ? 10 : 0) > 160)
+  if (cfg->n_gauss != NG) return fail(nullptr, SCANN_ERR_UNSUPPORTED, "scann_create: 20 Gaussians (custom_layers.py:39-53 as called by scann_model.py:378,384)");
+  // every shipped reference config is 128 / 8 / 128 / 128: the MFMA kernels; any other widths the reference accepts
+  // (scann_model.py:330-434): the plain-fp32 forward of scann_generic.hip, inference only
+  const bool generic = cfg->local_dim != D || cfg->global_dim != D || cfg->dense_out != D || cfg->num_head != NHEAD ||
+                       (getenv("SCANN_GENERIC") && atoi(getenv("SCANN_GENERIC")));
+  if (generic) {
+    if (cfg->local_dim <= 0 || cfg->num_head <= 0 || cfg->global_dim <= 0 || cfg->dense_out <= 0 || cfg->local_dim % cfg->num_head != 0)
+      return fail(nullptr, SCANN_ERR_INVALID, "scann_create: local_dim must be a positive multiple of num_head (attention.py:170-173), global_dim and dense_out positive");
+    if (cfg->local_dim > 1024 || cfg->global_dim > 1024 || cfg->dense_out > 1024 || cfg->embedding_dim > 1024)
+      return fail(nullptr, SCANN_ERR_UNSUPPORTED, "scann_create: widths above 1024 are not implemented");
+  } else if (cfg->embedding_dim + (cfg->use_ring ? 10 : 0) > 160) {
     return fail(nullptr, SCANN_ERR_UNSUPPORTED, "scann_create: embedding_dim (+10 ring features) must be <= 160");
+  }
   if (cfg->n_atoms <= 0 || cfg->embedding_dim <= 0 || cfg->n_attention < 0 || !(cfg->gaussian_d > 0))
     return fail(nullptr, SCANN_ERR_INVALID, "scann_create: bad hyper-parameter");
   int ndev = 0;
@@ -455,6 +467,7 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, SCANN_ERR_NO_DEVICE, "scann_create: device_id out of range");
   scann_handle* h = new scann_handle();
   h->cfg = *cfg;
+  h->generic = generic;
   h->device = device_id;
   h->specs = build_specs(*cfg);
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
@@ -497,6 +510,8 @@ void scann_destroy(scann_handle_t* h) {
   for (int i = 0; i < MAX_STREAM; ++i)
     if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
   if (h->d_weights) (void)hipFree(h->d_weights);
+  if (h->g_weights) (void)hipFree(h->g_weights);
+  if (h->g_centres) (void)hipFree(h->g_centres);
   if (h->sp_c) (void)hipFree(h->sp_c);
   if (h->d_layers) (void)hipFree(h->d_layers);
   for (scann_handle::Stage& st : h->stage) {
@@ -518,6 +533,7 @@ void scann_destroy(scann_handle_t* h) {
   for (hipEvent_t e : h->train_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->time_ev) (void)hipEventDestroy(e);
   if (h->sc_db) {
+    cached_free(h->sc_db->gen_ws);
     cached_free(h->sc_db->dbg_c);
     cached_free(h->sc_db->dbg_g);
     cached_free(h->sc_db->dbg_ctx);
@@ -568,6 +584,23 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       h->spec_off.push_back((int64_t)off);
       off += (size_t)s.numel();
     }
+  }
+  if (h->generic) {  // the plain-fp32 forward reads the Keras tensors as they are
+    for (float v : h->host_master)
+      if (!std::isfinite(v)) return fail(h, SCANN_ERR_WEIGHTS, "scann_load_weights: a parameter is not finite");
+    if (h->g_weights) (void)hipFree(h->g_weights);
+    h->g_weights = nullptr;
+    HIPCHK(h, hipMalloc((void**)&h->g_weights, h->host_master.size() * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->g_weights, h->host_master.data(), h->host_master.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!h->g_centres) {
+      float cen[2 * NG];
+      linspace20((double)h->cfg.gaussian_d, cen);
+      linspace20(M_PI * 2.0, cen + NG);
+      HIPCHK(h, hipMalloc((void**)&h->g_centres, sizeof(cen)));
+      HIPCHK(h, hipMemcpy(h->g_centres, cen, sizeof(cen), hipMemcpyHostToDevice));
+    }
+    h->loaded = true;
+    return SCANN_OK;
   }
   h->descs.clear();
   const float* const mbase = h->host_master.data();
@@ -819,6 +852,7 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
 
 int scann_set_debug(scann_handle_t* h, int on) {
   if (!h) return SCANN_ERR_INVALID;
+  if (on && h->generic) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_set_debug: per-layer intermediates exist for the 128-wide kernels only");
   h->debug = on != 0;
   return SCANN_OK;
 }
@@ -830,6 +864,7 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db) {
   if (h) (void)hipSetDevice(h->device);
   if (h) (void)hipDeviceSynchronize();
   if (db->arena && db->owns_arena) cached_free(db->arena);
+  cached_free(db->gen_ws);
   cached_free(db->dbg_c);
   cached_free(db->dbg_g);
   cached_free(db->dbg_ctx);
@@ -851,6 +886,7 @@ void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db) {
   }
   (void)hipSetDevice(h->device);
   if (db->arena && db->owns_arena) cached_free(db->arena);
+  cached_free(db->gen_ws);
   cached_free(db->dbg_c);
   cached_free(db->dbg_g);
   cached_free(db->dbg_ctx);
@@ -1145,6 +1181,101 @@ int ensure_debug(scann_handle* h, scann_dbatch* db) {
   return SCANN_OK;
 }
 
+int64_t spec_offset(const scann_handle* h, const std::string& name);  // (defined with the training code below)
+
+// create_model (scann_model.py:362-447) for a handle whose widths are not 128 / 8: one plain-fp32 kernel per formula
+// (scann_generic.hip) on the same packed batch.
+int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s) {
+  const scann_config_t& c = h->cfg;
+  const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
+  const int d = c.local_dim, dg = c.global_dim, dout = c.dense_out, H = c.num_head, emb = c.embedding_dim;
+  const int cin = emb + (c.use_ring ? 10 : 0);
+  if ((size_t)std::max(1, db->max_degree) * H * 4 > 60000 || ((size_t)db->max_atoms + dg + dout + 4) * 4 > 60000 || (size_t)4 * 3 * d * 4 > 60000)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "forward (generic widths): an atom's neighbours x heads, or a structure's atoms, exceed one workgroup's LDS");
+  auto W = [&](const std::string& name) -> const float* { return h->g_weights + spec_offset(h, name); };
+  // workspace: atom rows, edge rows, Gaussian bases
+  const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1);
+  const size_t need = 4 * (fA * (5 * (size_t)d + (size_t)cin + (size_t)emb + 10 + 3 * (size_t)dg) + fE * (3 * (size_t)d + 2 * NG)) + 4096;
+  if (db->gen_ws_bytes < need) {
+    HIPCHK(h, hipStreamSynchronize(s));
+    cached_free(db->gen_ws);
+    db->gen_ws = nullptr;
+    db->gen_ws_bytes = 0;
+    HIPCHK(h, cached_malloc((void**)&db->gen_ws, need));
+    db->gen_ws_bytes = need;
+  }
+  float* p = reinterpret_cast<float*>(db->gen_ws);
+  auto take = [&](size_t n) { float* q = p; p += (n + 63) & ~(size_t)63; return q; };
+  float *cc = take(fA * d), *ctx = take(fA * d), *t1 = take(fA * d), *t2 = take(fA * d), *q = take(fA * d);
+  float *embE = take(fA * emb), *ring10 = take(fA * 10);
+  float *z = take(fA * dg), *gq = take(fA * dg), *gk = take(fA * dg);
+  float *G = take(fE * d), *T = take(fE * d), *K = take(fE * d), *gd = take(fE * NG), *gw = take(fE * NG);
+  (void)cin;
+  auto dense = [&](GenSeg s0, GenSeg s1, GenSeg s2, int n_seg, int prod, const std::string& name, int K_, int N_, int rows, int act,
+                   const float* res, const float* row_scale, float* Y) {
+    GenDenseArgs a{};
+    a.seg[0] = s0; a.seg[1] = s1; a.seg[2] = s2; a.n_seg = n_seg; a.prod = prod;
+    a.W = W(name + "/kernel"); a.b = W(name + "/bias"); a.K = K_; a.N = N_; a.rows = rows; a.act = act;
+    a.res = res; a.res_idx = nullptr; a.row_scale = row_scale; a.Y = Y;
+    launch_gen_dense(a, s);
+  };
+  const GenSeg none{nullptr, nullptr, 0};
+  // ---- embedding (scann_model.py:362-374) ----
+  GenSeg e0;
+  if (c.feature_cgcnn) {
+    dense(GenSeg{db->cgcnn, nullptr, 92}, none, none, 1, 0, "embed_atom", 92, emb, A, 0, nullptr, nullptr, embE);
+    e0 = GenSeg{embE, nullptr, emb};
+  } else {
+    e0 = GenSeg{W("embed_atom/embeddings"), db->atomic, emb};
+  }
+  if (c.use_ring) {
+    dense(GenSeg{db->ring, nullptr, 2}, none, none, 1, 0, "extra_embed", 2, 10, A, 0, nullptr, nullptr, ring10);
+    dense(e0, GenSeg{ring10, nullptr, 10}, none, 2, 0, "dense_embed", emb + 10, d, A, 1, nullptr, nullptr, cc);
+  } else {
+    dense(e0, none, none, 1, 0, "dense_embed", emb, d, A, 1, nullptr, nullptr, cc);
+  }
+  // ---- Gaussian bases and the initial geometry (scann_model.py:376-391) ----
+  launch_gen_gauss(db->dist, h->g_centres, E, gd, s);
+  if (c.g_update) {
+    launch_gen_gauss(db->weight, h->g_centres + NG, E, gw, s);
+    dense(GenSeg{gd, nullptr, NG}, none, none, 1, 0, "neighbor_d", NG, d, E, 1, nullptr, nullptr, T);
+    dense(GenSeg{gw, nullptr, NG}, none, none, 1, 0, "neighbor_w", NG, d, E, 1, nullptr, nullptr, K);
+    launch_gen_mul(T, K, (size_t)E * d, G, s);
+  }
+  // ---- LocalAttention iterations (scann_model.py:413-421; attention.py:118-216, :37-40) ----
+  for (int l = 0; l < L; ++l) {
+    const std::string la = "local_attention_" + std::to_string(l), rn = "residual_norm_" + std::to_string(l);
+    const float* geomL;
+    if (c.g_update) {
+      dense(GenSeg{cc, db->edge_row, d}, GenSeg{G, nullptr, d}, GenSeg{cc, db->edge_col, d}, 3, 0, la + "/filter_geo", 3 * d, d, E, 1, G, nullptr, T);
+      launch_gen_layernorm(T, nullptr, W(la + "/layer_norm_g/gamma"), W(la + "/layer_norm_g/beta"), E, d, G, s);
+      geomL = G;
+    } else {
+      dense(GenSeg{gd, nullptr, NG}, none, none, 1, 0, la + "/filter_geo", NG, d, E, 1, nullptr, db->weight, T);
+      geomL = T;
+    }
+    dense(GenSeg{cc, db->edge_col, d}, GenSeg{geomL, nullptr, d}, none, 2, 1, la + "/key", d, d, E, 0, nullptr, nullptr, K);
+    dense(GenSeg{cc, nullptr, d}, none, none, 1, 0, la + "/query", d, d, A, 0, nullptr, nullptr, q);
+    launch_gen_attn(q, K, db->edge_offset, A, d, H, db->max_degree, t1, s);
+    launch_gen_layernorm(t1, nullptr, W(la + "/layer_norm/gamma"), W(la + "/layer_norm/beta"), A, d, ctx, s);
+    if (c.use_attn_norm) {
+      dense(GenSeg{ctx, nullptr, d}, none, none, 1, 0, rn + "/dense_1", d, d, A, 1, nullptr, nullptr, t1);
+      dense(GenSeg{t1, nullptr, d}, none, none, 1, 0, rn + "/dense_2", d, d, A, 0, nullptr, nullptr, t2);
+      launch_gen_layernorm(ctx, t2, W(rn + "/layer_norm/gamma"), W(rn + "/layer_norm/beta"), A, d, cc, s);
+    } else {
+      std::swap(cc, ctx);
+    }
+  }
+  // ---- readout (scann_model.py:424-447; attention.py:267-318) ----
+  dense(GenSeg{cc, nullptr, d}, none, none, 1, 0, "after_Lc", d, dg, A, 1, nullptr, nullptr, z);
+  dense(GenSeg{z, nullptr, dg}, none, none, 1, 0, "global_attention/query", dg, dg, A, 0, nullptr, nullptr, gq);
+  dense(GenSeg{z, nullptr, dg}, none, none, 1, 0, "global_attention/key", dg, dg, A, 0, nullptr, nullptr, gk);
+  launch_gen_readout(db->mol_offset, B, db->max_atoms, gq, gk, dg, dout, c.use_ga_norm, c.relu_out, W("bf_property/kernel"), W("bf_property/bias"),
+                     W("predict_property/kernel"), W("predict_property/bias"), db->ga, db->y, s);
+  HIPCHK(h, hipGetLastError());
+  return SCANN_OK;
+}
+
 // The forward graph of create_model (scann_model.py:362-447) as a launch schedule on one stream.
 // kind codes for the timer: 0 basis, 1 atom, 2 edge, 3 readout.
 int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, bool exact = false) {
@@ -1153,6 +1284,12 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
   db->fused_run = false;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
   if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
+  if (h->generic) {
+    if (tm) { tm->mark(-1); }
+    const int r = run_forward_generic(h, db, s);
+    if (tm) tm->mark(3);
+    return r;
+  }
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention;
   const size_t rowA = (size_t)db->n_atom * D * 4, rowE = (size_t)db->n_edge * D * 4;
@@ -1802,6 +1939,9 @@ int64_t scann_param_count(const scann_handle_t* h) {
 int scann_train_begin(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "scann_train_begin: weights not loaded");
+  if (h->generic)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: training is implemented for local_dim = global_dim = dense_out = 128, num_head = 8 "
+                                          "(every shipped reference config); other widths evaluate only");
   if (h->weights_exact)
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: a 128x128 kernel has |w| >= 255.9; the training kernels multiply in split-fp16 "
                                           "form only (inference of such a checkpoint runs on the exact-fp32 kernels)");

@@ -122,6 +122,87 @@ def test_ring_and_cgcnn_embeddings(hip_lib, ring, cgcnn):
     assert rel_err(y, y_ref) <= RTOL and rel_err(ga, ga_ref) <= RTOL
 
 
+@pytest.mark.parametrize("over", [
+    dict(local_dim=64, num_head=4, global_dim=96, dense_out=32),
+    dict(local_dim=192, num_head=6, global_dim=160, dense_out=200, n_attention=3),
+    dict(local_dim=48, num_head=48, global_dim=16, dense_out=8, g_update=False, use_attn_norm=False, use_ga_norm=False),
+    dict(local_dim=32, num_head=1, global_dim=300, dense_out=128, use_ring=True, n_attention=2),
+    dict(local_dim=128, num_head=16, global_dim=128, dense_out=128, n_attention=2),
+    dict(local_dim=96, num_head=8, global_dim=64, dense_out=64, feature="cgcnn", n_attention=2),
+], ids=["64x4", "192x6", "48x48_base_plain", "32x1_ring", "128x16", "96x8_cgcnn"])
+def test_widths_other_than_128_and_8_heads(hip_lib, over):
+    """scann_model.py:330-434 builds the graph for whatever local_dim / num_head / global_dim / dense_out the yaml holds (every
+    shipped one: 128 / 8 / 128 / 128, the MFMA kernels).  Any other widths run the plain-fp32 forward of csrc/scann_generic.hip:
+    same packed batch, same C ABI, fp32 products and sums; compared with the fp32 / fp64 restatements like the 128-wide kernels
+    (QM9-shaped and worst-case molecules, a structure with an atom without neighbours, and -- when GlobalAttention normalises --
+    the one-atom structure whose score is the reference's 0 / 0).  Training such a handle is refused, not faked."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    cfg["model"].update(over)
+    cfg["model"]["n_atoms"] = 100
+    ring, cg = bool(cfg["model"].get("use_ring")), cfg["model"].get("feature") == "cgcnn"
+    w = so.init_weights(cfg, 123, perturb=True)
+    de, dn = so.synth_dataset(9, 41, use_ring=ring)
+    de2, dn2 = so.synth_dataset(2, 42, "worst", use_ring=ring)
+    inputs, _ = so.pad_batch(list(de) + list(de2), list(dn) + list(dn2), True, use_ring=ring)
+    if cg:
+        table = np.random.default_rng(5).integers(0, 2, size=(101, 92)).astype("float32")
+        inputs["atomic"] = table[inputs["atomic"]]
+    model = HipModel(cfg, w, device=0, infer=True)
+    y, ga = model.predict(inputs)
+    y32, ga32 = so.forward(cfg, w, inputs, np.float32)
+    y64, ga64 = so.forward(cfg, w, inputs, np.float64)
+    assert rel_err(y, y64) <= max(RTOL, 2 * rel_err(y32, y64)), (rel_err(y, y64), rel_err(y32, y64))
+    assert rel_err(ga, ga64) <= max(RTOL, 2 * rel_err(ga32, ga64))
+    assert strict_rel_err(y, y32) <= 10 * RTOL
+    # the same structures through the resident-batch entry points, twice (the per-batch workspace is reused), and split in two
+    pk = _hip.pack_inputs(inputs)
+    rb = model.engine.upload(pk)
+    for slot in (0, 1):
+        model.engine.forward_resident(rb, slot)
+        y2, _ = model.engine.download(rb)
+        assert np.array_equal(np.asarray(y2).ravel(), np.asarray(y).ravel())
+    rb.free()
+    half = {k: v[:5] for k, v in inputs.items()}
+    yh, _ = model.predict(half)
+    assert np.array_equal(np.asarray(yh).ravel(), np.asarray(y).ravel()[:5])  # a structure's result does not depend on its batch
+    if not cg and not ring:  # packed edge cases: an atom without neighbours, a one-atom structure
+        lone = _hip.PackedBatch([6, 1, 8, 1], [0, 1, 4], [0, 0, 1, 2, 2], [2, 1], [1.1, 1.3], [0.9, 1.7])
+        rb = model.engine.upload(lone)
+        model.engine.forward_resident(rb, 0)
+        yl, gal = model.engine.download(rb)
+        rb.free()
+        if cfg["model"].get("use_ga_norm", True):
+            assert np.isnan(yl[0]) and np.isfinite(yl[1])
+        else:
+            assert np.all(np.isfinite(yl))
+        assert abs(float(np.sum(gal[1:])) - 1.0) < 1e-5
+    with pytest.raises(_hip.ScannHipError):
+        model.engine.train_begin()
+
+
+def test_plain_fp32_forward_cross_checks_the_mfma_kernels(hip_lib, monkeypatch):
+    """Two independent GPU implementations of the same graph: the split-fp16 MFMA kernels (csrc/scann_kernels.hip) and the plain-fp32
+    forward written for other widths (csrc/scann_generic.hip: scalar fmaf loops, no matrix instructions, no shared code beyond swish),
+    here forced onto the 128 / 8 QM9 and MP2018 configs with SCANN_GENERIC=1.  They must agree with each other as closely as each
+    agrees with the fp32 restatement (attention.py:118-216, :267-318; scann_model.py:362-447)."""
+    from scann.models.scann_model import HipModel
+
+    for name, kind, n in (("qm9", "qm9", 24), ("mp2018", "mp2018", 5)):
+        cfg, w, inputs, fast = make(name, n=n, seed=17, kind=kind)
+        y_fast, ga_fast = fast.predict(inputs)
+        monkeypatch.setenv("SCANN_GENERIC", "1")
+        plain = HipModel(cfg, w, device=0, infer=True)
+        monkeypatch.delenv("SCANN_GENERIC")
+        y_plain, ga_plain = plain.predict(inputs)
+        y32, ga32 = so.forward(cfg, w, inputs, np.float32)
+        assert rel_err(y_plain, y32) <= RTOL and rel_err(ga_plain, ga32) <= RTOL, name
+        assert rel_err(y_fast, y_plain) <= RTOL and rel_err(ga_fast, ga_plain) <= RTOL, (name, rel_err(y_fast, y_plain))
+        assert not np.array_equal(y_fast, y_plain)  # (they ARE different arithmetic)
+
+
 def test_keras_default_init_and_configs(hip_lib):
     """Keras-default weights (zero biases, unit gamma) and the other shipped architectures."""
     for name, kind, n in (("qm9", "qm9", 16), ("qm9_std", "qm9", 8), ("mp2018", "mp2018", 6)):

@@ -40,11 +40,15 @@ def test_unsupported_config_is_rejected(hip_lib):
     from scann import _hip
     from scann.models.scann_model import config_struct, normalize_config
 
-    cfg = normalize_config(so.default_config())
-    cfg["model"]["local_dim"] = 64
-    with pytest.raises(_hip.ScannHipError) as e:
-        _hip.Engine(config_struct(cfg))
-    assert e.value.code == -2
+    # (widths other than 128 / 8 are accepted since round 4 -- csrc/scann_generic.hip -- as long as the reference could build them)
+    for key, val, code in (("local_dim", 100, -1),   # not a multiple of num_head = 8: the reshape of attention.py:170-173 fails
+                           ("num_head", 0, -1), ("global_dim", 0, -1), ("dense_out", -3, -1),
+                           ("local_dim", 2048, -2), ("global_dim", 4096, -2)):  # beyond what the plain kernels stage in LDS
+        cfg = normalize_config(so.default_config())
+        cfg["model"][key] = val
+        with pytest.raises(_hip.ScannHipError) as e:
+            _hip.Engine(config_struct(cfg))
+        assert e.value.code == code, (key, val, e.value.code)
 
 
 def test_pack_inputs_matches_padded_semantics():

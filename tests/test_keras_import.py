@@ -261,7 +261,7 @@ def test_reference_checkpoint_maps_completely():
     assert rep["tensors"] == len(rep["names"]) and rep["parameters"] > 0
     cfg, w = load_keras_h5(REF_H5, _ref_config())
     assert cfg["model"]["use_ring"] == ("extra_embed/kernel" in w)
-    assert cfg["model"]["local_dim"] == 128 and cfg["model"]["num_head"] == 8, "outside what the kernels implement"
+    assert cfg["model"]["local_dim"] % cfg["model"]["num_head"] == 0  # (128 / 8: the MFMA kernels; anything else: csrc/scann_generic.hip)
 
 
 @pytest.mark.gpu
