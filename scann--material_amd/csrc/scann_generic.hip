@@ -19,8 +19,9 @@ namespace scann {
 
 namespace {
 
-constexpr int GR = 4;  // rows per workgroup of gen_dense_kernel: every weight element fetched serves four rows
-
+// GR rows per workgroup: every weight element fetched serves GR rows (8 while the staged rows fit 48 KB of LDS, else 4; a row's
+// sum over k is the same sequence either way)
+template <int GR>
 __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ float sX[];  // [GR][K]
@@ -239,7 +240,10 @@ __global__ __launch_bounds__(256) void gen_readout_kernel(const int32_t* __restr
 
 void launch_gen_dense(const GenDenseArgs& a, hipStream_t s) {
   if (a.rows <= 0) return;
-  hipLaunchKernelGGL(gen_dense_kernel, dim3((a.rows + GR - 1) / GR), dim3(256), (size_t)GR * a.K * sizeof(float), s, a);
+  if ((size_t)8 * a.K * sizeof(float) <= 48 * 1024)
+    hipLaunchKernelGGL(gen_dense_kernel<8>, dim3((a.rows + 7) / 8), dim3(256), (size_t)8 * a.K * sizeof(float), s, a);
+  else
+    hipLaunchKernelGGL(gen_dense_kernel<4>, dim3((a.rows + 3) / 4), dim3(256), (size_t)4 * a.K * sizeof(float), s, a);
 }
 void launch_gen_layernorm(const float* X, const float* res, const float* gamma, const float* beta, int rows, int N, float* Y, hipStream_t s) {
   if (rows <= 0) return;
