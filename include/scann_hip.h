@@ -151,6 +151,9 @@ int scann_set_resident_limit(scann_handle_t* h, int max_tiles);
  * tiles, edges and atoms of the <= 3-tile groups, edge tiles and rows per tile (32 | 64) of the whole-batch streamed plan }. */
 int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8);
 int scann_sync(scann_handle_t* h); /* all streams of the handle */
+/* hipMemGetInfo of the handle's device: what is left of the 288 GB for resident batches (the library keeps freed blocks in a
+ * per-device cache, so `free` does not rise when a batch is released; it must not FALL across repeated calls of one shape). */
+int scann_device_memory(scann_handle_t* h, int64_t* free_bytes, int64_t* total_bytes);
 /* Inference forwards whose range guard fired -- an activation left the range of the split-fp16 projections (|x| < 65504) -- are run
  * again by scann_batch_download / scann_forward on exact-fp32 matrix instructions (v_mfma_f32_32x32x2_f32, the arithmetic of the
  * reference's fp32 Dense layers, attention.py:95-113) instead of returning SCANN_ERR_RANGE; this counts them.  Env

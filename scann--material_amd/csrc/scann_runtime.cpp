@@ -970,7 +970,10 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     cached_free(db->dbg_ctx);
     if (db->stamps) (void)hipFree(db->stamps);
     free_train_ws(db);
+    char* const gen_ws = db->gen_ws;  // (the generic-width forward's workspace is kept across calls, like the arena below)
+    const size_t gen_ws_bytes = db->gen_ws_bytes;
     *db = scann_dbatch();
+    db->gen_ws = gen_ws; db->gen_ws_bytes = gen_ws_bytes;
     db->owns_arena = false;
   } else {
     db = new scann_dbatch();
@@ -1665,6 +1668,16 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
   }
   db->idle = true;
   return check_range(h, "scann_batch_download", db->last_slot);
+}
+
+int scann_device_memory(scann_handle_t* h, int64_t* free_bytes, int64_t* total_bytes) {
+  if (!h || !free_bytes || !total_bytes) return fail(h, SCANN_ERR_INVALID, "scann_device_memory: null argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  size_t f = 0, t = 0;
+  HIPCHK(h, hipMemGetInfo(&f, &t));
+  *free_bytes = (int64_t)f;
+  *total_bytes = (int64_t)t;
+  return SCANN_OK;
 }
 
 int64_t scann_exact_reruns(const scann_handle_t* h) { return h ? h->exact_reruns : -1; }

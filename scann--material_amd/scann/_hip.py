@@ -102,6 +102,7 @@ SYMBOLS = [
     ("scann_plan_layer", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P] + [C.POINTER(C.c_int32)] * 3),
     ("scann_set_resident_limit", C.c_int, [_P, C.c_int]),
     ("scann_exact_reruns", C.c_int64, [_P]),
+    ("scann_device_memory", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("scann_set_layer_fusion", C.c_int, [_P, C.c_int]),
     ("scann_layer_fusion_state", C.c_int, [_P]),
     ("scann_fused_forwards", C.c_int64, [_P]),
@@ -484,6 +485,12 @@ class Engine:
     def exact_reruns(self):
         """forwards this handle has re-run on the exact-fp32 kernels because an activation left the split-fp16 range"""
         return int(self.lib.scann_exact_reruns(self._h))
+
+    def device_memory(self):
+        """(free, total) bytes of the handle's device (hipMemGetInfo)"""
+        f, t = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.scann_device_memory(self._h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
 
     def set_layer_fusion(self, on):
         """atom tiles of the next iteration inside each edge launch (scann_layer.hip); applies to batches uploaded afterwards"""

@@ -203,6 +203,32 @@ def test_plain_fp32_forward_cross_checks_the_mfma_kernels(hip_lib, monkeypatch):
         assert not np.array_equal(y_fast, y_plain)  # (they ARE different arithmetic)
 
 
+@pytest.mark.parametrize("widths", ["128x8", "64x4"])
+def test_repeated_predicts_do_not_eat_device_memory(hip_lib, widths):
+    """The drop-in call in a loop (scann_model.py:315-319 as a user runs it): `predict` on batches of changing size, many times, on
+    one handle -- the MFMA kernels' and the plain-fp32 path's.  Per-call workspaces are reused or returned: after the first pass over
+    the sizes the device's free memory must not fall any further."""
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    if widths == "64x4":
+        cfg["model"].update(local_dim=64, num_head=4, global_dim=64, dense_out=64)
+    w = so.init_weights(cfg, 5, perturb=True)
+    model = HipModel(cfg, w, device=0, infer=True)
+    batches = []
+    for n, seed in ((6, 1), (40, 2), (17, 3), (64, 4)):
+        de, dn = so.synth_dataset(n, seed)
+        batches.append(so.pad_batch(de, dn, True)[0])
+    first = [model.predict(b)[0].copy() for b in batches]
+    free0, total = model.engine.device_memory()
+    assert 0 < free0 <= total
+    for rep in range(25):
+        for b, y0 in zip(batches, first):
+            assert np.array_equal(model.predict(b)[0], y0)
+    free1, _ = model.engine.device_memory()
+    assert free0 - free1 <= 32 << 20, (free0, free1)
+
+
 def test_keras_default_init_and_configs(hip_lib):
     """Keras-default weights (zero biases, unit gamma) and the other shipped architectures."""
     for name, kind, n in (("qm9", "qm9", 16), ("qm9_std", "qm9", 8), ("mp2018", "mp2018", 6)):
