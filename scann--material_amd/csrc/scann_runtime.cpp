@@ -1986,6 +1986,7 @@ int scann_train_begin(scann_handle_t* h) {
   HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
   if (!h->train_aux && !getenv("SCANN_TRAIN_ONE_STREAM")) {
     // (side streams created with the lowest priority changed nothing: 0.895 vs 0.895 ms per step, profiles/r04_notes.md)
+    // (and so did confining them to half / a quarter of the CUs with hipExtStreamCreateWithCUMask: 0.89-0.93 ms either way)
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux2, hipStreamNonBlocking));
     h->train_ev.resize(128);
