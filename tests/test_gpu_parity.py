@@ -183,6 +183,41 @@ def test_widths_other_than_128_and_8_heads(hip_lib, over):
         model.engine.train_begin()
 
 
+@pytest.mark.parametrize("over", [
+    dict(model=dict(g_update=False)),
+    dict(model=dict(use_attn_norm=False)),
+    dict(model=dict(use_ga_norm=False)),
+    dict(hyper=dict(target="e_b")),
+    dict(model=dict(g_update=False, use_attn_norm=False, use_ga_norm=False)),
+    dict(model=dict(n_attention=1)),
+    dict(model=dict(n_attention=0)),
+    dict(model=dict(use_ring=True)),
+], ids=["base", "no_attn_norm", "no_ga_norm", "e_b", "base_plain", "L1", "L0", "ring"])
+def test_every_branch_agrees_between_the_two_gpu_implementations(hip_lib, monkeypatch, over):
+    """Every architecture switch of create_model (scann_model.py:362-447) through BOTH GPU implementations -- the MFMA kernels and the
+    plain-fp32 forward (SCANN_GENERIC=1) -- on the same inputs: each within the fp32 restatement's own distance from the fp64
+    restatement, as in test_branches."""
+    from scann.models.scann_model import HipModel
+
+    ring = bool(over.get("model", {}).get("use_ring"))
+    cfg = so.default_config("qm9")
+    for k, v in over.items():
+        cfg[k].update(v)
+    w = so.init_weights(cfg, 31, perturb=True)
+    de, dn = so.synth_dataset(12, 7, use_ring=ring)
+    inputs, _ = so.pad_batch(de, dn, cfg["model"].get("g_update", True), use_ring=ring)
+    fast = HipModel(cfg, w, device=0, infer=True)
+    monkeypatch.setenv("SCANN_GENERIC", "1")
+    plain = HipModel(cfg, w, device=0, infer=True)
+    monkeypatch.delenv("SCANN_GENERIC")
+    y64, ga64 = so.forward(cfg, w, inputs, np.float64)
+    y32, ga32 = so.forward(cfg, w, inputs, np.float32)
+    for name, model in (("mfma", fast), ("plain", plain)):
+        y, ga = model.predict(inputs)
+        assert rel_err(y, y64) <= max(RTOL, 2 * rel_err(y32, y64)), name
+        assert rel_err(ga, ga64) <= max(RTOL, 2 * rel_err(ga32, ga64)), name
+
+
 def test_plain_fp32_forward_cross_checks_the_mfma_kernels(hip_lib, monkeypatch):
     """Two independent GPU implementations of the same graph: the split-fp16 MFMA kernels (csrc/scann_kernels.hip) and the plain-fp32
     forward written for other widths (csrc/scann_generic.hip: scalar fmaf loops, no matrix instructions, no shared code beyond swish),
