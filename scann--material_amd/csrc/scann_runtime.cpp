@@ -128,6 +128,7 @@ struct scann_handle {
   bool generic = false;        // widths other than 128 / 8: the plain-fp32 forward of scann_generic.hip (inference only)
   float* g_weights = nullptr;  // generic: the flat fp32 parameter vector on the device (spec order, spec_off offsets)
   float* g_centres = nullptr;  // generic: 20 + 20 Gaussian centres (distance, Voronoi weight)
+  std::map<std::string, int64_t> g_off;  // generic: tensor name -> offset in g_weights
   int train_fork_every = 1;    // env SCANN_TRAIN_FORK_EVERY: LocalAttention layers per weight-gradient launch on the side stream
   int fuse_layers = 0;         // env SCANN_FUSE_LAYERS=1 / scann_set_layer_fusion: the next iteration's atom tiles inside each edge launch
                                // (scann_layer.hip; measured no faster than separate launches, profiles/r04_notes.md: off by default);
@@ -599,6 +600,8 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
       HIPCHK(h, hipMalloc((void**)&h->g_centres, sizeof(cen)));
       HIPCHK(h, hipMemcpy(h->g_centres, cen, sizeof(cen), hipMemcpyHostToDevice));
     }
+    h->g_off.clear();
+    for (size_t i = 0; i < h->specs.size(); ++i) h->g_off[h->specs[i].name] = h->spec_off[i];
     h->loaded = true;
     return SCANN_OK;
   }
@@ -1184,8 +1187,6 @@ int ensure_debug(scann_handle* h, scann_dbatch* db) {
   return SCANN_OK;
 }
 
-int64_t spec_offset(const scann_handle* h, const std::string& name);  // (defined with the training code below)
-
 // create_model (scann_model.py:362-447) for a handle whose widths are not 128 / 8: one plain-fp32 kernel per formula
 // (scann_generic.hip) on the same packed batch.
 int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s) {
@@ -1195,7 +1196,7 @@ int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s) {
   const int cin = emb + (c.use_ring ? 10 : 0);
   if ((size_t)std::max(1, db->max_degree) * H * 4 > 60000 || ((size_t)db->max_atoms + dg + dout + 4) * 4 > 60000 || (size_t)4 * 3 * d * 4 > 60000)
     return fail(h, SCANN_ERR_UNSUPPORTED, "forward (generic widths): an atom's neighbours x heads, or a structure's atoms, exceed one workgroup's LDS");
-  auto W = [&](const std::string& name) -> const float* { return h->g_weights + spec_offset(h, name); };
+  auto W = [&](const std::string& name) -> const float* { return h->g_weights + h->g_off.at(name); };
   // workspace: atom rows, edge rows, Gaussian bases
   const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1);
   const size_t need = 4 * (fA * (5 * (size_t)d + (size_t)cin + (size_t)emb + 10 + 3 * (size_t)dg) + fE * (3 * (size_t)d + 2 * NG)) + 4096;
