@@ -186,6 +186,10 @@ struct scann_handle {
   static constexpr int N_STAGE = 8;
   Stage stage[N_STAGE];
   int stage_next = 0;
+  // results come back through one pinned block per stream slot (one D2H for y and the GlobalAttention scores, which sit next to each
+  // other in the batch arena) instead of two staged copies into the caller's pageable arrays
+  struct DlStage { char* p = nullptr; size_t cap = 0; };
+  DlStage dl_stage[MAX_STREAM];
   hipStream_t copy_stream = nullptr;
   hipStream_t train_aux2 = nullptr;      // second side stream: the basis-MLP gradients beside the embedding chain
   bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
@@ -511,6 +515,8 @@ void scann_destroy(scann_handle_t* h) {
   for (int i = 0; i < MAX_STREAM; ++i)
     if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
   if (h->d_weights) (void)hipFree(h->d_weights);
+  for (scann_handle::DlStage& st : h->dl_stage)
+    if (st.p) (void)hipHostFree(st.p);
   if (h->g_weights) (void)hipFree(h->g_weights);
   if (h->g_centres) (void)hipFree(h->g_centres);
   if (h->sp_c) (void)hipFree(h->sp_c);
@@ -1628,13 +1634,38 @@ int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8)
   return SCANN_OK;
 }
 
+// y (and the GlobalAttention scores) of the batch's last forward -> the caller's arrays: one D2H into the slot's pinned block, then
+// plain memcpy (two hipMemcpyAsync into pageable numpy arrays were two staged copies: 23 us of a one-batch call's 280;
+// polling the stream before the blocking wait changed nothing: hipStreamSynchronize already spins for waits this short)
+static int fetch_results(scann_handle_t* h, scann_dbatch_t* db, hipStream_t s, float* y_out, float* ga_attn_out) {
+  const char* src = reinterpret_cast<const char*>(ga_attn_out ? db->ga : db->y);
+  const size_t y_off = (size_t)(reinterpret_cast<const char*>(db->y) - src);
+  const size_t bytes = y_off + (size_t)db->n_struct * 4;
+  scann_handle::DlStage& st = h->dl_stage[db->last_slot];
+  if (st.cap < bytes) {
+    if (st.p) {
+      HIPCHK(h, hipStreamSynchronize(s));
+      (void)hipHostFree(st.p);
+      st.p = nullptr;
+      st.cap = 0;
+    }
+    const size_t cap = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
+    HIPCHK(h, hipHostMalloc((void**)&st.p, cap, hipHostMallocDefault));
+    st.cap = cap;
+  }
+  HIPCHK(h, hipMemcpyAsync(st.p, src, bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  memcpy(y_out, st.p + y_off, (size_t)db->n_struct * 4);
+  if (ga_attn_out) memcpy(ga_attn_out, st.p, (size_t)db->n_atom * 4);
+  return SCANN_OK;
+}
+
 int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out) {
   if (!h || !db || !y_out) return fail(h, SCANN_ERR_INVALID, "scann_batch_download: null argument");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = h->streams[db->last_slot];
-  HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
-  if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
+  const int rf = fetch_results(h, db, s, y_out, ga_attn_out);
+  if (rf) return rf;
   // The forward's range guard fired: an activation left the range of the split-fp16 projections (sites 1-4).  The reference runs any
   // fp32 values (attention.py:95-113), so the forward is run again on the exact-fp32 instantiations (1/16 of the matrix rate, this
   // batch only) instead of handing an error back -- unless SCANN_STRICT_RANGE=1 asks for the error.
@@ -1650,9 +1681,8 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
     h->range_flag[db->last_slot] = 0;  // whatever the discarded pass flagged
     const int r = run_forward(h, db, s, nullptr);
     if (r) return r;
-    HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
-    if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
+    const int rf2 = fetch_results(h, db, s, y_out, ga_attn_out);
+    if (rf2) return rf2;
   }
   if (h->range_flag && !h->strict_range && !db->kept) {
     const int32_t code = *reinterpret_cast<volatile int32_t*>(h->range_flag + db->last_slot);
@@ -1662,9 +1692,8 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
       const int r = run_forward(h, db, s, nullptr, true);
       if (r) return r;
       h->exact_reruns++;
-      HIPCHK(h, hipMemcpyAsync(y_out, db->y, (size_t)db->n_struct * 4, hipMemcpyDeviceToHost, s));
-      if (ga_attn_out) HIPCHK(h, hipMemcpyAsync(ga_attn_out, db->ga, (size_t)db->n_atom * 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(h, hipStreamSynchronize(s));
+      const int rf3 = fetch_results(h, db, s, y_out, ga_attn_out);
+      if (rf3) return rf3;
     }
   }
   db->idle = true;
