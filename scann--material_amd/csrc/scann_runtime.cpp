@@ -188,6 +188,8 @@ struct scann_handle {
   int stage_next = 0;
   // results come back through one pinned block per stream slot (one D2H for y and the GlobalAttention scores, which sit next to each
   // other in the batch arena) instead of two staged copies into the caller's pageable arrays
+  struct PadScratch { std::vector<int32_t> gidx, at, mol, eoff, col; std::vector<float> dist, wgt, ga; };  // scann_forward_padded
+  PadScratch pad_scratch;
   struct DlStage { char* p = nullptr; size_t cap = 0; };
   DlStage dl_stage[MAX_STREAM];
   hipStream_t copy_stream = nullptr;
@@ -1747,8 +1749,15 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
     return fail(h, SCANN_ERR_INVALID, "scann_forward_padded: bad argument");
   if (h->cfg.use_ring || h->cfg.feature_cgcnn) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_forward_padded: atomic feature without ring only");
   const size_t BM = (size_t)B * M;
-  std::vector<int32_t> gidx(BM), at(BM), mol((size_t)B + 1), eoff(BM + 1), col(BM * N);
-  std::vector<float> dist(BM * N), wgt(BM * N);
+  // the handle's own packing buffers, grown when a call needs more: seven fresh vectors per call were 0.6 MB of mmap + page faults +
+  // zero fill at the reference's batch size -- a good part of what a one-batch call spends before the device can start
+  scann_handle::PadScratch& ps = h->pad_scratch;
+  auto grow_i = [](std::vector<int32_t>& v, size_t n) { if (v.size() < n) v.resize(n + n / 4); };
+  auto grow_f = [](std::vector<float>& v, size_t n) { if (v.size() < n) v.resize(n + n / 4); };
+  grow_i(ps.gidx, BM); grow_i(ps.at, BM); grow_i(ps.mol, (size_t)B + 1); grow_i(ps.eoff, BM + 1); grow_i(ps.col, BM * N + 1);
+  grow_f(ps.dist, BM * N + 1); grow_f(ps.wgt, BM * N + 1);
+  std::vector<int32_t>&gidx = ps.gidx, &at = ps.at, &mol = ps.mol, &eoff = ps.eoff, &col = ps.col;
+  std::vector<float>&dist = ps.dist, &wgt = ps.wgt;
   int32_t na = 0, ne = 0;
   if (scann_pack_padded(B, M, N, atomic, nullptr, atom_mask, neighbors, neighbor_mask, neighbor_weight, neighbor_distance,
                         nullptr, at.data(), nullptr, nullptr, mol.data(), eoff.data(), col.data(), dist.data(), wgt.data(),
@@ -1758,7 +1767,8 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
   pb.n_struct = B; pb.n_atom = na; pb.n_edge = ne;
   pb.atomic = at.data(); pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
   pb.edge_col = col.data(); pb.edge_dist = dist.data(); pb.edge_weight = wgt.data();
-  std::vector<float> ga_packed(ga_out ? (size_t)na : 0);
+  if (ga_out) grow_f(ps.ga, (size_t)na);
+  std::vector<float>& ga_packed = ps.ga;
   const int r = scann_forward(h, &pb, y_out, ga_out ? ga_packed.data() : nullptr);
   if (r) return r;
   if (ga_out)
