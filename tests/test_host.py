@@ -587,6 +587,64 @@ def test_structure_resident_group_plan(hip_lib):
         _hip.plan_groups(pk, max_tiles=0)
 
 
+def _device_kernels(so_path):
+    """{mangled kernel name: (scratch bytes per lane, VGPRs)} of every gfx950 code object inside a shared library: the .hip_fatbin
+    section holds one clang offload bundle per .hip source file; their ELF notes carry the kernel descriptors' metadata."""
+    import shutil
+    import tempfile
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM binutils not found")
+    tmp = tempfile.mkdtemp(prefix="scann_co_")
+    try:
+        fat = os.path.join(tmp, "fatbin")
+        subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, so_path])
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts, i = [], blob.find(magic)
+        while i >= 0:
+            starts.append(i)
+            i = blob.find(magic, i + 1)
+        out = {}
+        for k, a in enumerate(starts):
+            part, co = os.path.join(tmp, "b%d" % k), os.path.join(tmp, "c%d.co" % k)
+            open(part, "wb").write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + part, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            name = scratch = None
+            for line in subprocess.check_output([tools[2], "--notes", co], text=True).splitlines():
+                line = line.strip()
+                if line.startswith(".name:"):
+                    name = line.split()[-1]
+                elif line.startswith(".private_segment_fixed_size:"):
+                    scratch = int(line.split()[-1])
+                elif line.startswith(".vgpr_count:") and name is not None:
+                    out[name] = (scratch, int(line.split()[-1]))
+                    name = scratch = None
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_default_forward_kernels_use_no_scratch(hip_lib):
+    """The instantiations an inference forward of a shipped config launches -- atom_kernel<FFN, MODE, RT, exact = false>,
+    edge_kernel<GUPD, RT, FB, exact = false> -- must not spill: at 166-168 VGPRs one more live value sends a weight fragment to scratch
+    (measured: 8 bytes per lane cost the dominant kernel 1.5 us of 81), and a source change far from the spill can cause it (a branch
+    around a training-only store did, in round 4).  Read from the BUILT library's kernel descriptors, not from a compiler log."""
+    from scann import _hip
+
+    kern = _device_kernels(_hip.LIB_PATH)
+    checked = 0
+    for name, (scratch, vgpr) in kern.items():
+        default = (name.startswith("_ZN5scann11atom_kernelILb") or name.startswith("_ZN5scann11edge_kernelILb")) and "ELb0EEEv" in name
+        if default:
+            checked += 1
+            assert scratch == 0, (name, scratch, vgpr)
+            assert vgpr <= 168, (name, vgpr)  # three workgroups per CU (64-row tiles); the 32-row ones stay <= 128
+    assert checked >= 18, sorted(kern)[:5]  # 12 atom_kernel + 6 edge_kernel instantiations
+
+
 def test_layer_launch_plan(hip_lib):
     """scann_plan_layer (host only): the work list of a layer launch (csrc/scann_layer.hip).  Every edge tile and every atom tile is
     there exactly once; workgroup b is item b >> 3 of XCD b & 7; an XCD's edge tiles are one contiguous run and its atom tiles cover
