@@ -11,6 +11,7 @@
 #include <string>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "../../include/scann_hip.h"
@@ -269,42 +270,90 @@ int scann_pack_padded(int32_t B, int32_t M, int32_t N, const int32_t* atomic, co
     return pack_fail("scann_pack_padded: null argument or negative shape");
   if ((atomic && !out_atomic) || (cgcnn && !out_cgcnn) || (ring && !out_ring))
     return pack_fail("scann_pack_padded: an input is given without its output array");
-  // pass 1: packed row of every real atom (the job of gather_shape, custom_layers.py:18-28, moved to the host)
-  int64_t na = 0;
-  out_mol_offset[0] = 0;
-  for (int32_t b = 0; b < B; ++b) {
-    const uint8_t* am = atom_mask + (int64_t)b * M;
-    int32_t* ro = out_row_of + (int64_t)b * M;
-    const int64_t first = na;
-    for (int32_t a = 0; a < M; ++a) ro[a] = am[a] ? (int32_t)na++ : -1;
-    if (na == first) return pack_fail("a structure in the batch has no atoms");
-    if (na > INT32_MAX) return pack_fail("batch too large for int32 atom rows");
-    out_mol_offset[b + 1] = (int32_t)na;
+  // Structures are independent: ranges of them are counted (pass 1: real atoms, unmasked neighbour slots of real atoms), the counts
+  // are turned into each range's first atom row / first edge, and the ranges are filled (pass 2) -- by one thread for a batch, by up
+  // to 8 for the reference's `model.predict(whole padded dataset)` (130 k structures: 100 ms -> 15-20 ms of host time).  The output
+  // does not depend on the number of threads.
+  const int64_t BM = (int64_t)B * M;
+  int n_thr = 1;
+  if (B >= 2048) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    n_thr = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 8u), B / 1024);
+    if (const char* e = getenv("SCANN_PACK_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    n_thr = std::max(1, std::min<int>(n_thr, B));
   }
-  // pass 2: unmasked neighbour slots of real atoms, in slot order
-  int64_t ne = 0, row = 0;
-  out_edge_offset[0] = 0;
-  for (int32_t b = 0; b < B; ++b) {
-    const int32_t* ro = out_row_of + (int64_t)b * M;
-    for (int32_t a = 0; a < M; ++a) {
-      if (ro[a] < 0) continue;
-      const int64_t base = ((int64_t)b * M + a) * N;
-      for (int32_t n = 0; n < N; ++n) {
-        if (!neighbor_mask[base + n]) continue;
-        const int32_t t = neighbors[base + n];
-        if (t < 0 || t >= M || ro[t] < 0) return pack_fail("an unmasked neighbour slot points at a padded atom");
-        if (ne >= INT32_MAX) return pack_fail("batch too large for int32 edge rows");
-        out_edge_col[ne] = ro[t];
-        out_edge_dist[ne] = neighbor_distance[base + n];
-        out_edge_weight[ne] = neighbor_weight[base + n];
-        ++ne;
+  std::vector<int64_t> cnt_a((size_t)n_thr + 1, 0), cnt_e((size_t)n_thr + 1, 0);
+  std::vector<const char*> err((size_t)n_thr, nullptr);
+  auto range = [&](int t) { return std::make_pair((int32_t)((int64_t)B * t / n_thr), (int32_t)((int64_t)B * (t + 1) / n_thr)); };
+  auto run = [&](auto&& fn) {
+    if (n_thr == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (std::thread& x : th) x.join();
+  };
+  // pass 1: counts per range
+  run([&](int t) {
+    const auto [b0, b1] = range(t);
+    int64_t na_t = 0, ne_t = 0;
+    for (int32_t b = b0; b < b1; ++b) {
+      const uint8_t* am = atom_mask + (int64_t)b * M;
+      int64_t here = 0;
+      for (int32_t a = 0; a < M; ++a) {
+        if (!am[a]) continue;
+        ++here;
+        const uint8_t* nm = neighbor_mask + ((int64_t)b * M + a) * N;
+        for (int32_t n = 0; n < N; ++n) ne_t += nm[n] != 0;
       }
-      if (atomic) out_atomic[row] = atomic[(int64_t)b * M + a];
-      if (cgcnn) memcpy(out_cgcnn + row * 92, cgcnn + ((int64_t)b * M + a) * 92, 92 * sizeof(float));
-      if (ring) memcpy(out_ring + row * 2, ring + ((int64_t)b * M + a) * 2, 2 * sizeof(float));
-      out_edge_offset[++row] = (int32_t)ne;
+      if (here == 0) { err[t] = "a structure in the batch has no atoms"; return; }
+      na_t += here;
     }
+    cnt_a[t + 1] = na_t;
+    cnt_e[t + 1] = ne_t;
+  });
+  for (int t = 0; t < n_thr; ++t) {
+    if (err[t]) return pack_fail(err[t]);
+    cnt_a[t + 1] += cnt_a[t];
+    cnt_e[t + 1] += cnt_e[t];
   }
+  const int64_t na = cnt_a[n_thr], ne = cnt_e[n_thr];
+  if (na > INT32_MAX) return pack_fail("batch too large for int32 atom rows");
+  if (ne > INT32_MAX) return pack_fail("batch too large for int32 edge rows");
+  (void)BM;
+  // pass 2: packed row of every real atom (the job of gather_shape, custom_layers.py:18-28, moved to the host), then the unmasked
+  // neighbour slots of real atoms, in slot order
+  out_mol_offset[0] = 0;
+  out_edge_offset[0] = 0;
+  run([&](int t) {
+    const auto [b0, b1] = range(t);
+    int64_t row = cnt_a[t], e = cnt_e[t];
+    for (int32_t b = b0; b < b1; ++b) {
+      const uint8_t* am = atom_mask + (int64_t)b * M;
+      int32_t* ro = out_row_of + (int64_t)b * M;
+      int64_t r = row;
+      for (int32_t a = 0; a < M; ++a) ro[a] = am[a] ? (int32_t)r++ : -1;
+      for (int32_t a = 0; a < M; ++a) {
+        if (ro[a] < 0) continue;
+        const int64_t base = ((int64_t)b * M + a) * N;
+        for (int32_t n = 0; n < N; ++n) {
+          if (!neighbor_mask[base + n]) continue;
+          const int32_t tgt = neighbors[base + n];
+          if (tgt < 0 || tgt >= M || ro[tgt] < 0) { err[t] = "an unmasked neighbour slot points at a padded atom"; return; }
+          out_edge_col[e] = ro[tgt];
+          out_edge_dist[e] = neighbor_distance[base + n];
+          out_edge_weight[e] = neighbor_weight[base + n];
+          ++e;
+        }
+        if (atomic) out_atomic[row] = atomic[(int64_t)b * M + a];
+        if (cgcnn) memcpy(out_cgcnn + row * 92, cgcnn + ((int64_t)b * M + a) * 92, 92 * sizeof(float));
+        if (ring) memcpy(out_ring + row * 2, ring + ((int64_t)b * M + a) * 2, 2 * sizeof(float));
+        out_edge_offset[++row] = (int32_t)e;
+      }
+      out_mol_offset[b + 1] = (int32_t)row;
+    }
+  });
+  for (int t = 0; t < n_thr; ++t)
+    if (err[t]) return pack_fail(err[t]);
   *n_atom = (int32_t)na;
   *n_edge = (int32_t)ne;
   return SCANN_OK;

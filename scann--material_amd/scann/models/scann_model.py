@@ -127,6 +127,8 @@ class HipModel:
         """``model.predict(inputs)`` (scann_model.py:266,316): ``[B,1]`` or, in infer mode,
         ``[[B,1], [B,M,1]]``."""
         m = self.config["model"]
+        if not isinstance(inputs, _hip.PackedBatch) and len(inputs["atom_mask"]) >= self.BIG_PREDICT:
+            return self._predict_chunked(inputs)
         if not isinstance(inputs, _hip.PackedBatch) and m["feature"] == "atomic" and not m["use_ring"]:
             y, ga = self.engine.forward_padded(inputs, want_ga=self.infer)  # native CSR packing
             return [y.reshape(-1, 1), ga] if self.infer else y.reshape(-1, 1)
@@ -138,6 +140,28 @@ class HipModel:
         return y
 
     __call__ = predict
+
+    BIG_PREDICT = 8192   # structures from which `predict(padded arrays)` runs as a pipeline of chunks
+    PREDICT_CHUNK = 2048  # structures per chunk: one launch sequence each (16 batches of the reference's 128)
+
+    def _predict_chunked(self, inputs):
+        """`model.predict(x)` on a WHOLE padded dataset (what the reference's evaluate / predict scripts do with Keras, which batches
+        internally: scann_model.py:266,316): rows are cut into chunks -- views, nothing is copied -- and run through the
+        `predict_dataset` pipeline: a producer thread packs and uploads chunk k + 1 (native code, outside the GIL) while the device
+        runs chunk k.  One giant launch sequence would leave the device idle while the host packs 45 M neighbour slots and the host idle
+        while the device runs."""
+        B = len(inputs["atom_mask"])
+        C = self.PREDICT_CHUNK
+        zero = np.zeros(0, np.float32)
+        chunks = [({k: v[i:i + C] for k, v in inputs.items()}, zero) for i in range(0, B, C)]
+        y, ga, _ = self.predict_dataset(chunks, group=1, want_ga=self.infer)
+        y = y.reshape(-1, 1)
+        if not self.infer:
+            return y
+        amask = np.asarray(inputs["atom_mask"]).reshape(B, -1) != 0
+        ga_pad = np.zeros(amask.shape, dtype=np.float32)  # softmax of -1e9 -> 0 on padded atoms
+        ga_pad[amask] = ga  # packed rows are the real atoms in (structure, atom) order
+        return [y, ga_pad[..., None]]
 
     @staticmethod
     def default_group(dataset):

@@ -238,6 +238,31 @@ def test_plain_fp32_forward_cross_checks_the_mfma_kernels(hip_lib, monkeypatch):
         assert not np.array_equal(y_fast, y_plain)  # (they ARE different arithmetic)
 
 
+@pytest.mark.parametrize("infer", [True, False])
+def test_predict_on_a_whole_padded_dataset_runs_as_a_pipeline_of_chunks(hip_lib, monkeypatch, infer):
+    """`model.predict(x)` with x the WHOLE padded dataset (Keras batches internally; scann_model.py:266,316 are called that way by
+    evaluate / predict_model.py): above HipModel.BIG_PREDICT structures the rows are cut into chunks that a producer thread packs and
+    uploads while the device runs the previous one.  A structure's result does not depend on its batch, so the chunked call must
+    return the BYTES of the plain call -- y, and in infer mode the padded [B, M, 1] GlobalAttention scores with zeros on padding."""
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    w = so.init_weights(cfg, 9, perturb=True)
+    de, dn = so.synth_dataset(1100, 21)
+    inputs, _ = so.pad_batch(de, dn, True)
+    model = HipModel(cfg, w, device=0, infer=infer)
+    plain = model.predict(inputs)
+    monkeypatch.setattr(HipModel, "BIG_PREDICT", 1000)
+    monkeypatch.setattr(HipModel, "PREDICT_CHUNK", 300)  # 300 + 300 + 300 + 200
+    chunked = model.predict(inputs)
+    if infer:
+        assert chunked[0].shape == plain[0].shape == (1100, 1) and chunked[1].shape == plain[1].shape
+        assert np.array_equal(chunked[0], plain[0]) and np.array_equal(chunked[1], plain[1])
+        assert np.all(chunked[1][np.asarray(inputs["atom_mask"]) == 0] == 0)
+    else:
+        assert chunked.shape == plain.shape == (1100, 1) and np.array_equal(chunked, plain)
+
+
 @pytest.mark.parametrize("widths", ["128x8", "64x4"])
 def test_repeated_predicts_do_not_eat_device_memory(hip_lib, widths):
     """The drop-in call in a loop (scann_model.py:315-319 as a user runs it): `predict` on batches of changing size, many times, on

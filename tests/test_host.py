@@ -587,6 +587,47 @@ def test_structure_resident_group_plan(hip_lib):
         _hip.plan_groups(pk, max_tiles=0)
 
 
+def test_pack_padded_threads_give_the_single_thread_arrays(hip_lib, monkeypatch):
+    """scann_pack_padded splits a large padded batch (the reference's `model.predict(whole padded dataset)`, scann_model.py:315-319)
+    into ranges of structures packed by several threads: the packed arrays must be the ones a single thread writes, for thread counts
+    that do and do not divide the batch, and the two refusals (a structure without atoms, an unmasked slot pointing at a padded
+    atom) must still be found wherever they sit."""
+    from scann import _hip
+
+    rng = np.random.default_rng(11)
+    B, M, N = 3001, 9, 5
+    na = rng.integers(1, M + 1, size=B)
+    amask = np.arange(M)[None, :] < na[:, None]
+    deg = rng.integers(0, N + 1, size=(B, M))
+    nmask = (np.arange(N)[None, None, :] < deg[:, :, None]) & amask[:, :, None]
+    nbr = np.where(nmask, rng.integers(0, 1 << 20, size=(B, M, N)) % na[:, None, None], 0).astype(np.int32)
+    inputs = {"atomic": np.where(amask, rng.integers(1, 9, size=(B, M)), 0).astype(np.int32), "atom_mask": amask[..., None].astype(np.float32),
+              "neighbors": nbr, "neighbor_mask": nmask.astype(np.float32), "neighbor_weight": rng.random((B, M, N)).astype(np.float32),
+              "neighbor_distance": rng.random((B, M, N)).astype(np.float32)}
+    packs = {}
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("SCANN_PACK_THREADS", threads)
+        packs[threads] = _hip.pack_inputs(inputs)
+    ref = packs["1"]
+    assert ref.n_struct == B and ref.n_atom == int(amask.sum()) and ref.n_edge == int(nmask.sum())
+    for threads in ("2", "7"):
+        pk = packs[threads]
+        for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+            assert np.array_equal(getattr(pk, f), getattr(ref, f)), (threads, f)
+    monkeypatch.setenv("SCANN_PACK_THREADS", "4")
+    bad = dict(inputs)
+    bad["atom_mask"] = inputs["atom_mask"].copy()
+    bad["atom_mask"][2900] = 0  # a structure without atoms, in the last range
+    with pytest.raises(ValueError, match="no atoms"):
+        _hip.pack_inputs(bad)
+    bad = dict(inputs)
+    bad["neighbors"] = inputs["neighbors"].copy()
+    b = int(np.argmax((na < M) & (deg[:, 0] > 0)))
+    bad["neighbors"][b, 0, 0] = M - 1  # a padded atom of that structure
+    with pytest.raises(ValueError, match="padded atom"):
+        _hip.pack_inputs(bad)
+
+
 def _device_kernels(so_path):
     """{mangled kernel name: (scratch bytes per lane, VGPRs)} of every gfx950 code object inside a shared library: the .hip_fatbin
     section holds one clang offload bundle per .hip source file; their ELF notes carry the kernel descriptors' metadata."""
