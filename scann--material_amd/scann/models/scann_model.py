@@ -127,8 +127,11 @@ class HipModel:
         """``model.predict(inputs)`` (scann_model.py:266,316): ``[B,1]`` or, in infer mode,
         ``[[B,1], [B,M,1]]``."""
         m = self.config["model"]
-        if not isinstance(inputs, _hip.PackedBatch) and len(inputs["atom_mask"]) >= self.BIG_PREDICT:
-            return self._predict_chunked(inputs)
+        if not isinstance(inputs, _hip.PackedBatch):
+            nb = np.shape(inputs["neighbors"])
+            slots = int(nb[0]) * int(nb[1]) * max(1, int(nb[2]))  # padded neighbour slots >= edges; >= atoms
+            if nb[0] >= self.BIG_PREDICT or (slots > self.BIG_SLOTS and nb[0] > 1):
+                return self._predict_chunked(inputs)
         if not isinstance(inputs, _hip.PackedBatch) and m["feature"] == "atomic" and not m["use_ring"]:
             y, ga = self.engine.forward_padded(inputs, want_ga=self.infer)  # native CSR packing
             return [y.reshape(-1, 1), ga] if self.infer else y.reshape(-1, 1)
@@ -143,6 +146,7 @@ class HipModel:
 
     BIG_PREDICT = 8192   # structures from which `predict(padded arrays)` runs as a pipeline of chunks
     PREDICT_CHUNK = 2048  # structures per chunk: one launch sequence each (16 batches of the reference's 128)
+    BIG_SLOTS = 6_000_000  # ... or padded neighbour slots (a launch sequence takes < 8,388,608 atoms / edges: few but large crystals)
 
     def _predict_chunked(self, inputs):
         """`model.predict(x)` on a WHOLE padded dataset (what the reference's evaluate / predict scripts do with Keras, which batches
@@ -151,7 +155,8 @@ class HipModel:
         runs chunk k.  One giant launch sequence would leave the device idle while the host packs 45 M neighbour slots and the host idle
         while the device runs."""
         B = len(inputs["atom_mask"])
-        C = self.PREDICT_CHUNK
+        nb = np.shape(inputs["neighbors"])
+        C = max(1, min(self.PREDICT_CHUNK, (self.BIG_SLOTS * 2 // 3) // max(1, int(nb[1]) * max(1, int(nb[2])))))
         zero = np.zeros(0, np.float32)
         chunks = [({k: v[i:i + C] for k, v in inputs.items()}, zero) for i in range(0, B, C)]
         y, ga, _ = self.predict_dataset(chunks, group=1, want_ga=self.infer)

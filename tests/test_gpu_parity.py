@@ -255,6 +255,10 @@ def test_predict_on_a_whole_padded_dataset_runs_as_a_pipeline_of_chunks(hip_lib,
     monkeypatch.setattr(HipModel, "BIG_PREDICT", 1000)
     monkeypatch.setattr(HipModel, "PREDICT_CHUNK", 300)  # 300 + 300 + 300 + 200
     chunked = model.predict(inputs)
+    monkeypatch.setattr(HipModel, "BIG_PREDICT", 1 << 30)
+    monkeypatch.setattr(HipModel, "BIG_SLOTS", 60_000)  # ... and by padded size: few structures, many slots
+    by_slots = model.predict(inputs)
+    assert np.array_equal(by_slots[0] if infer else by_slots, plain[0] if infer else plain)
     if infer:
         assert chunked[0].shape == plain[0].shape == (1100, 1) and chunked[1].shape == plain[1].shape
         assert np.array_equal(chunked[0], plain[0]) and np.array_equal(chunked[1], plain[1])
