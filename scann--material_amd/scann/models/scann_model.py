@@ -144,28 +144,64 @@ class HipModel:
 
     __call__ = predict
 
-    BIG_PREDICT = 8192   # structures from which `predict(padded arrays)` runs as a pipeline of chunks
+    BIG_PREDICT = 1024   # structures from which `predict(padded arrays)` runs as a pipeline of chunks
     PREDICT_CHUNK = 2048  # structures per chunk: one launch sequence each (16 batches of the reference's 128)
     BIG_SLOTS = 6_000_000  # ... or padded neighbour slots (a launch sequence takes < 8,388,608 atoms / edges: few but large crystals)
 
     def _predict_chunked(self, inputs):
         """`model.predict(x)` on a WHOLE padded dataset (what the reference's evaluate / predict scripts do with Keras, which batches
-        internally: scann_model.py:266,316): rows are cut into chunks -- views, nothing is copied -- and run through the
-        `predict_dataset` pipeline: a producer thread packs and uploads chunk k + 1 (native code, outside the GIL) while the device
-        runs chunk k.  One giant launch sequence would leave the device idle while the host packs 45 M neighbour slots and the host idle
-        while the device runs."""
+        internally: scann_model.py:266,316): rows are cut into chunks -- views, nothing is copied -- and software-pipelined on this
+        thread: chunk k + 1 is packed and uploaded (host, native code) while the device runs chunk k (launches are asynchronous),
+        a rolling window of chunks stays in flight over the handle's streams, results are fetched oldest first.  One launch sequence
+        for everything would leave the device idle while the host packs 45 M neighbour slots, and the host idle afterwards."""
+        eng = self.engine
         B = len(inputs["atom_mask"])
         nb = np.shape(inputs["neighbors"])
-        C = max(1, min(self.PREDICT_CHUNK, (self.BIG_SLOTS * 2 // 3) // max(1, int(nb[1]) * max(1, int(nb[2])))))
-        zero = np.zeros(0, np.float32)
-        chunks = [({k: v[i:i + C] for k, v in inputs.items()}, zero) for i in range(0, B, C)]
-        y, ga, _ = self.predict_dataset(chunks, group=1, want_ga=self.infer)
-        y = y.reshape(-1, 1)
+        # at least four chunks (the first chunk's packing is the only host work the device waits for), at most PREDICT_CHUNK
+        # structures and BIG_SLOTS * 2 / 3 padded slots each
+        C = min(self.PREDICT_CHUNK, max(512, -(-B // 4 // 128) * 128))
+        C = max(1, min(C, (self.BIG_SLOTS * 2 // 3) // max(1, int(nb[1]) * max(1, int(nb[2])))))
+        ns = eng.num_streams()
+        window = 2 * ns
+        pending, ys, gas = [], [], []
+
+        def fetch_oldest():
+            rb = pending.pop(0)
+            try:
+                y, ga = eng.download(rb, want_ga=self.infer)
+            except BaseException:
+                rb.free()
+                raise
+            ys.append(y)
+            if self.infer:
+                gas.append(ga)
+            rb.release()
+
+        k = 0
+        try:
+            for i in range(0, B, C):
+                pk = _hip.pack_inputs({key: v[i:i + C] for key, v in inputs.items()})
+                rb = eng.upload(pk)
+                try:
+                    if len(pending) >= window:
+                        fetch_oldest()
+                    eng.forward_resident(rb, k % ns)
+                except BaseException:
+                    rb.free()
+                    raise
+                k += 1
+                pending.append(rb)
+            while pending:
+                fetch_oldest()
+        finally:
+            for rb in pending:
+                rb.free()
+        y = np.concatenate(ys).reshape(-1, 1)
         if not self.infer:
             return y
         amask = np.asarray(inputs["atom_mask"]).reshape(B, -1) != 0
         ga_pad = np.zeros(amask.shape, dtype=np.float32)  # softmax of -1e9 -> 0 on padded atoms
-        ga_pad[amask] = ga  # packed rows are the real atoms in (structure, atom) order
+        ga_pad[amask] = np.concatenate(gas)  # packed rows are the real atoms in (structure, atom) order
         return [y, ga_pad[..., None]]
 
     @staticmethod
