@@ -251,7 +251,8 @@ def test_predict_on_a_whole_padded_dataset_runs_as_a_pipeline_of_chunks(hip_lib,
     de, dn = so.synth_dataset(1100, 21)
     inputs, _ = so.pad_batch(de, dn, True)
     model = HipModel(cfg, w, device=0, infer=infer)
-    plain = model.predict(inputs)
+    monkeypatch.setattr(HipModel, "BIG_PREDICT", 1 << 30)
+    plain = model.predict(inputs)  # one launch sequence
     monkeypatch.setattr(HipModel, "BIG_PREDICT", 1000)
     monkeypatch.setattr(HipModel, "PREDICT_CHUNK", 300)  # 300 + 300 + 300 + 200
     chunked = model.predict(inputs)
