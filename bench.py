@@ -382,7 +382,49 @@ def one_batch_leg(cfg, batches, batch_size, seconds=0.5):
     return {"value": n1 * batch_size / dt, "unit": "molecules/s", "steps": n1, "streams": 1}
 
 
-LEGS = {"two_streams": two_stream_leg, "one_batch_per_launch": one_batch_leg, "end_to_end": end_to_end, "training_step": training_leg}
+def padded_predict_leg(cfg, batches, batch_size, seconds=1.0):
+    """The reference's literal call on a whole dataset: `model.predict(x)` with x the padded Keras input dict of ALL the leg's molecules
+    (128 batches: 16,384 structures, [B, M, N] neighbour slots) -- host packing (padded -> CSR), uploads, forwards, downloads and Python
+    included; HipModel.predict software-pipelines chunks of it."""
+    import numpy as np
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    pk = _hip.concat_packed(batches)
+    mol, eoff = np.asarray(pk.mol_offset, np.int64), np.asarray(pk.edge_offset, np.int64)
+    B, A, E = pk.n_struct, pk.n_atom, pk.n_edge
+    s_of_a = np.repeat(np.arange(B), np.diff(mol))
+    a_loc = np.arange(A) - mol[s_of_a]
+    a_of_e = np.repeat(np.arange(A), np.diff(eoff))
+    n_loc = np.arange(E) - eoff[a_of_e]
+    M, N = int(np.diff(mol).max()), int(max(1, np.diff(eoff).max()))
+    atomic = np.zeros((B, M), np.int32)
+    atomic[s_of_a, a_loc] = pk.atomic
+    amask = np.zeros((B, M, 1), np.float32)
+    amask[s_of_a, a_loc, 0] = 1.0
+    nbr, nmask = np.zeros((B, M, N), np.int32), np.zeros((B, M, N), np.float32)
+    dist, wgt = np.zeros((B, M, N), np.float32), np.zeros((B, M, N), np.float32)
+    idx = (s_of_a[a_of_e], a_loc[a_of_e], n_loc)
+    nbr[idx] = np.asarray(pk.edge_col, np.int64) - mol[s_of_a[a_of_e]]
+    nmask[idx] = 1.0
+    dist[idx], wgt[idx] = pk.edge_dist, pk.edge_weight
+    inputs = {"atomic": atomic, "atom_mask": amask, "neighbors": nbr, "neighbor_mask": nmask, "neighbor_weight": wgt, "neighbor_distance": dist}
+    model = HipModel(cfg, device=int(os.environ.get("LOCAL_RANK", "0")), seed=1234)
+    y0 = model.predict(inputs)
+    t_all, t0 = [], time.perf_counter()
+    while time.perf_counter() - t0 < seconds or len(t_all) < 3:
+        t1 = time.perf_counter()
+        y = model.predict(inputs)
+        t_all.append(time.perf_counter() - t1)
+    assert y.shape == (B, 1) and np.array_equal(y, y0)
+    dt = float(np.median(t_all))
+    model.engine.close()
+    return {"value": B / dt, "unit": "molecules/s", "molecules": B, "ms_per_call": 1e3 * dt, "calls": len(t_all), "padded_shape": [B, M, N],
+            "what": "model.predict(padded input dict of the whole set): padded -> CSR packing, uploads, forwards, downloads, Python inclusive"}
+
+
+LEGS = {"two_streams": two_stream_leg, "one_batch_per_launch": one_batch_leg, "end_to_end": end_to_end, "training_step": training_leg,
+        "padded_predict": padded_predict_leg}
 
 
 def run_leg_here(name, batch_size, config_name):
@@ -629,7 +671,7 @@ def main():
         if not args.no_extras and world == 1 and args.config == "qm9" and not args.worst:
             # each in a process of its own (leg_in_subprocess); this process's engine goes first, so that the legs have the device
             eng.close()
-            for name in ("two_streams", "one_batch_per_launch", "end_to_end", "training_step"):
+            for name in ("two_streams", "one_batch_per_launch", "end_to_end", "padded_predict", "training_step"):
                 out[name] = leg_in_subprocess(name, args.batch)
         if not args.no_cpu_baseline and not args.no_extras and world == 1:
             out["cpu_baseline"] = cpu_baseline()
