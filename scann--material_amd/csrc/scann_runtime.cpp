@@ -1038,7 +1038,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (e == hipSuccess) {  // next pinned staging buffer of the ring: free once its previous copy has completed (normally long ago)
       stage = &h->stage[h->stage_next++ % scann_handle::N_STAGE];
       if (stage->used) (void)hipEventSynchronize(stage->ev);
-      if (!stage->ev) e = hipEventCreateWithFlags(&stage->ev, hipEventDisableTiming);
+      if (!stage->ev) e = hipEventCreateWithFlags(&stage->ev, hipEventDisableTiming | hipEventDisableSystemFence);  // (same-device ordering only)
       if (e == hipSuccess && in_bytes > stage->cap) {
         if (stage->p) (void)hipHostFree(stage->p);
         stage->p = nullptr; stage->cap = 0;
@@ -1113,7 +1113,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(stage->ev, h->copy_stream);
     if (e == hipSuccess) stage->used = true;
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&db->upload_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&db->upload_ev, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e == hipSuccess) e = hipEventRecord(db->upload_ev, h->copy_stream);
   }
   if (e != hipSuccess) {
@@ -2030,7 +2030,10 @@ int scann_train_begin(scann_handle_t* h) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux2, hipStreamNonBlocking));
     h->train_ev.resize(128);
-    for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // fork / join events between streams of ONE device: no system-scope fence (the kernels' own end-of-kernel release already makes
+    // their results visible device-wide); env SCANN_TRAIN_EV_FENCE=1 keeps the default events
+    const unsigned ev_flags = hipEventDisableTiming | ((getenv("SCANN_TRAIN_EV_FENCE") && atoi(getenv("SCANN_TRAIN_EV_FENCE"))) ? 0u : (unsigned)hipEventDisableSystemFence);
+    for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, ev_flags));
   }
   h->grads_zeroed = false;  // (re)allocated gradient vector: contents unknown
   h->step_begun = h->step_ended = 0;
