@@ -134,6 +134,25 @@ def _check_hw_queues():
         os.environ["GPU_MAX_HW_QUEUES"] = "4"
 
 
+def _check_runtime_env():
+    """Two more HIP-runtime variables whose non-default values cost this library 4-40 % (profiles/r04_notes.md, one box, one call):
+    ``HIP_FORCE_DEV_KERNARG=0`` (kernel arguments fetched from host memory by every workgroup: forward -12 %, one batch per launch -16 %,
+    training step +10 %), ``AMD_OPT_FLUSH`` other than 1 (-3 % / -11 % / +6 %), ``GPU_FLUSH_ON_EXECUTION=1`` (-12 % / -39 % / +93 %).
+    They are left as set -- they may be deliberate, for another library in the process -- but said out loud."""
+    bad = []
+    if os.environ.get("HIP_FORCE_DEV_KERNARG") == "0":
+        bad.append("HIP_FORCE_DEV_KERNARG=0")
+    if os.environ.get("AMD_OPT_FLUSH") not in (None, "", "1"):
+        bad.append("AMD_OPT_FLUSH=%s" % os.environ["AMD_OPT_FLUSH"])
+    if os.environ.get("GPU_FLUSH_ON_EXECUTION") not in (None, "", "0"):
+        bad.append("GPU_FLUSH_ON_EXECUTION=%s" % os.environ["GPU_FLUSH_ON_EXECUTION"])
+    if bad:
+        import warnings
+
+        warnings.warn("%s in the environment: measured 4-40 %% slower forwards and up to 2x slower training steps on MI355X than the "
+                      "HIP runtime's defaults (profiles/r04_notes.md)" % ", ".join(bad), RuntimeWarning, stacklevel=3)
+
+
 def load_library(path=None):
     """dlopen the in-tree library and type every entry point.  Raises if it is not built."""
     global _lib
@@ -156,6 +175,7 @@ def load_library(path=None):
 
         pin_to_device(int(os.environ.get("LOCAL_RANK", "0") or 0))
     _check_hw_queues()
+    _check_runtime_env()
     lib = C.CDLL(p)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)

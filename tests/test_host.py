@@ -587,6 +587,25 @@ def test_structure_resident_group_plan(hip_lib):
         _hip.plan_groups(pk, max_tiles=0)
 
 
+def test_runtime_env_warnings(monkeypatch):
+    """_hip._check_runtime_env: HIP-runtime variables measured to cost 4-40 % are named in a warning, defaults are silent."""
+    import warnings
+    from scann import _hip
+
+    for k in ("HIP_FORCE_DEV_KERNARG", "AMD_OPT_FLUSH", "GPU_FLUSH_ON_EXECUTION"):
+        monkeypatch.delenv(k, raising=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _hip._check_runtime_env()
+        monkeypatch.setenv("HIP_FORCE_DEV_KERNARG", "1")
+        monkeypatch.setenv("AMD_OPT_FLUSH", "1")
+        _hip._check_runtime_env()
+    monkeypatch.setenv("HIP_FORCE_DEV_KERNARG", "0")
+    monkeypatch.setenv("GPU_FLUSH_ON_EXECUTION", "1")
+    with pytest.warns(RuntimeWarning, match="HIP_FORCE_DEV_KERNARG=0, GPU_FLUSH_ON_EXECUTION=1"):
+        _hip._check_runtime_env()
+
+
 def test_pack_padded_threads_give_the_single_thread_arrays(hip_lib, monkeypatch):
     """scann_pack_padded splits a large padded batch (the reference's `model.predict(whole padded dataset)`, scann_model.py:315-319)
     into ranges of structures packed by several threads: the packed arrays must be the ones a single thread writes, for thread counts
