@@ -217,10 +217,10 @@ class HipModel:
         the end -- the throughput path behind ``SCANN.evaluate`` / ``predict_model.py``.  Returns ``(y [N], ga list | None,
         targets [N])`` in dataset order.
 
-        Two host threads: a producer slices and uploads group k+1, k+2, ... (native calls, outside the GIL; the upload returns when
-        its copy is enqueued) while this thread enqueues the launches of group k and fetches the oldest group in flight -- slicing +
-        upload cost about as much host time per group as the device needs for it, so one thread doing both left the device idle a
-        fifth of the time (tools/e2e_breakdown.py)."""
+        A software pipeline on the calling thread: group k + 1 is sliced and uploaded (native calls; the upload returns when its copy
+        is enqueued) right after group k's launches are enqueued, a rolling window of 2 x streams groups stays in flight, results are
+        fetched oldest first.  (Rounds 3-4 used a producer thread for slicing + upload; it is still there behind
+        SCANN_DATASET_THREAD=1.)"""
         import queue
         import threading
 
@@ -257,6 +257,33 @@ class HipModel:
                 tg.append(np.asarray(tgt, dtype=np.float32))
             return (_hip.concat_packed(parts) if len(parts) > 1 else parts[0]), tg
 
+        # One thread is enough, and faster: launches and uploads are asynchronous, so slicing + uploading group k + 1 right after
+        # enqueueing group k overlaps host and device by itself; the producer thread of rounds 3-4 (below, SCANN_DATASET_THREAD=1)
+        # cost more in Python thread hand-offs than it hid (bench.py end_to_end: 1.70-1.72 M -> 1.81 M molecules/s, one box).
+        if os.environ.get("SCANN_DATASET_THREAD", "0") != "1":
+            k = 0
+            try:
+                for g0 in range(0, n, group):
+                    pk, tg = make(g0)
+                    rb = eng.upload(pk)
+                    ts.extend(tg)
+                    try:
+                        if len(pending) >= 2 * ns:
+                            fetch_oldest()
+                        eng.forward_resident(rb, k % ns)
+                    except BaseException:
+                        rb.free()
+                        raise
+                    k += 1
+                    pending.append(rb)
+                while pending:
+                    fetch_oldest()
+            finally:
+                for rb in pending:
+                    rb.free()
+            if not ys:
+                return np.zeros(0, np.float32), (np.zeros(0, np.float32) if want_ga else None), np.zeros(0, np.float32)
+            return np.concatenate(ys), (np.concatenate(gas) if want_ga else None), np.concatenate(ts)
         ready = queue.Queue(maxsize=max(2, ns))  # uploaded groups waiting for their launches
         stop = threading.Event()
 

@@ -1326,10 +1326,13 @@ def test_train_cli_flags_and_overrides(tmp_path, monkeypatch):
     assert np.random.rand() == x
 
 
-def test_predict_dataset_pipeline_with_a_stub_engine():
-    """HipModel.predict_dataset's two-thread pipeline without a GPU: a producer thread uploads groups ahead, the caller launches and
-    fetches them in order; results come back in dataset order, an error raised by the engine on either thread reaches the caller, and
+@pytest.mark.parametrize("threaded", [False, True])
+def test_predict_dataset_pipeline_with_a_stub_engine(monkeypatch, threaded):
+    """HipModel.predict_dataset's pipeline without a GPU, in both forms: the default software pipeline on the calling thread (group
+    k + 1 uploaded right after group k's launches) and the producer-thread form of rounds 3-4 (SCANN_DATASET_THREAD=1: uploads on a
+    second thread).  Results come back in dataset order, an error raised by the engine in upload or download reaches the caller, and
     every uploaded batch is freed or released exactly once."""
+    monkeypatch.setenv("SCANN_DATASET_THREAD", "1" if threaded else "0")
     import threading
 
     from scann import _hip
@@ -1404,7 +1407,8 @@ def test_predict_dataset_pipeline_with_a_stub_engine():
         eng = Eng()
         y, ga, t = model(eng).predict_dataset(data, group=group, want_ga=True)
         assert np.array_equal(y, expect_y) and np.array_equal(t, expect_t) and len(ga) == sum(pk.n_atom for pk, _ in data)
-        assert not eng.live and eng.ended.count("release") == eng.n_up and threading.get_ident() not in eng.upload_threads
+        assert not eng.live and eng.ended.count("release") == eng.n_up
+        assert (threading.get_ident() not in eng.upload_threads) == threaded
     for kw in (dict(fail_upload_at=3), dict(fail_download_at=2)):
         eng = Eng(**kw)
         with pytest.raises(RuntimeError):
