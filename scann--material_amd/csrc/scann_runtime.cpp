@@ -195,6 +195,7 @@ struct scann_handle {
   hipStream_t copy_stream = nullptr;
   hipStream_t train_aux2 = nullptr;      // second side stream: the basis-MLP gradients beside the embedding chain
   bool train_fused = true;               // fused backward chains (scann_train_fused.hip); SCANN_TRAIN_FUSED=0: modular kernels
+  bool train_aux_borrowed = false;       // train_aux is streams[1] (not destroyed separately)
   hipStream_t train_aux = nullptr;       // side stream of the backward pass: weight-gradient GEMMs run beside the data-gradient chain
   std::vector<hipEvent_t> train_ev;      // ring of fork / join events between the two streams
   // reusable scratch of the synchronous scann_forward path (grow-only device arena + pinned host staging)
@@ -531,7 +532,7 @@ void scann_destroy(scann_handle_t* h) {
   for (void* q : {(void*)h->t_master, (void*)h->t_grad, (void*)h->t_m, (void*)h->t_v, (void*)h->t_l2, (void*)h->t_descs})
     if (q) (void)hipFree(q);
   if (h->comm) ncclCommDestroy(h->comm);
-  if (h->train_aux) (void)hipStreamDestroy(h->train_aux);
+  if (h->train_aux && !h->train_aux_borrowed) (void)hipStreamDestroy(h->train_aux);
   if (h->h_stat) (void)hipHostFree(h->h_stat);
   if (h->range_flag) (void)hipHostFree(h->range_flag);
   for (float* t : h->h_targets)
@@ -2027,7 +2028,15 @@ int scann_train_begin(scann_handle_t* h) {
   if (!h->train_aux && !getenv("SCANN_TRAIN_ONE_STREAM")) {
     // (side streams created with the lowest priority changed nothing: 0.895 vs 0.895 ms per step, profiles/r04_notes.md)
     // (and so did confining them to half / a quarter of the CUs with hipExtStreamCreateWithCUMask: 0.89-0.93 ms either way)
-    HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
+    // A handle with a second forward stream lends it to the backward pass as its side stream instead of creating a fifth stream: HIP
+    // deals a process's streams onto 4 hardware queues, and the fifth shares one (training step 0.91-0.92 -> 0.88-0.89 ms with the
+    // default two forward streams; validation forwards on that stream never overlap a step).
+    if (h->nstream >= 2) {
+      h->train_aux = h->streams[1];
+      h->train_aux_borrowed = true;
+    } else {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux, hipStreamNonBlocking));
+    }
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux2, hipStreamNonBlocking));
     h->train_ev.resize(128);
     // fork / join events between streams of ONE device: no system-scope fence (the kernels' own end-of-kernel release already makes
