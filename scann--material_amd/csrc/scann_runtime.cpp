@@ -2220,6 +2220,24 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     (void)hipEventRecord(e, aux);
     (void)hipStreamWaitEvent(s, e, 0);
   };
+  // The side stream's chain per layer is a gradient launch (~32 us) and two reductions of its partial slots (~34 us): as long as the
+  // main stream's chain per layer (~70 us), so the step ended when the SIDE stream did, ~65 us after the main one.  The reductions
+  // go to the second side stream (idle but for the basis leaf): gradient launch of layer l - 1 beside the reductions of layer l.
+  static const bool flush_on_aux2 = !(getenv("SCANN_TRAIN_FLUSH_STREAM") && atoi(getenv("SCANN_TRAIN_FLUSH_STREAM")) == 0);
+  bool aux2_used = false;
+  auto flush_side = [&](hipStream_t ws, WgradCtx& ctx, bool last) {
+    if (!side) return;
+    hipStream_t fs = ws;
+    // (the LAST layer's reductions stay behind their gradient launch: the second side stream is busy with the basis leaf, 46 us, by then)
+    if (h->train_aux2 && flush_on_aux2 && !last) {
+      hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
+      (void)hipEventRecord(e, ws);
+      (void)hipStreamWaitEvent(h->train_aux2, e, 0);
+      fs = h->train_aux2;
+      aux2_used = true;
+    }
+    wgrad_flush(ctx, fs);
+  };
   WgradCtx wg;
   wg.arena = w.wpart;
   // a fork costs the main stream ~7 us (tools/fork_probe.hip): the layers' gradient launches may share one (their operand sets live
@@ -2369,7 +2387,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
       // the layer's weight gradients, their reduction and the filter_geo leaf beside the chain of the layers below
       hipStream_t ws = fork();
       wgrad_launch(wg, ws);
-      if (side) wgrad_flush(wg, ws);
+      flush_side(ws, wg, l == 0);
       launch_base_geom_bwd(db->gd, p.Wfg, p.bfg, db->weight, eU, E, g(la + "filter_geo/kernel"), g(la + "filter_geo/bias"), ws);
       pend.n = 1;  // dC += dq.Wq^T: folded into the next rn_bwd_kernel (or launched by flush_pend)
       pend.X[0] = dQ; pend.Wh[0] = pt.WqTh; pend.W[0] = pt.WqT;
@@ -2413,7 +2431,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
       // partial slots (and of the layer's LayerNorm gamma / beta slots): both beside the chains of the layers below
       hipStream_t ws = fork();
       wgrad_launch(wg, ws);
-      if (side) wgrad_flush(wg, ws);
+      flush_side(ws, wg, l == 0);
     }
     // dC += dP1.W1^T + dP3.W3^T + dq.Wq^T: folded into the next layer's rn_bwd_kernel (or launched by flush_pend)
     pend.n = 3;
@@ -2447,7 +2465,13 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     return fail(h, SCANN_ERR_HIP, "scann_train_backward: weight-gradient partial arena overrun");
   if (!wg.jobs.empty()) wgrad_launch(wg, s);  // a model without LocalAttention layers: the readout's gradients were never launched
   join();
-  if (ev_basis) (void)hipStreamWaitEvent(s, ev_basis, 0);
+  if (aux2_used) {  // everything the second side stream was given (the basis leaf included)
+    hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
+    (void)hipEventRecord(e, h->train_aux2);
+    (void)hipStreamWaitEvent(s, e, 0);
+  } else if (ev_basis) {
+    (void)hipStreamWaitEvent(s, ev_basis, 0);
+  }
   wgrad_flush(wg, s);  // ONE launch adds the per-slab partials of every weight gradient, in slab order
   HIPCHK(h, hipGetLastError());
   return SCANN_OK;
