@@ -1171,6 +1171,10 @@ int scann_batch_upload(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
 
 namespace {
 
+// Events that only time kernels on one stream: no system-scope cache write-back / invalidate when they fire (the HIP headers' own
+// advice for timing events), so that a sampled launch is not lengthened by its own measurement.
+constexpr unsigned kTimingEventFlags = hipEventDisableSystemFence;
+
 struct Timer {
   hipStream_t s;
   bool on;
@@ -1179,7 +1183,7 @@ struct Timer {
   void mark(int k) {
     if (!on) return;
     hipEvent_t e;
-    (void)hipEventCreate(&e);
+    (void)hipEventCreateWithFlags(&e, kTimingEventFlags);
     (void)hipEventRecord(e, s);
     ev.push_back(e);
     kind.push_back(k);
@@ -1414,8 +1418,8 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
       const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && l > 0 && l + 1 < L;
       hipEvent_t ev0 = nullptr, ev1 = nullptr;
       if (sample) {
-        (void)hipEventCreate(&ev0);
-        (void)hipEventCreate(&ev1);
+        (void)hipEventCreateWithFlags(&ev0, kTimingEventFlags);
+        (void)hipEventCreateWithFlags(&ev1, kTimingEventFlags);
         (void)hipEventRecord(ev0, s);
       }
       launch_layer(ea, a, f, s);
@@ -1523,8 +1527,8 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     const bool sample = !resident && !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) {
-      (void)hipEventCreate(&ev0);
-      (void)hipEventCreate(&ev1);
+      (void)hipEventCreateWithFlags(&ev0, kTimingEventFlags);
+      (void)hipEventCreateWithFlags(&ev1, kTimingEventFlags);
       (void)hipEventRecord(ev0, s);
     }
     ea.tile_part = v_tile_part; ea.part_buf = v_part_buf;
@@ -1583,8 +1587,8 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && sa.n_group > 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) {
-      (void)hipEventCreate(&ev0);
-      (void)hipEventCreate(&ev1);
+      (void)hipEventCreateWithFlags(&ev0, kTimingEventFlags);
+      (void)hipEventCreateWithFlags(&ev1, kTimingEventFlags);
       (void)hipEventRecord(ev0, s);
     }
     launch_struct(sa, SR_NT_SMALL, s);
