@@ -139,16 +139,8 @@ void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);
 void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db); /* see scann_train_step_begin */
 int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot); /* async */
 int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, float* ga_attn_out); /* syncs that batch */
-/* Structure-resident forward (csrc/scann_struct.hip), EXPERIMENTAL and off by default (limit 0): an inference forward of a SCANN+
- * (g_update) handle runs every group of whole structures that fits `max_tiles` edge tiles (<= 64 edges of whole atoms each; 1..6)
- * as ONE workgroup that keeps the group's geometry rows in registers and its atom rows in LDS across all n_attention iterations
- * (the loop of create_model, scann_model.py:413-421); structures beyond the limit (and every structure when it is 0) take the
- * layer-streamed kernels.  Same results either way (to 1 ulp-level differences, tests/test_gpu_parity.py).  Measured 0.45-0.55 x the
- * streamed path's rate on MI355X (profiles/r04_notes.md): kept for the measurements and as a base, not as the product path.
- * The plan is made by scann_batch_upload: the limit applies to batches uploaded afterwards.  Env SCANN_RESIDENT sets the default. */
-int scann_set_resident_limit(scann_handle_t* h, int max_tiles);
-/* out8 = { resident groups of <= 3 tiles, resident groups of 4..6 tiles, structures left to the streamed kernels, resident edge
- * tiles, edges and atoms of the <= 3-tile groups, edge tiles and rows per tile (32 | 64) of the whole-batch streamed plan }. */
+/* out8 = { structures, atoms, edges, atoms with more than 64 neighbours, their softmax-merge slots, largest neighbour count, edge tiles
+ * and rows per tile (32 | 64) of the batch's tile plan }. */
 int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8);
 int scann_sync(scann_handle_t* h); /* all streams of the handle */
 /* hipMemGetInfo of the handle's device: what is left of the 288 GB for resident batches (the library keeps freed blocks in a
@@ -159,17 +151,6 @@ int scann_device_memory(scann_handle_t* h, int64_t* free_bytes, int64_t* total_b
  * reference's fp32 Dense layers, attention.py:95-113) instead of returning SCANN_ERR_RANGE; this counts them.  Env
  * SCANN_STRICT_RANGE=1 turns the re-run off (the error is returned).  Training entry points always return the error. */
 int64_t scann_exact_reruns(const scann_handle_t* h);
-/* Layer launches (csrc/scann_layer.hip; an experiment, OFF by default): on inference handles the atom tiles that turn the contexts
- * of LocalAttention iteration l into the centres and projections of iteration l + 1 (attention.py:148-160 -> scann_model.py:413-421)
- * run inside iteration l's edge launch, each behind a counter its feeding edge tiles bump -- one launch per iteration instead of two,
- * the same bytes, measured no faster (profiles/r04_notes.md).  Needs g_update, 64-row tiles and no chunked atoms in the batch's plan;
- * env SCANN_FUSE_LAYERS=1 or scann_set_layer_fusion(h, 1) turns it on for batches uploaded afterwards (SCANN_LF_DELAY: how many
- * workgroups behind its last feeding edge tile an atom tile is placed, default 400).  scann_layer_fusion_state: 1 on, 0 off, < 0: a
- * launch reported a fault (-1 a dependency wait ran out, -2 an atom tile ran on another XCD than its edge tiles); the handle then
- * re-ran the batch through separate launches and keeps doing so. */
-int scann_set_layer_fusion(scann_handle_t* h, int on);
-int scann_layer_fusion_state(const scann_handle_t* h);
-int64_t scann_fused_forwards(const scann_handle_t* h); /* forwards of this handle that ran as layer launches */
 int scann_num_streams(const scann_handle_t* h);
 
 /* Timed forward of a resident batch: HIP events around every kernel on its stream. */
@@ -277,22 +258,6 @@ int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offse
  * edge_end.  Returns the planned edge rows per tile (32 | 64) or a negative status (text: scann_pack_last_error). */
 int scann_plan_tiles(const scann_batch_t* batch, int32_t tile_rows, int32_t tile_atoms, int32_t allow_chunks, int32_t cap,
                      int32_t* tiles_out, int32_t* part_out, int32_t* n_tiles, int32_t* n_slots);
-/* The structure-resident plan scann_batch_upload builds (host only): structures in batch order; one whose own greedy tile plan
- * needs <= min(3, max_tiles) tiles joins the open group while the JOINT plan still fits, one that needs <= min(6, max_tiles) is a
- * group of its own, the rest are listed in streamed_out.  groups_out[cap_groups][4] = atom_begin, atom_end, tile_begin, n_tile
- * (the n_small groups of <= 3 tiles first, then the n_big others; each list by falling edge count); tiles_out[cap_tiles][4] as
- * scann_plan_tiles.  With null outputs only the counts are returned. */
-/* The work list of a LAYER LAUNCH (csrc/scann_layer.hip; host only): the 64-edge tiles of scann_plan_tiles dealt to the 8 XCDs in
- * contiguous runs, per XCD the 64-row atom tiles covering exactly its tiles' atoms (row_tab_out[cap_atiles][2] = first row, rows),
- * and the interleaved dispatch order work_out[cap_blocks][2] = {kind: 0 edge tile | 1 atom tile | -1 nothing, index} -- block b is
- * item b >> 3 of XCD b & 7; an atom tile comes `delay` items behind the last edge tile that feeds it.  e_atile_out[n_etiles][2] =
- * first atom tile an edge tile's atoms fall into and how many (1 | 2); a_need_out[n_atiles] = edge tiles feeding an atom tile. */
-int scann_plan_layer(const scann_batch_t* batch, int32_t tile_atoms, int32_t delay, int32_t cap_blocks, int32_t cap_atiles,
-                     int32_t* work_out, int32_t* row_tab_out, int32_t* e_atile_out, int32_t* a_need_out, int32_t* n_blocks,
-                     int32_t* n_atiles, int32_t* n_etiles);
-int scann_plan_groups(const scann_batch_t* batch, int32_t tile_atoms, int32_t max_tiles, int32_t cap_groups, int32_t cap_tiles,
-                      int32_t* groups_out, int32_t* tiles_out, int32_t* streamed_out, int32_t* n_small, int32_t* n_big,
-                      int32_t* n_tiles, int32_t* n_streamed);
 
 #ifdef __cplusplus
 }

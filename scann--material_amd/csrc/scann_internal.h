@@ -141,10 +141,6 @@ struct AtomArgs {
   unsigned long long* stamps;  // diagnostic build (-DSCANN_STAMPS, env SCANN_STAMP_ATOM=1) only: [n_tiles,16] phase clocks
   int32_t* range_flag;         // host-pinned range-guard word (flag_range) or null
   int32_t layer;               // layer whose projections this launch computes (for the range-guard message)
-  // a batch whose other structures run on the structure-resident path: {first row, rows (<= 64)} of every atom tile, n_row_tab of
-  // them (64-row tiles); null: tiles of consecutive rows over [0, n_atom)
-  const int32_t* row_tab;
-  int32_t n_row_tab;
   // exact-fp32 projections (EX instantiation): Wf1h, Wf2h, WAh .. WDh then point at fp32 fragment-order images (pack_weight)
   int32_t exact;
 };
@@ -169,6 +165,7 @@ struct EdgeArgs {
   float *keep_V, *keep_T, *keep_ang, *keep_K;
   float* geom_out;             // where geom' goes (null: in place) -- keep-mode writes each layer's geometry to its own slice
   int32_t tile_rows;           // 32 | 64: edge rows per tile of this batch's plan (selects the kernel instantiation)
+  int32_t geom_rows;           // the geometry tensors are [n_edge,128] ROWS (training, debug and exact forwards: someone else reads them); 0: piece-major tiles
   int32_t geom_dead;           // last layer of an inference forward: nobody reads geom' (scann_model.py:415-421 threads it to the NEXT layer only)
   const float* gd;             // [n_edge,20] raw distance basis (base)
   const float* edge_weight;    // [n_edge] (base; g_update with fuse_basis: the second input of the basis MLP)
@@ -197,76 +194,6 @@ void launch_edge(const EdgeArgs& a, hipStream_t s);
 // softmax merge of the chunk tiles of every big atom (+ unscaled-query residual + LayerNorm, attention.py:189-214)
 void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,
                        const float* ln_b, float* ctx, int32_t* range_flag, int layer, hipStream_t s);
-
-// ---- structure-resident forward (scann_struct.hip) -------------------------------------------------------------------------------
-// One workgroup per GROUP: a run of whole structures whose edges fit <= 3 (two workgroups per CU) or <= 6 (one) edge tiles; the
-// group's geometry rows live in registers across all layers.
-struct SrGroup {
-  int32_t atom_begin, atom_end;  // the group's atoms (whole structures)
-  int32_t tile_begin, n_tile;    // its edge tiles in SrArgs::tiles: whole atoms, <= TE_MAX edges and <= TQ atoms each
-};
-constexpr int SR_NT_SMALL = 3, SR_NT_BIG = 6;
-constexpr int SR_ATOMS_SMALL = 36, SR_ATOMS_BIG = 72;  // atoms per group: rows of the kernel's atom-row cache in LDS
-
-struct SrArgs {
-  const SrGroup* groups;
-  const EdgeTile* tiles;
-  int32_t n_group, n_layer, use_attn_norm, reserved;
-  const int32_t *edge_offset, *edge_col, *edge_row;
-  const float *dist, *edge_weight;
-  const float* x0;           // layer-0 input rows: the embedding LUT [n_species,128] (x0_index = atomic numbers) or c0 [n_atom,128]
-  const int32_t* x0_index;
-  BasisParams basis;
-  const LayerParams* layers;  // DEVICE array [n_layer]
-  HeadParams head;
-  float *c, *P1, *P3, *q, *ctx;  // [n_atom,128] scratch rows, private to the workgroup that owns the atoms
-  float *gq, *gk;                // out: GlobalAttention query / key rows for readout_kernel
-  int32_t* range_flag;
-  unsigned long long* stamps;    // diagnostic build (-DSCANN_STAMPS) only: [n_group,64] phase clocks of layer 2, else null
-  // test hook (env SCANN_SR_DEBUG=1): per-layer copies for scann_debug_read -- centres [L+1][n_atom,128], context [L][n_atom,128],
-  // geometry [L+1][n_edge,128] (slice 0, the basis MLP's output, is not written) -- else null
-  float *dbg_c, *dbg_ctx, *dbg_g;
-  int32_t n_atom_total, n_edge_total;
-};
-void launch_struct(const SrArgs& a, int nt_max, hipStream_t s);
-
-// Host-side plan of the structure-resident forward (scann_pack.cpp): structures in order; a structure whose own greedy tile plan
-// (whole atoms, <= TE_MAX edges and <= tile_atoms atoms per tile) needs <= SR_NT_SMALL tiles joins the open small group while the
-// JOINT plan of the group still fits, one that needs <= SR_NT_BIG tiles is a group of its own in the big list, anything else (more
-// tiles, an atom with more than TE_MAX neighbours) is listed in `streamed`.  Groups are ordered by falling edge count (the
-// longest workgroups start first); tiles of a group are contiguous in `tiles`.
-struct SrPlan {
-  std::vector<SrGroup> small, big;
-  std::vector<EdgeTile> tiles;
-  std::vector<int32_t> streamed;  // structure ids the resident kernels cannot take
-};
-void plan_groups(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset, int tile_atoms, int max_tiles, SrPlan& plan);
-// The streamed kernels' plan for the structures plan_groups left over (a batch with both kinds): 64-row edge tiles (chunk tiles for
-// atoms with more than 64 neighbours) and 64-row atom tiles {first row, rows}, per run of consecutive structures.
-void plan_streamed_subset(const int32_t* mol_offset, const int32_t* edge_offset, const std::vector<int32_t>& streamed, int tile_atoms,
-                          std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part, std::vector<int32_t>& big_tab, int32_t* n_slot_out,
-                          std::vector<int32_t>& atom_tab);
-
-// ---- layer launch (scann_layer.hip): edge tiles of layer l + atom tiles of layer l + 1 in one grid --------------------------------
-struct LayerFuse {
-  const int2* work;        // [n_block] {kind, index}: 0 edge tile, 1 atom tile (row_tab entry), -1 nothing; block b is item b >> 3 of XCD b & 7
-  int32_t n_block;
-  const int32_t* e_atile;  // [n_edge_tile][2]: first atom tile the edge tile's atoms fall into, how many (1 | 2)
-  const int32_t* a_need;   // [n_atom_tile]: edge tiles feeding the atom tile
-  unsigned long long* a_count;  // [n_atom_tile], this layer's (zeroed at the start of every forward): bits 0-7 arrivals, then 7 bits per
-                                // dispatch offset (XCC_ID - block) mod 8: the arrivals that ran with it
-  int32_t* fault;          // host-pinned word: 1 = a wait ran out, 2 | ... = an atom tile and one of its edge tiles ran on different XCDs
-};
-void launch_layer(const EdgeArgs& ea, const AtomArgs& aa, const LayerFuse& f, hipStream_t s);
-// Host side (scann_pack.cpp): per XCD a contiguous run of edge tiles, the 64-row atom tiles covering exactly their atoms, and the
-// interleaved work list (an atom tile `delay` items behind the last edge tile that feeds it).
-struct LayerPlan {
-  std::vector<int32_t> work;     // [n_block][2]
-  std::vector<int32_t> row_tab;  // [n_atom_tile][2] first row, rows
-  std::vector<int32_t> e_atile;  // [n_edge_tile][2]
-  std::vector<int32_t> a_need;   // [n_atom_tile]
-};
-void plan_layer_fusion(const std::vector<EdgeTile>& tiles, int delay, LayerPlan& plan);
 
 // ---- generic-width forward (scann_generic.hip): plain fp32 kernels for local_dim / num_head / global_dim / dense_out other than 128 / 8 ----
 struct GenSeg {

@@ -55,9 +55,8 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
   // launch is then the latency chain of a tile, and a 32-row tile's chain is shorter (one batch per launch: 490 k -> 568 k
   // molecules/s, training step 1.14 -> 1.09 ms).  Beyond that 64-row tiles (half the weight traffic per row).
   static const int force_rows = getenv("SCANN_ATOM_ROWS") ? atoi(getenv("SCANN_ATOM_ROWS")) : 0;  // A/B switch (32 | 64)
-  const int rows = a.row_tab ? TA : force_rows == 32 || force_rows == 64 ? force_rows : a.n_atom <= 32 * 1024 ? 32 : 64;
-  if (a.row_tab && a.n_row_tab <= 0) return;
-  const dim3 grid(a.row_tab ? a.n_row_tab : (a.n_atom + rows - 1) / rows), block(256);
+  const int rows = force_rows == 32 || force_rows == 64 ? force_rows : a.n_atom <= 32 * 1024 ? 32 : 64;
+  const dim3 grid((a.n_atom + rows - 1) / rows), block(256);
 #define SCANN_ATOM_CASE(F, M)                                                                  \
   do {                                                                                         \
     if (a.exact) {                                                                             \
@@ -106,13 +105,21 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
 // here on the tile's rows (Gaussian expansions -> planes -> two K = 20 products -> bias, swish, product), not out of memory.
 // EX: exact-fp32 projections for the 128x128 kernels (scann_mma.h; the K = 20 filters keep the split form: their inputs are Gaussians
 // in [0, 1]) -- the fallback run_forward takes when the split-fp16 range guard fired.  Never with FB.
-template <bool GUPD, int RT, bool FB = false, bool EX = false>
+// KEEP: the training forward's instantiation -- the keep_* stores and the attention dropout exist only there (as uniform branches in
+// the inference kernels they cut every epilogue into basic blocks of one LDS read -> wait -> arithmetic -> store each).
+// DEAD: the last layer of an inference forward -- nobody reads geom' (scann_model.py:415-421 threads it to the NEXT layer only).
+template <bool GUPD, int RT, bool FB = false, bool EX = false, bool KEEP = false, bool DEAD = false>
 __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) {
 #pragma clang fp contract(off)  // fusions are written out (fmaf): both unrolled row-tile copies of a formula must round alike,
                                 // so that a row's result does not depend on where in a tile it lands (batch-composition invariance)
   static_assert(!FB || GUPD, "the fused basis exists for the g_update kernel only");
   static_assert(!(FB && EX), "the exact fallback runs the plain first layer");
+  static_assert(!KEEP || (!FB && !EX && !DEAD), "the training forward runs the plain split-fp16 kernel and keeps every layer's geometry");
+  static_assert(!DEAD || GUPD, "the base branch stores no geometry");
   constexpr int TEK = 32 * RT;  // edge rows per tile: 64 (three workgroups per CU) or, for launches of one round, 32 (four)
+  // piece-major geometry tiles (scann_edge_body.inc): the inference kernels, whose geometry nobody else reads.  The training / debug
+  // forward (KEEP) and the exact re-run (EX: its first layer reads basis_kernel's row-major geom0) keep [n_edge,128] rows.
+  constexpr bool BLK = GUPD && !EX && !KEEP;
   // hi / lo planes of the A operand (G or the basis, then ang): 2 x 64 x 272 B; afterwards K as fp32 [64][LDS_STRIDE]
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TEK * PLANE_STRIDE * 2];
   __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];  // P1 rows, then query rows of the tile's atoms, then context
@@ -190,24 +197,33 @@ void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
   const dim3 grid(a.n_tile), block(256);
   // tile_rows is the height the batch's tile plan was made for (scann_batch_upload: 32 for launches of one round of workgroups)
-  if (a.exact) {  // exact-fp32 fallback: never with the fused first layer
-    if (a.tile_rows == 32) {
-      if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 1, false, true>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((edge_kernel<false, 1, false, true>), grid, block, 0, s, a);
-    } else {
-      if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 2, false, true>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((edge_kernel<false, 2, false, true>), grid, block, 0, s, a);
-    }
-  } else if (a.fuse_basis && a.g_update) {
-    if (a.tile_rows == 32) hipLaunchKernelGGL((edge_kernel<true, 1, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((edge_kernel<true, 2, true>), grid, block, 0, s, a);
-  } else if (a.tile_rows == 32) {
-    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((edge_kernel<false, 1>), grid, block, 0, s, a);
+  // three families: EX (exact-fp32 re-run of an inference forward), KEEP (training / debug forwards: row-major geometry, keep_* stores,
+  // attention dropout), and the inference kernels proper (piece-major geometry tiles; FB = the first layer, DEAD = the last)
+  const bool keep = !a.exact && (a.geom_rows || a.keep_V || a.keep_T || a.keep_ang || a.keep_K || a.attn_drop_p > 0.f);
+  const bool dead = a.g_update && a.geom_dead && !keep;
+#define SCANN_EDGE_GO(...) hipLaunchKernelGGL((edge_kernel<__VA_ARGS__>), grid, block, 0, s, a)
+#define SCANN_EDGE_ROWS(G, ...)                                             \
+  do {                                                                      \
+    if (a.tile_rows == 32) SCANN_EDGE_GO(G, 1, __VA_ARGS__);                \
+    else SCANN_EDGE_GO(G, 2, __VA_ARGS__);                                  \
+  } while (0)
+  if (a.exact) {  // never with the fused first layer (run_forward launches basis_kernel for it)
+    if (!a.g_update) SCANN_EDGE_ROWS(false, false, true, false, false);
+    else if (dead) SCANN_EDGE_ROWS(true, false, true, false, true);
+    else SCANN_EDGE_ROWS(true, false, true, false, false);
+  } else if (keep) {
+    if (a.g_update) SCANN_EDGE_ROWS(true, false, false, true, false);
+    else SCANN_EDGE_ROWS(false, false, false, true, false);
+  } else if (!a.g_update) {
+    SCANN_EDGE_ROWS(false, false, false, false, false);
+  } else if (a.fuse_basis) {  // (a one-layer model's only launch stores its geometry: no instantiation for that corner)
+    SCANN_EDGE_ROWS(true, true, false, false, false);
   } else {
-    if (a.g_update) hipLaunchKernelGGL((edge_kernel<true, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((edge_kernel<false, 2>), grid, block, 0, s, a);
+    if (dead) SCANN_EDGE_ROWS(true, false, false, false, true);
+    else SCANN_EDGE_ROWS(true, false, false, false, false);
   }
+#undef SCANN_EDGE_ROWS
+#undef SCANN_EDGE_GO
 }
 
 // ---- basis kernel ----------------------------------------------------------------------------------

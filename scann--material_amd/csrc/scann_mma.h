@@ -68,21 +68,19 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 }
 
 // hi / lo fp16 parts of four consecutive fp32 values: hi = fp16(x) (round to nearest), lo = fp16(x - hi).  Written out as the
-// eight instructions it takes -- two packed conversions, the four exact residuals x - hi as v_fma_mix_f32 (which reads the
-// fp16 half of a register as an fp32 operand: no separate conversion back), two packed conversions -- because hipcc makes 15
-// of the plain C form (scalar and packed conversions of the same values, conversions back, subtractions).  Same bits.
+// SIX instructions it takes -- two packed conversions, then the four residuals x - hi formed by v_fma_mixlo_f16 / v_fma_mixhi_f16, which
+// read the fp16 half of a register as an fp32 operand (no conversion back), compute hi * -1 + x exactly in fp32 and write its fp16
+// rounding straight into the low / high half of the destination (no second pair of packed conversions: the 8-instruction form of rounds
+// 2-4) -- because hipcc makes 15 of the plain C form.  Same bits as both (tools/split_probe.hip: every binade, fp16 subnormal residuals).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
   unsigned h01, h23, l01, l23;
-  float r0, r1, r2, r3;
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(v.x), "v"(v.y));
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(v.z), "v"(v.w));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v.x));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v.y));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v.z));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v.w));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l01) : "v"(r0), "v"(r1));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l23) : "v"(r2), "v"(r3));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(v.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(v.y));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(v.z));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(v.w));
   h = __builtin_bit_cast(f16x4, u32x2{h01, h23});
   l = __builtin_bit_cast(f16x4, u32x2{l01, l23});
 }
@@ -97,8 +95,10 @@ __device__ __forceinline__ void load_wsplit(const _Float16* __restrict__ Wp, int
   const unsigned off = ((unsigned)wave * (KT * 2 * 64) + (unsigned)lane) * 16u;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    wh[s] = *reinterpret_cast<const f16x8*>(base + (off + (unsigned)((2 * (s0 + s)) * 64 * 16)));
-    wl[s] = *reinterpret_cast<const f16x8*>(base + (off + (unsigned)((2 * (s0 + s) + 1) * 64 * 16)));
+    // (the k-step's 2 KiB go into the UNIFORM base -- an s_add -- not into the per-lane offset: added to the offset they are one address
+    //  VGPR per KiB beyond the instruction's 4 KiB immediate range, which hipcc then keeps alive, or spills, for the next slab's loads)
+    wh[s] = *reinterpret_cast<const f16x8*>((base + (size_t)((2 * (s0 + s)) * 64 * 16)) + off);
+    wl[s] = *reinterpret_cast<const f16x8*>((base + (size_t)((2 * (s0 + s) + 1) * 64 * 16)) + off);
   }
 }
 
@@ -125,7 +125,13 @@ __device__ __forceinline__ void mma_split(const _Float16* __restrict__ sH, const
   }
 }
 
-__device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32); }
+// v[lane] + v[lane ^ 32] through v_permlane32_swap (gfx950: the upper half of one register changes places with the lower half of another
+// -- a VALU instruction, no LDS round trip as the ds_bpermute of __shfl_xor): after swapping two copies of v, one holds the lower lanes'
+// values in both halves and the other the upper lanes', and their sum is the same addition in both halves (fp32 + commutes: same bits).
+__device__ __forceinline__ float xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // Global access as (uniform base pointer) + (32-bit per-lane BYTE offset): compiles to the saddr form of global_load / global_store
 // -- one offset VGPR per row instead of a 64-bit address pair per tensor (the tensors here are < 4 GiB each: scann_batch_upload
@@ -135,6 +141,22 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ base, unsigned b
 }
 __device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off, const float4 v) {
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+// Sum over groups of 8 consecutive lanes, every lane getting the total, through DPP operands (VALU; hipcc's __shfl_xor is a ds_bpermute:
+// an LDS round trip per step): lane ^ 1 and lane ^ 2 as quad permutations, then the 8-lane mirror (lane i <-> 7 - i), which pairs each quad
+// -- uniform by then -- with the other one.  Every step adds the same two numbers as the __shfl_xor(1 / 2 / 4) ladder: same bits.
+__device__ __forceinline__ float sum8(float v) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));   // quad_perm:[1,0,3,2]
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));   // quad_perm:[2,3,0,1]
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+// one 32-bit word the same way (an `int` index into a pointer costs a 64-bit shift-and-add per access)
+__device__ __forceinline__ int ld1i(const int32_t* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ld1f(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // ---- elementwise helpers shared by the forward kernels (scann_kernels.hip, scann_struct.hip) ----
@@ -203,7 +225,7 @@ __device__ __forceinline__ void load_wexact(const float* __restrict__ Wp, int wa
   const char* __restrict__ base = reinterpret_cast<const char*>(Wp);
   const unsigned off = ((unsigned)wave * (16 * 64) + (unsigned)lane) * 16u;
 #pragma unroll
-  for (int t = 0; t < NTT; ++t) w[t] = *reinterpret_cast<const float4*>(base + (off + (unsigned)((t0 + t) * 64 * 16)));
+  for (int t = 0; t < NTT; ++t) w[t] = *reinterpret_cast<const float4*>((base + (size_t)((t0 + t) * 64 * 16)) + off);
 }
 // acc[rt] (+)= X[rows][8 t0 .. 8 (t0 + NTT)) . W[same k][32 wave .. +32); sX points at the tile's first row, column 8 t0
 template <int NTT, bool FIRST, int RT>

@@ -114,144 +114,6 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
 }
 
 
-namespace {
-// Greedy tiling of atoms [a0, a1) by plan_tiles's rule (whole atoms, <= TE_MAX edges and <= tile_atoms atoms per tile); appends the
-// tiles to `out` when given.  Returns the number of tiles, or -1 when an atom has more than TE_MAX neighbours.
-int tile_run(const int32_t* eo, int32_t a0, int32_t a1, int tile_atoms, std::vector<EdgeTile>* out) {
-  int n = 0;
-  EdgeTile cur{a0, a0, eo[a0], eo[a0]};
-  for (int32_t a = a0; a < a1; ++a) {
-    const int32_t e0 = eo[a], e1 = eo[a + 1];
-    if (e1 - e0 > TE_MAX) return -1;
-    if ((e1 - cur.edge_begin) > TE_MAX || (a - cur.atom_begin) >= tile_atoms) {
-      cur.atom_end = a;
-      cur.edge_end = e0;
-      if (out) out->push_back(cur);
-      ++n;
-      cur = EdgeTile{a, a, e0, e0};
-    }
-  }
-  cur.atom_end = a1;
-  cur.edge_end = eo[a1];
-  if (out) out->push_back(cur);
-  return n + 1;
-}
-}  // namespace
-
-void plan_groups(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset, int tile_atoms, int max_tiles, SrPlan& plan) {
-  const int nt_small = std::min(SR_NT_SMALL, max_tiles), nt_big = std::min(SR_NT_BIG, max_tiles);
-  plan.small.clear(); plan.big.clear(); plan.tiles.clear(); plan.streamed.clear();
-  struct Run { int32_t a0, a1; };
-  std::vector<Run> small, big;
-  Run open{-1, -1};
-  auto close_open = [&]() {
-    if (open.a0 >= 0) small.push_back(open);
-    open = Run{-1, -1};
-  };
-  for (int32_t s = 0; s < B; ++s) {
-    const int32_t a0 = mol_offset[s], a1 = mol_offset[s + 1];
-    int own = tile_run(edge_offset, a0, a1, tile_atoms, nullptr);
-    if (a1 - a0 > SR_ATOMS_BIG) own = -1;
-    else if (a1 - a0 > SR_ATOMS_SMALL && own >= 0) own = std::max(own, nt_small + 1);  // too many atoms for the small kernel's cache
-    if (own < 0 || own > nt_big) {
-      close_open();
-      plan.streamed.push_back(s);
-    } else if (own > nt_small) {
-      close_open();
-      big.push_back(Run{a0, a1});
-    } else if (open.a0 >= 0 && a1 - open.a0 <= SR_ATOMS_SMALL && tile_run(edge_offset, open.a0, a1, tile_atoms, nullptr) <= nt_small) {
-      open.a1 = a1;  // the joint plan of the open group and this structure still fits
-    } else {
-      close_open();
-      open = Run{a0, a1};
-    }
-  }
-  close_open();
-  // the longest workgroups first: a launch ends with its short ones
-  auto by_edges = [&](const Run& x, const Run& y) {
-    return edge_offset[x.a1] - edge_offset[x.a0] > edge_offset[y.a1] - edge_offset[y.a0];
-  };
-  std::stable_sort(small.begin(), small.end(), by_edges);
-  std::stable_sort(big.begin(), big.end(), by_edges);
-  for (int pass = 0; pass < 2; ++pass)
-    for (const Run& r : pass ? big : small) {
-      const int32_t t0 = (int32_t)plan.tiles.size();
-      const int n = tile_run(edge_offset, r.a0, r.a1, tile_atoms, &plan.tiles);
-      (pass ? plan.big : plan.small).push_back(SrGroup{r.a0, r.a1, t0, n});
-    }
-}
-
-
-void plan_streamed_subset(const int32_t* mol_offset, const int32_t* edge_offset, const std::vector<int32_t>& streamed, int tile_atoms,
-                          std::vector<EdgeTile>& tiles, std::vector<int32_t>& tile_part, std::vector<int32_t>& big_tab, int32_t* n_slot_out,
-                          std::vector<int32_t>& atom_tab) {
-  tiles.clear(); tile_part.clear(); big_tab.clear(); atom_tab.clear();
-  int32_t n_slot = 0;
-  for (size_t i = 0; i < streamed.size();) {
-    size_t j = i + 1;
-    while (j < streamed.size() && streamed[j] == streamed[j - 1] + 1) ++j;  // a run of consecutive structures
-    const int32_t a0 = mol_offset[streamed[i]], a1 = mol_offset[streamed[j - 1] + 1];
-    tile_range(edge_offset, a0, a1, TE_MAX, tile_atoms, true, tiles, tile_part, big_tab, n_slot);
-    for (int32_t r = a0; r < a1; r += TA) {
-      atom_tab.push_back(r);
-      atom_tab.push_back(std::min<int32_t>(TA, a1 - r));
-    }
-    i = j;
-  }
-  *n_slot_out = n_slot;
-}
-
-
-void plan_layer_fusion(const std::vector<EdgeTile>& tiles, int delay, LayerPlan& plan) {
-  plan.work.clear(); plan.row_tab.clear(); plan.e_atile.clear(); plan.a_need.clear();
-  const int n_e = (int)tiles.size();
-  if (n_e == 0) return;
-  plan.e_atile.assign((size_t)2 * n_e, 0);
-  const int q = n_e >> 3, r = n_e & 7;
-  std::vector<std::vector<int32_t>> seq(8);  // per XCD: items (kind << 30 | index), in dispatch order
-  for (int x = 0; x < 8; ++x) {
-    const int t0 = x * q + std::min(x, r), t1 = t0 + q + (x < r ? 1 : 0);  // this XCD's contiguous run of edge tiles
-    if (t1 <= t0) continue;
-    const int32_t a0 = tiles[t0].atom_begin, a1 = tiles[t1 - 1].atom_end;
-    // 64-row atom tiles over exactly these tiles' atoms; `last[j]` = the last edge tile (position in the run) that feeds atom tile j
-    const int j0 = (int)plan.a_need.size();
-    const int nj = (a1 - a0 + TA - 1) / TA;
-    for (int j = 0; j < nj; ++j) {
-      plan.row_tab.push_back(a0 + j * TA);
-      plan.row_tab.push_back(std::min<int32_t>(TA, a1 - (a0 + j * TA)));
-      plan.a_need.push_back(0);
-    }
-    std::vector<int> last(nj, -1);
-    for (int t = t0; t < t1; ++t) {
-      const EdgeTile& tl = tiles[t];
-      const int ja = (tl.atom_begin - a0) / TA, jb = tl.atom_end > tl.atom_begin ? (tl.atom_end - 1 - a0) / TA : ja;
-      plan.e_atile[2 * t] = j0 + ja;
-      plan.e_atile[2 * t + 1] = jb - ja + 1;
-      for (int j = ja; j <= jb; ++j) {
-        ++plan.a_need[j0 + j];
-        last[j] = t - t0;
-      }
-    }
-    // an atom tile goes `delay` items behind the last edge tile that feeds it (by then that tile has most likely finished), in atom
-    // order; what is left goes to the end of the list
-    int next = 0;
-    for (int i = 0; i < t1 - t0; ++i) {
-      seq[x].push_back(t0 + i);
-      while (next < nj && last[next] + delay <= i) seq[x].push_back((1 << 30) | (j0 + next++));
-    }
-    while (next < nj) seq[x].push_back((1 << 30) | (j0 + next++));
-  }
-  size_t longest = 0;
-  for (int x = 0; x < 8; ++x) longest = std::max(longest, seq[x].size());
-  plan.work.assign(longest * 8 * 2, -1);
-  for (int x = 0; x < 8; ++x)
-    for (size_t i = 0; i < seq[x].size(); ++i) {
-      const size_t b = i * 8 + x;
-      plan.work[2 * b] = seq[x][i] >> 30;
-      plan.work[2 * b + 1] = seq[x][i] & ((1 << 30) - 1);
-    }
-}
-
 }  // namespace scann
 
 extern "C" {
@@ -446,69 +308,5 @@ int scann_plan_tiles(const scann_batch_t* b, int32_t tile_rows, int32_t tile_ato
   return rows;  // 32 or 64: the edge rows per tile actually planned
 }
 
-int scann_plan_groups(const scann_batch_t* b, int32_t tile_atoms, int32_t max_tiles, int32_t cap_groups, int32_t cap_tiles, int32_t* groups_out,
-                      int32_t* tiles_out, int32_t* streamed_out, int32_t* n_small, int32_t* n_big, int32_t* n_tiles,
-                      int32_t* n_streamed) {
-  if (!b || !n_small || !n_big || !n_tiles || !n_streamed || !b->mol_offset || !b->edge_offset || b->n_struct <= 0 || b->n_atom <= 0 ||
-      b->n_edge < 0 || tile_atoms <= 0 || tile_atoms > scann::TQ || max_tiles < 1)
-    return pack_fail("scann_plan_groups: bad argument");
-  if (b->mol_offset[0] != 0 || b->mol_offset[b->n_struct] != b->n_atom || b->edge_offset[0] != 0 || b->edge_offset[b->n_atom] != b->n_edge)
-    return pack_fail("scann_plan_groups: offsets do not cover the batch");
-  for (int s = 0; s < b->n_struct; ++s)
-    if (b->mol_offset[s + 1] <= b->mol_offset[s]) return pack_fail("scann_plan_groups: structure without atoms");
-  for (int a = 0; a < b->n_atom; ++a)
-    if (b->edge_offset[a + 1] < b->edge_offset[a]) return pack_fail("scann_plan_groups: edge_offset not monotone");
-  scann::SrPlan plan;
-  scann::plan_groups(b->mol_offset, b->n_struct, b->edge_offset, tile_atoms, max_tiles, plan);
-  *n_small = (int32_t)plan.small.size();
-  *n_big = (int32_t)plan.big.size();
-  *n_tiles = (int32_t)plan.tiles.size();
-  *n_streamed = (int32_t)plan.streamed.size();
-  if (!groups_out || !tiles_out || !streamed_out) return SCANN_OK;
-  if (*n_small + *n_big > cap_groups || *n_tiles > cap_tiles) return pack_fail("scann_plan_groups: output capacity too small");
-  int i = 0;
-  for (int pass = 0; pass < 2; ++pass)
-    for (const scann::SrGroup& g : pass ? plan.big : plan.small) {
-      groups_out[4 * i] = g.atom_begin; groups_out[4 * i + 1] = g.atom_end; groups_out[4 * i + 2] = g.tile_begin; groups_out[4 * i + 3] = g.n_tile;
-      ++i;
-    }
-  for (size_t t = 0; t < plan.tiles.size(); ++t) {
-    tiles_out[4 * t] = plan.tiles[t].atom_begin; tiles_out[4 * t + 1] = plan.tiles[t].atom_end;
-    tiles_out[4 * t + 2] = plan.tiles[t].edge_begin; tiles_out[4 * t + 3] = plan.tiles[t].edge_end;
-  }
-  for (size_t k = 0; k < plan.streamed.size(); ++k) streamed_out[k] = plan.streamed[k];
-  return SCANN_OK;
-}
-
-int scann_plan_layer(const scann_batch_t* b, int32_t tile_atoms, int32_t delay, int32_t cap_blocks, int32_t cap_atiles, int32_t* work_out,
-                     int32_t* row_tab_out, int32_t* e_atile_out, int32_t* a_need_out, int32_t* n_blocks, int32_t* n_atiles, int32_t* n_etiles) {
-  if (!b || !n_blocks || !n_atiles || !n_etiles || !b->mol_offset || !b->edge_offset || (b->n_edge > 0 && !b->edge_col) || b->n_struct <= 0 ||
-      b->n_atom <= 0 || b->n_edge < 0 || tile_atoms <= 0 || tile_atoms > scann::TQ || delay < 0)
-    return pack_fail("scann_plan_layer: bad argument");
-  std::vector<scann::EdgeTile> tiles;
-  std::vector<int32_t> part, big, row;
-  int rows = 0;
-  int32_t maxdeg = 0, nslot = 0;
-  std::string err;
-  const int r = scann::plan_tiles(b->mol_offset, b->n_struct, b->edge_offset, b->edge_col, b->n_atom, b->n_edge, scann::TE_MAX, tile_atoms, true,
-                                  tiles, part, big, row, &rows, &maxdeg, &nslot, err, false);
-  if (r) {
-    t_pack_error = "scann_plan_layer: " + err;
-    return r;
-  }
-  if (!big.empty()) return pack_fail("scann_plan_layer: the batch has atoms with more than 64 neighbours (chunk tiles are merged by a launch of their own)");
-  scann::LayerPlan plan;
-  scann::plan_layer_fusion(tiles, delay, plan);
-  *n_blocks = (int32_t)plan.work.size() / 2;
-  *n_atiles = (int32_t)plan.a_need.size();
-  *n_etiles = (int32_t)tiles.size();
-  if (!work_out || !row_tab_out || !e_atile_out || !a_need_out) return SCANN_OK;
-  if (*n_blocks > cap_blocks || *n_atiles > cap_atiles) return pack_fail("scann_plan_layer: output capacity too small");
-  memcpy(work_out, plan.work.data(), plan.work.size() * 4);
-  memcpy(row_tab_out, plan.row_tab.data(), plan.row_tab.size() * 4);
-  memcpy(e_atile_out, plan.e_atile.data(), plan.e_atile.size() * 4);
-  memcpy(a_need_out, plan.a_need.data(), plan.a_need.size() * 4);
-  return SCANN_OK;
-}
-
 }  // extern "C"
+

@@ -121,25 +121,15 @@ struct scann_handle {
   int fuse_attn = 1;   // env SCANN_TRAIN_FUSE_ATTN=0: attn_bwd16_kernel as a launch of its own before edge_bwd_kernel
   int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
   int species_tables = 1;  // env SCANN_SPECIES_TABLES=0: the first layer's atom rows come from an atom launch, not from per-species tables
-  // structure-resident forward (scann_struct.hip): the largest group, in edge tiles, that scann_batch_upload plans for it; 0 (the
-  // default: measured slower than the layer-streamed kernels, profiles/r04_notes.md): every structure stays on the layer-streamed
-  // kernels (env SCANN_RESIDENT, scann_set_resident_limit)
-  int sr_max_tiles = 0;
   bool generic = false;        // widths other than 128 / 8: the plain-fp32 forward of scann_generic.hip (inference only)
   float* g_weights = nullptr;  // generic: the flat fp32 parameter vector on the device (spec order, spec_off offsets)
   float* g_centres = nullptr;  // generic: 20 + 20 Gaussian centres (distance, Voronoi weight)
   std::map<std::string, int64_t> g_off;  // generic: tensor name -> offset in g_weights
   int train_fork_every = 1;    // env SCANN_TRAIN_FORK_EVERY: LocalAttention layers per weight-gradient launch on the side stream
-  int fuse_layers = 0;         // env SCANN_FUSE_LAYERS=1 / scann_set_layer_fusion: the next iteration's atom tiles inside each edge launch
-                               // (scann_layer.hip; measured no faster than separate launches, profiles/r04_notes.md: off by default);
-                               // cleared for good when a layer launch reports a fault
-  int64_t fused_forwards = 0;  // forwards that went through layer launches
-  int fuse_fault = 0;          // the fault code that switched layer launches off (0: none)
   bool weights_exact = false;  // a loaded 128x128 kernel has |w| >= 255.9: the split-fp16 images cannot hold it, inference runs exact
   bool force_exact = false;    // env SCANN_EXACT=1: every inference forward on the exact-fp32 kernels (test / diagnosis switch)
   bool strict_range = false;   // env SCANN_STRICT_RANGE=1: SCANN_ERR_RANGE instead of the exact-fp32 re-run of an inference forward
   int64_t exact_reruns = 0;    // forwards re-run on the exact-fp32 kernels so far (scann_exact_reruns)
-  LayerParams* d_layers = nullptr;  // device copy of `layers` (the resident kernel walks the layers itself)
   float* d_weights = nullptr;  // one arena with every device-side weight image
   std::vector<LayerParams> layers;
   HeadParams head{};
@@ -229,25 +219,8 @@ struct scann_dbatch {
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
   float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
   int32_t n_big = 0, n_slot = 0;
-  // structure-resident plan (plan_groups): groups of <= 3 tiles first, then the groups of 4..6; tiles of their own
-  SrGroup* sr_groups = nullptr;
-  EdgeTile* sr_tiles = nullptr;
-  int32_t n_sr_small = 0, n_sr_big = 0, n_sr_tile = 0, n_streamed = 0;
-  int32_t sr_small_edges = 0, sr_small_atoms = 0;  // edges / atoms of the groups of <= 3 tiles (what one sr_kernel<3> launch processes)
-  // ... and, when the batch also holds structures the resident kernels cannot take, the streamed kernels' plan for THOSE
-  EdgeTile* s2_tiles = nullptr;
-  int32_t *s2_tile_part = nullptr, *s2_big_tab = nullptr, *s2_row_tab = nullptr;
-  float* s2_part_buf = nullptr;
-  int32_t s2_n_tile = 0, s2_n_big = 0, s2_n_slot = 0, s2_n_row = 0;
-  // layer launches (scann_layer.hip): work list, atom tiles, dependency tables (inputs) and counters + the second half of the
-  // double-buffered atom rows (workspace); lf_n_block == 0: no plan (32-row tiles, chunk tiles, training handle, base branch)
-  int32_t *lf_work = nullptr, *lf_row_tab = nullptr, *lf_e_atile = nullptr, *lf_a_need = nullptr;
-  unsigned long long* lf_a_count = nullptr;
-  int32_t lf_n_block = 0, lf_n_atile = 0;
   size_t gen_ws_bytes = 0;
   char* gen_ws = nullptr;  // generic-width forward: its per-batch workspace (sized by the handle's widths; cached_malloc)
-  bool fused_run = false;  // the last forward went through layer launches (scann_batch_download checks their fault word)
-  float *c_b = nullptr, *P1_b = nullptr, *P3_b = nullptr, *q_b = nullptr;
   // workspace
   float *geom = nullptr, *gd = nullptr, *c = nullptr, *ctx = nullptr, *P1 = nullptr, *P3 = nullptr, *q = nullptr;
   float *gq = nullptr, *gk = nullptr, *ga = nullptr, *y = nullptr;
@@ -483,10 +456,8 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   if (const char* fa = getenv("SCANN_TRAIN_FUSE_ATTN")) h->fuse_attn = atoi(fa) != 0;
   if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
   if (const char* sg = getenv("SCANN_STRICT_RANGE")) h->strict_range = atoi(sg) != 0;
-  if (const char* fl = getenv("SCANN_FUSE_LAYERS")) h->fuse_layers = atoi(fl) != 0;
   if (const char* fk = getenv("SCANN_TRAIN_FORK_EVERY")) h->train_fork_every = std::max(1, atoi(fk));
   if (const char* fe = getenv("SCANN_EXACT")) h->force_exact = atoi(fe) != 0;
-  if (const char* sr = getenv("SCANN_RESIDENT")) h->sr_max_tiles = std::min((int)SR_NT_BIG, std::max(0, atoi(sr)));
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -496,11 +467,11 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
     delete h;
     return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipSetDevice failed");
   }
-  if (hipHostMalloc((void**)&h->range_flag, 128, hipHostMallocDefault) != hipSuccess) {  // [0, 16): range guard per stream; [16]: layer-launch fault
+  if (hipHostMalloc((void**)&h->range_flag, 128, hipHostMallocDefault) != hipSuccess) {  // [0, 16): range guard per stream
     delete h;
     return fail(nullptr, SCANN_ERR_HIP, "scann_create: hipHostMalloc failed");
   }
-  for (int i = 0; i < 32; ++i) h->range_flag[i] = 0;  // one range-guard word per stream slot, then the layer-launch fault word
+  for (int i = 0; i < 32; ++i) h->range_flag[i] = 0;  // one range-guard word per stream slot
   for (int i = 0; i < h->nstream; ++i) {
     if (hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking) != hipSuccess) {
       delete h;
@@ -523,7 +494,6 @@ void scann_destroy(scann_handle_t* h) {
   if (h->g_weights) (void)hipFree(h->g_weights);
   if (h->g_centres) (void)hipFree(h->g_centres);
   if (h->sp_c) (void)hipFree(h->sp_c);
-  if (h->d_layers) (void)hipFree(h->d_layers);
   for (scann_handle::Stage& st : h->stage) {
     if (st.p) (void)hipHostFree(st.p);
     if (st.ev) (void)hipEventDestroy(st.ev);
@@ -843,10 +813,6 @@ int scann_load_weights(scann_handle_t* h, const float* blob, const scann_tensor_
   h->embed.emb = P(oemb); h->embed.We = P(oWc); h->embed.be = P(obc); h->embed.Wr = P(oWr); h->embed.br = P(obr);
   h->embed.Wde = P(oWe); h->embed.bde = P(obe);
   h->sp_dirty = true;
-  if (L > 0) {  // the structure-resident kernel reads the per-layer pointer table from the device
-    if (!h->d_layers) HIPCHK(h, hipMalloc((void**)&h->d_layers, (size_t)L * sizeof(LayerParams)));
-    HIPCHK(h, hipMemcpy(h->d_layers, h->layers.data(), (size_t)L * sizeof(LayerParams), hipMemcpyHostToDevice));
-  }
   if (!general_embed && !h->sp_c && c.g_update) {  // c | P1 | P3 | q tables of the first layer, one allocation
     const size_t tab = (size_t)c.n_atoms * D;
     HIPCHK(h, hipMalloc((void**)&h->sp_c, 4 * tab * sizeof(float)));
@@ -954,23 +920,6 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     }
   }
   const int32_t n_big = (int32_t)big_tab.size() / 3;
-  // structure-resident plan (inference handles, SCANN+ only) and, for a batch with structures beyond it, the streamed kernels' plan
-  // for exactly those
-  SrPlan sr;
-  std::vector<EdgeTile> tiles2;
-  std::vector<int32_t> tile_part2, big_tab2, row_tab2;
-  int32_t n_slot2 = 0;
-  if (h->sr_max_tiles > 0 && h->cfg.g_update && E > 0 && !h->t_master) {
-    plan_groups(b->mol_offset, B, b->edge_offset, h->tile_atoms, h->sr_max_tiles, sr);
-    if (sr.small.empty() && sr.big.empty()) sr.streamed.clear();  // nothing resident: the whole-batch plan above serves
-    else if (!sr.streamed.empty())
-      plan_streamed_subset(b->mol_offset, b->edge_offset, sr.streamed, h->tile_atoms, tiles2, tile_part2, big_tab2, &n_slot2, row_tab2);
-  }
-  LayerPlan lplan;  // edge tiles + the next layer's atom tiles in one launch (64-row plans without chunk tiles, inference handles)
-  if (h->fuse_layers && h->cfg.g_update && E > 0 && !h->t_master && tile_rows == TE_MAX && n_big == 0 && !h->cfg.use_ring && !h->cfg.feature_cgcnn)
-    plan_layer_fusion(tiles, getenv("SCANN_LF_DELAY") ? atoi(getenv("SCANN_LF_DELAY")) : 400, lplan);
-  const int32_t n_big2 = (int32_t)big_tab2.size() / 3;
-  const size_t n_srg = sr.small.size() + sr.big.size();
   HIPCHK(h, hipSetDevice(h->device));
   scann_dbatch* db = nullptr;
   if (scratch) {
@@ -1000,21 +949,13 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_tpart = take(n_big ? tiles.size() * 4 : 0), o_big = take((size_t)n_big * 3 * 4);
   const size_t o_inoff = take((size_t)(A + 1) * 4), o_inedge = take((size_t)E * 4);
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
-  const size_t o_srg = take(n_srg * sizeof(SrGroup)), o_srt = take(sr.tiles.size() * sizeof(EdgeTile));
-  const size_t o_t2 = take(tiles2.size() * sizeof(EdgeTile)), o_tp2 = take(n_big2 ? tiles2.size() * 4 : 0), o_big2 = take((size_t)n_big2 * 3 * 4);
-  const size_t o_row2 = take(row_tab2.size() * 4);
-  const size_t o_lfw = take(lplan.work.size() * 4), o_lfr = take(lplan.row_tab.size() * 4), o_lfe = take(lplan.e_atile.size() * 4);
-  const size_t o_lfn = take(lplan.a_need.size() * 4);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
   const size_t o_geom = take(h->cfg.g_update ? rowE : 0), o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
   const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
-  const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4), o_pbuf2 = take((size_t)n_slot2 * 3 * D * 4);
-  const bool lf = !lplan.work.empty();
-  const size_t o_lfc = take(lplan.a_need.size() * 8 * (size_t)std::max(1, h->cfg.n_attention));
-  const size_t o_cb = take(lf ? rowA : 0), o_P1b = take(lf ? rowA : 0), o_P3b = take(lf ? rowA : 0), o_qb = take(lf ? rowA : 0);
+  const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4);
   hipError_t e = hipSuccess;
   scann_handle::Stage* stage = nullptr;
   char* img_ptr = nullptr;
@@ -1086,23 +1027,6 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     memcpy(img.data() + o_tpart, tile_part.data(), tiles.size() * 4);
     memcpy(img.data() + o_big, big_tab.data(), (size_t)n_big * 3 * 4);
   }
-  if (lf) {
-    memcpy(img.data() + o_lfw, lplan.work.data(), lplan.work.size() * 4);
-    memcpy(img.data() + o_lfr, lplan.row_tab.data(), lplan.row_tab.size() * 4);
-    memcpy(img.data() + o_lfe, lplan.e_atile.data(), lplan.e_atile.size() * 4);
-    memcpy(img.data() + o_lfn, lplan.a_need.data(), lplan.a_need.size() * 4);
-  }
-  if (n_srg) {
-    memcpy(img.data() + o_srg, sr.small.data(), sr.small.size() * sizeof(SrGroup));
-    memcpy(img.data() + o_srg + sr.small.size() * sizeof(SrGroup), sr.big.data(), sr.big.size() * sizeof(SrGroup));
-    memcpy(img.data() + o_srt, sr.tiles.data(), sr.tiles.size() * sizeof(EdgeTile));
-    if (!tiles2.empty()) memcpy(img.data() + o_t2, tiles2.data(), tiles2.size() * sizeof(EdgeTile));
-    if (!row_tab2.empty()) memcpy(img.data() + o_row2, row_tab2.data(), row_tab2.size() * 4);
-    if (n_big2) {
-      memcpy(img.data() + o_tp2, tile_part2.data(), tiles2.size() * 4);
-      memcpy(img.data() + o_big2, big_tab2.data(), (size_t)n_big2 * 3 * 4);
-    }
-  }
   // (the centre atom of every edge is derived from the offsets on the device, behind the copy: no host loop, no bytes over the bus)
   int32_t* const d_eoff = (int32_t*)(db->arena + o_eoff);
   int32_t* const d_erow = (int32_t*)(db->arena + o_row);
@@ -1139,27 +1063,6 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->ga = (float*)(a0 + o_ga); db->y = (float*)(a0 + o_y);
   if (n_big) {
     db->tile_part = (int32_t*)(a0 + o_tpart); db->big_tab = (int32_t*)(a0 + o_big); db->part_buf = (float*)(a0 + o_pbuf);
-  }
-  if (lf) {
-    db->lf_work = (int32_t*)(a0 + o_lfw); db->lf_row_tab = (int32_t*)(a0 + o_lfr); db->lf_e_atile = (int32_t*)(a0 + o_lfe);
-    db->lf_a_need = (int32_t*)(a0 + o_lfn); db->lf_a_count = (unsigned long long*)(a0 + o_lfc);
-    db->lf_n_block = (int32_t)lplan.work.size() / 2; db->lf_n_atile = (int32_t)lplan.a_need.size();
-    db->c_b = (float*)(a0 + o_cb); db->P1_b = (float*)(a0 + o_P1b); db->P3_b = (float*)(a0 + o_P3b); db->q_b = (float*)(a0 + o_qb);
-  }
-  if (n_srg) {
-    db->sr_groups = (SrGroup*)(a0 + o_srg); db->sr_tiles = (EdgeTile*)(a0 + o_srt);
-    db->n_sr_small = (int32_t)sr.small.size(); db->n_sr_big = (int32_t)sr.big.size(); db->n_sr_tile = (int32_t)sr.tiles.size();
-    db->n_streamed = (int32_t)sr.streamed.size();
-    for (const SrGroup& g : sr.small) {
-      db->sr_small_edges += b->edge_offset[g.atom_end] - b->edge_offset[g.atom_begin];
-      db->sr_small_atoms += g.atom_end - g.atom_begin;
-    }
-    db->s2_tiles = (EdgeTile*)(a0 + o_t2); db->s2_n_tile = (int32_t)tiles2.size();
-    db->s2_row_tab = (int32_t*)(a0 + o_row2); db->s2_n_row = (int32_t)row_tab2.size() / 2;
-    db->s2_n_big = n_big2; db->s2_n_slot = n_slot2;
-    if (n_big2) {
-      db->s2_tile_part = (int32_t*)(a0 + o_tp2); db->s2_big_tab = (int32_t*)(a0 + o_big2); db->s2_part_buf = (float*)(a0 + o_pbuf2);
-    }
   }
   *out = db;
   return SCANN_OK;
@@ -1298,7 +1201,6 @@ int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s) {
 int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, bool exact = false) {
   if ((h->force_exact || h->weights_exact) && !h->debug && !h->in_train_forward) exact = true;
   db->idle = false;  // work is being enqueued on the batch (scann_batch_release)
-  db->fused_run = false;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
   if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
   if (h->generic) {
@@ -1323,22 +1225,12 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
   auto g_of = [&](int l) { return direct && c.g_update ? db->dbg_g + (size_t)l * nE_ : db->geom; };
   int32_t* const rflag = h->range_flag ? h->range_flag + db->last_slot : nullptr;  // this stream's range-guard word
   if (tm) tm->mark(-1);
-  // Structure-resident path (scann_struct.hip) for the groups scann_batch_upload planned; the layer-streamed launches below then
-  // cover only the structures beyond it (none in a QM9-shaped batch), through the plan made for exactly those.
   // exact: the forward's range guard fired (an operand outside the split-fp16 range): the same launches on the EX instantiations of
   // the atom / edge kernels -- exact-fp32 projections -- with the plain first layer (basis_kernel, no per-species tables)
-  const bool resident = !exact && db->n_sr_small + db->n_sr_big > 0 && L > 0 && !h->debug && !h->in_train_forward && h->train_drop_p == 0.f && h->d_layers;
-  const bool streamed_any = !resident || db->n_streamed > 0;
-  const EdgeTile* const v_tiles = resident ? db->s2_tiles : db->tiles;
-  const int v_n_tile = resident ? db->s2_n_tile : db->n_tile, v_n_big = resident ? db->s2_n_big : db->n_big;
-  const int32_t* const v_tile_part = resident ? db->s2_tile_part : db->tile_part;
-  const int32_t* const v_big_tab = resident ? db->s2_big_tab : db->big_tab;
-  float* const v_part_buf = resident ? db->s2_part_buf : db->part_buf;
-  const int v_tile_rows = resident ? TE_MAX : db->tile_rows;
   // inference: the first layer's edge kernel computes its geometry rows from (dist, weight) itself -- geom0 is never written by a
   // basis launch and read back (282 MB of the 16-batch forward's traffic and one launch)
   const bool fuse_basis = !exact && h->fuse_basis && c.g_update && L > 0 && !h->debug && !h->in_train_forward && db->n_edge > 0;
-  if (fuse_basis || !streamed_any) {}
+  if (fuse_basis) {}  // (nothing to launch)
   else if (c.g_update) launch_basis(h->basis, db->dist, db->weight, db->n_edge, g_of(0), s);
   else launch_basis_raw(h->cd, db->dist, db->n_edge, db->gd, s);
   if (tm) tm->mark(0);
@@ -1355,7 +1247,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
   }
   // first layer from per-species tables: no atom launch at all (see EdgeArgs::species)
   // (not with chunked atoms: edge_merge_kernel reads the query rows per atom)
-  const bool species0 = streamed_any && fuse_basis && h->species_tables && !general_embed && h->train_drop_p == 0.f && h->sp_c && v_n_big == 0;
+  const bool species0 = fuse_basis && h->species_tables && !general_embed && h->train_drop_p == 0.f && h->sp_c && db->n_big == 0;
   if (species0 && h->sp_dirty) {
     AtomArgs a{};
     a.n_atom = c.n_atoms; a.x = h->lut; a.ffn = 0; a.c = h->sp_c;
@@ -1368,79 +1260,12 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     HIPCHK(h, hipStreamSynchronize(s));  // once per weight change: forwards on the handle's other streams read the tables too
     h->sp_dirty = false;
   }
-  // Layer launches (scann_layer.hip): the atom tiles of layer l + 1 ride in layer l's edge launch behind per-XCD counters; the atom
-  // rows are double-buffered because edge tiles of the launch still gather the current ones.  Same bytes as the schedule below.
-  const bool fused = species0 && !resident && h->fuse_layers && db->lf_n_block > 0 && v_tile_rows == TE_MAX && !h->in_train_forward;
-  if (fused) {
-    HIPCHK(h, hipMemsetAsync(db->lf_a_count, 0, (size_t)L * db->lf_n_atile * 8, s));  // one counter word per layer and atom tile
-    float* const cS[2] = {db->c, db->c_b};
-    float* const p1S[2] = {db->P1, db->P1_b};
-    float* const p3S[2] = {db->P3, db->P3_b};
-    float* const qS[2] = {db->q, db->q_b};
-    for (int l = 0; l < L; ++l) {
-      const int in = l & 1, out = in ^ 1;
-      EdgeArgs ea{};
-      ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = 1; ea.tile_rows = TE_MAX;
-      ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
-      ea.geom = db->geom; ea.gd = db->gd; ea.edge_weight = db->weight;
-      ea.geom_dead = l == L - 1 ? 1 : 0;
-      ea.ctx = db->ctx;
-      if (l == 0) {
-        ea.fuse_basis = 1; ea.dist = db->dist; ea.basis = h->basis;
-        ea.species = db->atomic; ea.c = h->sp_c; ea.P1 = h->sp_P1; ea.P3 = h->sp_P3; ea.q = h->sp_q;
-      } else {
-        ea.c = cS[in]; ea.P1 = p1S[in]; ea.P3 = p3S[in]; ea.q = qS[in];
-      }
-      ea.p = h->layers[l];
-      ea.range_flag = rflag; ea.layer = l;
-      AtomArgs a{};  // head of layer l + 1: ResidualNorm of layer l, centres, projections of layer l + 1 (or the readout's rows)
-      a.n_atom = db->n_atom;
-      a.row_tab = db->lf_row_tab; a.n_row_tab = db->lf_n_atile;
-      a.x = db->ctx; a.ffn = c.use_attn_norm ? 1 : 0;
-      const LayerParams& pp = h->layers[l];
-      a.Wf1h = pp.Wf1h; a.bf1 = pp.bf1; a.Wf2h = pp.Wf2h; a.bf2 = pp.bf2; a.lnr_g = pp.lnr_g; a.lnr_b = pp.lnr_b;
-      a.c = cS[out];
-      a.range_flag = rflag; a.layer = l + 1;
-      if (l + 1 < L) {
-        const LayerParams& p = h->layers[l + 1];
-        a.mode = 0;
-        a.WAh = p.W1h; a.bA = p.bg; a.WBh = p.W3h; a.WCh = p.Wqh; a.bC = p.bq;
-        a.oA = p1S[out]; a.oB = p3S[out]; a.oC = qS[out];
-      } else {
-        a.mode = 2;
-        a.WAh = h->head.Wah; a.bA = h->head.ba; a.WCh = h->head.Wgqh; a.bC = h->head.bgq; a.WDh = h->head.Wgkh; a.bD = h->head.bgk;
-        a.oB = db->gk; a.oC = db->gq;
-      }
-      LayerFuse f{};
-      f.work = reinterpret_cast<const int2*>(db->lf_work); f.n_block = db->lf_n_block;
-      f.e_atile = db->lf_e_atile; f.a_need = db->lf_a_need; f.a_count = db->lf_a_count + (size_t)l * db->lf_n_atile; f.fault = h->range_flag + 16;
-      // (scann_edge_timing: the sampled kernel is layer_kernel<false, ..., 0>, the launches of layers 1 .. L-2)
-      const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && l > 0 && l + 1 < L;
-      hipEvent_t ev0 = nullptr, ev1 = nullptr;
-      if (sample) {
-        (void)hipEventCreateWithFlags(&ev0, kTimingEventFlags);
-        (void)hipEventCreateWithFlags(&ev1, kTimingEventFlags);
-        (void)hipEventRecord(ev0, s);
-      }
-      launch_layer(ea, a, f, s);
-      if (sample) {
-        (void)hipEventRecord(ev1, s);
-        h->time_ev.push_back(ev0);
-        h->time_ev.push_back(ev1);
-        h->time_edges.push_back(db->n_edge);
-      }
-      if (tm) tm->mark(2);
-    }
-    db->fused_run = true;
-    h->fused_forwards++;
-  }
-  for (int l = 0; l <= L && streamed_any && !fused; ++l) {
+  for (int l = 0; l <= L; ++l) {
     // training forward through edge_kernel_lean: q, V, T, ang, K of every layer are kept for the backward
     const bool keep = direct && h->in_train_forward && db->keep_K && l < L;
     // atom kernel at the head of layer l: ResidualNorm of layer l-1, centres, projections of layer l
     AtomArgs a{};
     a.n_atom = db->n_atom;
-    if (resident) { a.row_tab = db->s2_row_tab; a.n_row_tab = db->s2_n_row; }
     if (l == 0) {
       a.x = general_embed ? db->c0 : h->lut;
       a.x_index = general_embed ? nullptr : db->atomic;
@@ -1502,10 +1327,11 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     if (h->debug && !direct) HIPCHK(h, hipMemcpyAsync(db->dbg_c + (size_t)l * db->n_atom * D, db->c, rowA, hipMemcpyDeviceToDevice, s));
     if (l == L) break;
     EdgeArgs ea{};
-    ea.tiles = v_tiles; ea.n_tile = v_n_tile; ea.g_update = c.g_update; ea.tile_rows = v_tile_rows;
+    ea.tiles = db->tiles; ea.n_tile = db->n_tile; ea.g_update = c.g_update; ea.tile_rows = db->tile_rows;
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = g_of(l); ea.geom_out = direct && c.g_update ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
     if (fuse_basis && l == 0) { ea.fuse_basis = 1; ea.dist = db->dist; ea.basis = h->basis; }
+    ea.geom_rows = fuse_basis ? 0 : 1;  // piece-major tiles only when the first layer computed its own geometry rows (plain inference)
     ea.geom_dead = (l == L - 1 && !h->debug) ? 1 : 0;  // the geometry leaving the last layer is never consumed (141 MB of writes per 16-batch launch)
     ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
     if (species0 && l == 0) { ea.species = db->atomic; ea.c = h->sp_c; ea.P1 = h->sp_P1; ea.P3 = h->sp_P3; ea.q = h->sp_q; }
@@ -1524,14 +1350,14 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     }
     ea.range_flag = rflag; ea.layer = l;
     // (the first layer's launch with the basis MLP fused in is a different kernel: not part of edge_kernel's sampled average)
-    const bool sample = !resident && !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
+    const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && !(fuse_basis && l == 0);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (sample) {
       (void)hipEventCreateWithFlags(&ev0, kTimingEventFlags);
       (void)hipEventCreateWithFlags(&ev1, kTimingEventFlags);
       (void)hipEventRecord(ev0, s);
     }
-    ea.tile_part = v_tile_part; ea.part_buf = v_part_buf;
+    ea.tile_part = db->tile_part; ea.part_buf = db->part_buf;
     ea.xcd_remap = h->xcd_remap;
     if (h->in_train_forward && h->attn_drop_p > 0.f) {  // validation passes run with scann_set_attention_dropout(h, 0): trainer.fit
       ea.attn_drop_p = h->attn_drop_p;
@@ -1546,7 +1372,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     }
 #endif
     launch_edge(ea, s);
-    launch_edge_merge(v_big_tab, v_n_big, v_part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, rflag, l, s);
+    launch_edge_merge(db->big_tab, db->n_big, db->part_buf, ea.q, ea.p.ln_g, ea.p.ln_b, ea.ctx, rflag, l, s);
     if (sample) {
       (void)hipEventRecord(ev1, s);
       h->time_ev.push_back(ev0);
@@ -1559,51 +1385,6 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
       if (c.g_update && db->n_edge)
         HIPCHK(h, hipMemcpyAsync(db->dbg_g + (size_t)(l + 1) * db->n_edge * D, db->geom, rowE, hipMemcpyDeviceToDevice, s));
     }
-  }
-  if (resident) {
-    SrArgs sa{};
-    sa.groups = db->sr_groups; sa.tiles = db->sr_tiles; sa.n_group = db->n_sr_small; sa.n_layer = L; sa.use_attn_norm = c.use_attn_norm;
-    sa.edge_offset = db->edge_offset; sa.edge_col = db->edge_col; sa.edge_row = db->edge_row;
-    sa.dist = db->dist; sa.edge_weight = db->weight;
-    sa.x0 = general_embed ? db->c0 : h->lut; sa.x0_index = general_embed ? nullptr : db->atomic;
-    sa.basis = h->basis; sa.layers = h->d_layers; sa.head = h->head;
-    sa.c = db->c; sa.P1 = db->P1; sa.P3 = db->P3; sa.q = db->q; sa.ctx = db->ctx; sa.gq = db->gq; sa.gk = db->gk;
-    sa.range_flag = rflag;
-    if (getenv("SCANN_SR_DEBUG")) {  // test hook: per-layer intermediates of the resident kernels for scann_debug_read
-      const int r = ensure_debug(h, db);
-      if (r) return r;
-      sa.dbg_c = db->dbg_c; sa.dbg_ctx = db->dbg_ctx; sa.dbg_g = db->dbg_g;
-      sa.n_atom_total = db->n_atom; sa.n_edge_total = db->n_edge;
-    }
-#ifdef SCANN_STAMPS
-    if (!db->stamps && db->n_sr_small > 0) {
-      HIPCHK(h, hipMalloc((void**)&db->stamps, (size_t)db->n_sr_small * 64 * sizeof(unsigned long long)));
-      HIPCHK(h, hipMemsetAsync(db->stamps, 0, (size_t)db->n_sr_small * 64 * sizeof(unsigned long long), s));
-    }
-    sa.stamps = db->stamps;
-    db->n_stamp = 4 * db->n_sr_small;  // scann_debug_stamps copies 16-word records
-#endif
-    // (scann_edge_timing: with this path the sampled kernel is sr_kernel<3>, the whole forward of the groups of <= 3 tiles)
-    const bool sample = !tm && h->time_every > 0 && (h->time_count % h->time_every) == 0 && sa.n_group > 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (sample) {
-      (void)hipEventCreateWithFlags(&ev0, kTimingEventFlags);
-      (void)hipEventCreateWithFlags(&ev1, kTimingEventFlags);
-      (void)hipEventRecord(ev0, s);
-    }
-    launch_struct(sa, SR_NT_SMALL, s);
-    if (sample) {
-      (void)hipEventRecord(ev1, s);
-      h->time_ev.push_back(ev0);
-      h->time_ev.push_back(ev1);
-      h->time_edges.push_back(db->sr_small_edges);
-    }
-    if (db->n_sr_big) {
-      sa.groups = db->sr_groups + db->n_sr_small; sa.n_group = db->n_sr_big;
-      sa.stamps = nullptr;
-      launch_struct(sa, SR_NT_BIG, s);
-    }
-    if (tm) tm->mark(2);
   }
   if (!tm) h->time_count++;
   ReadoutArgs r{};
@@ -1628,16 +1409,10 @@ int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slo
   return run_forward(h, db, h->streams[slot], nullptr);
 }
 
-int scann_set_resident_limit(scann_handle_t* h, int max_tiles) {
-  if (!h || max_tiles < 0) return fail(h, SCANN_ERR_INVALID, "scann_set_resident_limit: bad argument");
-  h->sr_max_tiles = std::min((int)SR_NT_BIG, max_tiles);
-  return SCANN_OK;
-}
-
 int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8) {
   if (!h || !db || !out8) return fail(h, SCANN_ERR_INVALID, "scann_batch_info: null argument");
-  out8[0] = db->n_sr_small; out8[1] = db->n_sr_big; out8[2] = db->n_streamed; out8[3] = db->n_sr_tile;
-  out8[4] = db->sr_small_edges; out8[5] = db->sr_small_atoms; out8[6] = db->n_tile; out8[7] = db->tile_rows;
+  out8[0] = db->n_struct; out8[1] = db->n_atom; out8[2] = db->n_edge; out8[3] = db->n_big;
+  out8[4] = db->n_slot; out8[5] = db->max_degree; out8[6] = db->n_tile; out8[7] = db->tile_rows;
   return SCANN_OK;
 }
 
@@ -1676,21 +1451,6 @@ int scann_batch_download(scann_handle_t* h, scann_dbatch_t* db, float* y_out, fl
   // The forward's range guard fired: an activation left the range of the split-fp16 projections (sites 1-4).  The reference runs any
   // fp32 values (attention.py:95-113), so the forward is run again on the exact-fp32 instantiations (1/16 of the matrix rate, this
   // batch only) instead of handing an error back -- unless SCANN_STRICT_RANGE=1 asks for the error.
-  // A layer launch reported that its hand-off assumptions did not hold (a wait ran out, or workgroups were not dealt round-robin over
-  // the XCDs): layer launches are switched off on the handle for good and this batch goes through the unfused schedule.
-  if (db->fused_run && h->range_flag && *reinterpret_cast<volatile int32_t*>(h->range_flag + 16) != 0) {
-    if (h->fuse_layers) {
-      h->fuse_fault = h->range_flag[16];
-      h->fuse_layers = 0;
-      fprintf(stderr, "scann_hip: layer launches disabled on device %d (fault 0x%x: %s); using one launch per kernel\n", h->device, h->fuse_fault,
-              h->fuse_fault & 2 ? "an atom tile ran on another XCD than its edge tiles" : "a dependency wait ran out");
-    }
-    h->range_flag[db->last_slot] = 0;  // whatever the discarded pass flagged
-    const int r = run_forward(h, db, s, nullptr);
-    if (r) return r;
-    const int rf2 = fetch_results(h, db, s, y_out, ga_attn_out);
-    if (rf2) return rf2;
-  }
   if (h->range_flag && !h->strict_range && !db->kept) {
     const int32_t code = *reinterpret_cast<volatile int32_t*>(h->range_flag + db->last_slot);
     const int site = code >> 8;
@@ -1718,17 +1478,6 @@ int scann_device_memory(scann_handle_t* h, int64_t* free_bytes, int64_t* total_b
 }
 
 int64_t scann_exact_reruns(const scann_handle_t* h) { return h ? h->exact_reruns : -1; }
-
-int scann_set_layer_fusion(scann_handle_t* h, int on) {
-  if (!h) return SCANN_ERR_INVALID;
-  if (on && h->fuse_fault) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_set_layer_fusion: layer launches faulted on this device");
-  h->fuse_layers = on ? 1 : 0;  // batches uploaded while it was off carry no plan: they keep the unfused schedule
-  return SCANN_OK;
-}
-
-int64_t scann_fused_forwards(const scann_handle_t* h) { return h ? h->fused_forwards : -1; }
-
-int scann_layer_fusion_state(const scann_handle_t* h) { return !h ? SCANN_ERR_INVALID : h->fuse_fault ? -(h->fuse_fault & 3) : h->fuse_layers; }
 
 int scann_sync(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;

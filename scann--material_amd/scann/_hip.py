@@ -98,14 +98,8 @@ SYMBOLS = [
     ("scann_slice_count", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("scann_slice_batch", C.c_int, [_P] * 8 + [C.c_int32, C.c_int64] + [_P] * 7),
     ("scann_plan_tiles", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    ("scann_plan_groups", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P] + [C.POINTER(C.c_int32)] * 4),
-    ("scann_plan_layer", C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P] + [C.POINTER(C.c_int32)] * 3),
-    ("scann_set_resident_limit", C.c_int, [_P, C.c_int]),
     ("scann_exact_reruns", C.c_int64, [_P]),
     ("scann_device_memory", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    ("scann_set_layer_fusion", C.c_int, [_P, C.c_int]),
-    ("scann_layer_fusion_state", C.c_int, [_P]),
-    ("scann_fused_forwards", C.c_int64, [_P]),
     ("scann_batch_info", C.c_int, [_P, _P, _P]),
 ]
 
@@ -322,38 +316,6 @@ def plan_tiles(packed, tile_rows=64, tile_atoms=24, allow_chunks=True):
     return rc, tiles[:nt.value].copy(), part[:nt.value].copy(), ns.value
 
 
-def plan_layer(packed, tile_atoms=24, delay=96):
-    """The work list of a layer launch (csrc/scann_layer.hip) for `packed` (host only): dict with `work` [n_block,2] = kind (0 edge
-    tile, 1 atom tile, -1 nothing) and index, `row_tab` [n_atile,2], `e_atile` [n_etile,2], `a_need` [n_atile]."""
-    lib = load_library()
-    cap_b, cap_a = packed.n_atom + packed.n_edge // 16 + 64, packed.n_atom // 32 + 16
-    work, rows = np.empty((cap_b, 2), np.int32), np.empty((cap_a, 2), np.int32)
-    eat, need = np.empty((cap_b, 2), np.int32), np.empty(cap_a, np.int32)
-    nb, na, ne = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-    st = packed.as_struct()
-    rc = lib.scann_plan_layer(C.byref(st), tile_atoms, delay, cap_b, cap_a, _ptr(work), _ptr(rows), _ptr(eat), _ptr(need),
-                              C.byref(nb), C.byref(na), C.byref(ne))
-    if rc < 0:
-        raise ScannHipError(rc, (lib.scann_pack_last_error() or b"").decode())
-    return {"work": work[:nb.value].copy(), "row_tab": rows[:na.value].copy(), "e_atile": eat[:ne.value].copy(), "a_need": need[:na.value].copy()}
-
-
-def plan_groups(packed, tile_atoms=24, max_tiles=6):
-    """The structure-resident plan scann_batch_upload would build for `packed` (host only): dict with `small` / `big` groups
-    [n,4] = atom_begin, atom_end, tile_begin, n_tile (<= 3 tiles / 4..6 tiles), `tiles` [n,4] and the `streamed` structure ids."""
-    lib = load_library()
-    cap_g, cap_t = packed.n_struct + 1, packed.n_atom + packed.n_edge // 32 + 2
-    groups, tiles, streamed = np.empty((cap_g, 4), np.int32), np.empty((cap_t, 4), np.int32), np.empty(cap_g, np.int32)
-    ns, nb, nt, nst = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
-    st = packed.as_struct()
-    rc = lib.scann_plan_groups(C.byref(st), tile_atoms, max_tiles, cap_g, cap_t, _ptr(groups), _ptr(tiles), _ptr(streamed),
-                               C.byref(ns), C.byref(nb), C.byref(nt), C.byref(nst))
-    if rc < 0:
-        raise ScannHipError(rc, (lib.scann_pack_last_error() or b"").decode())
-    return {"small": groups[:ns.value].copy(), "big": groups[ns.value:ns.value + nb.value].copy(), "tiles": tiles[:nt.value].copy(),
-            "streamed": streamed[:nst.value].copy()}
-
-
 def slice_dataset(ds_mol_offset, ds_edge_offset, ds_atomic, ds_ring, ds_edge_local, ds_edge_dist, ds_edge_weight, sel):
     """Structures `sel` of a dataset kept in CSR form -> PackedBatch (scann_slice_batch; the batch that
     DataIterator.__getitem__, datagenerator.py:69-135, would assemble from nested lists)."""
@@ -497,11 +459,6 @@ class Engine:
     def sync(self):
         self._check(self.lib.scann_sync(self._h))
 
-    def set_resident_limit(self, max_tiles):
-        """largest group (in edge tiles, 0..6) the structure-resident forward takes; 0 = layer-streamed kernels only.
-        Applies to batches uploaded afterwards."""
-        self._check(self.lib.scann_set_resident_limit(self._h, int(max_tiles)))
-
     def exact_reruns(self):
         """forwards this handle has re-run on the exact-fp32 kernels because an activation left the split-fp16 range"""
         return int(self.lib.scann_exact_reruns(self._h))
@@ -512,21 +469,10 @@ class Engine:
         self._check(self.lib.scann_device_memory(self._h, C.byref(f), C.byref(t)))
         return int(f.value), int(t.value)
 
-    def set_layer_fusion(self, on):
-        """atom tiles of the next iteration inside each edge launch (scann_layer.hip); applies to batches uploaded afterwards"""
-        self._check(self.lib.scann_set_layer_fusion(self._h, int(bool(on))))
-
-    def layer_fusion_state(self):
-        """1 on, 0 off, < 0: a layer launch faulted and the handle fell back to separate launches (-1 a wait ran out, -2 tiles on different XCDs)"""
-        return int(self.lib.scann_layer_fusion_state(self._h))
-
-    def fused_forwards(self):
-        return int(self.lib.scann_fused_forwards(self._h))
-
     def batch_info(self, rb):
         out = np.zeros(8, dtype=np.int32)
         self._check(self.lib.scann_batch_info(self._h, rb._h, _ptr(out)))
-        keys = ("resident_small", "resident_big", "streamed_structs", "resident_tiles", "small_edges", "small_atoms", "tiles", "tile_rows")
+        keys = ("structs", "atoms", "edges", "big_atoms", "merge_slots", "max_degree", "tiles", "tile_rows")
         return dict(zip(keys, (int(v) for v in out)))
 
     def num_streams(self):

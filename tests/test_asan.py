@@ -44,10 +44,6 @@ for n, seed in ((1, 0), (7, 1), (33, 2)):
         assert pk.n_struct == n and pk.edge_offset[-1] == pk.n_edge == int(inputs["neighbor_mask"].sum())
         for tr in (32, 64):
             _hip.plan_tiles(pk, tile_rows=tr) if hasattr(_hip, "plan_tiles") else None
-        for mt in (1, 2, 3, 6):
-            pl = _hip.plan_groups(pk, max_tiles=mt)
-            assert sum(g[1] - g[0] for g in list(pl["small"]) + list(pl["big"])) + sum(
-                pk.mol_offset[s + 1] - pk.mol_offset[s] for s in pl["streamed"]) == pk.n_atom
     ds = PackedDataset(data_energy=de, data_neighbor=dn, batch_size=5, use_ring=False, feature="atomic", g_update=True,
                        atomic_features=None, shuffle=False)
     it = DataIterator(de, dn, batch_size=5, g_update=True)

@@ -922,117 +922,3 @@ def test_first_layer_computes_its_geometry_rows_itself(hip_lib, monkeypatch):
     sub = {k: v[:48] for k, v in inputs.items()}
     y_ref, _ = so.forward(cfg, w, sub, np.float32)
     assert rel_err(out["1"][0][:48], y_ref) <= RTOL
-
-
-@pytest.mark.parametrize("variant", ["qm9", "no_attn_norm", "L1", "L2", "bench_shape", "bench_shape_tight"])
-def test_layer_launches_give_the_unfused_bytes(hip_lib, variant, monkeypatch):
-    """Layer launches (csrc/scann_layer.hip; opt-in, scann_set_layer_fusion): the atom tiles of iteration l + 1 run inside
-    iteration l's edge launch behind per-XCD counters.  The arithmetic is the separate kernels' own text, so the outputs are the
-    same BYTES as with separate launches -- on a mixed batch (QM9-shaped and worst-case molecules, crystals, tiny structures, a
-    one-atom structure, an atom without neighbours), for 1 / 2 / all iterations, without the ResidualNorm blocks, and at the
-    benchmark's launch size (1,280 molecules: every CU busy), there also with the atom tiles placed right behind their edge tiles
-    (SCANN_LF_DELAY=8: every one of them waits on a live counter); repeated on both streams; no launch reported a fault
-    (attention.py:118-216, :37-40; scann_model.py:413-421)."""
-    from scann import _hip
-    from scann.models.scann_model import HipModel
-
-    cfg = so.default_config("qm9")
-    if variant == "no_attn_norm":
-        cfg["model"]["use_attn_norm"] = False
-    if variant in ("L1", "L2"):
-        cfg["model"]["n_attention"] = int(variant[1])
-    cfg["model"]["n_atoms"] = 100
-    w = so.init_weights(cfg, 78, perturb=True)
-    if variant == "bench_shape_tight":
-        monkeypatch.setenv("SCANN_LF_DELAY", "8")
-    if variant.startswith("bench_shape"):
-        de, dn = so.synth_dataset(1280, 5, "qm9")
-        pk = _hip.pack_inputs(so.pad_batch(de, dn, True)[0])
-    else:
-        parts = []
-        for n, seed, kind in ((140, 11, "qm9"), (3, 12, "worst"), (5, 13, "mp2018"), (130, 14, "qm9")):
-            de, dn = so.synth_dataset(n, seed, kind)
-            parts.append(_hip.pack_inputs(so.pad_batch(de, dn, True)[0]))
-        parts.append(_hip.PackedBatch([6, 1, 8, 1], [0, 1, 4], [0, 0, 1, 2, 2], [2, 1], [1.1, 1.3], [0.9, 1.7]))
-        pk = _hip.concat_packed(parts)
-    out = {}
-    for name, on in (("fused", 1), ("separate", 0)):
-        m = HipModel(cfg, w, device=0, infer=True)
-        m.engine.set_layer_fusion(on)
-        rb = m.engine.upload(pk)
-        m.engine.forward_resident(rb, 0)
-        out[name] = m.engine.download(rb)
-        for rep in range(6 if variant.startswith("bench_shape") else 2):  # the same resident batch again, either stream: no state left behind
-            m.engine.forward_resident(rb, rep & 1)
-            again = m.engine.download(rb)
-            assert np.array_equal(out[name][0], again[0], equal_nan=True) and np.array_equal(out[name][1], again[1], equal_nan=True), (name, rep)
-        assert m.engine.layer_fusion_state() == on
-        assert (m.engine.fused_forwards() > 0) == bool(on)
-        rb.free()
-    assert np.array_equal(out["fused"][0], out["separate"][0], equal_nan=True), float(np.nanmax(np.abs(out["fused"][0] - out["separate"][0])))
-    assert np.array_equal(out["fused"][1], out["separate"][1], equal_nan=True)
-    if not variant.startswith("bench_shape"):
-        y = out["fused"][0]
-        assert np.isnan(y[-2]) and np.all(np.isfinite(np.delete(y, -2)))  # the one-atom structure alone is the reference's NaN
-
-
-@pytest.mark.parametrize("variant", ["qm9", "ring", "no_attn_norm", "L1"])
-def test_resident_and_streamed_structures_mixed(hip_lib, variant):
-    """The structure-resident forward (csrc/scann_struct.hip; opt-in, scann_set_resident_limit) against the layer-streamed
-    kernels: one batch of QM9-shaped molecules, worst-case molecules (29 atoms x 12 neighbours: 6 tiles, the one-workgroup-per-CU
-    kernel), tiny ones and MP2018-shaped crystals (beyond both resident kernels), run (a) streamed, (b) with every structure that
-    fits resident, (c) with a limit of 2 tiles, which leaves most molecules to the streamed kernels in the SAME batch.  Every
-    formula of the resident kernel is the streamed kernels' instruction sequence on the same rows, so the three give the same
-    BYTES (attention.py:118-216, :37-40; scann_model.py:413-421)."""
-    from scann import _hip
-    from scann.models.scann_model import HipModel
-
-    cfg = so.default_config("qm9")
-    ring = variant == "ring"
-    if ring:
-        cfg["model"]["use_ring"] = True
-    if variant == "no_attn_norm":
-        cfg["model"]["use_attn_norm"] = False
-    if variant == "L1":
-        cfg["model"]["n_attention"] = 1
-    cfg["model"]["n_atoms"] = 100  # room for the crystals' species
-    w = so.init_weights(cfg, 77, perturb=True)
-    parts = []
-    for n, seed, kind in ((40, 11, "qm9"), (3, 12, "worst"), (5, 13, "mp2018"), (30, 14, "qm9")):
-        de, dn = so.synth_dataset(n, seed, kind, use_ring=ring)
-        parts.append(_hip.pack_inputs(so.pad_batch(de, dn, True, use_ring=ring)[0]))
-    tiny = so.synth_dataset(6, 15, "qm9", use_ring=ring)
-    for i in range(6):  # 3- and 4-atom molecules: several share one group
-        keep = 3 + (i & 1)
-        tiny[0][i][0] = tiny[0][i][0][:keep]
-        if ring:
-            tiny[0][i][2] = tiny[0][i][2][:keep]
-        tiny[1][i] = [[e for e in atom if e[1] < keep] or [[atom[0][0], (a + 1) % keep, 1.0, 1.0, 1.5]] for a, atom in enumerate(tiny[1][i][:keep])]
-    parts.append(_hip.pack_inputs(so.pad_batch(tiny[0], tiny[1], True, use_ring=ring)[0]))
-    # a one-atom structure (no edges at all: its GlobalAttention normalisation is the reference's 0 / 0) and a three-atom one whose last
-    # atom has no neighbours (context = LayerNorm(query), attention.py:186-214): both inside the resident kernels' reach
-    lone = _hip.PackedBatch([6, 1, 8, 1], [0, 1, 4], [0, 0, 1, 2, 2], [2, 1], [1.1, 1.3], [0.9, 1.7],
-                            ring=np.zeros((4, 2), np.float32) if ring else None)
-    parts.append(lone)
-    pk = _hip.concat_packed(parts)
-    out, infos = {}, {}
-    for name, limit in (("streamed", 0), ("resident", 6), ("mixed", 2)):
-        m = HipModel(cfg, w, device=0, infer=True)
-        m.engine.set_resident_limit(limit)
-        rb = m.engine.upload(pk)
-        infos[name] = m.engine.batch_info(rb)
-        m.engine.forward_resident(rb, 0)
-        out[name] = m.engine.download(rb)
-        m.engine.forward_resident(rb, 1)  # a second forward of the same resident batch: no state left behind
-        again = m.engine.download(rb)
-        assert np.array_equal(out[name][0], again[0], equal_nan=True) and np.array_equal(out[name][1], again[1], equal_nan=True)
-        rb.free()
-    assert infos["streamed"]["resident_small"] == infos["streamed"]["resident_big"] == 0
-    assert infos["resident"]["resident_small"] > 0 and infos["resident"]["resident_big"] >= 3 and infos["resident"]["streamed_structs"] >= 1
-    assert infos["mixed"]["resident_small"] > 0 and infos["mixed"]["streamed_structs"] > infos["resident"]["streamed_structs"]
-    for name in ("resident", "mixed"):
-        assert np.array_equal(out[name][0], out["streamed"][0], equal_nan=True), (name, float(np.nanmax(np.abs(out[name][0] - out["streamed"][0]))))
-        assert np.array_equal(out[name][1], out["streamed"][1], equal_nan=True), name
-    # (the oracle comparison of these shapes is the other tests' job; here: the two paths against each other)
-    y = out["streamed"][0]
-    assert np.isnan(y[-2]) and np.all(np.isfinite(np.delete(y, -2)))  # the one-atom structure alone is the reference's NaN

@@ -535,58 +535,6 @@ def test_process_per_gpu_predictor_does_not_hang_on_a_dead_worker(monkeypatch):
     assert time.monotonic() - t0 < 30
 
 
-def test_structure_resident_group_plan(hip_lib):
-    """scann_plan_groups (host only): the plan scann_batch_upload makes for the structure-resident forward (csrc/scann_struct.hip).
-    Every structure lands in exactly one place -- a group of <= 3 tiles, a group of 4..6 tiles, or the streamed list -- groups hold
-    whole structures and their tiles whole atoms within the kernel's limits (64 edges, 24 atoms per tile; 36 / 72 atoms per group:
-    the LDS atom-row caches), small structures share a group, the lists are ordered by falling edge count, and anything the
-    kernels cannot hold (more tiles, more atoms, an atom with more than 64 neighbours) is left to the streamed path."""
-    from scann import _hip
-
-    parts = []
-    for n, seed, kind in ((60, 21, "qm9"), (4, 22, "worst"), (12, 23, "mp2018")):
-        de, dn = so.synth_dataset(n, seed, kind)
-        parts.append(_hip.pack_inputs(so.pad_batch(de, dn, True)[0]))
-    # five 4-atom rings (share a group), one 80-atom chain (too many atoms), one star whose centre has 70 neighbours
-    ring4 = _hip.PackedBatch(np.full(20, 6), np.arange(0, 21, 4), np.arange(21), np.arange(20) // 4 * 4 + (np.arange(20) + 1) % 4, np.ones(20), np.ones(20))
-    chain = _hip.PackedBatch(np.full(80, 6), [0, 80], np.arange(81), (np.arange(80) + 1) % 80, np.ones(80), np.ones(80))
-    deg = np.array([70] + [1] * 70)
-    star = _hip.PackedBatch(np.full(71, 6), [0, 71], np.concatenate([[0], np.cumsum(deg)]), np.concatenate([np.arange(1, 71), np.zeros(70, dtype=np.int64)]),
-                            np.ones(140), np.ones(140))
-    pk = _hip.concat_packed(parts + [ring4, chain, star])
-    B = pk.n_struct
-    for limit in (6, 3, 2, 1):
-        pl = _hip.plan_groups(pk, tile_atoms=24, max_tiles=limit)
-        small, big, tiles, streamed = pl["small"], pl["big"], pl["tiles"], pl["streamed"]
-        owner = np.zeros(pk.n_atom, dtype=np.int64)
-        for g in list(small) + list(big):
-            owner[g[0]:g[1]] += 1
-            assert g[0] in pk.mol_offset and g[1] in pk.mol_offset  # whole structures
-            t = tiles[g[2]:g[2] + g[3]]
-            assert t[0, 0] == g[0] and t[-1, 1] == g[1] and np.array_equal(t[1:, 0], t[:-1, 1])  # its tiles partition its atoms in order
-            assert np.array_equal(t[:, 2], pk.edge_offset[t[:, 0]]) and np.array_equal(t[:, 3], pk.edge_offset[t[:, 1]])
-            assert ((t[:, 3] - t[:, 2]) <= 64).all() and ((t[:, 1] - t[:, 0]) <= 24).all() and ((t[:, 1] - t[:, 0]) >= 1).all()
-        for s in streamed:
-            owner[pk.mol_offset[s]:pk.mol_offset[s + 1]] += 1
-        assert (owner == 1).all()  # every atom exactly once
-        assert (small[:, 3] <= min(3, limit)).all() and ((small[:, 1] - small[:, 0]) <= 36).all()
-        assert len(big) == 0 or ((big[:, 3] <= limit).all() and (big[:, 3] > 3).all() and ((big[:, 1] - big[:, 0]) <= 72).all())
-        if limit <= 3:
-            assert len(big) == 0
-        for lst in (small, big):
-            e = pk.edge_offset[lst[:, 1]] - pk.edge_offset[lst[:, 0]]
-            assert (np.diff(e) <= 0).all()  # the longest workgroups first
-        assert B - 2 in streamed and B - 1 in streamed  # the 80-atom chain (atom cache) and the 70-neighbour star (tile rows)
-        ring_groups = [g for g in small if g[0] >= pk.mol_offset[B - 7] and g[1] <= pk.mol_offset[B - 2]]
-        assert len(ring_groups) == 1 and ring_groups[0][1] - ring_groups[0][0] == 20  # the five rings share one group
-    full = _hip.plan_groups(pk, max_tiles=6)
-    assert len(full["big"]) >= 4  # the 29 x 12 molecules need six tiles each
-    none = _hip.plan_groups(_hip.concat_packed([chain, star]))
-    assert len(none["small"]) == len(none["big"]) == 0 and list(none["streamed"]) == [0, 1]
-    with pytest.raises(_hip.ScannHipError):
-        _hip.plan_groups(pk, max_tiles=0)
-
-
 def test_runtime_env_warnings(monkeypatch):
     """_hip._check_runtime_env: HIP-runtime variables measured to cost 4-40 % are named in a warning, defaults are silent."""
     import warnings
@@ -688,78 +636,23 @@ def _device_kernels(so_path):
 
 
 def test_default_forward_kernels_use_no_scratch(hip_lib):
-    """The instantiations an inference forward of a shipped config launches -- atom_kernel<FFN, MODE, RT, exact = false>,
-    edge_kernel<GUPD, RT, FB, exact = false> -- must not spill: at 166-168 VGPRs one more live value sends a weight fragment to scratch
-    (measured: 8 bytes per lane cost the dominant kernel 1.5 us of 81), and a source change far from the spill can cause it (a branch
-    around a training-only store did, in round 4).  Read from the BUILT library's kernel descriptors, not from a compiler log."""
+    """Every instantiation of atom_kernel<FFN, MODE, RT, EX> and edge_kernel<GUPD, RT, FB, EX, KEEP, DEAD> that a forward can launch --
+    the inference kernels, the exact-fp32 (EX) re-run's and the training forward's (KEEP) -- must not spill: at 166-168 VGPRs one more
+    live value sends a weight fragment to scratch (measured: 8 bytes per lane cost the dominant kernel 1.5 us of 81), and a source change
+    far from the spill can cause it (a branch around a training-only store did, in round 4).  Read from the BUILT library's kernel
+    descriptors, not from a compiler log."""
     from scann import _hip
 
     kern = _device_kernels(_hip.LIB_PATH)
     checked = 0
     for name, (scratch, vgpr) in kern.items():
-        default = (name.startswith("_ZN5scann11atom_kernelILb") or name.startswith("_ZN5scann11edge_kernelILb")) and "ELb0EEEv" in name
-        if default:
+        if name.startswith("_ZN5scann11atom_kernelILb") or name.startswith("_ZN5scann11edge_kernelILb"):
             checked += 1
             assert scratch == 0, (name, scratch, vgpr)
-            assert vgpr <= 168, (name, vgpr)  # three workgroups per CU (64-row tiles); the 32-row ones stay <= 128
-    assert checked >= 18, sorted(kern)[:5]  # 12 atom_kernel + 6 edge_kernel instantiations
-
-
-def test_layer_launch_plan(hip_lib):
-    """scann_plan_layer (host only): the work list of a layer launch (csrc/scann_layer.hip).  Every edge tile and every atom tile is
-    there exactly once; workgroup b is item b >> 3 of XCD b & 7; an XCD's edge tiles are one contiguous run and its atom tiles cover
-    exactly that run's atoms (so producer and consumer of a context row share an L2); an atom tile's `need` is the number of edge
-    tiles whose atoms fall into it and those tiles all sit EARLIER in the same XCD's list (the waits cannot deadlock: workgroups are
-    dispatched in order), at least `delay` items earlier unless the list ran out."""
-    from scann import _hip
-
-    parts = []
-    for n, seed, kind in ((300, 31, "qm9"), (5, 32, "worst"), (20, 33, "mp2018")):
-        de, dn = so.synth_dataset(n, seed, kind)
-        parts.append(_hip.pack_inputs(so.pad_batch(de, dn, True)[0]))
-    lone = _hip.PackedBatch(np.full(3, 6), [0, 3], np.zeros(4, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0), np.zeros(0))  # no edges at all
-    for pk, delay in ((_hip.concat_packed(parts), 96), (_hip.concat_packed(parts + [lone]), 7), (parts[1], 96), (parts[0], 0)):
-        _, tiles, part, _ = _hip.plan_tiles(pk, 64, 24, False)
-        assert (part < 0).all()
-        pl = _hip.plan_layer(pk, 24, delay)
-        work, rows, eat, need = pl["work"], pl["row_tab"], pl["e_atile"], pl["a_need"]
-        assert len(work) % 8 == 0 and len(eat) == len(tiles)
-        for kind, n in ((0, len(tiles)), (1, len(rows))):
-            assert np.array_equal(np.sort(work[work[:, 0] == kind, 1]), np.arange(n))  # exactly once
-        assert set(np.unique(work[:, 0])) <= {-1, 0, 1}
-        covered = np.zeros(pk.n_atom, dtype=np.int64)
-        for r0, n in rows:
-            assert 1 <= n <= 64
-            covered[r0:r0 + n] += 1
-        assert (covered == 1).all()
-        fed = np.zeros(len(rows), dtype=np.int64)
-        for x in range(8):
-            lst = work[x::8]
-            lst = lst[lst[:, 0] >= 0]
-            et = lst[lst[:, 0] == 0, 1]
-            if len(et) == 0:
-                assert len(lst) == 0
-                continue
-            assert np.array_equal(et, np.arange(et[0], et[0] + len(et)))  # contiguous run, in order
-            at = lst[lst[:, 0] == 1, 1]
-            assert np.array_equal(at, np.arange(at[0], at[0] + len(at)))
-            assert rows[at[0], 0] == tiles[et[0], 0] and rows[at[-1], 0] + rows[at[-1], 1] == tiles[et[-1], 1]  # the same atoms
-            pos_e = {int(t): i for i, (k, t) in enumerate(lst) if k == 0}
-            pos_a = {int(j): i for i, (k, j) in enumerate(lst) if k == 1}
-            for t in et:
-                j0, nj = eat[t]
-                assert 1 <= nj <= 2
-                lo, hi = tiles[t, 0], tiles[t, 1]
-                for j in range(j0, j0 + nj):
-                    assert j in pos_a  # same XCD
-                    assert rows[j, 0] < hi and rows[j, 0] + rows[j, 1] > lo  # the tile's atoms do fall into atom tile j
-                    assert pos_a[j] > pos_e[int(t)]
-                    assert pos_a[j] - pos_e[int(t)] > delay or pos_a[j] >= len(et)  # `delay` items behind, or in the tail
-                    fed[j] += 1
-                assert rows[j0, 0] <= lo and rows[j0 + nj - 1, 0] + rows[j0 + nj - 1, 1] >= hi  # ... and nowhere else
-        assert np.array_equal(fed, need) and (need >= 1).all()
-    with pytest.raises(_hip.ScannHipError):
-        _hip.plan_layer(_hip.concat_packed([parts[0], lone]), 24, -1)
+            m = re.match(r"_ZN5scann11atom_kernelILb\dELi\dELi(\d)E", name) or re.match(r"_ZN5scann11edge_kernelILb\dELi(\d)E", name)
+            rt1 = m.group(1) == "1"  # RT = 1: 32-row tiles, four workgroups per CU
+            assert vgpr <= (128 if rt1 else 168), (name, vgpr)  # 64-row tiles: three workgroups per CU
+    assert checked >= 24 + 18, sorted(kern)[:5]  # 24 atom_kernel + 18 edge_kernel instantiations
 
 
 def test_edge_tile_plan_invariants(hip_lib):
