@@ -165,6 +165,7 @@ struct EdgeArgs {
   float *keep_V, *keep_T, *keep_ang, *keep_K;
   float* geom_out;             // where geom' goes (null: in place) -- keep-mode writes each layer's geometry to its own slice
   int32_t tile_rows;           // 32 | 64: edge rows per tile of this batch's plan (selects the kernel instantiation)
+  int32_t n_edge;              // edges of the batch: geom has ONE SPARE ROW behind them (scann_batch_upload), the dump row of edge-less tiles
   int32_t geom_rows;           // the geometry tensors are [n_edge,128] ROWS (training, debug and exact forwards: someone else reads them); 0: piece-major tiles
   int32_t geom_dead;           // last layer of an inference forward: nobody reads geom' (scann_model.py:415-421 threads it to the NEXT layer only)
   const float* gd;             // [n_edge,20] raw distance basis (base)

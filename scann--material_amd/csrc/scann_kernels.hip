@@ -172,9 +172,8 @@ __global__ __launch_bounds__(128) void edge_merge_kernel(const int32_t* __restri
   if ((c & 63) == 0) sRed[1][c >> 6] = v;
   __syncthreads();
   if (!(sRed[1][0] + sRed[1][1] < RANGE_FINITE) && c == 0) flag_range(range_flag, 2, layer);
-  const float rstd = 1.0f / sqrtf((sRed[1][0] + sRed[1][1]) * (1.0f / D) + 1e-6f);
-  const float inv = rstd * ln_g[c];
-  ctx[(size_t)atom * D + c] = t * inv + (ln_b[c] - mean * inv);
+  const float rstd = ln_rstd((sRed[1][0] + sRed[1][1]) * (1.0f / D));
+  ctx[(size_t)atom * D + c] = ln_apply(t, rstd, -mean * rstd, ln_g[c], ln_b[c]);
 }
 
 void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf, const float* q, const float* ln_g,

@@ -151,6 +151,15 @@ __device__ __forceinline__ float sum8(float v) {
   v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   return v;
 }
+// LayerNormalization(epsilon = 1e-6) in the forward kernels (attention.py:35,111,113; Keras' non-fused form is x inv + (beta - mean inv),
+// inv = rsqrt(var + eps) gamma: four roundings per element).  Here 1 / sqrt(var + eps) is ONE v_rsq_f32 (1 ulp; the correctly rounded
+// sqrt + division it replaces are ~28 instructions per row) and an element is two fused multiply-adds, ((x rstd - mean rstd) gamma +
+// beta): two roundings, two instructions instead of four.  Measured against the fp64 restatement the outputs sit no further away than
+// with the Keras form (tests/test_gpu_parity.py keeps its bounds; profiles/r05_notes.md has the numbers).
+__device__ __forceinline__ float ln_rstd(float var) { return __builtin_amdgcn_rsqf(var + 1e-6f); }
+__device__ __forceinline__ float ln_apply(float x, float rstd, float nmr /* -mean * rstd */, float g, float b) {
+  return fmaf(fmaf(x, rstd, nmr), g, b);
+}
 // one 32-bit word the same way (an `int` index into a pointer costs a 64-bit shift-and-add per access)
 __device__ __forceinline__ int ld1i(const int32_t* __restrict__ base, unsigned byte_off) {
   return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off);

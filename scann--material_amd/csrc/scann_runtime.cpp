@@ -951,7 +951,8 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
-  const size_t o_geom = take(h->cfg.g_update ? rowE : 0), o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
+  const size_t o_geom = take(h->cfg.g_update ? rowE + D * 4 : 0);  // + the spare row edge-less tiles store to (EdgeArgs::n_edge)
+  const size_t o_gd = take(h->cfg.g_update ? 0 : (size_t)std::max(E, 1) * NG * 4);
   const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
@@ -1331,6 +1332,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
     ea.edge_offset = db->edge_offset; ea.edge_col = db->edge_col; ea.edge_row = db->edge_row;
     ea.geom = g_of(l); ea.geom_out = direct && c.g_update ? g_of(l + 1) : nullptr; ea.gd = db->gd; ea.edge_weight = db->weight;
     if (fuse_basis && l == 0) { ea.fuse_basis = 1; ea.dist = db->dist; ea.basis = h->basis; }
+    ea.n_edge = db->n_edge;
     ea.geom_rows = fuse_basis ? 0 : 1;  // piece-major tiles only when the first layer computed its own geometry rows (plain inference)
     ea.geom_dead = (l == L - 1 && !h->debug) ? 1 : 0;  // the geometry leaving the last layer is never consumed (141 MB of writes per 16-batch launch)
     ea.c = c_of(l); ea.P1 = db->P1; ea.P3 = db->P3; ea.q = keep ? db->keep_q + (size_t)l * nA_ : db->q; ea.ctx = ctx_of(l);
