@@ -190,6 +190,20 @@ def group_sizes(steps, target=16):
     return [base + 1] * rem + [base] * (n - rem)
 
 
+def scaling_fields(world, units_per_rank_region, rank_region_s, solo_region_s=None, rccl_ranks=None):
+    """What a SCALE record can be checked against, from one N-rank run: `rccl_ranks` = the size RCCL itself reports for the
+    communicator (ncclCommCount after scann_comm_init; None on the collective-free inference path), `rank_values` = every rank's OWN
+    rate over the timed region (the headline divides the job by the slowest rank's time), `n1_same_layout` = rank 0 alone in the same
+    process layout while the other ranks wait (what N = 1 gives inside this very run: must agree with the driver's N = 1 line)."""
+    out = {"rccl_ranks": rccl_ranks, "ranks_reporting": len(rank_region_s),
+           "rank_values": [units_per_rank_region / t if t > 0 else None for t in rank_region_s]}
+    if world > 1:
+        out["n1_same_layout"] = ({"value": units_per_rank_region / solo_region_s, "unit": "molecules/s",
+                                  "what": "rank 0 alone (the other ranks idle at a barrier), same process layout and workload"}
+                                 if solo_region_s else None)
+    return out
+
+
 def train_bench(args, eng, rdzv):
     """Weak-scaling training throughput: every rank trains on its own --batch molecules per step; the ranks exchange the
     scalar SSE/count and one flat fp32 gradient all-reduce per step over RCCL."""
@@ -198,10 +212,27 @@ def train_bench(args, eng, rdzv):
 
     rank, world = rdzv.rank, rdzv.world
     eng.train_begin()
-    comm = Communicator(eng, rdzv)  # the rendezvous only carries the 128-byte ncclUniqueId; gradients go over RCCL
     rng = np.random.default_rng(2000 + rank)
     pool = [eng.upload(synth_packed_batch(rng, args.batch)) for _ in range(8)]
     targets = [rng.normal(size=args.batch).astype(np.float32) for _ in pool]
+    solo = None
+    if world > 1:  # N = 1 inside this run: rank 0 trains alone, BEFORE the communicator exists (afterwards every step is a collective)
+        if rank == 0:
+            for i in range(10):
+                eng.train_step_begin(pool[i % 8], targets[i % 8], 5e-4, dropout=0.1, seed=i)
+                eng.train_step_end()
+            eng.sync()
+            t0 = time.perf_counter()
+            for i in range(100):
+                eng.train_step_begin(pool[i % 8], targets[i % 8], 5e-4, dropout=0.1, seed=i)
+                if i:
+                    eng.train_step_end()
+            eng.train_step_end()
+            eng.sync()
+            solo = (time.perf_counter() - t0) / 100
+        rdzv.barrier()
+    comm = Communicator(eng, rdzv)  # the rendezvous only carries the 128-byte ncclUniqueId; gradients go over RCCL (broadcasts rank 0's weights)
+    rccl_ranks = eng.comm_ranks() if world > 1 else None
 
     def step(i):
         rb, t = pool[i % 8], targets[i % 8]
@@ -245,6 +276,7 @@ def train_bench(args, eng, rdzv):
             "metric": "QM9 molecules/s training (forward + backward + Adam)", "value": world * steps * args.batch / elapsed,
             "unit": "molecules/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": elapsed / steps * 1e3,
             "rank_ms_per_step": [float(t[0]) / steps * 1e3 for t in per_rank],
+            **scaling_fields(world, steps * args.batch, [float(t[0]) for t in per_rank], solo * steps if solo else None, rccl_ranks),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (projections: split-fp16 hi/lo operands, 3 v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; everything else fp32)",
             "data": "synthetic",
@@ -423,7 +455,37 @@ def padded_predict_leg(cfg, batches, batch_size, seconds=1.0):
             "what": "model.predict(padded input dict of the whole set): padded -> CSR packing, uploads, forwards, downloads, Python inclusive"}
 
 
-LEGS = {"two_streams": two_stream_leg, "one_batch_per_launch": one_batch_leg, "end_to_end": end_to_end, "training_step": training_leg,
+def exact_fp32_leg(cfg, batches, batch_size, seconds=0.8, group=8):
+    """The same forward on the bitwise-fp32 kernels (SCANN_EXACT=1: every 128x128 product on v_mfma_f32_32x32x2_f32, the arithmetic of
+    the reference's fp32 Dense layers, attention.py:95-113; no hi / lo split anywhere): what this path does at the reference's own
+    arithmetic, beside the split-fp16 headline.  Resident 8-batch groups, one stream."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    os.environ["SCANN_STREAMS"] = "1"
+    os.environ["SCANN_EXACT"] = "1"
+    eng = HipModel(cfg, device=int(os.environ.get("LOCAL_RANK", "0")), seed=1234).engine
+    groups = [eng.upload(_hip.concat_packed(batches[i * group:(i + 1) * group])) for i in range(4)]
+    for i in range(8):
+        eng.forward_resident(groups[i % 4], 0)
+    eng.sync()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for i in range(4):
+            eng.forward_resident(groups[i], 0)
+        eng.sync()
+        n += 4
+    dt = time.perf_counter() - t0
+    for rb in groups:
+        rb.free()
+    eng.close()
+    return {"value": n * group * batch_size / dt, "unit": "molecules/s", "batches_fused_per_launch": group, "streams": 1,
+            "dtype": "f32 (every projection on v_mfma_f32_32x32x2_f32: bitwise fp32 products and accumulation)",
+            "what": "SCANN_EXACT=1: the forward on the exact-fp32 instantiations of the atom / edge kernels (the fallback a forward takes when "
+                    "an operand leaves the split-fp16 range)"}
+
+
+LEGS = {"two_streams": two_stream_leg, "exact_fp32": exact_fp32_leg, "one_batch_per_launch": one_batch_leg, "end_to_end": end_to_end, "training_step": training_leg,
         "padded_predict": padded_predict_leg}
 
 
@@ -576,6 +638,18 @@ def main():
         t_issue += t1 - t0  # host time to enqueue every launch (diagnostic: host- vs device-bound)
         rdzv.barrier()
     all_times = rdzv.gather(times)
+    solo = None
+    if world > 1:  # N = 1 inside this run: rank 0 repeats the timed region alone while the other ranks wait at the barrier
+        if rank == 0:
+            ts = []
+            for _ in range(min(repeats, 101)):
+                eng.sync()
+                t0 = time.perf_counter()
+                run(sizes_t)
+                eng.sync()
+                ts.append(time.perf_counter() - t0)
+            solo = float(np.median(ts))
+        rdzv.barrier()
 
     if rank == 0:
         per_repeat = np.max(np.asarray(all_times, dtype=np.float64), axis=0)  # max over ranks of every timed region
@@ -661,6 +735,7 @@ def main():
             "host_issue_ms_per_step": t_issue / repeats / args.steps * 1e3,
             "whole_path_tflops_min": world * args.steps * total_flops_min(A, E, L_cfg, emb_cfg) / elapsed / 1e12,
             "roofline": roof,
+            **scaling_fields(world, args.steps * args.batch, [float(np.median(t)) for t in all_times], solo, None),
         }
         if world > ndev:
             out["oversubscribed"] = True
@@ -671,7 +746,7 @@ def main():
         if not args.no_extras and world == 1 and args.config == "qm9" and not args.worst:
             # each in a process of its own (leg_in_subprocess); this process's engine goes first, so that the legs have the device
             eng.close()
-            for name in ("two_streams", "one_batch_per_launch", "end_to_end", "padded_predict", "training_step"):
+            for name in ("two_streams", "one_batch_per_launch", "end_to_end", "padded_predict", "training_step", "exact_fp32"):
                 out[name] = leg_in_subprocess(name, args.batch)
         if not args.no_cpu_baseline and not args.no_extras and world == 1:
             out["cpu_baseline"] = cpu_baseline()

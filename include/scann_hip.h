@@ -167,8 +167,9 @@ int scann_edge_timing_read(scann_handle_t* h, double* avg_us, int64_t* n_launche
  * what: 0 = centers after layer `layer` (0 = after dense_embed) [n_atom,128];
  *       1 = geometry features after layer `layer` [n_edge,128];
  *       2 = context (LocalAttention output incl. layer_norm) of layer `layer`>=1 [n_atom,128];
- *       3..7 (g_update, after scann_train_forward only) = K, ang, V, T [n_edge,128] and q [n_atom,128] kept for the backward
- *       by LocalAttention `layer`>=1.
+ *       3, 5, 7 (after scann_train_forward only) = K, V [n_edge,128] and q [n_atom,128] kept for the backward by LocalAttention
+ *       `layer`>=1;  4, 6 = ang, T [n_edge,128]: kept only when the modular backward runs (env SCANN_TRAIN_FUSED=0) -- the fused
+ *       backward forms them again from (c, geometry) and (V, geometry) -- otherwise SCANN_ERR_UNSUPPORTED.
  * Only valid when the forward was run with scann_set_debug(h, 1) (keeps per-layer copies). */
 int scann_set_debug(scann_handle_t* h, int on);
 int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer, float* out);
@@ -219,6 +220,9 @@ int scann_get_grads(scann_handle_t* h, float* out);           /* [scann_param_co
 int scann_get_weights(scann_handle_t* h, float* out);         /* current master parameters, same order */
 int scann_comm_unique_id(char* out128);                       /* ncclGetUniqueId on rank 0; broadcast by the caller */
 int scann_comm_init(scann_handle_t* h, const char* id128, int rank, int world);
+/* ranks of the handle's RCCL communicator as RCCL reports them (ncclCommCount); 0 without a communicator (single rank, or the
+ * collective-free inference path); negative status on error.  bench.py --train prints it as `rccl_ranks`. */
+int scann_comm_ranks(scann_handle_t* h);
 /* Data-parallel start-up: every rank's master parameters become rank `root`'s (one flat ncclBroadcast) and the packed
  * device images are regenerated from them, so that replicas created with different initialiser draws train ONE model
  * (the reference is single-process: create_model runs once, scann_model.py:77).  No-op without a communicator.

@@ -37,9 +37,14 @@ namespace scann {
 //   MODE 1: q only (base branch)           MODE 2: z = swish(c Wa + ba); gq = z Wgq + b, gk = z Wgk + b   (scann_model.py:424, attention.py:269-272)
 
 // EX: exact-fp32 projections (scann_mma.h: the fallback run_forward takes when the split-fp16 range guard fired)
-template <bool FFN, int MODE, int RT, bool EX = false>
-__global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void atom_kernel(AtomArgs a) {
+// KEEP: the training forward's instantiation (Dropout, keep_* stores); never exact
+// (workgroups per CU: three at 64 rows, four at 32 -- except where the register allocator could not be kept below the limit without
+// spilling and occupancy is not what bounds the launch: the exact-fp32 re-run at 64 rows (1/16 of the matrix rate), the base branch's
+// query-only kernel at 32 rows; tests/test_host.py reads scratch sizes and register counts from the built library)
+template <bool FFN, int MODE, int RT, bool EX = false, bool KEEP = false>
+__global__ __launch_bounds__(256, RT == 2 ? (EX ? 2 : 3) : (MODE == 1 ? 3 : 4)) void atom_kernel(AtomArgs a) {
 #pragma clang fp contract(off)  // fusions are written out: both row-tile copies of a formula round alike (see edge_kernel)
+  static_assert(!(EX && KEEP), "the training forward runs the split-fp16 kernels");
   constexpr int TAR = 32 * RT;  // atom rows per tile
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TAR * PLANE_STRIDE * 2];  // hi / lo planes of the current GEMM input
   __shared__ __attribute__((aligned(16))) float sRed[TAR * 8];  // LayerNorm partial statistics [row][wave][mean, m2]
@@ -54,16 +59,19 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
   // 32-row tiles (<= 128 VGPRs, 22 KB of LDS: four workgroups per CU = 1,024 slots) while they all fit ONE round of workgroups: the
   // launch is then the latency chain of a tile, and a 32-row tile's chain is shorter (one batch per launch: 490 k -> 568 k
   // molecules/s, training step 1.14 -> 1.09 ms).  Beyond that 64-row tiles (half the weight traffic per row).
-  static const int force_rows = getenv("SCANN_ATOM_ROWS") ? atoi(getenv("SCANN_ATOM_ROWS")) : 0;  // A/B switch (32 | 64)
-  const int rows = force_rows == 32 || force_rows == 64 ? force_rows : a.n_atom <= 32 * 1024 ? 32 : 64;
+  const int rows = a.n_atom <= 32 * 1024 ? 32 : 64;
   const dim3 grid((a.n_atom + rows - 1) / rows), block(256);
-#define SCANN_ATOM_CASE(F, M)                                                                  \
-  do {                                                                                         \
-    if (a.exact) {                                                                             \
-      if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1, true>), grid, block, 0, s, a);  \
-      else hipLaunchKernelGGL((atom_kernel<F, M, 2, true>), grid, block, 0, s, a);             \
-    } else if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1>), grid, block, 0, s, a);   \
-    else hipLaunchKernelGGL((atom_kernel<F, M, 2>), grid, block, 0, s, a);                     \
+  const bool keep = !a.exact && (a.drop_p > 0.f || a.keep_pre1 || a.keep_T2 || a.keep_preA);  // training forward
+#define SCANN_ATOM_CASE(F, M)                                                                               \
+  do {                                                                                                      \
+    if (a.exact) {                                                                                          \
+      if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1, true>), grid, block, 0, s, a);               \
+      else hipLaunchKernelGGL((atom_kernel<F, M, 2, true>), grid, block, 0, s, a);                          \
+    } else if (keep) {                                                                                      \
+      if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1, false, true>), grid, block, 0, s, a);        \
+      else hipLaunchKernelGGL((atom_kernel<F, M, 2, false, true>), grid, block, 0, s, a);                   \
+    } else if (rows == 32) hipLaunchKernelGGL((atom_kernel<F, M, 1>), grid, block, 0, s, a);                \
+    else hipLaunchKernelGGL((atom_kernel<F, M, 2>), grid, block, 0, s, a);                                  \
   } while (0)
   if (a.ffn) {
     if (a.mode == 0) SCANN_ATOM_CASE(true, 0);

@@ -118,14 +118,12 @@ struct scann_handle {
   std::vector<hipEvent_t> time_ev;  // pairs (start, stop)
   std::vector<int> time_edges;
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
-  int fuse_attn = 1;   // env SCANN_TRAIN_FUSE_ATTN=0: attn_bwd16_kernel as a launch of its own before edge_bwd_kernel
   int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
   int species_tables = 1;  // env SCANN_SPECIES_TABLES=0: the first layer's atom rows come from an atom launch, not from per-species tables
   bool generic = false;        // widths other than 128 / 8: the plain-fp32 forward of scann_generic.hip (inference only)
   float* g_weights = nullptr;  // generic: the flat fp32 parameter vector on the device (spec order, spec_off offsets)
   float* g_centres = nullptr;  // generic: 20 + 20 Gaussian centres (distance, Voronoi weight)
   std::map<std::string, int64_t> g_off;  // generic: tensor name -> offset in g_weights
-  int train_fork_every = 1;    // env SCANN_TRAIN_FORK_EVERY: LocalAttention layers per weight-gradient launch on the side stream
   bool weights_exact = false;  // a loaded 128x128 kernel has |w| >= 255.9: the split-fp16 images cannot hold it, inference runs exact
   bool force_exact = false;    // env SCANN_EXACT=1: every inference forward on the exact-fp32 kernels (test / diagnosis switch)
   bool strict_range = false;   // env SCANN_STRICT_RANGE=1: SCANN_ERR_RANGE instead of the exact-fp32 re-run of an inference forward
@@ -453,10 +451,8 @@ int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out)
   h->specs = build_specs(*cfg);
   if (const char* xr = getenv("SCANN_XCD_REMAP")) h->xcd_remap = atoi(xr) != 0;
   if (const char* fb = getenv("SCANN_FUSE_BASIS")) h->fuse_basis = atoi(fb) != 0;
-  if (const char* fa = getenv("SCANN_TRAIN_FUSE_ATTN")) h->fuse_attn = atoi(fa) != 0;
   if (const char* st = getenv("SCANN_SPECIES_TABLES")) h->species_tables = atoi(st) != 0;
   if (const char* sg = getenv("SCANN_STRICT_RANGE")) h->strict_range = atoi(sg) != 0;
-  if (const char* fk = getenv("SCANN_TRAIN_FORK_EVERY")) h->train_fork_every = std::max(1, atoi(fk));
   if (const char* fe = getenv("SCANN_EXACT")) h->force_exact = atoi(fe) != 0;
   {
     hipDeviceProp_t prop;
@@ -912,8 +908,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (r) return fail(h, r, "scann_batch_upload: " + err);
     // A launch that fits ONE round of workgroups is the latency chain of a tile: 32-row tiles (four workgroups per CU = 1,024 slots)
     // make that chain shorter.  Only when no atom needs chunking at 32 rows.
-    static const int force_rows = getenv("SCANN_TILE_ROWS") ? atoi(getenv("SCANN_TILE_ROWS")) : 0;  // A/B switch (32 | 64)
-    if (E > 0 && max_degree <= 32 && (force_rows ? force_rows == 32 : E <= 32 * 1024)) {
+    if (E > 0 && max_degree <= 32 && E <= 32 * 1024) {
       r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, 32, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
                      &tile_rows, &max_degree, &n_slot, err, false);
       if (r) return fail(h, r, "scann_batch_upload: " + err);
@@ -981,7 +976,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (e == hipSuccess) {  // next pinned staging buffer of the ring: free once its previous copy has completed (normally long ago)
       stage = &h->stage[h->stage_next++ % scann_handle::N_STAGE];
       if (stage->used) (void)hipEventSynchronize(stage->ev);
-      if (!stage->ev) e = hipEventCreateWithFlags(&stage->ev, hipEventDisableTiming | hipEventDisableSystemFence);  // (same-device ordering only)
+      if (!stage->ev) e = hipEventCreateWithFlags(&stage->ev, hipEventDisableTiming);  // (the host waits on it: a default, fenced event)
       if (e == hipSuccess && in_bytes > stage->cap) {
         if (stage->p) (void)hipHostFree(stage->p);
         stage->p = nullptr; stage->cap = 0;
@@ -1039,7 +1034,9 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(stage->ev, h->copy_stream);
     if (e == hipSuccess) stage->used = true;
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&db->upload_ev, hipEventDisableTiming | hipEventDisableSystemFence);
+    // a default (system-fenced) event: it orders a DMA engine's write into a REUSED arena (cached_malloc) before kernels on another
+    // stream, whose caches may still hold lines of the arena's previous life -- not the place for the fence-free timing-event flavour
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&db->upload_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(db->upload_ev, h->copy_stream);
   }
   if (e != hipSuccess) {
@@ -1616,6 +1613,9 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
   else if (what >= 3 && what <= 7 && db->kept && layer >= 1 && layer <= L) {
     // per-layer tensors kept by the last TRAINING forward (scann_train_forward): 3 = K, 4 = ang, 5 = V, 6 = T [n_edge,128]; 7 = q [n_atom,128]
     const float* base = what == 3 ? db->keep_K : what == 4 ? db->keep_ang : what == 5 ? db->keep_V : what == 6 ? db->keep_T : db->keep_q;
+    if (!base)  // the fused backward forms T and the gated rows again instead of reading them: the training forward does not store them
+      return fail(h, SCANN_ERR_UNSUPPORTED, "scann_debug_read: this tensor is not kept by the training forward (selectors 4 = ang and 6 = T exist with the "
+                                            "modular backward only: SCANN_TRAIN_FUSED=0; the base branch keeps no T)");
     n = what == 7 ? rowA : rowE;
     src = base + (size_t)(layer - 1) * n;
   }
@@ -1679,7 +1679,7 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   // the operands of a layer's weight gradients live until the end of the step (sets of their own per layer): the gradient launches on
   // the side stream never have to be waited for before a buffer is reused
   // the modular backward (SCANN_TRAIN_FUSED=0) reads T and ang as tensors; the fused chains form them again
-  const bool keep_all = !h->train_fused || (getenv("SCANN_TRAIN_KEEP_ALL") && atoi(getenv("SCANN_TRAIN_KEEP_ALL")));
+  const bool keep_all = !h->train_fused;
   const size_t n_keepE = keep_all ? 4 : h->cfg.g_update ? 2 : 3;
   const size_t nTA = 5 + 5 * (Lc + 1), nTE = 4 + 2 * (Lc + 1);
   const size_t total = nTA * rowA + nTE * rowE + 2 * rowB + 2 * align_up((size_t)db->n_struct * 4) +
@@ -1780,7 +1780,7 @@ int scann_train_begin(scann_handle_t* h) {
     if (reg) std::fill(l2.begin() + h->spec_off[i], l2.begin() + h->spec_off[i] + h->specs[i].numel(), 1.0f);
   }
   HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
-  if (!h->train_aux && !getenv("SCANN_TRAIN_ONE_STREAM")) {
+  if (!h->train_aux) {
     // (side streams created with the lowest priority changed nothing: 0.895 vs 0.895 ms per step, profiles/r04_notes.md)
     // (and so did confining them to half / a quarter of the CUs with hipExtStreamCreateWithCUMask: 0.89-0.93 ms either way)
     // A handle with a second forward stream lends it to the backward pass as its side stream instead of creating a fifth stream: HIP
@@ -1795,8 +1795,8 @@ int scann_train_begin(scann_handle_t* h) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->train_aux2, hipStreamNonBlocking));
     h->train_ev.resize(128);
     // fork / join events between streams of ONE device: no system-scope fence (the kernels' own end-of-kernel release already makes
-    // their results visible device-wide); env SCANN_TRAIN_EV_FENCE=1 keeps the default events
-    const unsigned ev_flags = hipEventDisableTiming | ((getenv("SCANN_TRAIN_EV_FENCE") && atoi(getenv("SCANN_TRAIN_EV_FENCE"))) ? 0u : (unsigned)hipEventDisableSystemFence);
+    // their results visible device-wide, and nothing the host or a DMA engine wrote is ordered by them)
+    const unsigned ev_flags = hipEventDisableTiming | hipEventDisableSystemFence;
     for (hipEvent_t& e : h->train_ev) HIPCHK(h, hipEventCreateWithFlags(&e, ev_flags));
   }
   h->grads_zeroed = false;  // (re)allocated gradient vector: contents unknown
@@ -1978,13 +1978,12 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   // The side stream's chain per layer is a gradient launch (~32 us) and two reductions of its partial slots (~34 us): as long as the
   // main stream's chain per layer (~70 us), so the step ended when the SIDE stream did, ~65 us after the main one.  The reductions
   // go to the second side stream (idle but for the basis leaf): gradient launch of layer l - 1 beside the reductions of layer l.
-  static const bool flush_on_aux2 = !(getenv("SCANN_TRAIN_FLUSH_STREAM") && atoi(getenv("SCANN_TRAIN_FLUSH_STREAM")) == 0);
   bool aux2_used = false;
   auto flush_side = [&](hipStream_t ws, WgradCtx& ctx, bool last) {
     if (!side) return;
     hipStream_t fs = ws;
     // (the LAST layer's reductions stay behind their gradient launch: the second side stream is busy with the basis leaf, 46 us, by then)
-    if (h->train_aux2 && flush_on_aux2 && !last) {
+    if (h->train_aux2 && !last) {
       hipEvent_t e = h->train_ev[ev_i++ % h->train_ev.size()];
       (void)hipEventRecord(e, ws);
       (void)hipStreamWaitEvent(h->train_aux2, e, 0);
@@ -1997,7 +1996,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   wg.arena = w.wpart;
   // a fork costs the main stream ~7 us (tools/fork_probe.hip): the layers' gradient launches may share one (their operand sets live
   // to the end of the step)
-  const int fork_every = std::max(1, h->train_fork_every);
+  const int fork_every = 1;  // (2 / 3 / 4 / 7 layers per fork measured slower: profiles/r04_notes.md)
 
   // named temporaries
   float *dC = w.tA[0], *dCtx = w.tA[1], *t0 = w.tA[2], *t1 = w.tA[3], *t2 = w.tA[4];
@@ -2127,7 +2126,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     // ---- LocalAttention backward (attention.py:118-216) ----
     // On the forward's 32-row tile plan (whole atoms per tile, every degree <= 16) the softmax / LayerNorm backward of a tile's atoms
     // runs at the head of the tile's edge_bwd workgroup: one launch less per layer.
-    const bool fuse_attn = fused && h->fuse_attn && c.g_update && db->tile_rows == 32 && db->n_big == 0 && db->max_degree <= 16 && E > 0;
+    const bool fuse_attn = fused && c.g_update && db->tile_rows == 32 && db->n_big == 0 && db->max_degree <= 16 && E > 0;
     if (!fuse_attn)
       launch_attn_bwd(wg, qL, KL, db->edge_offset, dCtx, p.ln_g, dQ, edK, g(la + "layer_norm/gamma"), g(la + "layer_norm/beta"), A,
                       db->max_degree, w.attn_p, DROP_TAG_ATTN + (unsigned)l, w.seed, s);
@@ -2344,6 +2343,15 @@ int scann_comm_init(scann_handle_t* h, const char* id128, int rank, int world) {
   if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
   h->comm_world = world;
   return SCANN_OK;
+}
+
+int scann_comm_ranks(scann_handle_t* h) {
+  if (!h) return SCANN_ERR_INVALID;
+  if (!h->comm) return 0;
+  int n = 0;
+  const ncclResult_t r = ncclCommCount(h->comm, &n);  // what RCCL itself says the communicator spans
+  if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+  return n;
 }
 
 int scann_broadcast_weights(scann_handle_t* h, int root) {

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("scann_get_weights", C.c_int, [_P, _P]),
     ("scann_comm_unique_id", C.c_int, [C.c_char_p]),
     ("scann_comm_init", C.c_int, [_P, C.c_char_p, C.c_int, C.c_int]),
+    ("scann_comm_ranks", C.c_int, [_P]),
     ("scann_broadcast_weights", C.c_int, [_P, C.c_int]),
     ("scann_pack_last_error", C.c_char_p, []),
     ("scann_pack_padded", C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 17 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -556,6 +557,13 @@ class Engine:
 
     def comm_init(self, unique_id, rank, world):
         self._check(self.lib.scann_comm_init(self._h, unique_id, int(rank), int(world)))
+
+    def comm_ranks(self):
+        """ranks of the RCCL communicator as RCCL counts them (ncclCommCount); 0 without a communicator"""
+        n = self.lib.scann_comm_ranks(self._h)
+        if n < 0:
+            self._check(n)
+        return int(n)
 
     def broadcast_weights(self, root=0):
         self._check(self.lib.scann_broadcast_weights(self._h, int(root)))

@@ -649,10 +649,13 @@ def test_default_forward_kernels_use_no_scratch(hip_lib):
         if name.startswith("_ZN5scann11atom_kernelILb") or name.startswith("_ZN5scann11edge_kernelILb"):
             checked += 1
             assert scratch == 0, (name, scratch, vgpr)
-            m = re.match(r"_ZN5scann11atom_kernelILb\dELi\dELi(\d)E", name) or re.match(r"_ZN5scann11edge_kernelILb\dELi(\d)E", name)
-            rt1 = m.group(1) == "1"  # RT = 1: 32-row tiles, four workgroups per CU
-            assert vgpr <= (128 if rt1 else 168), (name, vgpr)  # 64-row tiles: three workgroups per CU
-    assert checked >= 24 + 18, sorted(kern)[:5]  # 24 atom_kernel + 18 edge_kernel instantiations
+            ma = re.match(r"_ZN5scann11atom_kernelILb\dELi(\d)ELi(\d)ELb(\d)E", name)
+            me = re.match(r"_ZN5scann11edge_kernelILb\dELi(\d)ELb\dELb(\d)E", name)
+            rt1 = (ma.group(2) if ma else me.group(1)) == "1"  # RT = 1: 32-row tiles, four workgroups per CU; else three
+            relaxed = ma is not None and ((not rt1 and ma.group(3) == "1") or (rt1 and ma.group(1) == "1"))  # see atom_kernel's launch bounds
+            if not relaxed:
+                assert vgpr <= (128 if rt1 else 168), (name, vgpr)
+    assert checked >= 36 + 18, sorted(kern)[:5]  # 36 atom_kernel + 18 edge_kernel instantiations
 
 
 def test_edge_tile_plan_invariants(hip_lib):
@@ -1099,6 +1102,52 @@ def test_two_rank_rccl_worker_script_on_the_cpu_stand_in(tmp_path):
         with contextlib.redirect_stdout(f):
             rc = spawn_ranks([str(script)], 2, env=env, timeout=600)
     assert rc == 0
+
+
+_SCALE_WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, ROOT)
+import bench
+from scann.parallel import Rendezvous
+from scann.models.trainer import Communicator
+import cpu_engine, scann_oracle as so
+
+rdzv = Rendezvous()
+cfg = so.default_config("qm9"); cfg["model"]["n_attention"] = 1
+eng = cpu_engine.CpuEngine(cfg, so.init_weights(cfg, 1 + rdzv.rank))
+comm = Communicator(eng, rdzv)
+region = 0.010 * (1 + rdzv.rank)                      # this rank's own time for the K steps
+per_rank = rdzv.gather([region])
+if rdzv.rank == 0:
+    line = {"n_gpus": rdzv.world, **bench.scaling_fields(rdzv.world, 20 * 128, [t[0] for t in per_rank], 0.009, eng.comm_ranks())}
+    assert line["rccl_ranks"] == 2 and line["ranks_reporting"] == 2, line
+    assert line["rank_values"] == [20 * 128 / 0.010, 20 * 128 / 0.020], line
+    assert abs(line["n1_same_layout"]["value"] - 20 * 128 / 0.009) < 1e-6, line
+    json.dumps(line)
+rdzv.barrier()
+'''
+
+
+def test_two_rank_bench_line_carries_the_scaling_fields(tmp_path):
+    """What a SCALE record reads off a `bench.py --gpus N` line (VERDICT r4 item 5): `rccl_ranks` (the communicator's size as the
+    engine reports it -- ncclCommCount on the GPU, the stand-in's world here; None on the collective-free inference path), every
+    rank's own value, and the N = 1 value of the same process layout.  Two CPU ranks, the engine replaced by the stand-in."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    one = bench.scaling_fields(1, 2560, [1.5e-3])
+    assert one["rccl_ranks"] is None and one["ranks_reporting"] == 1 and "n1_same_layout" not in one
+    inf2 = bench.scaling_fields(2, 2560, [1.5e-3, 1.6e-3], 1.45e-3, None)
+    assert inf2["rccl_ranks"] is None and len(inf2["rank_values"]) == 2 and inf2["n1_same_layout"]["value"] == 2560 / 1.45e-3
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.parallel.launch import spawn_ranks
+
+    prelude = ("import os, sys\nROOT = %r\n"
+               "sys.path[:0] = [os.path.join(ROOT, 'scann--material_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')]\n" % ROOT)
+    script = tmp_path / "scale_worker.py"
+    script.write_text(prelude + _SCALE_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="2", SCANN_NO_AFFINITY="1")
+    assert spawn_ranks([str(script)], 2, env=env, timeout=300) == 0
 
 
 def test_checkpoint_replace_is_atomic(tmp_path):
