@@ -36,7 +36,10 @@ print("\n".join(lines))
 if "--traffic" in sys.argv:
     key = sys.argv[sys.argv.index("--traffic") + 1]
     # the plain g_update kernel on 64-row tiles (not the first layer's launch with the basis MLP fused in: `<true, 2, true>`)
-    ek = [v for k, v in avg.items() if k in ("scann::edge_kernel<true, 2>", "scann::edge_kernel<true, 2, false>", "scann::edge_kernel<true, 2, false, false>") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+    # (template arguments: GUPD, RT, FB, EX, KEEP, DEAD since round 5; earlier rounds had fewer)
+    names = ("scann::edge_kernel<true, 2>", "scann::edge_kernel<true, 2, false>", "scann::edge_kernel<true, 2, false, false>",
+             "scann::edge_kernel<true, 2, false, false, false, false>")
+    ek = [v for k, v in avg.items() if k in names and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
     if ek:
         path = os.path.join(root, "profiles", "edge_kernel.json")
         j = json.load(open(path))
