@@ -135,6 +135,20 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
  * afterwards waits for the copy through the batch's event.  May be called from a second thread while the handle's owner thread
  * launches and fetches other batches (HipModel.predict_dataset, trainer.fit do). */
 int scann_batch_upload(scann_handle_t* h, const scann_batch_t* batch, scann_dbatch_t** out);
+/* The same, from the PADDED Keras input arrays (scann_model.py:338-357; shapes as scann_forward_padded; masks of 1-byte bool / uint8
+ * or 4-byte float32 / int32 elements): the host reads the masks only (real atoms, neighbour counts -> offsets -> edge-tile plan), the
+ * payload arrays are copied to the device as they are and packed to CSR there (pack_padded_kernel; replaces the host loop
+ * DataIterator.__getitem__ + gather_shape amount to, datagenerator.py:69-135, custom_layers.py:18-28).  What the host packer refuses at
+ * packing time -- an unmasked slot that points at a padded atom, an atomic number outside the embedding table -- is reported by
+ * scann_batch_download of this batch (SCANN_ERR_INVALID).  feature="atomic" without ring features, inference handles.
+ * n_atom_out / n_edge_out (or NULL) receive the packed counts.  scann_batch_read_csr copies the packed arrays of a resident batch back
+ * (any pointer may be NULL): the test hook behind "device packing == scann_pack_padded, byte for byte". */
+int scann_upload_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, const int32_t* atomic, const void* atom_mask,
+                        int32_t atom_mask_size, const int32_t* neighbors, const void* neighbor_mask, int32_t neighbor_mask_size,
+                        const float* neighbor_weight, const float* neighbor_distance, scann_dbatch_t** out, int32_t* n_atom_out,
+                        int32_t* n_edge_out);
+int scann_batch_read_csr(scann_handle_t* h, scann_dbatch_t* db, int32_t* atomic, int32_t* mol_offset, int32_t* edge_offset,
+                         int32_t* edge_col, float* edge_dist, float* edge_weight);
 void scann_batch_free(scann_handle_t* h, scann_dbatch_t* db);
 void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db); /* see scann_train_step_begin */
 int scann_forward_resident(scann_handle_t* h, scann_dbatch_t* db, int stream_slot); /* async */
@@ -255,6 +269,12 @@ int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offse
                       const float* ds_edge_weight, const int64_t* sel, int32_t n_sel, int64_t n_struct_total,
                       int32_t* out_atomic, float* out_ring, int32_t* out_mol_offset, int32_t* out_edge_offset,
                       int32_t* out_edge_col, float* out_edge_dist, float* out_edge_weight);
+/* The host half of scann_upload_padded (host only; exposed so that it can be checked without a GPU): the MASKS of a padded Keras input
+ * (1-byte bool / uint8 or 4-byte float32 / int32 elements) -> mol_offset[B+1], edge_offset[n_atom+1] (capacity B*M+1) and the packed row
+ * of every padded atom slot, row_of[B*M] (-1: padded).  Same arrays as scann_pack_padded gives. */
+int scann_count_padded(int32_t B, int32_t M, int32_t N, const void* atom_mask, int32_t atom_mask_size, const void* neighbor_mask,
+                       int32_t neighbor_mask_size, int32_t* out_mol_offset, int32_t* out_edge_offset, int32_t* out_row_of,
+                       int32_t* n_atom, int32_t* n_edge);
 /* The edge-tile plan scann_batch_upload builds for a packed batch (host only; exposed so that it can be checked without a
  * GPU): whole atoms per tile, <= tile_rows (32 | 64) edges and <= tile_atoms (<= 32) atoms; with allow_chunks an atom with
  * more than 64 neighbours becomes ceil(deg/64) single-atom chunk tiles, part_out[tile] = its softmax-merge slot (-1 for

@@ -245,6 +245,23 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
 // edge_row[e] = centre atom of edge e from the CSR offsets, on the device (scann_batch_upload: behind the input copy)
 void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, hipStream_t s);
 
+// Padded Keras input -> packed CSR on the device (scann_upload_padded): the payload arrays of the padded dict as they came over the bus.
+struct PackPaddedArgs {
+  int32_t B, M, N, n_species;
+  const int32_t* row_of;        // [B*M] packed row of every padded atom slot, -1 = padded (host: scann_count_padded)
+  const int32_t* edge_offset;   // [n_atom+1]
+  const int32_t* atomic;        // [B*M]
+  const int32_t* neighbors;     // [B*M*N] intra-structure atom index
+  const void* neighbor_mask;    // [B*M*N] 1- or 4-byte elements
+  int32_t mask_size;
+  const float *weight, *dist;   // [B*M*N]
+  int32_t* out_atomic;          // [n_atom]
+  int32_t* out_col;             // [n_edge] global atom row of the neighbour
+  float *out_dist, *out_weight; // [n_edge]
+  int32_t* flag;                // |= 1: an unmasked slot points at a padded atom, |= 2: atomic number outside the embedding table
+};
+void launch_pack_padded(const PackPaddedArgs& a, hipStream_t s);
+
 // Host-side permutation of a row-major [128,128] (in,out) kernel into MFMA fragment order.
 void pack_weight(const float* W, int ld, float* Wp);
 // Split-fp16 image of rows [0, k_real) of a row-major [*,128] kernel for v_mfma_f32_32x32x16_f16 (edge_kernel: mma_split):

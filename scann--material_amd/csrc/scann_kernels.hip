@@ -200,6 +200,40 @@ void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, 
   if (n_atom > 0) hipLaunchKernelGGL(edge_row_kernel, dim3((n_atom + 255) / 256), dim3(256), 0, s, edge_offset, n_atom, edge_row);
 }
 
+// Padded -> CSR (what gather_shape + the masks express: custom_layers.py:18-28, datagenerator.py:69-135): one thread per padded atom
+// slot.  A real atom walks its N neighbour slots in slot order and writes the unmasked ones behind edge_offset[row] -- the neighbour's
+// intra-structure index becomes its packed row through row_of -- HBM-bound streaming work (13 bytes read, 12 written per kept slot;
+// 160 B per atom slot read in all), a few tens of microseconds per 2,048-structure chunk.
+__global__ __launch_bounds__(256) void pack_padded_kernel(PackPaddedArgs a) {
+  const int bm = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bm >= a.B * a.M) return;
+  const int row = a.row_of[bm];
+  if (row < 0) return;
+  const int z = a.atomic[bm];
+  int bad = (z < 0 || z >= a.n_species) ? 2 : 0;
+  a.out_atomic[row] = bad ? 0 : z;  // (a valid table row either way: the forward must not fault on an input that is about to be refused)
+  const int b0 = (bm / a.M) * a.M;  // first atom slot of this structure
+  int e = a.edge_offset[row];
+  const size_t base = (size_t)bm * a.N;
+  for (int n = 0; n < a.N; ++n) {
+    const bool on = a.mask_size == 1 ? static_cast<const uint8_t*>(a.neighbor_mask)[base + n] != 0
+                                     : (static_cast<const uint32_t*>(a.neighbor_mask)[base + n] & 0x7fffffffu) != 0;
+    if (!on) continue;
+    const int tgt = a.neighbors[base + n];
+    const int r = (tgt >= 0 && tgt < a.M) ? a.row_of[b0 + tgt] : -1;
+    if (r < 0) bad |= 1;
+    a.out_col[e] = r < 0 ? row : r;
+    a.out_dist[e] = a.dist[base + n];
+    a.out_weight[e] = a.weight[base + n];
+    ++e;
+  }
+  if (bad) atomicOr(a.flag, bad);
+}
+void launch_pack_padded(const PackPaddedArgs& a, hipStream_t s) {
+  const int n = a.B * a.M;
+  if (n > 0) hipLaunchKernelGGL(pack_padded_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
 void launch_edge(const EdgeArgs& a, hipStream_t s) {
   if (a.n_tile <= 0) return;
   const dim3 grid(a.n_tile), block(256);

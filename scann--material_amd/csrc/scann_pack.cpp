@@ -85,7 +85,7 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
           "the g_update path, has none)";
     return SCANN_ERR_UNSUPPORTED;
   }
-  for (int s = 0; s < B; ++s) {  // every neighbour index inside its own structure
+  for (int s = 0; s < B && edge_col; ++s) {  // every neighbour index inside its own structure (device packing: checked by pack_padded_kernel)
     const int32_t a0 = mol_offset[s], a1 = mol_offset[s + 1];
     int32_t mn = a0, mx = a0;
     for (int e = edge_offset[a0]; e < edge_offset[a1]; ++e) {
@@ -218,6 +218,102 @@ int scann_pack_padded(int32_t B, int32_t M, int32_t N, const int32_t* atomic, co
     if (err[t]) return pack_fail(err[t]);
   *n_atom = (int32_t)na;
   *n_edge = (int32_t)ne;
+  return SCANN_OK;
+}
+
+// The host half of the DEVICE packing (scann_upload_padded): only the 1-byte (or 4-byte) MASKS are read here -- which atoms are real, how
+// many unmasked neighbour slots each has -- and turned into mol_offset / edge_offset / the packed row of every padded atom slot.  The
+// 4-byte payload arrays (neighbour indices, distances, weights, atomic numbers: 13/14 of the bytes) are never touched by the host: they
+// are copied to the device as they are and compacted there (pack_padded_kernel).  Same semantics as scann_pack_padded (datagenerator.py:
+// 69-135, custom_layers.py:18-28): a real atom = atom_mask != 0; an edge = an unmasked slot of a real atom, in slot order.
+// Masks of 1 byte (bool / uint8) or 4 bytes (the float32 masks of the Keras input dict, int32; -0.0f counts as 0).
+namespace {
+inline bool mask_at(const void* m, int size, int64_t i) {
+  return size == 1 ? static_cast<const uint8_t*>(m)[i] != 0 : (static_cast<const uint32_t*>(m)[i] & 0x7fffffffu) != 0;
+}
+}  // namespace
+
+int scann_count_padded(int32_t B, int32_t M, int32_t N, const void* atom_mask, int32_t atom_mask_size, const void* neighbor_mask,
+                       int32_t neighbor_mask_size, int32_t* out_mol_offset, int32_t* out_edge_offset, int32_t* out_row_of, int32_t* n_atom,
+                       int32_t* n_edge) {
+  if (B < 0 || M < 0 || N < 0 || !atom_mask || (N > 0 && !neighbor_mask) || !out_mol_offset || !out_edge_offset || !out_row_of || !n_atom || !n_edge)
+    return pack_fail("scann_count_padded: null argument or negative shape");
+  if ((atom_mask_size != 1 && atom_mask_size != 4) || (neighbor_mask_size != 1 && neighbor_mask_size != 4))
+    return pack_fail("scann_count_padded: masks must have 1-byte or 4-byte elements");
+  int n_thr = 1;
+  if (B >= 2048) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    n_thr = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 8u), B / 1024);
+    if (const char* e = getenv("SCANN_PACK_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+    n_thr = std::max(1, std::min<int>(n_thr, B));
+  }
+  std::vector<int64_t> cnt_a((size_t)n_thr + 1, 0), cnt_e((size_t)n_thr + 1, 0);
+  std::vector<const char*> err((size_t)n_thr, nullptr);
+  auto range = [&](int t) { return std::make_pair((int32_t)((int64_t)B * t / n_thr), (int32_t)((int64_t)B * (t + 1) / n_thr)); };
+  auto run = [&](auto&& fn) {
+    if (n_thr == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (std::thread& x : th) x.join();
+  };
+  // degree of every padded atom slot (0 for a padded atom), kept in out_row_of until the second pass turns it into the row
+  auto degree = [&](int64_t bm) {
+    int32_t d = 0;
+    if (neighbor_mask_size == 1) {
+      const uint8_t* nm = static_cast<const uint8_t*>(neighbor_mask) + bm * N;
+      for (int32_t n = 0; n < N; ++n) d += nm[n] != 0;
+    } else {
+      const uint32_t* nm = static_cast<const uint32_t*>(neighbor_mask) + bm * N;
+      for (int32_t n = 0; n < N; ++n) d += (nm[n] & 0x7fffffffu) != 0;
+    }
+    return d;
+  };
+  run([&](int t) {
+    const auto [b0, b1] = range(t);
+    int64_t na_t = 0, ne_t = 0;
+    for (int32_t b = b0; b < b1; ++b) {
+      int64_t here = 0;
+      for (int32_t a = 0; a < M; ++a) {
+        const int64_t bm = (int64_t)b * M + a;
+        if (!mask_at(atom_mask, atom_mask_size, bm)) { out_row_of[bm] = -1; continue; }
+        ++here;
+        const int32_t d = degree(bm);
+        out_row_of[bm] = d;
+        ne_t += d;
+      }
+      if (here == 0) { err[t] = "a structure in the batch has no atoms"; return; }
+      na_t += here;
+    }
+    cnt_a[t + 1] = na_t;
+    cnt_e[t + 1] = ne_t;
+  });
+  for (int t = 0; t < n_thr; ++t) {
+    if (err[t]) return pack_fail(err[t]);
+    cnt_a[t + 1] += cnt_a[t];
+    cnt_e[t + 1] += cnt_e[t];
+  }
+  if (cnt_a[n_thr] > INT32_MAX) return pack_fail("batch too large for int32 atom rows");
+  if (cnt_e[n_thr] > INT32_MAX) return pack_fail("batch too large for int32 edge rows");
+  out_mol_offset[0] = 0;
+  out_edge_offset[0] = 0;
+  run([&](int t) {
+    const auto [b0, b1] = range(t);
+    int64_t row = cnt_a[t], e = cnt_e[t];
+    for (int32_t b = b0; b < b1; ++b) {
+      for (int32_t a = 0; a < M; ++a) {
+        const int64_t bm = (int64_t)b * M + a;
+        const int32_t d = out_row_of[bm];
+        if (d < 0) continue;
+        out_row_of[bm] = (int32_t)row;
+        e += d;
+        out_edge_offset[++row] = (int32_t)e;
+      }
+      out_mol_offset[b + 1] = (int32_t)row;
+    }
+  });
+  *n_atom = (int32_t)cnt_a[n_thr];
+  *n_edge = (int32_t)cnt_e[n_thr];
   return SCANN_OK;
 }
 

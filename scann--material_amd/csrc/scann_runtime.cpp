@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace scann;
@@ -217,6 +218,7 @@ struct scann_dbatch {
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
   float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
   int32_t n_big = 0, n_slot = 0;
+  int32_t* pack_flag = nullptr;  // device packing (scann_upload_padded): what pack_padded_kernel found wrong with the input, behind y
   size_t gen_ws_bytes = 0;
   char* gen_ws = nullptr;  // generic-width forward: its per-batch workspace (sized by the handle's widths; cached_malloc)
   // workspace
@@ -870,13 +872,42 @@ void scann_batch_release(scann_handle_t* h, scann_dbatch_t* db) {
   delete db;
 }
 
-static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t** out, bool scratch) {
+// Device packing (scann_upload_padded): the payload arrays of a padded Keras input dict, which go to the device AS THEY ARE and are
+// compacted there (pack_padded_kernel); `b` then carries the counts and the two offset arrays only (host: scann_count_padded).
+struct PaddedSrc {
+  int32_t M, N;
+  const int32_t *atomic, *neighbors;
+  const void* neighbor_mask;
+  int32_t mask_size;
+  const float *weight, *dist;
+  const int32_t* row_of;  // [B*M] host
+};
+
+// memcpy of a large block on up to 8 threads (the padded payload of a 2,048-structure chunk is ~10 MB, of a whole dataset ~100: one
+// thread moves ~7-10 GB/s, which would make the staging copy the longest host step of the padded path)
+static void par_memcpy(void* dst, const void* src, size_t bytes) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t n_thr = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), bytes >> 22);  // >= 4 MiB per thread
+  if (n_thr <= 1) { memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < n_thr; ++t) {
+    const size_t o0 = (bytes * t / n_thr) & ~(size_t)63, o1 = t + 1 == n_thr ? bytes : (bytes * (t + 1) / n_thr) & ~(size_t)63;
+    th.emplace_back([=] { memcpy(static_cast<char*>(dst) + o0, static_cast<const char*>(src) + o0, o1 - o0); });
+  }
+  memcpy(dst, src, (bytes / n_thr) & ~(size_t)63);
+  for (std::thread& x : th) x.join();
+}
+
+static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t** out, bool scratch, const PaddedSrc* pad = nullptr) {
   if (!h || !b || !out) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: null argument");
   *out = nullptr;
   const int32_t B = b->n_struct, A = b->n_atom, E = b->n_edge;
   if (B <= 0 || A <= 0 || E < 0) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: empty batch");
-  if ((!b->atomic && !h->cfg.feature_cgcnn) || !b->mol_offset || !b->edge_offset || (E > 0 && (!b->edge_col || !b->edge_dist || !b->edge_weight)))
+  if (!b->mol_offset || !b->edge_offset ||
+      (!pad && ((!b->atomic && !h->cfg.feature_cgcnn) || (E > 0 && (!b->edge_col || !b->edge_dist || !b->edge_weight)))))
     return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: null array");
+  if (pad && (h->cfg.feature_cgcnn || h->cfg.use_ring || h->t_master))
+    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_upload_padded: atomic feature without ring, inference handles (a training handle needs the edges on the host)");
   if (b->mol_offset[0] != 0 || b->mol_offset[B] != A || b->edge_offset[0] != 0 || b->edge_offset[A] != E)
     return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: offsets do not cover the batch");
   int32_t max_atoms = 0;
@@ -888,7 +919,9 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   if ((size_t)max_atoms * 5 * sizeof(float) > 60000) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: structure too large");
   if ((uint64_t)std::max(A, E) * D * 4 >= (1ull << 32))  // edge_kernel addresses a tensor row as base + 32-bit byte offset
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_batch_upload: more than 8,388,607 atoms or edges in one batch; split it");
-  if (!h->cfg.feature_cgcnn) {
+  if (pad) {
+    // (atomic numbers and neighbour indices are checked where they are read: pack_padded_kernel's flag word, scann_batch_download)
+  } else if (!h->cfg.feature_cgcnn) {
     for (int a = 0; a < A; ++a)
       if (b->atomic[a] < 0 || b->atomic[a] >= h->cfg.n_atoms)
         return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: atomic number outside the embedding table (n_atoms)");
@@ -903,13 +936,13 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   int tile_rows = TE_MAX;
   {
     std::string err;
-    int r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles,
+    int r = plan_tiles(b->mol_offset, B, b->edge_offset, pad ? nullptr : b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles,
                        tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err, false);
     if (r) return fail(h, r, "scann_batch_upload: " + err);
     // A launch that fits ONE round of workgroups is the latency chain of a tile: 32-row tiles (four workgroups per CU = 1,024 slots)
     // make that chain shorter.  Only when no atom needs chunking at 32 rows.
     if (E > 0 && max_degree <= 32 && E <= 32 * 1024) {
-      r = plan_tiles(b->mol_offset, B, b->edge_offset, b->edge_col, A, E, 32, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
+      r = plan_tiles(b->mol_offset, B, b->edge_offset, pad ? nullptr : b->edge_col, A, E, 32, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
                      &tile_rows, &max_degree, &n_slot, err, false);
       if (r) return fail(h, r, "scann_batch_upload: " + err);
     }
@@ -944,6 +977,10 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_tpart = take(n_big ? tiles.size() * 4 : 0), o_big = take((size_t)n_big * 3 * 4);
   const size_t o_inoff = take((size_t)(A + 1) * 4), o_inedge = take((size_t)E * 4);
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
+  // device packing: the padded payload as it came (transient: read once by pack_padded_kernel), the row map and the flag word
+  const size_t BM = pad ? (size_t)B * pad->M : 0, BMN = pad ? BM * pad->N : 0;
+  const size_t o_prow = take(BM * 4), o_pat = take(BM * 4), o_pnbr = take(BMN * 4), o_pmask = take(pad ? BMN * pad->mask_size : 0);
+  const size_t o_pw = take(BMN * 4), o_pd = take(BMN * 4);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
   const size_t o_geom = take(h->cfg.g_update ? rowE + D * 4 : 0);  // + the spare row edge-less tiles store to (EdgeArgs::n_edge)
@@ -951,6 +988,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_c0 = take((h->cfg.use_ring || h->cfg.feature_cgcnn) ? rowA : 0);
   const size_t o_c = take(rowA), o_ctx = take(rowA), o_P1 = take(rowA), o_P3 = take(rowA), o_q = take(rowA);
   const size_t o_gq = take(rowA), o_gk = take(rowA), o_ga = take((size_t)A * 4), o_y = take((size_t)B * 4);
+  const size_t o_pflag = take(pad ? 4 : 0);  // right behind y: fetched with the results in one copy
   const size_t o_pbuf = take((size_t)n_slot * 3 * D * 4);
   hipError_t e = hipSuccess;
   scann_handle::Stage* stage = nullptr;
@@ -995,12 +1033,20 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     return fail(h, e == hipErrorOutOfMemory ? SCANN_ERR_OOM : SCANN_ERR_HIP, std::string("hipMalloc(batch arena): ") + hipGetErrorString(e));
   }
   struct ImgView { char* p; char* data() const { return p; } } img{img_ptr};
-  if (b->atomic) memcpy(img.data() + o_atomic, b->atomic, (size_t)A * 4);
+  if (b->atomic && !pad) memcpy(img.data() + o_atomic, b->atomic, (size_t)A * 4);
+  if (pad) {
+    memcpy(img.data() + o_prow, pad->row_of, BM * 4);
+    memcpy(img.data() + o_pat, pad->atomic, BM * 4);
+    par_memcpy(img.data() + o_pnbr, pad->neighbors, BMN * 4);
+    par_memcpy(img.data() + o_pmask, pad->neighbor_mask, BMN * pad->mask_size);
+    par_memcpy(img.data() + o_pw, pad->weight, BMN * 4);
+    par_memcpy(img.data() + o_pd, pad->dist, BMN * 4);
+  }
   if (h->cfg.use_ring) memcpy(img.data() + o_ring, b->ring, (size_t)A * 2 * 4);
   if (h->cfg.feature_cgcnn) memcpy(img.data() + o_cg, b->cgcnn, (size_t)A * 92 * 4);
   memcpy(img.data() + o_mol, b->mol_offset, (size_t)(B + 1) * 4);
   memcpy(img.data() + o_eoff, b->edge_offset, (size_t)(A + 1) * 4);
-  if (E > 0) {
+  if (E > 0 && !pad) {
     memcpy(img.data() + o_col, b->edge_col, (size_t)E * 4);
     memcpy(img.data() + o_dist, b->edge_dist, (size_t)E * 4);
     memcpy(img.data() + o_wgt, b->edge_weight, (size_t)E * 4);
@@ -1026,11 +1072,26 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   // (the centre atom of every edge is derived from the offsets on the device, behind the copy: no host loop, no bytes over the bus)
   int32_t* const d_eoff = (int32_t*)(db->arena + o_eoff);
   int32_t* const d_erow = (int32_t*)(db->arena + o_row);
-  if (scratch) {  // pinned staging, ordered before the kernels on stream 0
-    e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->streams[0]);
+  PackPaddedArgs pa{};
+  if (pad) {
+    char* a0 = db->arena;
+    pa.B = B; pa.M = pad->M; pa.N = pad->N; pa.n_species = h->cfg.n_atoms;
+    pa.row_of = (const int32_t*)(a0 + o_prow); pa.edge_offset = d_eoff; pa.atomic = (const int32_t*)(a0 + o_pat);
+    pa.neighbors = (const int32_t*)(a0 + o_pnbr); pa.neighbor_mask = a0 + o_pmask; pa.mask_size = pad->mask_size;
+    pa.weight = (const float*)(a0 + o_pw); pa.dist = (const float*)(a0 + o_pd);
+    pa.out_atomic = (int32_t*)(a0 + o_atomic); pa.out_col = (int32_t*)(a0 + o_col);
+    pa.out_dist = (float*)(a0 + o_dist); pa.out_weight = (float*)(a0 + o_wgt);
+    pa.flag = (int32_t*)(a0 + o_pflag);
+  }
+  hipStream_t const up_s = scratch ? h->streams[0] : h->copy_stream;  // scratch: pinned staging, ordered before the kernels on stream 0
+  if (pad) e = hipMemsetAsync(db->arena + o_pflag, 0, 4, up_s);
+  if (scratch) {
+    if (e == hipSuccess) e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->streams[0]);
+    if (e == hipSuccess && pad) launch_pack_padded(pa, h->streams[0]);
     if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->streams[0]);
   } else {
-    e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->copy_stream);
+    if (e == hipSuccess && pad) launch_pack_padded(pa, h->copy_stream);
     if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(stage->ev, h->copy_stream);
     if (e == hipSuccess) stage->used = true;
@@ -1059,6 +1120,7 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   db->c = (float*)(a0 + o_c); db->ctx = (float*)(a0 + o_ctx); db->P1 = (float*)(a0 + o_P1); db->P3 = (float*)(a0 + o_P3);
   db->q = (float*)(a0 + o_q); db->gq = (float*)(a0 + o_gq); db->gk = (float*)(a0 + o_gk);
   db->ga = (float*)(a0 + o_ga); db->y = (float*)(a0 + o_y);
+  db->pack_flag = pad ? (int32_t*)(a0 + o_pflag) : nullptr;
   if (n_big) {
     db->tile_part = (int32_t*)(a0 + o_tpart); db->big_tab = (int32_t*)(a0 + o_big); db->part_buf = (float*)(a0 + o_pbuf);
   }
@@ -1421,7 +1483,8 @@ int scann_batch_info(scann_handle_t* h, const scann_dbatch_t* db, int32_t* out8)
 static int fetch_results(scann_handle_t* h, scann_dbatch_t* db, hipStream_t s, float* y_out, float* ga_attn_out) {
   const char* src = reinterpret_cast<const char*>(ga_attn_out ? db->ga : db->y);
   const size_t y_off = (size_t)(reinterpret_cast<const char*>(db->y) - src);
-  const size_t bytes = y_off + (size_t)db->n_struct * 4;
+  const size_t f_off = db->pack_flag ? (size_t)(reinterpret_cast<const char*>(db->pack_flag) - src) : 0;  // (behind y in the arena)
+  const size_t bytes = db->pack_flag ? f_off + 4 : y_off + (size_t)db->n_struct * 4;
   scann_handle::DlStage& st = h->dl_stage[db->last_slot];
   if (st.cap < bytes) {
     if (st.p) {
@@ -1436,6 +1499,11 @@ static int fetch_results(scann_handle_t* h, scann_dbatch_t* db, hipStream_t s, f
   }
   HIPCHK(h, hipMemcpyAsync(st.p, src, bytes, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
+  if (db->pack_flag) {  // a batch packed on the device: what the host packer refuses when it packs, the kernel reports here
+    const int32_t bad = *reinterpret_cast<const int32_t*>(st.p + f_off);
+    if (bad & 1) return fail(h, SCANN_ERR_INVALID, "scann_batch_download: an unmasked neighbour slot points at a padded atom (or outside the structure)");
+    if (bad & 2) return fail(h, SCANN_ERR_INVALID, "scann_batch_download: atomic number outside the embedding table (n_atoms)");
+  }
   memcpy(y_out, st.p + y_off, (size_t)db->n_struct * 4);
   if (ga_attn_out) memcpy(ga_attn_out, st.p, (size_t)db->n_atom * 4);
   return SCANN_OK;
@@ -1507,25 +1575,78 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
   scann_handle::PadScratch& ps = h->pad_scratch;
   auto grow_i = [](std::vector<int32_t>& v, size_t n) { if (v.size() < n) v.resize(n + n / 4); };
   auto grow_f = [](std::vector<float>& v, size_t n) { if (v.size() < n) v.resize(n + n / 4); };
-  grow_i(ps.gidx, BM); grow_i(ps.at, BM); grow_i(ps.mol, (size_t)B + 1); grow_i(ps.eoff, BM + 1); grow_i(ps.col, BM * N + 1);
-  grow_f(ps.dist, BM * N + 1); grow_f(ps.wgt, BM * N + 1);
-  std::vector<int32_t>&gidx = ps.gidx, &at = ps.at, &mol = ps.mol, &eoff = ps.eoff, &col = ps.col;
-  std::vector<float>&dist = ps.dist, &wgt = ps.wgt;
+  grow_i(ps.gidx, BM); grow_i(ps.mol, (size_t)B + 1); grow_i(ps.eoff, BM + 1);
+  std::vector<int32_t>&gidx = ps.gidx, &mol = ps.mol, &eoff = ps.eoff;
   int32_t na = 0, ne = 0;
-  if (scann_pack_padded(B, M, N, atomic, nullptr, atom_mask, neighbors, neighbor_mask, neighbor_weight, neighbor_distance,
-                        nullptr, at.data(), nullptr, nullptr, mol.data(), eoff.data(), col.data(), dist.data(), wgt.data(),
-                        gidx.data(), &na, &ne))
-    return fail(h, SCANN_ERR_INVALID, std::string("scann_forward_padded: ") + scann_pack_last_error());
+  // the host reads the MASKS only (real atoms, degrees -> offsets, tile plan); the payload arrays go to the device as they are and
+  // are compacted there (pack_padded_kernel) -- a training handle, whose uploads carry the reverse adjacency, packs on the host
+  const bool device_pack = !h->t_master;
   scann_batch_t pb{};
-  pb.n_struct = B; pb.n_atom = na; pb.n_edge = ne;
-  pb.atomic = at.data(); pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
-  pb.edge_col = col.data(); pb.edge_dist = dist.data(); pb.edge_weight = wgt.data();
-  if (ga_out) grow_f(ps.ga, (size_t)na);
   std::vector<float>& ga_packed = ps.ga;
-  const int r = scann_forward(h, &pb, y_out, ga_out ? ga_packed.data() : nullptr);
+  int r;
+  if (device_pack) {
+    if (scann_count_padded(B, M, N, atom_mask, 1, neighbor_mask, 1, mol.data(), eoff.data(), gidx.data(), &na, &ne))
+      return fail(h, SCANN_ERR_INVALID, std::string("scann_forward_padded: ") + scann_pack_last_error());
+    pb.n_struct = B; pb.n_atom = na; pb.n_edge = ne; pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
+    const PaddedSrc src{M, N, atomic, neighbors, neighbor_mask, 1, neighbor_weight, neighbor_distance, gidx.data()};
+    if (ga_out) grow_f(ps.ga, (size_t)na);
+    scann_dbatch_t* db = nullptr;
+    r = upload_impl(h, &pb, &db, true, &src);
+    if (!r) r = scann_forward_resident(h, db, 0);
+    if (!r) r = scann_batch_download(h, db, y_out, ga_out ? ga_packed.data() : nullptr);
+  } else {
+    grow_i(ps.at, BM); grow_i(ps.col, BM * N + 1); grow_f(ps.dist, BM * N + 1); grow_f(ps.wgt, BM * N + 1);
+    if (scann_pack_padded(B, M, N, atomic, nullptr, atom_mask, neighbors, neighbor_mask, neighbor_weight, neighbor_distance,
+                          nullptr, ps.at.data(), nullptr, nullptr, mol.data(), eoff.data(), ps.col.data(), ps.dist.data(), ps.wgt.data(),
+                          gidx.data(), &na, &ne))
+      return fail(h, SCANN_ERR_INVALID, std::string("scann_forward_padded: ") + scann_pack_last_error());
+    pb.n_struct = B; pb.n_atom = na; pb.n_edge = ne;
+    pb.atomic = ps.at.data(); pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
+    pb.edge_col = ps.col.data(); pb.edge_dist = ps.dist.data(); pb.edge_weight = ps.wgt.data();
+    if (ga_out) grow_f(ps.ga, (size_t)na);
+    r = scann_forward(h, &pb, y_out, ga_out ? ga_packed.data() : nullptr);
+  }
   if (r) return r;
   if (ga_out)
     for (size_t i = 0; i < BM; ++i) ga_out[i] = gidx[i] >= 0 ? ga_packed[gidx[i]] : 0.f;  // softmax of -1e9 -> 0
+  return SCANN_OK;
+}
+
+int scann_upload_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, const int32_t* atomic, const void* atom_mask,
+                        int32_t atom_mask_size, const int32_t* neighbors, const void* neighbor_mask, int32_t neighbor_mask_size,
+                        const float* neighbor_weight, const float* neighbor_distance, scann_dbatch_t** out, int32_t* n_atom_out,
+                        int32_t* n_edge_out) {
+  if (!h || !out || B <= 0 || M <= 0 || N < 0 || !atomic || !atom_mask || (N > 0 && (!neighbors || !neighbor_mask || !neighbor_weight || !neighbor_distance)))
+    return fail(h, SCANN_ERR_INVALID, "scann_upload_padded: bad argument");
+  *out = nullptr;
+  const size_t BM = (size_t)B * M;
+  std::vector<int32_t> row_of(BM), mol((size_t)B + 1), eoff(BM + 1);  // (per call: the caller may upload from a second thread)
+  int32_t na = 0, ne = 0;
+  if (scann_count_padded(B, M, N, atom_mask, atom_mask_size, neighbor_mask, neighbor_mask_size, mol.data(), eoff.data(), row_of.data(), &na, &ne))
+    return fail(h, SCANN_ERR_INVALID, std::string("scann_upload_padded: ") + scann_pack_last_error());
+  scann_batch_t pb{};
+  pb.n_struct = B; pb.n_atom = na; pb.n_edge = ne; pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
+  const PaddedSrc src{M, N, atomic, neighbors, neighbor_mask, neighbor_mask_size, neighbor_weight, neighbor_distance, row_of.data()};
+  const int r = upload_impl(h, &pb, out, false, &src);
+  if (r) return r;
+  if (n_atom_out) *n_atom_out = na;
+  if (n_edge_out) *n_edge_out = ne;
+  return SCANN_OK;
+}
+
+int scann_batch_read_csr(scann_handle_t* h, scann_dbatch_t* db, int32_t* atomic, int32_t* mol_offset, int32_t* edge_offset, int32_t* edge_col,
+                         float* edge_dist, float* edge_weight) {
+  if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_batch_read_csr: null argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (db->upload_ev) HIPCHK(h, hipEventSynchronize(db->upload_ev));
+  else HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  const size_t A = (size_t)db->n_atom, E = (size_t)db->n_edge;
+  if (atomic) HIPCHK(h, hipMemcpy(atomic, db->atomic, A * 4, hipMemcpyDeviceToHost));
+  if (mol_offset) HIPCHK(h, hipMemcpy(mol_offset, db->mol_offset, ((size_t)db->n_struct + 1) * 4, hipMemcpyDeviceToHost));
+  if (edge_offset) HIPCHK(h, hipMemcpy(edge_offset, db->edge_offset, (A + 1) * 4, hipMemcpyDeviceToHost));
+  if (edge_col && E) HIPCHK(h, hipMemcpy(edge_col, db->edge_col, E * 4, hipMemcpyDeviceToHost));
+  if (edge_dist && E) HIPCHK(h, hipMemcpy(edge_dist, db->dist, E * 4, hipMemcpyDeviceToHost));
+  if (edge_weight && E) HIPCHK(h, hipMemcpy(edge_weight, db->weight, E * 4, hipMemcpyDeviceToHost));
   return SCANN_OK;
 }
 

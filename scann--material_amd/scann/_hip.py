@@ -102,6 +102,10 @@ SYMBOLS = [
     ("scann_exact_reruns", C.c_int64, [_P]),
     ("scann_device_memory", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("scann_batch_info", C.c_int, [_P, _P, _P]),
+    ("scann_count_padded", C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("scann_upload_padded", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, C.c_int32, _P, _P, C.POINTER(_P),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("scann_batch_read_csr", C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
 ]
 
 _lib = None
@@ -338,6 +342,44 @@ def slice_dataset(ds_mol_offset, ds_edge_offset, ds_atomic, ds_ring, ds_edge_loc
     return PackedBatch(o_atomic, o_mol, o_eoff, o_col, o_dist, o_wgt, ring=o_ring)
 
 
+def _mask_arg(m):
+    """A mask of the Keras input dict as the C ABI takes it: (contiguous array, element size 1 | 4) -- bool / uint8 and float32 / int32
+    masks go through AS THEY ARE (no `!= 0` pass over a whole dataset's neighbour slots); anything else is compared once."""
+    m = np.asarray(m)
+    if m.dtype in (np.bool_, np.uint8, np.int8):
+        return np.ascontiguousarray(m), 1
+    if m.dtype in (np.float32, np.int32, np.uint32):
+        return np.ascontiguousarray(m), 4
+    return np.ascontiguousarray(m != 0), 1
+
+
+def count_padded(inputs):
+    """The host half of the device packing (scann_count_padded; host only): masks -> (mol_offset, edge_offset, row_of [B, M])."""
+    lib = load_library()
+    amask, asz = _mask_arg(inputs["atom_mask"])
+    nmask, nsz = _mask_arg(inputs["neighbor_mask"])
+    B, M, N = nmask.shape
+    mol, eoff, row_of = np.empty(B + 1, np.int32), np.empty(B * M + 1, np.int32), np.empty(B * M, np.int32)
+    na, ne = C.c_int32(0), C.c_int32(0)
+    if lib.scann_count_padded(B, M, N, _ptr(amask), asz, _ptr(nmask), nsz, _ptr(mol), _ptr(eoff), _ptr(row_of), C.byref(na), C.byref(ne)) != SCANN_OK:
+        raise ValueError((lib.scann_pack_last_error() or b"").decode())
+    return mol, eoff[:na.value + 1], row_of.reshape(B, M)
+
+
+class PaddedInfo:
+    """What the host knows of a batch that was packed on the DEVICE (Engine.upload_padded): counts and where the real atoms sit."""
+
+    def __init__(self, n_struct, n_atom, n_edge, atom_mask):
+        self.n_struct, self.n_atom, self.n_edge = n_struct, n_atom, n_edge
+        self.atom_mask = atom_mask  # [B, M] bool
+        self.pad_shape = atom_mask.shape
+
+    def repad_ga(self, ga_packed):
+        out = np.zeros(self.pad_shape + (1,), dtype=np.float32)
+        out[self.atom_mask, 0] = ga_packed
+        return out
+
+
 class ResidentBatch:
     """A batch uploaded to HBM (scann_dbatch_t) together with its workspace."""
 
@@ -375,6 +417,7 @@ class Engine:
         self._h = h
         self.cfg = cfg_struct
         self.device = device
+        self.training = False
 
     def _check(self, rc):
         if rc != SCANN_OK:
@@ -448,6 +491,32 @@ class Engine:
         self._check(self.lib.scann_batch_upload(self._h, C.byref(st), C.byref(db)))
         return ResidentBatch(self, packed, db)
 
+    def upload_padded(self, inputs):
+        """The padded Keras input dict (or row views of one) -> a resident batch, packed to CSR ON THE DEVICE (scann_upload_padded): the
+        host reads the masks, the payload arrays cross the bus as they are.  feature = "atomic" without ring, inference handles."""
+        atomic = np.ascontiguousarray(inputs["atomic"], dtype=np.int32)
+        B, M = atomic.shape
+        amask, asz = _mask_arg(np.asarray(inputs["atom_mask"]).reshape(B, M))
+        nbr = np.ascontiguousarray(inputs["neighbors"], dtype=np.int32)
+        N = nbr.shape[2]
+        nmask, nsz = _mask_arg(inputs["neighbor_mask"])
+        wgt = np.ascontiguousarray(inputs["neighbor_weight"], dtype=np.float32)
+        dst = np.ascontiguousarray(inputs["neighbor_distance"], dtype=np.float32)
+        if nbr.shape != (B, M, N) or nmask.shape != nbr.shape or wgt.shape != nbr.shape or dst.shape != nbr.shape or amask.shape != (B, M):
+            raise ValueError("inconsistent input shapes")
+        db, na, ne = _P(), C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.scann_upload_padded(self._h, B, M, N, _ptr(atomic), _ptr(amask), asz, _ptr(nbr), _ptr(nmask), nsz, _ptr(wgt),
+                                                 _ptr(dst), C.byref(db), C.byref(na), C.byref(ne)))
+        return ResidentBatch(self, PaddedInfo(B, na.value, ne.value, amask != 0 if amask.dtype != np.bool_ else amask), db)
+
+    def read_csr(self, rb):
+        """The packed arrays of a resident batch, copied back (test hook: device packing against the host packer)."""
+        p = rb.packed
+        atomic, mol, eoff = np.empty(p.n_atom, np.int32), np.empty(p.n_struct + 1, np.int32), np.empty(p.n_atom + 1, np.int32)
+        col, dist, wgt = np.empty(p.n_edge, np.int32), np.empty(p.n_edge, np.float32), np.empty(p.n_edge, np.float32)
+        self._check(self.lib.scann_batch_read_csr(self._h, rb._h, _ptr(atomic), _ptr(mol), _ptr(eoff), _ptr(col), _ptr(dist), _ptr(wgt)))
+        return {"atomic": atomic, "mol_offset": mol, "edge_offset": eoff, "edge_col": col, "edge_dist": dist, "edge_weight": wgt}
+
     def forward_resident(self, rb, slot=0):
         self._check(self.lib.scann_forward_resident(self._h, rb._h, int(slot)))
 
@@ -498,6 +567,7 @@ class Engine:
 
     def train_begin(self):
         self._check(self.lib.scann_train_begin(self._h))
+        self.training = True  # uploads of a training handle carry the reverse adjacency: packed on the host
 
     def train_forward(self, rb, targets, dropout=0.0, seed=0):
         t = np.ascontiguousarray(targets, dtype=np.float32)

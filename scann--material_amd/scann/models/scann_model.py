@@ -177,11 +177,14 @@ class HipModel:
                 gas.append(ga)
             rb.release()
 
+        # feature = "atomic" without ring: the chunk is packed to CSR on the DEVICE (the host reads its masks only); else the native host packer
+        m = self.config["model"]
+        device_pack = m["feature"] == "atomic" and not m["use_ring"] and not eng.training
         k = 0
         try:
             for i in range(0, B, C):
-                pk = _hip.pack_inputs({key: v[i:i + C] for key, v in inputs.items()})
-                rb = eng.upload(pk)
+                chunk = {key: v[i:i + C] for key, v in inputs.items()}
+                rb = eng.upload_padded(chunk) if device_pack else eng.upload(_hip.pack_inputs(chunk))
                 try:
                     if len(pending) >= window:
                         fetch_oldest()

@@ -922,3 +922,79 @@ def test_first_layer_computes_its_geometry_rows_itself(hip_lib, monkeypatch):
     sub = {k: v[:48] for k, v in inputs.items()}
     y_ref, _ = so.forward(cfg, w, sub, np.float32)
     assert rel_err(out["1"][0][:48], y_ref) <= RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["qm9", "worst", "mp2018", "corners"])
+def test_device_packing_gives_the_host_packers_arrays(hip_lib, case):
+    """Padded -> CSR on the DEVICE (scann_upload_padded: the host reads the masks, pack_padded_kernel compacts the payload arrays that
+    crossed the bus as they were) against the native host packer (scann_pack_padded, i.e. what DataIterator.__getitem__ + gather_shape
+    amount to: datagenerator.py:69-135, custom_layers.py:18-28): every CSR array byte for byte -- QM9-shaped, worst-case 29 x 12,
+    MP2018-shaped crystals (hundreds of atoms, up to 24 neighbours), and the corners: an atom without neighbours, a one-atom structure,
+    garbage in masked slots, float32 masks.  Then the forward on the device-packed batch: the bytes of the host-packed one."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    rng = np.random.default_rng(11)
+    name = "mp2018" if case == "mp2018" else "qm9"
+    cfg = so.default_config(name)
+    w = so.init_weights(cfg, 1234, perturb=True)
+    if case == "corners":
+        de, dn = so.synth_dataset(9, 4)
+        de[2] = [[6], 0.5]
+        dn[2] = [[]]           # a one-atom structure (no neighbour at all)
+        dn[5][1] = []           # an atom without neighbours inside an ordinary molecule
+    else:
+        de, dn = so.synth_dataset({"qm9": 300, "worst": 64, "mp2018": 24}[case], 7, kind=case)
+    inputs, _ = so.pad_batch(de, dn, True)
+    inputs["neighbors"] = np.where(inputs["neighbor_mask"], inputs["neighbors"], rng.integers(0, 2**30, inputs["neighbors"].shape)).astype(np.int32)
+    inputs["neighbor_distance"] = np.where(inputs["neighbor_mask"], inputs["neighbor_distance"], np.float32(np.nan)).astype(np.float32)
+    ref = _hip.pack_inputs(inputs)
+    model = HipModel(cfg, w, device=0, infer=True)
+    eng = model.engine
+    for mask_dtype in (np.bool_, np.float32):
+        x = dict(inputs)
+        x["atom_mask"] = np.asarray(inputs["atom_mask"]).astype(mask_dtype)
+        x["neighbor_mask"] = np.asarray(inputs["neighbor_mask"]).astype(mask_dtype)
+        rb = eng.upload_padded(x)
+        assert (rb.packed.n_struct, rb.packed.n_atom, rb.packed.n_edge) == (ref.n_struct, ref.n_atom, ref.n_edge)
+        got = eng.read_csr(rb)
+        for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+            assert np.array_equal(got[f].view(np.int32), np.asarray(getattr(ref, f)).view(np.int32)), (case, mask_dtype, f)
+        eng.forward_resident(rb, 0)
+        y_dev, ga_dev = eng.download(rb)
+        rb.free()
+    y_host, ga_host = eng.forward(ref)
+    assert np.array_equal(y_dev.view(np.int32), y_host.view(np.int32)) and np.array_equal(ga_dev.view(np.int32), ga_host.view(np.int32))
+    # the drop-in call (scann_forward_padded packs on the device too): the same numbers, GlobalAttention scores re-padded with zeros
+    y, ga = model.predict(inputs)
+    # (bit patterns: the one-atom structure's score is the reference's own NaN, tf.linalg.normalize of a zero vector)
+    assert np.array_equal(y[:, 0].view(np.int32), y_host.view(np.int32)) and np.array_equal(ga.view(np.int32), ref.repad_ga(ga_host).view(np.int32))
+
+
+@pytest.mark.gpu
+def test_device_packing_reports_what_the_host_packer_refuses(hip_lib):
+    """An unmasked neighbour slot that points at a padded atom, an atomic number outside the embedding table: the host packer raises
+    when it packs; a batch packed on the device reports the same at its download (no fault, no NaN, the handle stays usable)."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    model = HipModel(cfg, so.init_weights(cfg, 3), device=0, infer=True)
+    de, dn = so.synth_dataset(12, 1)
+    inputs, _ = so.pad_batch(de, dn, True)
+    na = np.asarray(inputs["atom_mask"]).reshape(len(de), -1).sum(1)
+    M = inputs["neighbors"].shape[1]
+    b = int(np.argmax(na < M))
+    bad = dict(inputs)
+    bad["neighbors"] = inputs["neighbors"].copy()
+    bad["neighbors"][b, 0, 0] = M - 1  # a padded atom of that structure
+    with pytest.raises(_hip.ScannHipError, match="padded atom"):
+        model.predict(bad)
+    bad = dict(inputs)
+    bad["atomic"] = inputs["atomic"].copy()
+    bad["atomic"][0, 0] = cfg["model"]["n_atoms"] + 3
+    with pytest.raises(_hip.ScannHipError, match="embedding table"):
+        model.predict(bad)
+    y, _ = model.predict(inputs)
+    assert np.isfinite(y).all()

@@ -1358,3 +1358,35 @@ def test_predict_dataset_pipeline_with_a_stub_engine(monkeypatch, threaded):
         assert not eng.live  # nothing uploaded is left behind, launched or not
     y, ga, t = model(Eng()).predict_dataset([], group=4)
     assert len(y) == 0 and ga is None and len(t) == 0
+
+
+def test_mask_counting_matches_the_host_packer(hip_lib):
+    """scann_count_padded (the host half of the device packing): from the MASKS alone -- bool, uint8 or the float32 masks of the Keras
+    input dict, -0.0 counting as 0 -- the same mol_offset / edge_offset / packed-row map as scann_pack_padded builds while it packs;
+    a structure without atoms is refused with the packer's message; thread count does not matter."""
+    from scann import _hip
+
+    rng = np.random.default_rng(5)
+    de, dn = so.synth_dataset(40, 3)
+    inputs, _ = so.pad_batch(de, dn, True)
+    inputs["neighbors"] = np.where(inputs["neighbor_mask"], inputs["neighbors"], rng.integers(0, 2**30, inputs["neighbors"].shape)).astype(np.int32)
+    ref = _hip.pack_inputs(inputs)
+    for cast in (np.bool_, np.uint8, np.float32, np.float64):
+        x = dict(inputs)
+        x["atom_mask"] = np.asarray(inputs["atom_mask"]).astype(cast)
+        x["neighbor_mask"] = np.asarray(inputs["neighbor_mask"]).astype(cast)
+        if cast == np.float32:
+            x["neighbor_mask"] = np.where(x["neighbor_mask"] != 0, x["neighbor_mask"], np.float32(-0.0))
+        mol, eoff, row_of = _hip.count_padded(x)
+        assert np.array_equal(mol, ref.mol_offset) and np.array_equal(eoff, ref.edge_offset), cast
+        am = np.asarray(inputs["atom_mask"]).reshape(row_of.shape) != 0
+        assert np.array_equal(row_of >= 0, am) and np.array_equal(row_of[am], np.arange(ref.n_atom)), cast
+    bad = dict(inputs)
+    bad["atom_mask"] = np.asarray(inputs["atom_mask"]).copy()
+    bad["atom_mask"][3] = 0
+    with pytest.raises(ValueError, match="no atoms"):
+        _hip.count_padded(bad)
+    big = {k: np.concatenate([v] * 60) for k, v in inputs.items()}  # 2,400 structures: the threaded path
+    mol, eoff, row_of = _hip.count_padded(big)
+    refb = _hip.pack_inputs(big)
+    assert np.array_equal(mol, refb.mol_offset) and np.array_equal(eoff, refb.edge_offset)
