@@ -142,6 +142,26 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ base, unsigned b
 __device__ __forceinline__ void st4(float* __restrict__ base, unsigned byte_off, const float4 v) {
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+// the same for max, and for lane ^ 16 (v_permlane16_swap: odd rows of 16 lanes of one register <-> even rows of the other)
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// max over the whole wave, every lane getting it: three DPP steps inside a row of 16 (lane ^ 1, lane ^ 2, the 8-lane mirror, the 16-lane
+// mirror), then the two lane swaps -- six VALU instructions in place of six ds_bpermute round trips
+__device__ __forceinline__ float wave_max64(float v) {
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return xor32_max(v);
+}
 // Sum over groups of 8 consecutive lanes, every lane getting the total, through DPP operands (VALU; hipcc's __shfl_xor is a ds_bpermute:
 // an LDS round trip per step): lane ^ 1 and lane ^ 2 as quad permutations, then the 8-lane mirror (lane i <-> 7 - i), which pairs each quad
 // -- uniform by then -- with the other one.  Every step adds the same two numbers as the __shfl_xor(1 / 2 / 4) ladder: same bits.

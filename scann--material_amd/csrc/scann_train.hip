@@ -289,8 +289,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
         bsum += db[s2][j];
         mx = fmaxf(mx, fabsf(db[s2][j]));
       }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max64(mx);
     {
       const int e = (__float_as_int(mx) >> 23) & 0xff;
       if (e != 0) {
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradSet set) {
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) part[(size_t)(32 * m + acc_row_(i, lane)) * D + col] = acc[m][i] * inv;
-  bsum += __shfl_xor(bsum, 32);
+  bsum = xor32(bsum);
   if (bpart && kh == 0) bpart[(size_t)blockIdx.x * D + col] = bsum;
 }
 
@@ -897,8 +896,8 @@ __device__ __forceinline__ float red8(float v) {
 __device__ __forceinline__ float red64(float v) {
   v = red8(v);
   v += SCANN_DPP(v, 0x128);  // row_ror:8 -- the other half of the row of 16
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+  v = xor16(v);  // (lane swaps: no LDS round trip, same additions)
+  v = xor32(v);
   return v;
 }
 

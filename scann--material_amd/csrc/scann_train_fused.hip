@@ -49,7 +49,7 @@ __device__ __forceinline__ void put_rowmax(float* __restrict__ sMax, const float
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       m = fmaxf(fmaxf(m, fmaxf(fabsf(v[rt][j].x), fabsf(v[rt][j].y))), fmaxf(fabsf(v[rt][j].z), fabsf(v[rt][j].w)));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = xor32_max(m);
     if (lh == 0) sMax[(lrow + 32 * rt) * 4 + wave] = m;
   }
 }
@@ -332,8 +332,8 @@ __device__ __forceinline__ float red8_(float v) {
 __device__ __forceinline__ float red64_(float v) {
   v = red8_(v);
   v += SCANN_DPP_(v, 0x128);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+  v = xor16(v);  // (v_permlane16_swap / v_permlane32_swap: no LDS round trip, same additions)
+  v = xor32(v);
   return v;
 }
 

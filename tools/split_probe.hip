@@ -46,6 +46,12 @@ __global__ void probe(const float4* x, int n, unsigned long long* bad, float* xs
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   const float b = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(bad + 1, 1ull);
+  const float a16 = v + __shfl_xor(v, 16);
+  auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float b16 = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+  if (__float_as_uint(a16) != __float_as_uint(b16)) atomicAdd(bad + 1, 1ull);
+  const float am = fmaxf(v, __shfl_xor(v, 32)), bm = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  if (__float_as_uint(am) != __float_as_uint(bm)) atomicAdd(bad + 1, 1ull);
   if (i == 0) xs[0] = a, xs[1] = b;
 }
 int main() {
@@ -68,6 +74,6 @@ int main() {
   probe<<<n / 256, 256>>>(d, n, bad, xs);
   unsigned long long hb[2];
   hipMemcpy(hb, bad, 16, hipMemcpyDeviceToHost);
-  printf("split6 vs split8: %llu of %d float4 differ; xor32 swap vs bpermute: %llu differ\n", hb[0], n, hb[1]);
+  printf("split6 vs split8: %llu of %d float4 differ; xor32 / xor16 / max-xor32 by lane swaps vs bpermute: %llu differ\n", hb[0], n, hb[1]);
   return hb[0] || hb[1];
 }
