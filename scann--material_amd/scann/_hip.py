@@ -109,16 +109,18 @@ SYMBOLS = [
 ]
 
 _lib = None
+_pinned = False  # the process has pinned itself to its device's cores (Engine.__init__, multi-rank runs)
 
 
 def _check_hw_queues():
     """``GPU_MAX_HW_QUEUES`` above ROCm's default of 4 makes a stream that waits for an event of a later-created stream (the upload
     copy stream, the basis-gradient stream of the training step) stall ~2 ms per wait: two queues time-sliced on one hardware pipe,
     the waiter holding it.  Measured (profiles/r03_notes.md, tools/queue_matrix.sh): ``trainer.fit`` 0.93 -> 2.85 ms per step with
-    6-16 queues and 2-3 streams per handle; inference is unaffected.  The HIP runtime reads the variable at its first call, which is
-    after this point: a value above 4 is therefore put back to 4, loudly.  ``SCANN_KEEP_HW_QUEUES=1`` leaves it alone."""
+    6-16 queues and 2-3 streams per handle; inference is unaffected.  The variable is the PROCESS's (torch and RCCL in the same process
+    read it too), so importing this package only SAYS so; ``SCANN_FIX_HW_QUEUES=1`` asks for the value to be put back to 4 -- which works
+    only because the HIP runtime reads it at its first call, i.e. if nothing in the process has touched HIP yet."""
     v = os.environ.get("GPU_MAX_HW_QUEUES")
-    if not v or os.environ.get("SCANN_KEEP_HW_QUEUES") == "1":
+    if not v:
         return
     try:
         n = int(v)
@@ -127,10 +129,13 @@ def _check_hw_queues():
     if n > 4:
         import warnings
 
+        fix = os.environ.get("SCANN_FIX_HW_QUEUES") == "1"
         warnings.warn("GPU_MAX_HW_QUEUES=%d: with more than 4 hardware queues a stream waiting on a later-created stream stalls ~2 ms "
-                      "per wait (trainer.fit: 3x slower, profiles/r03_notes.md); using 4 for this process -- set SCANN_KEEP_HW_QUEUES=1 "
-                      "to keep your value" % n, RuntimeWarning, stacklevel=3)
-        os.environ["GPU_MAX_HW_QUEUES"] = "4"
+                      "per wait (trainer.fit: 3x slower, profiles/r03_notes.md); %s" % (n, "SCANN_FIX_HW_QUEUES=1: using 4 for this process "
+                      "(effective only if HIP has not started yet)" if fix else "left as set -- SCANN_FIX_HW_QUEUES=1 puts it back to 4"),
+                      RuntimeWarning, stacklevel=3)
+        if fix:
+            os.environ["GPU_MAX_HW_QUEUES"] = "4"
 
 
 def _check_runtime_env():
@@ -168,11 +173,6 @@ def load_library(path=None):
         # i.e. at the first HIP call of the process -- so it is set HERE, before the library is even loaded.  spawn_ranks sets
         # it for its children; ranks made by torch.distributed.run get it this way.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # ... and one rank per GPU means one rank per NUMA neighbourhood: pin this process to the cores next to its device before
-        # the first GPU call (scann/parallel/affinity.py; SCANN_NO_AFFINITY=1 leaves the affinity alone)
-        from .parallel.affinity import pin_to_device
-
-        pin_to_device(int(os.environ.get("LOCAL_RANK", "0") or 0))
     _check_hw_queues()
     _check_runtime_env()
     lib = C.CDLL(p)
@@ -410,6 +410,15 @@ class Engine:
     def __init__(self, cfg_struct, device=0):
         self.lib = load_library()
         self._h = None
+        global _pinned
+        if not _pinned and int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+            # one rank per GPU means one rank per NUMA neighbourhood: the rank's FIRST engine pins the calling thread (and the threads it
+            # starts afterwards; threads that already exist keep their mask) to the cores next to the device it actually opens
+            # (scann/parallel/affinity.py; SCANN_NO_AFFINITY=1, or both *_VISIBLE_DEVICES set, leave the affinity alone)
+            from .parallel.affinity import pin_to_device
+
+            pin_to_device(int(device))
+            _pinned = True
         h = _P()
         rc = self.lib.scann_create(C.byref(cfg_struct), int(device), C.byref(h))
         if rc != SCANN_OK:

@@ -91,9 +91,12 @@ def cpus_for_device(device, sysfs="/sys", allowed=None):
 
 
 def pin_to_device(device, sysfs="/sys"):
-    """Pin the calling process (all its current threads' future children inherit it) to ``cpus_for_device``; returns the set or
-    None.  Call before the first GPU call and before any thread is started."""
+    """Pin the CALLING THREAD (threads it starts later inherit the mask; threads that already exist keep theirs) to
+    ``cpus_for_device``; returns the set or None.  Call before any worker thread is started.  With both HIP_VISIBLE_DEVICES and
+    ROCR_VISIBLE_DEVICES set the device index cannot be mapped back to a physical card from here (HIP's list indexes ROCR's): no pinning."""
     if os.environ.get("SCANN_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    if os.environ.get("HIP_VISIBLE_DEVICES") and os.environ.get("ROCR_VISIBLE_DEVICES"):
         return None
     try:
         cpus = cpus_for_device(int(device), sysfs, allowed=os.sched_getaffinity(0))

@@ -67,14 +67,24 @@ class MultiProcessPredictor:
                 self._procs.append(subprocess.Popen([sys.executable, "-m", "scann.parallel._mp_worker", listener.address], env=env))
             # accept() has no timeout of its own: do it on a thread and watch the children meanwhile -- a worker that dies before
             # it connects (import error, missing libscann_hip.so, bad PYTHONPATH) must not hang the parent
-            accepted, failure = [], []
+            accepted, failure, stop = [], [], threading.Event()
+            try:  # accept() polls (0.2 s) so that the thread ends when start-up is abandoned: closing a listener does not wake a blocked accept()
+                listener._listener._socket.settimeout(0.2)
+            except Exception:
+                pass
 
             def _accept_all():
+                import socket
+
                 try:
-                    for _ in self.devices:
-                        accepted.append(listener.accept())
+                    while len(accepted) < len(self.devices) and not stop.is_set():
+                        try:
+                            accepted.append(listener.accept())
+                        except socket.timeout:
+                            continue
                 except BaseException as e:  # listener closed under us, authentication failure
-                    failure.append(e)
+                    if not stop.is_set():
+                        failure.append(e)
 
             t = threading.Thread(target=_accept_all, daemon=True)
             t.start()
@@ -84,8 +94,9 @@ class MultiProcessPredictor:
                 dead = [(i, p.poll()) for i, p in enumerate(self._procs) if p.poll() is not None]
                 if dead and len(accepted) < len(self.devices):
                     i, code = dead[0]
-                    raise RuntimeError("MultiProcessPredictor: the worker for device %s exited with code %s before it connected "
-                                       "(its stderr has the reason)" % (self.devices[i], code))
+                    raise RuntimeError("MultiProcessPredictor: the worker started for device %s exited with code %s during start-up, before "
+                                       "every worker had connected (%d of %d had; its stderr has the reason)"
+                                       % (self.devices[i], code, len(accepted), len(self.devices)))
                 if time.monotonic() > deadline:
                     raise RuntimeError("MultiProcessPredictor: %d of %d workers connected within %.0f s (SCANN_MP_START_TIMEOUT)"
                                        % (len(accepted), len(self.devices), START_TIMEOUT))
@@ -94,17 +105,20 @@ class MultiProcessPredictor:
             for d, c in zip(self.devices, accepted):
                 c.send((d, config, w, infer))
                 self._conns.append(c)
-            for i, c in enumerate(self._conns):
-                while not c.poll(0.05):  # the model is being built: keep watching the process
-                    code = self._procs[i].poll() if i < len(self._procs) else None
-                    if code is not None and not c.poll(0):
-                        raise RuntimeError("MultiProcessPredictor: a worker exited with code %s while loading its model" % code)
+            for c in self._conns:
+                # the model is being built: keep watching the processes -- ALL of them: connections were accepted in arrival order, so
+                # connection i is not necessarily process i's, and a dead worker must not be waited for behind a live one's handle
+                while not c.poll(0.05):
+                    dead = [p.poll() for p in self._procs if p.poll() is not None]
+                    if dead and not c.poll(0):
+                        raise RuntimeError("MultiProcessPredictor: a worker exited with code %s while loading its model" % dead[0])
                     if time.monotonic() > deadline:
                         raise RuntimeError("MultiProcessPredictor: a worker did not report ready within %.0f s" % START_TIMEOUT)
                 self._expect(c, "ready")
         except BaseException:
+            stop.set()  # the accept thread sees it within its 0.2 s poll
             try:
-                listener.close()  # unblocks the accept thread
+                listener.close()
             except Exception:
                 pass
             for p in self._procs:
