@@ -422,16 +422,10 @@ void launch_embed(const EmbedArgs& a, hipStream_t s) {
 
 // ---- readout kernel ----------------------------------------------------------------------------------
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
+// (DPP / lane-swap forms of the xor butterflies: the same additions and maxima without six LDS round trips each -- in the readout
+//  they sit one behind the other: norm -> maximum -> sum of the exponentials -> head)
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_max64(v); }
 
 // One workgroup per structure.  GlobalAttention.call (attention.py:267-318) on the real atoms only (the
 // multiplicative atom mask zeroes every padded term).  The pair energies E[i][j] = k_i . q_j (:279) are 32x32 MFMA
@@ -483,12 +477,7 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float v = part[i];
-      v += __shfl_xor(v, 1);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 4);
-      v += __shfl_xor(v, 8);
-      v += __shfl_xor(v, 16);
+      const float v = sum32(part[i]);  // over the 32 query columns of this lane's half
       if (r == 0) sPart[wave * npad + it * 32 + acc_row(i, lane)] = v;
     }
   }
@@ -529,7 +518,19 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
   {
     const int f = tid & (D - 1), half = tid >> 7;
     float rsum = 0.f;
-    for (int i = half; i < n; i += 2) rsum += sAgg[i] * a.gk[(size_t)(a0 + i) * D + f];
+    // (four key rows requested per step -- the terms past the last atom are a valid row times an exact zero, added in the order of the
+    //  one-row-per-step loop: each step was a memory round trip of its own)
+    for (int i = half; i < n; i += 8) {
+      float kv[4], av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int iu = i + 2 * u;
+        kv[u] = a.gk[(size_t)(a0 + min(iu, n - 1)) * D + f];
+        av[u] = iu < n ? sAgg[iu] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rsum += av[u] * kv[u];
+    }
     if (half == 1) sRep[f] = rsum;
     __syncthreads();
     if (half == 0) sRep[f] = rsum + sRep[f];
@@ -544,12 +545,17 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
     float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;  // four interleaved chains, fixed association
     const float* __restrict__ wcol = a.p.Wb + (size_t)(64 * half) * D + f;
     const float* __restrict__ rp = sRep + 64 * half;
-#pragma unroll 4
-    for (int k = 0; k < 64; k += 4) {
-      h0 = fmaf(rp[k], wcol[(size_t)k * D], h0);
-      h1 = fmaf(rp[k + 1], wcol[(size_t)(k + 1) * D], h1);
-      h2 = fmaf(rp[k + 2], wcol[(size_t)(k + 2) * D], h2);
-      h3 = fmaf(rp[k + 3], wcol[(size_t)(k + 3) * D], h3);
+    for (int k0 = 0; k0 < 64; k0 += 16) {  // sixteen weights requested per step: four memory round trips instead of sixteen
+      float wv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wv[u] = wcol[(size_t)(k0 + u) * D];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        h0 = fmaf(rp[k0 + u], wv[u], h0);
+        h1 = fmaf(rp[k0 + u + 1], wv[u + 1], h1);
+        h2 = fmaf(rp[k0 + u + 2], wv[u + 2], h2);
+        h3 = fmaf(rp[k0 + u + 3], wv[u + 3], h3);
+      }
     }
     const float hs = (h0 + h1) + (h2 + h3);
     if (half == 1) sHead[f] = hs;

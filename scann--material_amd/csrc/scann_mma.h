@@ -162,6 +162,16 @@ __device__ __forceinline__ float wave_max64(float v) {
   v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
   return xor32_max(v);
 }
+// sum over the whole wave / over each half of 32 lanes, every lane getting it: the additions of the lane ^ 1, ^ 2, ^ 4, ^ 8, ^ 16 (, ^ 32)
+// butterfly -- after a step every group holds ONE value, so the mirror a DPP step pairs a lane with carries what its xor partner does
+__device__ __forceinline__ float sum32(float v) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return xor16(v);
+}
+__device__ __forceinline__ float wave_sum64(float v) { return xor32(sum32(v)); }
 // Sum over groups of 8 consecutive lanes, every lane getting the total, through DPP operands (VALU; hipcc's __shfl_xor is a ds_bpermute:
 // an LDS round trip per step): lane ^ 1 and lane ^ 2 as quad permutations, then the 8-lane mirror (lane i <-> 7 - i), which pairs each quad
 // -- uniform by then -- with the other one.  Every step adds the same two numbers as the __shfl_xor(1 / 2 / 4) ladder: same bits.

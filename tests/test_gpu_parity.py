@@ -708,6 +708,11 @@ def test_bench_two_ranks_through_the_self_spawning_launcher(hip_lib):
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0
     assert out.get("oversubscribed", False) == (ndev < 2)
     assert out["roofline"]["launches_sampled"] > 0 and 0 < out["roofline"]["frac"] < 1.5
+    # what a SCALE record reads off the line: inference has no collective (rccl_ranks null), every rank's own rate, and the N = 1 rate
+    # of the same process layout measured inside this run
+    assert out["rccl_ranks"] is None and out["ranks_reporting"] == 2 and len(out["rank_values"]) == 2 and min(out["rank_values"]) > 0
+    assert out["n1_same_layout"]["value"] > 0
+    assert out["value"] <= 2.0 * max(out["rank_values"]) * 1.001  # the job's rate is 2 x the SLOWEST rank's
 
 
 def test_keras_h5_checkpoint_loads_and_predicts(hip_lib, tmp_path):
