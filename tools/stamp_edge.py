@@ -25,6 +25,11 @@ print("tiles", st.shape[0], "total cycles/tile mean", (st[:, 7] - st[:, 0]).mean
 for n, (i, j) in zip(names, zip(order[:-1], order[1:])):
     col = st[:, j] - st[:, i]
     print("%-70s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))
+if st[:, 6].any():  # finer prologue stamps (thread 0 of the workgroup): descriptor, indices, rows staged
+    for nm, (i, j) in (("  prologue: entry -> tile descriptor", (0, 6)), ("  prologue: descriptor -> neighbour indices", (6, 10)),
+                       ("  prologue: indices -> rows arrived, split and written to the planes", (10, 11)), ("  prologue: staged -> barrier passed", (11, 1))):
+        col = st[:, j] - st[:, i]
+        print("%-70s mean %8.0f  median %8.0f  max %8.0f" % (nm, col.mean(), np.median(col), col.max()))
 print("kernel span (first start -> last end) cycles:", st[:, 7].max() - st[:, 0].min(), "(s_memtime ticks at 100MHz? see guide: tick = shader cycle)")
 if st[:, 12].any() and st[:, 13].any():
     ticks = (st[:, 13] - st[:, 12]).astype(np.float64)
