@@ -124,9 +124,10 @@ void launch_rn_bwd(WgradCtx& ctx, RnBwdArgs a, float* dgamma, float* dbeta, hipS
 void launch_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, float* dgamma, float* dbeta, hipStream_t s);
 // attention backward + edge_bwd in one launch over the n_tile tiles of the plan (32-row tiles, every degree <= 16)
 void launch_attn_edge_bwd(WgradCtx& ctx, EdgeBwdArgs a, AttnPart b, int n_tile, float* dgamma_g, float* dbeta_g, float* dgamma_ln,
-                          float* dbeta_ln, hipStream_t s);
+                          float* dbeta_ln, hipStream_t s, hipEvent_t done = nullptr);
+// (`done`: an event recorded by the kernel's own completion signal, for a side stream to wait on -- see launch_attn_edge_bwd)
 void launch_atom_gather3(const float* dang, const float* G, const float* dV, const int* edge_offset, const int* in_off, const int* in_edge,
-                         float* dC, float* dP1, float* dP3, int n_atom, hipStream_t s);
+                         float* dC, float* dP1, float* dP3, int n_atom, hipStream_t s, hipEvent_t done = nullptr);
 void launch_readout_bwd(const ReadoutBwdArgs& a, hipStream_t s);
 void launch_basis_bwd(const BasisParams& p, const float* dist, const float* weight, const float* dgeom, int n_edge, float* dWd,
                       float* dbd, float* dWw, float* dbw, hipStream_t s);

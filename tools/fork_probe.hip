@@ -2,9 +2,12 @@
 //   (a) hipEventRecord(main) + hipStreamWaitEvent(side)            -- what scann_train_backward's fork() does
 //   (b) the producer kernel's last workgroup stores a sequence number, the side stream waits with hipStreamWaitValue64(>=)
 //   (c) no dependency at all (lower bound)
+//   (d) the producer kernel launched with hipExtLaunchKernelGGL(..., stopEvent): the event IS the kernel's own completion signal -- no
+//       marker packet behind it on the producing stream -- + hipStreamWaitEvent(side)
 // Main stream: N x [busy kernel A, busy kernel B]; side stream: one small kernel per iteration after A.
 // Build: hipcc --offload-arch=gfx950 -O2 tools/fork_probe.hip -o /tmp/fork_probe
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdint>
@@ -45,12 +48,16 @@ int main() {
   hipEvent_t ev[64];
   for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   unsigned long long seq = 0;
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 4; ++mode) {
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipDeviceSynchronize());
       const auto t0 = std::chrono::steady_clock::now();
       for (int i = 0; i < N; ++i) {
         ++seq;
+        if (mode == 3) {
+          hipExtLaunchKernelGGL(busy, dim3(WG), dim3(T), 0, s, nullptr, ev[i % 64], 0, buf, ITERS, (unsigned long long*)nullptr, counter, seq);
+          CK(hipStreamWaitEvent(aux, ev[i % 64], 0));
+        } else
         hipLaunchKernelGGL(busy, dim3(WG), dim3(T), 0, s, buf, ITERS, mode == 1 ? flag : nullptr, counter, seq);
         if (mode == 0) {
           CK(hipEventRecord(ev[i % 64], s));
@@ -65,7 +72,7 @@ int main() {
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       CK(hipDeviceSynchronize());
       printf("mode %d (%s): %.2f us per iteration (two main-stream kernels + one side kernel)\n", mode,
-             mode == 0 ? "event record + wait" : mode == 1 ? "in-kernel flag + hipStreamWaitValue64" : "no dependency", us / N);
+             mode == 0 ? "event record + wait" : mode == 1 ? "in-kernel flag + hipStreamWaitValue64" : mode == 2 ? "no dependency" : "stop event of the kernel's own launch + wait", us / N);
     }
   }
   return 0;
