@@ -978,6 +978,32 @@ def test_device_packing_gives_the_host_packers_arrays(hip_lib, case):
 
 
 @pytest.mark.gpu
+def test_device_packing_of_a_large_batch_uses_the_threaded_paths(hip_lib):
+    """7,200 structures in ONE scann_upload_padded call: the mask pass runs on several threads (>= 2,048 structures) and so does the
+    staging copy of the payload arrays (>= 8 MiB each) -- same CSR arrays as the host packer, same outputs as the chunked call."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    model = HipModel(cfg, so.init_weights(cfg, 5, perturb=True), device=0)
+    de, dn = so.synth_dataset(300, 13)
+    small, _ = so.pad_batch(de, dn, True)
+    inputs = {k: np.concatenate([np.asarray(v)] * 24) for k, v in small.items()}
+    assert inputs["neighbors"].nbytes >= 8 << 20
+    ref = _hip.pack_inputs(inputs)
+    rb = model.engine.upload_padded(inputs)
+    got = model.engine.read_csr(rb)
+    for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+        assert np.array_equal(got[f].view(np.int32), np.asarray(getattr(ref, f)).view(np.int32)), f
+    model.engine.forward_resident(rb, 0)
+    y_one, _ = model.engine.download(rb, want_ga=False)
+    rb.free()
+    y = model.predict(inputs)  # 7,200 >= BIG_PREDICT: the chunked pipeline
+    assert np.array_equal(y[:, 0].view(np.int32), y_one.view(np.int32))
+    assert np.array_equal(y[:300], y[300:600])  # a structure's result does not depend on its batch
+
+
+@pytest.mark.gpu
 def test_device_packing_reports_what_the_host_packer_refuses(hip_lib):
     """An unmasked neighbour slot that points at a padded atom, an atomic number outside the embedding table: the host packer raises
     when it packs; a batch packed on the device reports the same at its download (no fault, no NaN, the handle stays usable)."""
