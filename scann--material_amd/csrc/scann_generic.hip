@@ -85,12 +85,13 @@ __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
   }
 }
 
-__device__ __forceinline__ float wave_sum64(float v) {
+// (xor butterflies of its own, 32 down to 1: the plain-fp32 path keeps its summation order whatever scann_mma.h does)
+__device__ __forceinline__ float gen_wave_sum64(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-__device__ __forceinline__ float wave_max64(float v) {
+__device__ __forceinline__ float gen_wave_max64(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
@@ -106,13 +107,13 @@ __global__ __launch_bounds__(256) void gen_layernorm_kernel(const float* __restr
   const float* q = res ? res + (size_t)r * N : nullptr;
   float s = 0.f;
   for (int k = lane; k < N; k += 64) s += q ? x[k] + q[k] : x[k];
-  const float mean = wave_sum64(s) / (float)N;
+  const float mean = gen_wave_sum64(s) / (float)N;
   float v = 0.f;
   for (int k = lane; k < N; k += 64) {
     const float d = (q ? x[k] + q[k] : x[k]) - mean;
     v += d * d;
   }
-  const float rstd = 1.0f / sqrtf(wave_sum64(v) / (float)N + 1e-6f);
+  const float rstd = 1.0f / sqrtf(gen_wave_sum64(v) / (float)N + 1e-6f);
   for (int k = lane; k < N; k += 64) Y[(size_t)r * N + k] = ((q ? x[k] + q[k] : x[k]) - mean) * rstd * gamma[k] + beta[k];
 }
 
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void gen_readout_kernel(const int32_t* __restr
   }
   __syncthreads();
   auto block_sum = [&](float v) {
-    v = wave_sum64(v);
+    v = gen_wave_sum64(v);
     if (lane == 0) sRed[wave] = v;
     __syncthreads();
     const float t = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void gen_readout_kernel(const int32_t* __restr
     return t;
   };
   auto block_max = [&](float v) {
-    v = wave_max64(v);
+    v = gen_wave_max64(v);
     if (lane == 0) sRed[wave] = v;
     __syncthreads();
     const float t = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
