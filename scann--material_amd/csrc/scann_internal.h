@@ -243,7 +243,7 @@ int plan_tiles(const int32_t* mol_offset, int32_t B, const int32_t* edge_offset,
                std::vector<int32_t>& big_tab, std::vector<int32_t>& edge_row, int* tile_rows_out, int32_t* max_degree,
                int32_t* n_slot, std::string& err, bool fill_edge_row = true);
 // edge_row[e] = centre atom of edge e from the CSR offsets, on the device (scann_batch_upload: behind the input copy)
-void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, hipStream_t s);
+void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, hipStream_t s, int32_t* zero_word = nullptr);
 
 // Padded Keras input -> packed CSR on the device (scann_upload_padded): the payload arrays of the padded dict as they came over the bus.
 struct PackPaddedArgs {

@@ -18,6 +18,7 @@
 //                   scann_model.py:437-447), one workgroup per structure (pair energies: exact-fp32 MFMA)
 //   basis_kernel  : Gaussian expansion + neighbor_d/neighbor_w MLP (custom_layers.py:63-65,
 //                   scann_model.py:378-389)
+#include <algorithm>
 #include <cstdlib>
 #include "scann_internal.h"
 #include "scann_mma.h"
@@ -59,6 +60,8 @@ void launch_atom(const AtomArgs& a, hipStream_t s) {
   // 32-row tiles (<= 128 VGPRs, 22 KB of LDS: four workgroups per CU = 1,024 slots) while they all fit ONE round of workgroups: the
   // launch is then the latency chain of a tile, and a 32-row tile's chain is shorter (one batch per launch: 490 k -> 568 k
   // molecules/s, training step 1.14 -> 1.09 ms).  Beyond that 64-row tiles (half the weight traffic per row).
+  // (re-measured in round 5 at the driver's 10-batch shape, 23 k atoms: 64-row tiles -- half the weight traffic, 360 tiles -- 0.159-0.170 ms
+  //  of atom launches per forward against 0.152-0.157 ms for the 720 32-row tiles: the threshold stays)
   const int rows = a.n_atom <= 32 * 1024 ? 32 : 64;
   const dim3 grid((a.n_atom + rows - 1) / rows), block(256);
   const bool keep = !a.exact && (a.drop_p > 0.f || a.keep_pre1 || a.keep_T2 || a.keep_preA);  // training forward
@@ -191,13 +194,16 @@ void launch_edge_merge(const int32_t* big_tab, int n_big, const float* part_buf,
 }
 
 // centre atom of every edge: one thread per atom writes its CSR row's entries (a batch has ~8 edges per atom)
-__global__ void edge_row_kernel(const int32_t* __restrict__ edge_offset, int n_atom, int32_t* __restrict__ edge_row) {
+// (zero_word: a device word this launch clears on its way -- the flag of the pack_padded_kernel launch behind it)
+__global__ void edge_row_kernel(const int32_t* __restrict__ edge_offset, int n_atom, int32_t* __restrict__ edge_row, int32_t* __restrict__ zero_word) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a == 0 && zero_word) *zero_word = 0;
   if (a >= n_atom) return;
   for (int e = edge_offset[a]; e < edge_offset[a + 1]; ++e) edge_row[e] = a;
 }
-void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, hipStream_t s) {
-  if (n_atom > 0) hipLaunchKernelGGL(edge_row_kernel, dim3((n_atom + 255) / 256), dim3(256), 0, s, edge_offset, n_atom, edge_row);
+void launch_edge_row(const int32_t* edge_offset, int n_atom, int32_t* edge_row, hipStream_t s, int32_t* zero_word) {
+  if (n_atom > 0 || zero_word)
+    hipLaunchKernelGGL(edge_row_kernel, dim3(std::max(1, (n_atom + 255) / 256)), dim3(256), 0, s, edge_offset, n_atom, edge_row, zero_word);
 }
 
 // Padded -> CSR (what gather_shape + the masks express: custom_layers.py:18-28, datagenerator.py:69-135): one thread per padded atom

@@ -936,13 +936,15 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   int tile_rows = TE_MAX;
   {
     std::string err;
-    int r = plan_tiles(b->mol_offset, B, b->edge_offset, pad ? nullptr : b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles,
+    // A launch that fits ONE round of workgroups is the latency chain of a tile: 32-row tiles (four workgroups per CU = 1,024 slots)
+    // make that chain shorter.  Only when no atom needs chunking at 32 rows: such a batch is planned at 32 rows first (one pass for
+    // the reference's batch of 128) and again at 64 if an atom turns out to have more than 32 neighbours.
+    const bool small = E > 0 && E <= 32 * 1024;
+    int r = plan_tiles(b->mol_offset, B, b->edge_offset, pad ? nullptr : b->edge_col, A, E, small ? 32 : TE_MAX, h->tile_atoms, true, tiles,
                        tile_part, big_tab, edge_row, &tile_rows, &max_degree, &n_slot, err, false);
     if (r) return fail(h, r, "scann_batch_upload: " + err);
-    // A launch that fits ONE round of workgroups is the latency chain of a tile: 32-row tiles (four workgroups per CU = 1,024 slots)
-    // make that chain shorter.  Only when no atom needs chunking at 32 rows.
-    if (E > 0 && max_degree <= 32 && E <= 32 * 1024) {
-      r = plan_tiles(b->mol_offset, B, b->edge_offset, pad ? nullptr : b->edge_col, A, E, 32, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
+    if (small && max_degree > 32) {
+      r = plan_tiles(b->mol_offset, B, b->edge_offset, pad ? nullptr : b->edge_col, A, E, TE_MAX, h->tile_atoms, true, tiles, tile_part, big_tab, edge_row,
                      &tile_rows, &max_degree, &n_slot, err, false);
       if (r) return fail(h, r, "scann_batch_upload: " + err);
     }
@@ -1083,16 +1085,15 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
     pa.out_dist = (float*)(a0 + o_dist); pa.out_weight = (float*)(a0 + o_wgt);
     pa.flag = (int32_t*)(a0 + o_pflag);
   }
-  hipStream_t const up_s = scratch ? h->streams[0] : h->copy_stream;  // scratch: pinned staging, ordered before the kernels on stream 0
-  if (pad) e = hipMemsetAsync(db->arena + o_pflag, 0, 4, up_s);
+  // (the pack kernel's flag word is zeroed by edge_row_kernel, launched BEFORE it: no memset command of its own)
   if (scratch) {
     if (e == hipSuccess) e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->streams[0]);
+    if (e == hipSuccess && (E > 0 || pad)) launch_edge_row(d_eoff, E > 0 ? A : 0, d_erow, h->streams[0], pad ? pa.flag : nullptr);
     if (e == hipSuccess && pad) launch_pack_padded(pa, h->streams[0]);
-    if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->streams[0]);
   } else {
     if (e == hipSuccess) e = hipMemcpyAsync(db->arena, img.data(), in_bytes, hipMemcpyHostToDevice, h->copy_stream);
+    if (e == hipSuccess && (E > 0 || pad)) launch_edge_row(d_eoff, E > 0 ? A : 0, d_erow, h->copy_stream, pad ? pa.flag : nullptr);
     if (e == hipSuccess && pad) launch_pack_padded(pa, h->copy_stream);
-    if (e == hipSuccess && E > 0) launch_edge_row(d_eoff, A, d_erow, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(stage->ev, h->copy_stream);
     if (e == hipSuccess) stage->used = true;
     // a default (system-fenced) event: it orders a DMA engine's write into a REUSED arena (cached_malloc) before kernels on another
