@@ -704,10 +704,11 @@ def main():
                 "mfma": {"pipe": kinfo.get("mfma_pipe", "f32"), "passes": passes, "executed_tflops": tfl * passes, "peak": pipe_peak,
                          "frac": frac_mfma, "frac_of_fp32_mfma_peak_algorithmic": tfl / PEAK_FP32_MFMA_TFLOPS},
                 "hbm": {"achieved_gbs": tbs * 1e3, "peak_gbs": PEAK_HBM_TBS * 1e3, "frac": frac_hbm},
-                "note": "avg_launch_us = HIP events around sampled edge_kernel<true, 2, false, false> launches inside the timed regions, on the "
-                        "launch stream (1 stream: launches never overlap); the first layer's launch of a forward is a different kernel (basis "
-                        "MLP and per-species atom rows fused in: edge_kernel<true, 2, true, false>, profiles/r04_kernel_stats_g16.csv) and is "
-                        "not sampled; achieved = ALGORITHMIC bytes or FLOPs of a launch / that time",
+                "note": "avg_launch_us = HIP events around sampled edge_kernel<true, 2, false, false, false, false> launches (template arguments "
+                        "GUPD, RT, FB, EX, KEEP, DEAD) inside the timed regions, on the launch stream (1 stream: launches never overlap): the "
+                        "layers between the first and the last.  Not sampled: the first layer's launch (a different kernel: basis MLP and "
+                        "per-species atom rows fused in, FB = true) and the last layer's (DEAD = true: geom' is not stored, ~10 % shorter) -- "
+                        "profiles/r05_kernel_stats_g10.csv lists all three; achieved = ALGORITHMIC bytes or FLOPs of a launch / that time",
                 "per_forward_ms": {k: float(np.mean([p[k] for p in prof])) for k in
                                    ("ms_basis", "ms_atom", "ms_edge", "ms_readout", "ms_total")} if prof else None}
         value = world * args.steps * args.batch / elapsed
