@@ -1819,6 +1819,9 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   w.dy = (float*)p; p += align_up((size_t)db->n_struct * 4);
   w.targets = (float*)p; p += align_up((size_t)db->n_struct * 4);
   w.dlut = (float*)p; p += align_up((size_t)h->cfg.n_atoms * D * 4);
+  // (zero from here on between steps: embed_bwd_kernel clears every row it consumes -- one memset command per step less on the
+  //  main stream; this one is the workspace's first and only, on the stream every training launch of the handle goes to)
+  HIPCHK(h, hipMemsetAsync(w.dlut, 0, (size_t)h->cfg.n_atoms * D * 4, h->streams[0]));
   w.sse = (double*)p; p += 256;
   w.wpart = (float*)p; p += align_up(w.wpart_floats * 4);
   if (Lk) {  // slices are [rows,128] without padding between layers: size them from the un-aligned row counts
@@ -2349,7 +2352,6 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
                              c.use_ring ? g("extra_embed/kernel") : nullptr, c.use_ring ? g("extra_embed/bias") : nullptr,
                              g("dense_embed/kernel"), g("dense_embed/bias"), s);
   } else {
-    HIPCHK(h, hipMemsetAsync(w.dlut, 0, (size_t)c.n_atoms * D * 4, s));
     launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
                      c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), w.seed,
                      DROP_TAG_EMBED, w.drop_p, s);

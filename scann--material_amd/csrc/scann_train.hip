@@ -1099,32 +1099,35 @@ __global__ __launch_bounds__(128) void readout_bwd_kernel(ReadoutBwdArgs a) {
     const float2 q2 = reinterpret_cast<const float2*>(a.gq)[(size_t)(a0 + i) * 64 + lane];
     float d1 = sV[2 * lane] * k2.x + sV[2 * lane + 1] * k2.y;
     float d2 = k2.x * (sS[2 * lane] - q2.x) + k2.y * (sS[2 * lane + 1] - q2.y);
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      d1 += __shfl_xor(d1, o);
-      d2 += __shfl_xor(d2, o);
-    }
+    d1 = wave_sum64(d1);  // (the lane ^ 1 ... ^ 32 butterfly's additions as DPP / lane swaps: no LDS round trips)
+    d2 = wave_sum64(d2);
     if (lane == 0) {
       sDa[i] = d1;   // dat_i
       sAgg[i] = d2;  // a_i
     }
   }
   __syncthreads();
-  if (tid == 0) {  // softmax and normalisation backward (n is small)
+  if (wave == 0) {  // softmax and normalisation backward: one wave, a lane per atom (strided beyond 64), sums across the lanes
+    // (round 5: thread 0 used to walk the atoms three times on its own -- ~50 dependent LDS reads and divisions per structure)
     float dot = 0.f, nrm2 = 0.f;
-    for (int i = 0; i < n; ++i) {
+    for (int i = lane; i < n; i += 64) {
       dot += sAt[i] * sDa[i];
       nrm2 += sAgg[i] * sAgg[i];
     }
+    dot = wave_sum64(dot);
+    nrm2 = wave_sum64(nrm2);
     const float nrm = sqrtf(nrm2);
     float proj = 0.f;
-    for (int i = 0; i < n; ++i) {
-      sDa[i] = sAt[i] * (sDa[i] - dot);  // dan_i
-      if (a.use_ga_norm) proj += (sAgg[i] / nrm) * sDa[i];
+    for (int i = lane; i < n; i += 64) {
+      const float dan = sAt[i] * (sDa[i] - dot);  // dan_i
+      sDa[i] = dan;
+      if (a.use_ga_norm) proj += (sAgg[i] / nrm) * dan;
     }
-    if (a.use_ga_norm)
-      for (int i = 0; i < n; ++i) sDa[i] = (sDa[i] - (sAgg[i] / nrm) * proj) / nrm;  // da_i
-    sRed[0] = 0.f;
+    if (a.use_ga_norm) {
+      proj = wave_sum64(proj);
+      for (int i = lane; i < n; i += 64) sDa[i] = (sDa[i] - (sAgg[i] / nrm) * proj) / nrm;  // da_i
+    }
+    if (lane == 0) sRed[0] = 0.f;
   }
   __syncthreads();
   // W = sum_i da_i gk_i ; dgk_i = at_i*drep + da_i (S - gq_i) ; dgq_j = W - da_j gk_j
@@ -1280,9 +1283,22 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
   const int col = threadIdx.x, a0 = blockIdx.x * run, a1 = min(n_atom, a0 + run);
   for (int sp = 0; sp < n_species; ++sp) sTab[sp * D + col] = 0.f;
   // (the Dropout(0.1) mask of the embedding rows, scann_model.py:374, is applied on the way in: no dropout launch before this one)
-  for (int a = a0; a < a1; ++a) {
-    const size_t i = (size_t)a * D + col;
-    sTab[atomic[a] * D + col] += drop_p > 0.f ? dc0[i] * drop_scale(drop_seed, drop_tag, i, drop_p) : dc0[i];
+  // (eight rows requested per step, added in row order: a load per iteration made this a chain of `run` memory round trips)
+  for (int ab = a0; ab < a1; ab += 8) {
+    float v[8];
+    int z[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int a = min(ab + u, a1 - 1);
+      v[u] = dc0[(size_t)a * D + col];
+      z[u] = atomic[a];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (ab + u < a1) {
+        const size_t i = (size_t)(ab + u) * D + col;
+        sTab[z[u] * D + col] += drop_p > 0.f ? v[u] * drop_scale(drop_seed, drop_tag, i, drop_p) : v[u];
+      }
   }
   for (int sp = 0; sp < n_species; ++sp) {
     const float v = sTab[sp * D + col];
@@ -1290,12 +1306,13 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
   }
 }
 __global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ W,
-                                                        const float* __restrict__ b, const float* __restrict__ dlut,
+                                                        const float* __restrict__ b, float* __restrict__ dlut,
                                                         int n_species, int emb_dim, float* dEmb, float* dW, float* db) {
   // one workgroup per species; thread = output column
   extern __shared__ float sdp[];  // [128] dpre
   const int sp = blockIdx.x, col = threadIdx.x;
   const float dl = dlut[sp * D + col];
+  dlut[sp * D + col] = 0.f;  // consumed: the table is zero again for the next step's embed_scatter_kernel (no memset per step)
   // a species absent from the batch has a zero row: nothing to add anywhere (QM9: 5 of the table's species occur; their workgroups'
   // atomics on the shared dW / db addresses were queueing behind ~20 x as many adds of zero)
   if (!__syncthreads_or(dl != 0.f)) return;
@@ -1321,7 +1338,18 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict_
   __syncthreads();
   for (int k = col; k < emb_dim; k += 128) {
     float acc = 0.f;
-    for (int j = 0; j < D; ++j) acc += sdp[j] * W[k * D + j];
+    for (int j0 = 0; j0 < D; j0 += 16) {  // this thread's row of W, sixteen elements per step (same order of additions)
+      float4 w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(W + (size_t)k * D + j0 + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc += sdp[j0 + 4 * u] * w[u].x;
+        acc += sdp[j0 + 4 * u + 1] * w[u].y;
+        acc += sdp[j0 + 4 * u + 2] * w[u].z;
+        acc += sdp[j0 + 4 * u + 3] * w[u].w;
+      }
+    }
     dEmb[sp * emb_dim + k] += acc;  // accumulate; each species row is touched by exactly one workgroup
   }
 }
