@@ -198,7 +198,7 @@ __device__ __forceinline__ float ld1f(const float* __restrict__ base, unsigned b
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// ---- elementwise helpers shared by the forward kernels (scann_kernels.hip, scann_struct.hip) ----
+// ---- elementwise helpers shared by the forward kernels (scann_kernels.hip) and the fused backward kernels ----
 
 // swish(x) = x * sigmoid(x) on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32, 1 ulp each.
 // Measured effect on the end-to-end parity error: DESIGN.md "numerics".
