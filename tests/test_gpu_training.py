@@ -244,7 +244,9 @@ def test_rccl_single_rank_communicator(hip_lib):
     cfg, w, pk, targets, model = setup(n=4)
     eng = model.engine
     eng.train_begin()
+    assert eng.comm_ranks() == 0  # no communicator yet
     eng.comm_init(_hip.comm_unique_id(), 0, 1)
+    assert eng.comm_ranks() == 1  # ncclCommCount of the live communicator: what bench.py --train prints as rccl_ranks
     rb = eng.upload(pk)
     sse = eng.train_forward(rb, targets)
     s2, c2 = eng.allreduce_sse(sse, pk.n_struct)
