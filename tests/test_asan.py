@@ -21,7 +21,7 @@ from scann import _hip
 # the packer entry points from the sanitized build, behind the package's own ctypes signatures
 lib = C.CDLL(os.path.join(ASAN_DIR, "libscann_pack_asan.so"))
 for name, res, args in _hip.SYMBOLS:
-    if name.startswith(("scann_pack", "scann_slice", "scann_plan")):
+    if name.startswith(("scann_pack", "scann_slice", "scann_plan", "scann_count")):
         fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
 _hip._lib = lib
 spec = importlib.util.spec_from_file_location("scann._listwalk", os.path.join(ASAN_DIR, "_listwalk.so"))
@@ -44,6 +44,11 @@ for n, seed in ((1, 0), (7, 1), (33, 2)):
         assert pk.n_struct == n and pk.edge_offset[-1] == pk.n_edge == int(inputs["neighbor_mask"].sum())
         for tr in (32, 64):
             _hip.plan_tiles(pk, tile_rows=tr) if hasattr(_hip, "plan_tiles") else None
+        # the host half of the device packing: masks (bool and float32) -> the packer's own offsets
+        for cast in (np.bool_, np.float32):
+            x = dict(inputs, atom_mask=np.asarray(inputs["atom_mask"]).astype(cast), neighbor_mask=np.asarray(inputs["neighbor_mask"]).astype(cast))
+            mol, eoff, row_of = _hip.count_padded(x)
+            assert np.array_equal(mol, pk.mol_offset) and np.array_equal(eoff, pk.edge_offset) and int((row_of >= 0).sum()) == pk.n_atom
     ds = PackedDataset(data_energy=de, data_neighbor=dn, batch_size=5, use_ring=False, feature="atomic", g_update=True,
                        atomic_features=None, shuffle=False)
     it = DataIterator(de, dn, batch_size=5, g_update=True)
