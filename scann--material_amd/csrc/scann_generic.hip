@@ -3,7 +3,8 @@
 // scann_kernels.hip, which are written for exactly those).  A handle created with other widths evaluates here: plain fp32 FMA kernels on
 // the same packed CSR batch, one formula of the reference per kernel, no matrix instructions, no tuning -- the point is that such a
 // checkpoint evaluates on the GPU at all, with the reference's arithmetic (fp32 products, fp32 sums); it is one to two orders of
-// magnitude slower than the 128-wide path and has no training counterpart (scann_train_begin refuses).
+// magnitude slower than the 128-wide path.  Its training counterpart (the same kernels keeping their pre-activations and applying the
+// Dropout layers, and one plain kernel per backward formula) is scann_generic_train.hip.
 //
 //   gen_dense_kernel      y = act(x . W + b) [+ residual] [* row scale], x assembled per row from up to three gathered segments
 //                         (concat[c_i, g_ij, c_j], attention.py:142-150) or as the product of two (c_j * g'_ij, :157)
@@ -77,7 +78,9 @@ __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
       const int r = r0 + rb + rr;
       if (r >= a.rows) break;
       float y = acc[rr] + bias;
+      if (a.pre) a.pre[(size_t)r * a.N + o] = y;  // training forward: the pre-activation the backward differentiates swish at
       if (a.act) y = swish_exact(y);
+      if (a.drop_p > 0.f) y = y * drop_scale(a.drop_seed, a.drop_tag, (size_t)r * a.N + o, a.drop_p);  // Dropout on the layer's OUTPUT
       if (a.res) y = y + a.res[(size_t)(a.res_idx ? a.res_idx[r] : r) * a.N + o];
       if (a.row_scale) y = y * a.row_scale[r];
       a.Y[(size_t)r * a.N + o] = y;
@@ -133,7 +136,8 @@ __global__ void gen_mul_kernel(const float* __restrict__ a, const float* __restr
 // one workgroup per atom.  logits[n][h] = (q[h] * hd^-0.5) . K[n][h] over the atom's CSR row, softmax over n per head, context[o] =
 // sum_n attn[n][head(o)] K[n][o] + q[o] (the residual is the UNSCALED query, attention.py:198-212).  No edges: context = q.
 __global__ __launch_bounds__(256) void gen_attn_kernel(const float* __restrict__ q, const float* __restrict__ K, const int32_t* __restrict__ edge_offset,
-                                                       int n_atom, int d, int H, float* __restrict__ ctx) {
+                                                       int n_atom, int d, int H, float* __restrict__ ctx, float drop_p, unsigned drop_tag,
+                                                       unsigned long long drop_seed) {
 #pragma clang fp contract(off)
   extern __shared__ float sL[];  // [deg][H] logits -> attention
   const int at = blockIdx.x, tid = threadIdx.x;
@@ -157,7 +161,11 @@ __global__ __launch_bounds__(256) void gen_attn_kernel(const float* __restrict__
       sL[n * H + h] = e;
       ss += e;
     }
-    for (int n = 0; n < deg; ++n) sL[n * H + h] = sL[n * H + h] / ss;
+    for (int n = 0; n < deg; ++n) {
+      float at = sL[n * H + h] / ss;
+      if (drop_p > 0.f) at = at * drop_scale(drop_seed, drop_tag, (size_t)(e0 + n) * H + h, drop_p);  // Dropout(0.05), attention.py:191 (training)
+      sL[n * H + h] = at;
+    }
   }
   __syncthreads();
   for (int o = tid; o < d; o += 256) {
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void gen_attn_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gen_readout_kernel(const int32_t* __restrict__ mol_offset, const float* __restrict__ gq, const float* __restrict__ gk, int dg,
                                                           int dout, int use_ga_norm, int relu_out, const float* __restrict__ Wb, const float* __restrict__ bb,
                                                           const float* __restrict__ wo, const float* __restrict__ bo, float* __restrict__ ga_attn,
-                                                          float* __restrict__ y) {
+                                                          float* __restrict__ y, float* __restrict__ rep_out) {
 #pragma clang fp contract(off)
   extern __shared__ float sm[];  // [n] scores -> attention, [dg] pooled rows, [dout] hidden, [4] reductions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,7 +246,9 @@ __global__ __launch_bounds__(256) void gen_readout_kernel(const int32_t* __restr
     float s = 0.f;
     for (int i = 0; i < n; ++i) s = fmaf(sA[i], gk[(size_t)(a0 + i) * dg + o], s);
     sRep[o] = s;
+    if (rep_out) rep_out[(size_t)blockIdx.x * dg + o] = s;
   }
+  if (rep_out) return;  // training forward: bf_property / predict_property run as dense launches that keep their pre-activations
   __syncthreads();
   float part = 0.f;
   for (int o = tid; o < dout; o += 256) {
@@ -288,15 +298,19 @@ void launch_gen_mul(const float* a, const float* b, size_t n, float* out, hipStr
   if (!n) return;
   hipLaunchKernelGGL(gen_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, out);
 }
-void launch_gen_attn(const float* q, const float* K, const int32_t* edge_offset, int n_atom, int d, int H, int max_degree, float* ctx, hipStream_t s) {
+void launch_gen_attn(const float* q, const float* K, const int32_t* edge_offset, int n_atom, int d, int H, int max_degree, float* ctx, hipStream_t s,
+                     float drop_p, unsigned drop_tag, unsigned long long drop_seed) {
   if (n_atom <= 0) return;
-  hipLaunchKernelGGL(gen_attn_kernel, dim3(n_atom), dim3(256), (size_t)std::max(1, max_degree) * H * sizeof(float), s, q, K, edge_offset, n_atom, d, H, ctx);
+  hipLaunchKernelGGL(gen_attn_kernel, dim3(n_atom), dim3(256), (size_t)std::max(1, max_degree) * H * sizeof(float), s, q, K, edge_offset, n_atom, d, H, ctx,
+                     drop_p, drop_tag, drop_seed);
 }
 void launch_gen_readout(const int32_t* mol_offset, int n_struct, int max_atoms, const float* gq, const float* gk, int dg, int dout, int use_ga_norm,
-                        int relu_out, const float* Wb, const float* bb, const float* wo, const float* bo, float* ga_attn, float* y, hipStream_t s) {
+                        int relu_out, const float* Wb, const float* bb, const float* wo, const float* bo, float* ga_attn, float* y, hipStream_t s,
+                        float* rep_out) {
   if (n_struct <= 0) return;
   const size_t lds = ((size_t)max_atoms + dg + dout + 4) * sizeof(float);
-  hipLaunchKernelGGL(gen_readout_kernel, dim3(n_struct), dim3(256), lds, s, mol_offset, gq, gk, dg, dout, use_ga_norm, relu_out, Wb, bb, wo, bo, ga_attn, y);
+  hipLaunchKernelGGL(gen_readout_kernel, dim3(n_struct), dim3(256), lds, s, mol_offset, gq, gk, dg, dout, use_ga_norm, relu_out, Wb, bb, wo, bo, ga_attn, y,
+                     rep_out);
 }
 
 }  // namespace scann

@@ -214,14 +214,51 @@ struct GenDenseArgs {
   const int32_t* res_idx;
   const float* row_scale;  // [rows] or null: multiplied last
   float* Y;                // [rows, N]
+  // training forward (zero / null in inference): the pre-activation kept for the backward, Dropout on the layer's output
+  float* pre;              // [rows, N] or null
+  float drop_p;
+  uint32_t drop_tag;
+  unsigned long long drop_seed;
 };
 void launch_gen_dense(const GenDenseArgs& a, hipStream_t s);
 void launch_gen_layernorm(const float* X, const float* res, const float* gamma, const float* beta, int rows, int N, float* Y, hipStream_t s);
 void launch_gen_gauss(const float* x, const float* centres, int n, float* out, hipStream_t s);
 void launch_gen_mul(const float* a, const float* b, size_t n, float* out, hipStream_t s);
-void launch_gen_attn(const float* q, const float* K, const int32_t* edge_offset, int n_atom, int d, int H, int max_degree, float* ctx, hipStream_t s);
+void launch_gen_attn(const float* q, const float* K, const int32_t* edge_offset, int n_atom, int d, int H, int max_degree, float* ctx, hipStream_t s,
+                     float drop_p = 0.f, unsigned drop_tag = 0, unsigned long long drop_seed = 0);
+// rep_out non-null (training forward): the pooled rows [n_struct, dg] are stored and the property head is NOT evaluated
 void launch_gen_readout(const int32_t* mol_offset, int n_struct, int max_atoms, const float* gq, const float* gk, int dg, int dout, int use_ga_norm,
-                        int relu_out, const float* Wb, const float* bb, const float* wo, const float* bo, float* ga_attn, float* y, hipStream_t s);
+                        int relu_out, const float* Wb, const float* bb, const float* wo, const float* bo, float* ga_attn, float* y, hipStream_t s,
+                        float* rep_out = nullptr);
+
+// ---- generic-width training (scann_generic_train.hip) ----
+struct GenTransDesc {  // WT[dst + o * kn + kk] = W[src + (k0 + kk) * N + o]: rows [k0, k0 + kn) of a row-major [*, N] kernel, transposed
+  int64_t src, dst;
+  int32_t k0, kn, N;
+};
+struct GenDwArgs {
+  GenSeg seg[3];  // the forward operand X, assembled as in GenDenseArgs
+  int32_t n_seg, prod;
+  const float* dZ;  // [rows, N] gradient of the layer's pre-activation
+  int32_t K, N, rows;
+  float *dW, *db;   // [K, N], [N] (null: no bias): ACCUMULATED into
+};
+void launch_gen_transpose(const GenTransDesc* descs, int n_desc, int max_elems, const float* W, float* WT, hipStream_t s);
+void launch_gen_act_bwd(const float* dY, const float* pre, const float* row_scale, int rows, int N, float drop_p, unsigned drop_tag,
+                        unsigned long long drop_seed, float* out, hipStream_t s);
+void launch_gen_mul_gather(const float* a, const float* B, const int32_t* idx, const float* c, int rows, int N, float* out, hipStream_t s);
+void launch_gen_relu(float* y, int n, hipStream_t s);
+void launch_gen_dense_dw(const GenDwArgs& a, hipStream_t s);
+int gen_ln_chunks(int rows);  // row chunks of the gamma / beta sums: `part` holds gen_ln_chunks(rows) * 2 * N floats
+void launch_gen_layernorm_bwd(const float* X, const float* res, const float* gamma, const float* dY, int rows, int N, float* dX, float* stats,
+                              float* part, float* dgamma, float* dbeta, hipStream_t s);
+void launch_gen_attn_bwd(const float* q, const float* K, const int32_t* edge_offset, int n_atom, int d, int H, int max_degree, const float* dctx,
+                         float drop_p, unsigned drop_tag, unsigned long long drop_seed, float* dq, float* dK, hipStream_t s);
+void launch_gen_pool_bwd(const int32_t* mol_offset, int n_struct, int max_atoms, const float* gq, const float* gk, int dg, int use_ga_norm,
+                         const float* drep, float* dgq, float* dgk, hipStream_t s);
+void launch_gen_edge_to_atom(const int32_t* edge_offset, const int32_t* in_off, const int32_t* in_edge, const float* S_out, const float* S_in,
+                             const float* P_a, const float* P_b, const float* acc, int n_atom, int d, float* out, hipStream_t s);
+void launch_gen_table_grad(const int32_t* atomic, int n_atom, const float* dV, int emb, int n_species, float* dTable, hipStream_t s);
 
 struct ReadoutArgs {
   const int32_t* mol_offset;  // [n_struct+1]

@@ -101,6 +101,10 @@ struct WeightSpec {
 
 }  // namespace
 
+namespace {
+struct GenKeep;
+}
+
 struct scann_handle {
   scann_config_t cfg{};
   int device = 0;
@@ -121,10 +125,17 @@ struct scann_handle {
   int xcd_remap = 1;   // env SCANN_XCD_REMAP=0 disables the XCD-contiguous tile order
   int fuse_basis = 1;  // env SCANN_FUSE_BASIS=0: basis_kernel writes geom0 and layer 0 reads it, as in training (A/B switch)
   int species_tables = 1;  // env SCANN_SPECIES_TABLES=0: the first layer's atom rows come from an atom launch, not from per-species tables
-  bool generic = false;        // widths other than 128 / 8: the plain-fp32 forward of scann_generic.hip (inference only)
+  bool generic = false;        // widths other than 128 / 8: the plain-fp32 kernels of scann_generic.hip / scann_generic_train.hip
   float* g_weights = nullptr;  // generic: the flat fp32 parameter vector on the device (spec order, spec_off offsets)
   float* g_centres = nullptr;  // generic: 20 + 20 Gaussian centres (distance, Voronoi weight)
   std::map<std::string, int64_t> g_off;  // generic: tensor name -> offset in g_weights
+  // generic-width training: W^T images of the kernels (refreshed at the head of every backward), one descriptor per transposed block
+  std::vector<GenTransDesc> gt_descs;
+  GenTransDesc* d_gt_descs = nullptr;
+  std::map<std::string, int64_t> gt_off;  // "<tensor name>#<block>" -> offset in g_WT
+  float* g_WT = nullptr;
+  int gt_max = 0;                         // elements of the largest block
+  GenKeep* gen_keep = nullptr;            // inside a training forward: where run_forward_generic keeps its tensors
   bool weights_exact = false;  // a loaded 128x128 kernel has |w| >= 255.9: the split-fp16 images cannot hold it, inference runs exact
   bool force_exact = false;    // env SCANN_EXACT=1: every inference forward on the exact-fp32 kernels (test / diagnosis switch)
   bool strict_range = false;   // env SCANN_STRICT_RANGE=1: SCANN_ERR_RANGE instead of the exact-fp32 re-run of an inference forward
@@ -491,6 +502,8 @@ void scann_destroy(scann_handle_t* h) {
     if (st.p) (void)hipHostFree(st.p);
   if (h->g_weights) (void)hipFree(h->g_weights);
   if (h->g_centres) (void)hipFree(h->g_centres);
+  if (h->g_WT) (void)hipFree(h->g_WT);
+  if (h->d_gt_descs) (void)hipFree(h->d_gt_descs);
   if (h->sp_c) (void)hipFree(h->sp_c);
   for (scann_handle::Stage& st : h->stage) {
     if (st.p) (void)hipHostFree(st.p);
@@ -1164,44 +1177,95 @@ int ensure_debug(scann_handle* h, scann_dbatch* db) {
   return SCANN_OK;
 }
 
+// What the generic-width TRAINING forward keeps for the backward (gen_backward): every tensor a formula's derivative reads, in buffers of
+// their own per layer (the inference forward rotates five atom-row and three edge-row buffers instead).
+struct GenLayerKeep {
+  float *cc_in = nullptr, *G_in = nullptr;  // centres / geometry entering the layer
+  float *Z = nullptr;                       // filter_geo pre-activation
+  float *T = nullptr;                       // g_update: swish(Z) + G_in, the input of layer_norm_g
+  float *Gn = nullptr;                      // the geometry the key projection is gated with (g_update: the layer's output geometry)
+  float *K = nullptr, *q = nullptr;
+  float *t1 = nullptr, *ctx = nullptr;      // attention context + query (input of layer_norm), its LayerNorm
+  float *pre1 = nullptr, *h1 = nullptr, *t2 = nullptr;  // ResidualNorm: dense_1 pre-activation, its swish, Dropout(dense_2)
+  float *cc_out = nullptr;
+};
+struct GenKeep {
+  char* arena = nullptr;   // forward tensors
+  size_t bytes = 0;
+  char* barena = nullptr;  // backward temporaries + the transposed kernels
+  size_t bbytes = 0;
+  std::vector<GenLayerKeep> layer;
+  float *embE = nullptr, *ring10 = nullptr, *pre_e = nullptr, *cc0 = nullptr;
+  float *gd = nullptr, *gw = nullptr, *pre_d = nullptr, *pre_w = nullptr, *Td = nullptr, *Tw = nullptr, *G0 = nullptr;
+  float *cc_L = nullptr, *z_pre = nullptr, *z = nullptr, *gq = nullptr, *gk = nullptr, *rep = nullptr, *hid_pre = nullptr, *hid = nullptr;
+  float drop_p = 0.f, attn_p = 0.f;
+  unsigned long long seed = 0;
+};
+
 // create_model (scann_model.py:362-447) for a handle whose widths are not 128 / 8: one plain-fp32 kernel per formula
-// (scann_generic.hip) on the same packed batch.
-int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s) {
+// (scann_generic.hip) on the same packed batch.  kp non-null: the training forward -- Dropout layers active (kp->drop_p, kp->attn_p,
+// kp->seed), every intermediate kept in kp, the property head as dense launches.
+int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s, GenKeep* kp = nullptr) {
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
   const int d = c.local_dim, dg = c.global_dim, dout = c.dense_out, H = c.num_head, emb = c.embedding_dim;
   const int cin = emb + (c.use_ring ? 10 : 0);
-  if ((size_t)std::max(1, db->max_degree) * H * 4 > 60000 || ((size_t)db->max_atoms + dg + dout + 4) * 4 > 60000 || (size_t)4 * 3 * d * 4 > 60000)
+  if ((size_t)std::max(1, db->max_degree) * H * 4 * (kp ? 3 : 1) > 60000 || ((size_t)db->max_atoms * (kp ? 3 : 1) + dg + dout + 4) * 4 > 60000 ||
+      (size_t)4 * 3 * d * 4 > 60000)
     return fail(h, SCANN_ERR_UNSUPPORTED, "forward (generic widths): an atom's neighbours x heads, or a structure's atoms, exceed one workgroup's LDS");
   auto W = [&](const std::string& name) -> const float* { return h->g_weights + h->g_off.at(name); };
   // workspace: atom rows, edge rows, Gaussian bases
-  const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1);
-  const size_t need = 4 * (fA * (5 * (size_t)d + (size_t)cin + (size_t)emb + 10 + 3 * (size_t)dg) + fE * (3 * (size_t)d + 2 * NG)) + 4096;
-  if (db->gen_ws_bytes < need) {
-    HIPCHK(h, hipStreamSynchronize(s));
-    cached_free(db->gen_ws);
-    db->gen_ws = nullptr;
-    db->gen_ws_bytes = 0;
-    HIPCHK(h, cached_malloc((void**)&db->gen_ws, need));
-    db->gen_ws_bytes = need;
+  const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1), fB = (size_t)B, Ls = (size_t)L;
+  float* p = nullptr;
+  char* p_end = nullptr;
+  if (!kp) {
+    const size_t need = 4 * (fA * (5 * (size_t)d + (size_t)cin + (size_t)emb + 10 + 3 * (size_t)dg) + fE * (3 * (size_t)d + 2 * NG)) + 4096;
+    if (db->gen_ws_bytes < need) {
+      HIPCHK(h, hipStreamSynchronize(s));
+      cached_free(db->gen_ws);
+      db->gen_ws = nullptr;
+      db->gen_ws_bytes = 0;
+      HIPCHK(h, cached_malloc((void**)&db->gen_ws, need));
+      db->gen_ws_bytes = need;
+    }
+    p = reinterpret_cast<float*>(db->gen_ws);
+    p_end = db->gen_ws + db->gen_ws_bytes;
+  } else {
+    const size_t need = 4 * (fA * ((size_t)emb + 10 + (2 + 7 * Ls) * (size_t)d + 4 * (size_t)dg) + fE * (2 * NG + (5 + 4 * Ls) * (size_t)d) +
+                             fB * ((size_t)dg + 2 * (size_t)dout + 1)) + 256 * (32 + 12 * Ls);
+    if (kp->bytes < need) {
+      HIPCHK(h, hipStreamSynchronize(s));
+      cached_free(kp->arena);
+      kp->arena = nullptr;
+      kp->bytes = 0;
+      HIPCHK(h, cached_malloc((void**)&kp->arena, need));
+      kp->bytes = need;
+    }
+    p = reinterpret_cast<float*>(kp->arena);
+    p_end = kp->arena + kp->bytes;
+    kp->layer.assign((size_t)L, GenLayerKeep{});
   }
-  float* p = reinterpret_cast<float*>(db->gen_ws);
   auto take = [&](size_t n) { float* q = p; p += (n + 63) & ~(size_t)63; return q; };
-  float *cc = take(fA * d), *ctx = take(fA * d), *t1 = take(fA * d), *t2 = take(fA * d), *q = take(fA * d);
+  float *cc = take(fA * d), *ctx = nullptr, *t1 = nullptr, *t2 = nullptr, *q = nullptr;
+  if (!kp) { ctx = take(fA * d); t1 = take(fA * d); t2 = take(fA * d); q = take(fA * d); }
   float *embE = take(fA * emb), *ring10 = take(fA * 10);
   float *z = take(fA * dg), *gq = take(fA * dg), *gk = take(fA * dg);
-  float *G = take(fE * d), *T = take(fE * d), *K = take(fE * d), *gd = take(fE * NG), *gw = take(fE * NG);
-  (void)cin;
+  float *G = take(fE * d), *T = nullptr, *K = nullptr, *gd = take(fE * NG), *gw = take(fE * NG);
+  if (!kp) { T = take(fE * d); K = take(fE * d); }
+  const float tp = kp ? kp->drop_p : 0.f;
+  const unsigned long long seed = kp ? kp->seed : 0;
   auto dense = [&](GenSeg s0, GenSeg s1, GenSeg s2, int n_seg, int prod, const std::string& name, int K_, int N_, int rows, int act,
-                   const float* res, const float* row_scale, float* Y) {
+                   const float* res, const float* row_scale, float* Y, float* pre = nullptr, float drop_p = 0.f, unsigned drop_tag = 0) {
     GenDenseArgs a{};
     a.seg[0] = s0; a.seg[1] = s1; a.seg[2] = s2; a.n_seg = n_seg; a.prod = prod;
     a.W = W(name + "/kernel"); a.b = W(name + "/bias"); a.K = K_; a.N = N_; a.rows = rows; a.act = act;
     a.res = res; a.res_idx = nullptr; a.row_scale = row_scale; a.Y = Y;
+    a.pre = pre; a.drop_p = drop_p; a.drop_tag = drop_tag; a.drop_seed = seed;
     launch_gen_dense(a, s);
   };
   const GenSeg none{nullptr, nullptr, 0};
-  // ---- embedding (scann_model.py:362-374) ----
+  // ---- embedding (scann_model.py:362-374; Dropout(0.1) on the centres in training, :374) ----
+  float* pre_e = kp ? take(fA * d) : nullptr;
   GenSeg e0;
   if (c.feature_cgcnn) {
     dense(GenSeg{db->cgcnn, nullptr, 92}, none, none, 1, 0, "embed_atom", 92, emb, A, 0, nullptr, nullptr, embE);
@@ -1211,48 +1275,76 @@ int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s) {
   }
   if (c.use_ring) {
     dense(GenSeg{db->ring, nullptr, 2}, none, none, 1, 0, "extra_embed", 2, 10, A, 0, nullptr, nullptr, ring10);
-    dense(e0, GenSeg{ring10, nullptr, 10}, none, 2, 0, "dense_embed", emb + 10, d, A, 1, nullptr, nullptr, cc);
+    dense(e0, GenSeg{ring10, nullptr, 10}, none, 2, 0, "dense_embed", emb + 10, d, A, 1, nullptr, nullptr, cc, pre_e, tp, DROP_TAG_EMBED);
   } else {
-    dense(e0, none, none, 1, 0, "dense_embed", emb, d, A, 1, nullptr, nullptr, cc);
+    dense(e0, none, none, 1, 0, "dense_embed", emb, d, A, 1, nullptr, nullptr, cc, pre_e, tp, DROP_TAG_EMBED);
   }
+  if (kp) { kp->embE = embE; kp->ring10 = ring10; kp->pre_e = pre_e; kp->cc0 = cc; kp->gd = gd; kp->gw = gw; }
   // ---- Gaussian bases and the initial geometry (scann_model.py:376-391) ----
   launch_gen_gauss(db->dist, h->g_centres, E, gd, s);
   if (c.g_update) {
     launch_gen_gauss(db->weight, h->g_centres + NG, E, gw, s);
-    dense(GenSeg{gd, nullptr, NG}, none, none, 1, 0, "neighbor_d", NG, d, E, 1, nullptr, nullptr, T);
-    dense(GenSeg{gw, nullptr, NG}, none, none, 1, 0, "neighbor_w", NG, d, E, 1, nullptr, nullptr, K);
-    launch_gen_mul(T, K, (size_t)E * d, G, s);
+    float *Td = kp ? take(fE * d) : T, *Tw = kp ? take(fE * d) : K;
+    float *pre_d = kp ? take(fE * d) : nullptr, *pre_w = kp ? take(fE * d) : nullptr;
+    dense(GenSeg{gd, nullptr, NG}, none, none, 1, 0, "neighbor_d", NG, d, E, 1, nullptr, nullptr, Td, pre_d);
+    dense(GenSeg{gw, nullptr, NG}, none, none, 1, 0, "neighbor_w", NG, d, E, 1, nullptr, nullptr, Tw, pre_w);
+    launch_gen_mul(Td, Tw, (size_t)E * d, G, s);
+    if (kp) { kp->Td = Td; kp->Tw = Tw; kp->pre_d = pre_d; kp->pre_w = pre_w; kp->G0 = G; }
   }
   // ---- LocalAttention iterations (scann_model.py:413-421; attention.py:118-216, :37-40) ----
   for (int l = 0; l < L; ++l) {
     const std::string la = "local_attention_" + std::to_string(l), rn = "residual_norm_" + std::to_string(l);
-    const float* geomL;
-    if (c.g_update) {
-      dense(GenSeg{cc, db->edge_row, d}, GenSeg{G, nullptr, d}, GenSeg{cc, db->edge_col, d}, 3, 0, la + "/filter_geo", 3 * d, d, E, 1, G, nullptr, T);
-      launch_gen_layernorm(T, nullptr, W(la + "/layer_norm_g/gamma"), W(la + "/layer_norm_g/beta"), E, d, G, s);
-      geomL = G;
+    GenLayerKeep b;
+    b.cc_in = cc; b.G_in = G;
+    if (kp) {
+      b.Z = take(fE * d); b.Gn = take(fE * d); b.K = take(fE * d);
+      if (c.g_update) b.T = take(fE * d);
+      b.q = take(fA * d); b.t1 = take(fA * d); b.ctx = take(fA * d);
+      if (c.use_attn_norm) { b.pre1 = take(fA * d); b.h1 = take(fA * d); b.t2 = take(fA * d); b.cc_out = take(fA * d); }
+      else b.cc_out = b.ctx;
     } else {
-      dense(GenSeg{gd, nullptr, NG}, none, none, 1, 0, la + "/filter_geo", NG, d, E, 1, nullptr, db->weight, T);
-      geomL = T;
+      b.T = T; b.Gn = c.g_update ? G : T; b.K = K; b.q = q; b.t1 = t1; b.ctx = ctx; b.h1 = t1; b.t2 = t2;
+      b.cc_out = c.use_attn_norm ? cc : ctx;
     }
-    dense(GenSeg{cc, db->edge_col, d}, GenSeg{geomL, nullptr, d}, none, 2, 1, la + "/key", d, d, E, 0, nullptr, nullptr, K);
-    dense(GenSeg{cc, nullptr, d}, none, none, 1, 0, la + "/query", d, d, A, 0, nullptr, nullptr, q);
-    launch_gen_attn(q, K, db->edge_offset, A, d, H, db->max_degree, t1, s);
-    launch_gen_layernorm(t1, nullptr, W(la + "/layer_norm/gamma"), W(la + "/layer_norm/beta"), A, d, ctx, s);
-    if (c.use_attn_norm) {
-      dense(GenSeg{ctx, nullptr, d}, none, none, 1, 0, rn + "/dense_1", d, d, A, 1, nullptr, nullptr, t1);
-      dense(GenSeg{t1, nullptr, d}, none, none, 1, 0, rn + "/dense_2", d, d, A, 0, nullptr, nullptr, t2);
-      launch_gen_layernorm(ctx, t2, W(rn + "/layer_norm/gamma"), W(rn + "/layer_norm/beta"), A, d, cc, s);
+    if (c.g_update) {
+      dense(GenSeg{cc, db->edge_row, d}, GenSeg{G, nullptr, d}, GenSeg{cc, db->edge_col, d}, 3, 0, la + "/filter_geo", 3 * d, d, E, 1, G, nullptr, b.T, b.Z);
+      launch_gen_layernorm(b.T, nullptr, W(la + "/layer_norm_g/gamma"), W(la + "/layer_norm_g/beta"), E, d, b.Gn, s);
     } else {
+      dense(GenSeg{gd, nullptr, NG}, none, none, 1, 0, la + "/filter_geo", NG, d, E, 1, nullptr, db->weight, b.Gn, b.Z);
+    }
+    dense(GenSeg{cc, db->edge_col, d}, GenSeg{b.Gn, nullptr, d}, none, 2, 1, la + "/key", d, d, E, 0, nullptr, nullptr, b.K);
+    dense(GenSeg{cc, nullptr, d}, none, none, 1, 0, la + "/query", d, d, A, 0, nullptr, nullptr, b.q);
+    launch_gen_attn(b.q, b.K, db->edge_offset, A, d, H, db->max_degree, b.t1, s, kp ? kp->attn_p : 0.f, DROP_TAG_ATTN + (unsigned)l, seed);
+    launch_gen_layernorm(b.t1, nullptr, W(la + "/layer_norm/gamma"), W(la + "/layer_norm/beta"), A, d, b.ctx, s);
+    if (c.use_attn_norm) {  // ResidualNorm (attention.py:37-40): LayerNorm(x + Dropout(dense_2(swish(dense_1 x))))
+      dense(GenSeg{b.ctx, nullptr, d}, none, none, 1, 0, rn + "/dense_1", d, d, A, 1, nullptr, nullptr, b.h1, b.pre1);
+      dense(GenSeg{b.h1, nullptr, d}, none, none, 1, 0, rn + "/dense_2", d, d, A, 0, nullptr, nullptr, b.t2, nullptr, tp, (unsigned)l);
+      launch_gen_layernorm(b.ctx, b.t2, W(rn + "/layer_norm/gamma"), W(rn + "/layer_norm/beta"), A, d, b.cc_out, s);
+    }
+    if (kp) {
+      kp->layer[(size_t)l] = b;
+      cc = b.cc_out;
+      if (c.g_update) G = b.Gn;
+    } else if (!c.use_attn_norm) {
       std::swap(cc, ctx);
     }
   }
   // ---- readout (scann_model.py:424-447; attention.py:267-318) ----
-  dense(GenSeg{cc, nullptr, d}, none, none, 1, 0, "after_Lc", d, dg, A, 1, nullptr, nullptr, z);
+  float* z_pre = kp ? take(fA * dg) : nullptr;
+  dense(GenSeg{cc, nullptr, d}, none, none, 1, 0, "after_Lc", d, dg, A, 1, nullptr, nullptr, z, z_pre);
   dense(GenSeg{z, nullptr, dg}, none, none, 1, 0, "global_attention/query", dg, dg, A, 0, nullptr, nullptr, gq);
   dense(GenSeg{z, nullptr, dg}, none, none, 1, 0, "global_attention/key", dg, dg, A, 0, nullptr, nullptr, gk);
+  float* rep = kp ? take(fB * dg) : nullptr;
   launch_gen_readout(db->mol_offset, B, db->max_atoms, gq, gk, dg, dout, c.use_ga_norm, c.relu_out, W("bf_property/kernel"), W("bf_property/bias"),
-                     W("predict_property/kernel"), W("predict_property/bias"), db->ga, db->y, s);
+                     W("predict_property/kernel"), W("predict_property/bias"), db->ga, db->y, s, rep);
+  if (kp) {
+    float *hid_pre = take(fB * dout), *hid = take(fB * dout);
+    dense(GenSeg{rep, nullptr, dg}, none, none, 1, 0, "bf_property", dg, dout, B, 1, nullptr, nullptr, hid, hid_pre);
+    dense(GenSeg{hid, nullptr, dout}, none, none, 1, 0, "predict_property", dout, 1, B, 0, nullptr, nullptr, db->y);
+    if (c.relu_out) launch_gen_relu(db->y, B, s);  // mrelu forward (custom_layers.py:15); its gradient is the identity
+    kp->cc_L = cc; kp->z_pre = z_pre; kp->z = z; kp->gq = gq; kp->gk = gk; kp->rep = rep; kp->hid_pre = hid_pre; kp->hid = hid;
+  }
+  if (reinterpret_cast<char*>(p) > p_end) return fail(h, SCANN_ERR_HIP, "forward (generic widths): workspace overrun");
   HIPCHK(h, hipGetLastError());
   return SCANN_OK;
 }
@@ -1266,7 +1358,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
   if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
   if (h->generic) {
     if (tm) { tm->mark(-1); }
-    const int r = run_forward_generic(h, db, s);
+    const int r = run_forward_generic(h, db, s, h->in_train_forward ? h->gen_keep : nullptr);
     if (tm) tm->mark(3);
     return r;
   }
@@ -1767,6 +1859,7 @@ struct scann_train_ws {  // per resident batch, allocated on first use
   double* sse = nullptr;
   float drop_p = 0.f, attn_p = 0.f;
   unsigned long long seed = 0;
+  GenKeep gen;  // generic widths: the training forward's tensors and the backward's temporaries
 };
 
 namespace {
@@ -1783,6 +1876,14 @@ int ensure_train_ws(scann_handle* h, scann_dbatch* db, scann_train_ws** out) {
   scann_train_ws& w = *wp;
   *out = &w;
   if (w.arena) return SCANN_OK;
+  if (h->generic) {  // loss statistics, targets, d loss / d y; the tensors live in w.gen (run_forward_generic, gen_backward)
+    const size_t nb = align_up((size_t)db->n_struct * 4);
+    HIPCHK(h, cached_malloc((void**)&w.arena, 256 + 2 * nb));
+    w.sse = (double*)w.arena;
+    w.dy = (float*)(w.arena + 256);
+    w.targets = (float*)(w.arena + 256 + nb);
+    return SCANN_OK;
+  }
   const size_t rowA = align_up((size_t)db->n_atom * D * 4), rowE = align_up((size_t)std::max(db->n_edge, 1) * D * 4);
   const size_t rowB = align_up((size_t)db->n_struct * D * 4);
   // per-layer tensors kept by the training forward (edge_kernel_lean on 64-edge tiles): q [A,128]; V, T, ang, K [E,128]
@@ -1850,6 +1951,8 @@ static void free_train_ws(scann_dbatch* db) {
   auto it = g_train_ws.find(db);
   if (it == g_train_ws.end()) return;
   cached_free(it->second.arena);
+  cached_free(it->second.gen.arena);
+  cached_free(it->second.gen.barena);
   g_train_ws.erase(it);
 }
 
@@ -1875,9 +1978,6 @@ int64_t scann_param_count(const scann_handle_t* h) {
 int scann_train_begin(scann_handle_t* h) {
   if (!h) return SCANN_ERR_INVALID;
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "scann_train_begin: weights not loaded");
-  if (h->generic)
-    return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: training is implemented for local_dim = global_dim = dense_out = 128, num_head = 8 "
-                                          "(every shipped reference config); other widths evaluate only");
   if (h->weights_exact)
     return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_begin: a 128x128 kernel has |w| >= 255.9; the training kernels multiply in split-fp16 "
                                           "form only (inference of such a checkpoint runs on the exact-fp32 kernels)");
@@ -1889,13 +1989,13 @@ int scann_train_begin(scann_handle_t* h) {
     HIPCHK(h, hipMalloc((void**)&h->t_m, n * 4));
     HIPCHK(h, hipMalloc((void**)&h->t_v, n * 4));
     HIPCHK(h, hipMalloc((void**)&h->t_l2, n * 4));
-    HIPCHK(h, hipMalloc((void**)&h->t_descs, h->descs.size() * sizeof(RepackDesc)));
+    if (!h->generic) HIPCHK(h, hipMalloc((void**)&h->t_descs, h->descs.size() * sizeof(RepackDesc)));
   }
   HIPCHK(h, hipMemcpy(h->t_master, h->host_master.data(), n * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(h->t_grad, 0, n * 4));
   HIPCHK(h, hipMemset(h->t_m, 0, n * 4));
   HIPCHK(h, hipMemset(h->t_v, 0, n * 4));
-  HIPCHK(h, hipMemcpy(h->t_descs, h->descs.data(), h->descs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
+  if (!h->generic) HIPCHK(h, hipMemcpy(h->t_descs, h->descs.data(), h->descs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
   // kernel_regularizer=l2(1e-4) mask: LocalAttention query/key/filter_geo, ResidualNorm dense_1/2, GlobalAttention
   // query/key, after_Lc, bf_property (attention.py:27-28,95-109,260-265; scann_model.py:428,441)
   std::vector<float> l2(n, 0.f);
@@ -1907,7 +2007,38 @@ int scann_train_begin(scann_handle_t* h) {
     if (reg) std::fill(l2.begin() + h->spec_off[i], l2.begin() + h->spec_off[i] + h->specs[i].numel(), 1.0f);
   }
   HIPCHK(h, hipMemcpy(h->t_l2, l2.data(), n * 4, hipMemcpyHostToDevice));
-  if (!h->train_aux) {
+  if (h->generic) {
+    // the backward's d x = d z . W^T runs through gen_dense_kernel on transposed images of the kernels: one block per kernel, except
+    // that filter_geo of the g_update branch is cut into its centre / geometry / neighbour thirds (attention.py:142-150) and
+    // dense_embed with the ring input into its embedding / ring rows (scann_model.py:367-373) -- each third's d x is a tensor of its own
+    h->gt_descs.clear();
+    h->gt_off.clear();
+    int64_t off = 0;
+    h->gt_max = 0;
+    const int d = h->cfg.local_dim, emb = h->cfg.embedding_dim;
+    for (size_t i = 0; i < h->specs.size(); ++i) {
+      const WeightSpec& sp = h->specs[i];
+      const std::string& nm = sp.name;
+      if (!(sp.cols > 0 && nm.size() > 7 && nm.compare(nm.size() - 7, 7, "/kernel") == 0)) continue;
+      std::vector<int> cuts{0, (int)sp.rows};
+      if (h->cfg.g_update && nm.find("/filter_geo/") != std::string::npos && sp.rows == 3 * d) cuts = {0, d, 2 * d, 3 * d};
+      if (nm == "dense_embed/kernel" && h->cfg.use_ring) cuts = {0, emb, emb + 10};
+      for (size_t b = 0; b + 1 < cuts.size(); ++b) {
+        const int kn = cuts[b + 1] - cuts[b];
+        h->gt_descs.push_back(GenTransDesc{h->spec_off[i], off, cuts[b], kn, (int32_t)sp.cols});
+        h->gt_off[nm + "#" + std::to_string(b)] = off;
+        off += (int64_t)kn * sp.cols;
+        h->gt_max = std::max(h->gt_max, kn * (int)sp.cols);
+      }
+    }
+    if (h->g_WT) (void)hipFree(h->g_WT);
+    if (h->d_gt_descs) (void)hipFree(h->d_gt_descs);
+    h->g_WT = nullptr;
+    h->d_gt_descs = nullptr;
+    HIPCHK(h, hipMalloc((void**)&h->g_WT, (size_t)std::max<int64_t>(off, 1) * 4));
+    HIPCHK(h, hipMalloc((void**)&h->d_gt_descs, h->gt_descs.size() * sizeof(GenTransDesc)));
+    HIPCHK(h, hipMemcpy(h->d_gt_descs, h->gt_descs.data(), h->gt_descs.size() * sizeof(GenTransDesc), hipMemcpyHostToDevice));
+  } else if (!h->train_aux) {
     // (side streams created with the lowest priority changed nothing: 0.895 vs 0.895 ms per step, profiles/r04_notes.md)
     // (and so did confining them to half / a quarter of the CUs with hipExtStreamCreateWithCUMask: 0.89-0.93 ms either way)
     // A handle with a second forward stream lends it to the backward pass as its side stream instead of creating a fifth stream: HIP
@@ -1987,7 +2118,13 @@ static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float
   db->keep_preA = w->keep_preA; db->keep_z = w->keep_z;
   db->kept = false;
   const bool dbg = h->debug;
-  h->debug = true;  // keep centres / geometry / context of every layer (and, with edge_kernel_lean, q / V / T / ang / K)
+  if (h->generic) {  // run_forward_generic keeps its tensors in w->gen
+    w->gen.drop_p = dropout;
+    w->gen.attn_p = h->attn_drop_p;
+    w->gen.seed = seed;
+    h->gen_keep = &w->gen;
+  }
+  h->debug = !h->generic;  // keep centres / geometry / context of every layer (and, with edge_kernel_lean, q / V / T / ang / K)
   h->train_drop_p = dropout;
   h->train_seed = seed;
   h->in_train_forward = true;
@@ -1997,7 +2134,12 @@ static int train_forward_impl(scann_handle_t* h, scann_dbatch_t* db, const float
   h->in_train_forward = false;
   h->train_drop_p = 0.f;
   h->debug = dbg;
+  h->gen_keep = nullptr;
   if (r) return r;
+  if (h->generic) {
+    db->kept = true;
+    db->dbg_layers = h->cfg.n_attention;
+  }
   // targets: staged in pinned memory that the loss kernel reads directly (it leaves the device copy the backward uses): no copy operation
   if (h->h_targets_cap[slot] < (size_t)db->n_struct) {
     if (h->h_targets[slot]) {
@@ -2073,8 +2215,11 @@ static int ensure_reverse(scann_handle_t* h, scann_dbatch_t* db) {
 }
 
 // d_stat (device, {global sse, global count}) non-null: the loss scale is formed on the device (scann_train_step: no host round trip)
+static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat, bool dy_done);
+
 static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat, bool dy_done) {
   if (const int r = ensure_reverse(h, db)) return r;
+  if (h->generic) return gen_backward(h, db, w, scale, d_stat, dy_done);
   hipStream_t s = h->streams[0];
   const scann_config_t& c = h->cfg;
   const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
@@ -2372,6 +2517,147 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   return SCANN_OK;
 }
 
+// The backward pass of create_model (scann_model.py:362-447) for a generic-width handle: the formulas of backward_impl above, one plain
+// kernel each (scann_generic_train.hip), on the tensors the training forward kept (GenKeep).  One stream; gradients are ACCUMULATED
+// into the flat gradient vector (two backward calls give the gradient of the sum, as on the 128-wide path).
+static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w, float scale, const double* d_stat, bool dy_done) {
+  hipStream_t s = h->streams[0];
+  const scann_config_t& c = h->cfg;
+  GenKeep& kp = w.gen;
+  const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
+  const int d = c.local_dim, dg = c.global_dim, dout = c.dense_out, H = c.num_head, emb = c.embedding_dim;
+  const int cin = emb + (c.use_ring ? 10 : 0);
+  if (!kp.arena || (int)kp.layer.size() != L) return fail(h, SCANN_ERR_INVALID, "scann_train_backward: run scann_train_forward on this batch first");
+  if ((size_t)std::max(std::max(dg, dout), std::max(3 * d, std::max(cin, 92))) * 4 * 4 > 60000)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): a layer's rows exceed one workgroup's LDS");
+  // ---- temporaries ----
+  const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1), fB = (size_t)B;
+  const size_t dmax = (size_t)std::max(d, std::max(dg, dout));
+  const size_t need = 4 * (fA * (8 * (size_t)d + 4 * (size_t)dg + (size_t)emb + 10) + fE * 9 * (size_t)d + fB * (2 * (size_t)dout + (size_t)dg) +
+                           2 * std::max(fA, fE) + 2 * 64 * dmax) + 256 * 48;
+  if (kp.bbytes < need) {
+    HIPCHK(h, hipStreamSynchronize(s));
+    cached_free(kp.barena);
+    kp.barena = nullptr;
+    kp.bbytes = 0;
+    HIPCHK(h, cached_malloc((void**)&kp.barena, need));
+    kp.bbytes = need;
+  }
+  float* p = reinterpret_cast<float*>(kp.barena);
+  auto take = [&](size_t n) { float* q = p; p += (n + 63) & ~(size_t)63; return q; };
+  float *dCa = take(fA * d), *dCb = take(fA * d), *dXr = take(fA * d), *tA1 = take(fA * d), *tA2 = take(fA * d), *dT1 = take(fA * d), *dQ = take(fA * d);
+  float *dz = take(fA * dg), *dgq = take(fA * dg), *dgk = take(fA * dg), *dv = take(fA * (emb + 10));
+  float *dK = take(fE * d), *dang = take(fE * d), *dGt = take(fE * d), *dT = take(fE * d), *dZ = take(fE * d), *dXi = take(fE * d), *dXj = take(fE * d);
+  float *dGa = take(fE * d), *dGb = take(fE * d);
+  float *dhid = take(fB * dout), *drep = take(fB * dg);
+  float *stats = take(2 * std::max(fA, fE)), *part = take(2 * 64 * dmax);
+  if (reinterpret_cast<char*>(p) > kp.barena + kp.bbytes) return fail(h, SCANN_ERR_HIP, "backward (generic widths): workspace overrun");
+  // ---- helpers ----
+  launch_gen_transpose(h->d_gt_descs, (int)h->gt_descs.size(), h->gt_max, h->g_weights, h->g_WT, s);
+  auto Wp = [&](const std::string& name) -> const float* { return h->g_weights + h->g_off.at(name); };
+  auto WT = [&](const std::string& name, int blk = 0) -> const float* { return h->g_WT + h->gt_off.at(name + "/kernel#" + std::to_string(blk)); };
+  auto G = [&](const std::string& name) -> float* { return h->t_grad + h->g_off.at(name); };
+  const GenSeg none{nullptr, nullptr, 0};
+  // d x [rows, n_in] = d z [rows, n_out] . W^T (+ res)
+  auto dx = [&](const float* dZ_, int rows, int n_out, int n_in, const float* wt, const float* res, float* out) {
+    GenDenseArgs a{};
+    a.seg[0] = GenSeg{dZ_, nullptr, n_out}; a.seg[1] = none; a.seg[2] = none; a.n_seg = 1;
+    a.W = wt; a.b = nullptr; a.K = n_out; a.N = n_in; a.rows = rows; a.res = res; a.Y = out;
+    launch_gen_dense(a, s);
+  };
+  auto dw = [&](GenSeg s0, GenSeg s1, GenSeg s2, int n_seg, int prod, const float* dZ_, int K_, int N_, int rows, const std::string& name) {
+    GenDwArgs a{};
+    a.seg[0] = s0; a.seg[1] = s1; a.seg[2] = s2; a.n_seg = n_seg; a.prod = prod;
+    a.dZ = dZ_; a.K = K_; a.N = N_; a.rows = rows; a.dW = G(name + "/kernel"); a.db = G(name + "/bias");
+    launch_gen_dense_dw(a, s);
+  };
+  auto lnb = [&](const float* X, const float* res, const std::string& name, const float* dY, int rows, float* dX) {
+    launch_gen_layernorm_bwd(X, res, Wp(name + "/gamma"), dY, rows, d, dX, stats, part, G(name + "/gamma"), G(name + "/beta"), s);
+  };
+  if (!dy_done) launch_dy(db->y, w.targets, B, scale, d_stat, w.dy, s);
+  // ---- property head (scann_model.py:437-447; mrelu's gradient is the identity, custom_layers.py:6-15) ----
+  dw(GenSeg{kp.hid, nullptr, dout}, none, none, 1, 0, w.dy, dout, 1, B, "predict_property");
+  dx(w.dy, B, 1, dout, WT("predict_property"), nullptr, dhid);
+  launch_gen_act_bwd(dhid, kp.hid_pre, nullptr, B, dout, 0.f, 0, 0, dhid, s);
+  dw(GenSeg{kp.rep, nullptr, dg}, none, none, 1, 0, dhid, dg, dout, B, "bf_property");
+  dx(dhid, B, dout, dg, WT("bf_property"), nullptr, drep);
+  // ---- GlobalAttention pooling, its projections, after_Lc (attention.py:279-316; scann_model.py:424-434) ----
+  launch_gen_pool_bwd(db->mol_offset, B, db->max_atoms, kp.gq, kp.gk, dg, c.use_ga_norm, drep, dgq, dgk, s);
+  dw(GenSeg{kp.z, nullptr, dg}, none, none, 1, 0, dgq, dg, dg, A, "global_attention/query");
+  dw(GenSeg{kp.z, nullptr, dg}, none, none, 1, 0, dgk, dg, dg, A, "global_attention/key");
+  dx(dgq, A, dg, dg, WT("global_attention/query"), nullptr, dz);
+  dx(dgk, A, dg, dg, WT("global_attention/key"), dz, dz);
+  launch_gen_act_bwd(dz, kp.z_pre, nullptr, A, dg, 0.f, 0, 0, dz, s);
+  dw(GenSeg{kp.cc_L, nullptr, d}, none, none, 1, 0, dz, d, dg, A, "after_Lc");
+  float *dC = dCa, *dC_other = dCb;
+  dx(dz, A, dg, d, WT("after_Lc"), nullptr, dC);
+  const float* dGn = nullptr;  // gradient of the geometry leaving layer l (nothing reads the last layer's)
+  float *dG_next = dGa, *dG_spare = dGb;
+  // ---- LocalAttention + ResidualNorm iterations, last to first (attention.py:118-216, :37-40) ----
+  for (int l = L - 1; l >= 0; --l) {
+    const GenLayerKeep& b = kp.layer[(size_t)l];
+    const std::string la = "local_attention_" + std::to_string(l), rn = "residual_norm_" + std::to_string(l);
+    const float* dCtx = dC;
+    if (c.use_attn_norm) {  // c' = LayerNorm(ctx + Dropout(dense_2(swish(dense_1 ctx))))
+      lnb(b.ctx, b.t2, rn + "/layer_norm", dC, A, dXr);
+      launch_gen_act_bwd(dXr, nullptr, nullptr, A, d, kp.drop_p, (unsigned)l, kp.seed, tA1, s);  // through the Dropout mask
+      dw(GenSeg{b.h1, nullptr, d}, none, none, 1, 0, tA1, d, d, A, rn + "/dense_2");
+      dx(tA1, A, d, d, WT(rn + "/dense_2"), nullptr, tA2);
+      launch_gen_act_bwd(tA2, b.pre1, nullptr, A, d, 0.f, 0, 0, tA2, s);
+      dw(GenSeg{b.ctx, nullptr, d}, none, none, 1, 0, tA2, d, d, A, rn + "/dense_1");
+      dx(tA2, A, d, d, WT(rn + "/dense_1"), dXr, dXr);  // + the residual branch
+      dCtx = dXr;
+    }
+    lnb(b.t1, nullptr, la + "/layer_norm", dCtx, A, dT1);
+    launch_gen_attn_bwd(b.q, b.K, db->edge_offset, A, d, H, db->max_degree, dT1, kp.attn_p, DROP_TAG_ATTN + (unsigned)l, kp.seed, dQ, dK, s);
+    dw(GenSeg{b.cc_in, nullptr, d}, none, none, 1, 0, dQ, d, d, A, la + "/query");
+    dw(GenSeg{b.cc_in, db->edge_col, d}, GenSeg{b.Gn, nullptr, d}, none, 2, 1, dK, d, d, E, la + "/key");
+    dx(dQ, A, d, d, WT(la + "/query"), nullptr, dC_other);
+    dx(dK, E, d, d, WT(la + "/key"), nullptr, dang);  // gradient of the gated rows c[j] * g (attention.py:157)
+    if (c.g_update) {
+      launch_gen_mul_gather(dang, b.cc_in, db->edge_col, dGn, E, d, dGt, s);  // d g' = dang * c[j] + what the layer above left
+      lnb(b.T, nullptr, la + "/layer_norm_g", dGt, E, dT);
+      launch_gen_act_bwd(dT, b.Z, nullptr, E, d, 0.f, 0, 0, dZ, s);
+      dw(GenSeg{b.cc_in, db->edge_row, d}, GenSeg{b.G_in, nullptr, d}, GenSeg{b.cc_in, db->edge_col, d}, 3, 0, dZ, 3 * d, d, E, la + "/filter_geo");
+      dx(dZ, E, d, d, WT(la + "/filter_geo", 0), nullptr, dXi);
+      dx(dZ, E, d, d, WT(la + "/filter_geo", 1), dT, dG_next);  // + the residual geometry (attention.py:152)
+      dx(dZ, E, d, d, WT(la + "/filter_geo", 2), nullptr, dXj);
+      launch_gen_edge_to_atom(db->edge_offset, db->in_off, db->in_edge, dXi, dXj, dang, b.Gn, dC_other, A, d, dC_other, s);
+      dGn = dG_next;
+      std::swap(dG_next, dG_spare);
+    } else {  // g = swish(basis . Wf + bf) * Voronoi weight (attention.py:159-163)
+      launch_gen_mul_gather(dang, b.cc_in, db->edge_col, nullptr, E, d, dGt, s);
+      launch_gen_act_bwd(dGt, b.Z, db->weight, E, d, 0.f, 0, 0, dZ, s);
+      dw(GenSeg{kp.gd, nullptr, NG}, none, none, 1, 0, dZ, NG, d, E, la + "/filter_geo");
+      launch_gen_edge_to_atom(db->edge_offset, db->in_off, db->in_edge, nullptr, nullptr, dang, b.Gn, dC_other, A, d, dC_other, s);
+    }
+    std::swap(dC, dC_other);
+  }
+  // ---- basis MLP of the initial geometry (scann_model.py:386-391) ----
+  if (c.g_update && dGn) {
+    launch_gen_mul_gather(dGn, kp.Tw, nullptr, nullptr, E, d, dT, s);
+    launch_gen_act_bwd(dT, kp.pre_d, nullptr, E, d, 0.f, 0, 0, dT, s);
+    dw(GenSeg{kp.gd, nullptr, NG}, none, none, 1, 0, dT, NG, d, E, "neighbor_d");
+    launch_gen_mul_gather(dGn, kp.Td, nullptr, nullptr, E, d, dZ, s);
+    launch_gen_act_bwd(dZ, kp.pre_w, nullptr, E, d, 0.f, 0, 0, dZ, s);
+    dw(GenSeg{kp.gw, nullptr, NG}, none, none, 1, 0, dZ, NG, d, E, "neighbor_w");
+  }
+  // ---- embedding (scann_model.py:362-374) ----
+  launch_gen_act_bwd(dC, kp.pre_e, nullptr, A, d, kp.drop_p, DROP_TAG_EMBED, kp.seed, tA1, s);
+  const GenSeg e0 = c.feature_cgcnn ? GenSeg{kp.embE, nullptr, emb} : GenSeg{Wp("embed_atom/embeddings"), db->atomic, emb};
+  if (c.use_ring) dw(e0, GenSeg{kp.ring10, nullptr, 10}, none, 2, 0, tA1, cin, d, A, "dense_embed");
+  else dw(e0, none, none, 1, 0, tA1, emb, d, A, "dense_embed");
+  dx(tA1, A, d, emb, WT("dense_embed", 0), nullptr, dv);
+  if (c.feature_cgcnn) dw(GenSeg{db->cgcnn, nullptr, 92}, none, none, 1, 0, dv, 92, emb, A, "embed_atom");
+  else launch_gen_table_grad(db->atomic, A, dv, emb, c.n_atoms, G("embed_atom/embeddings"), s);
+  if (c.use_ring) {
+    dx(tA1, A, d, 10, WT("dense_embed", 1), nullptr, dv);
+    dw(GenSeg{db->ring, nullptr, 2}, none, none, 1, 0, dv, 2, 10, A, "extra_embed");
+  }
+  HIPCHK(h, hipGetLastError());
+  return SCANN_OK;
+}
+
 static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2, int zero_g) {
   hipStream_t s = h->streams[0];
   h->t_step += 1;
@@ -2380,6 +2666,10 @@ static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, fl
   const size_t n = h->host_master.size();
   // t_l2 holds a 0/1 mask; fold the coefficient in by scaling through the kernel argument
   launch_adam(h->t_master, h->t_grad, h->t_m, h->t_v, h->t_l2, n, lr_hat, beta1, beta2, eps, l2, zero_g, s);
+  if (h->generic) {  // the plain kernels read the Keras tensors as they are: the forward's copy is the master vector
+    HIPCHK(h, hipMemcpyAsync(h->g_weights, h->t_master, n * 4, hipMemcpyDeviceToDevice, s));
+    return SCANN_OK;
+  }
   launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, h->range_flag, s);
   h->sp_dirty = true;
   if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
@@ -2503,11 +2793,15 @@ int scann_broadcast_weights(scann_handle_t* h, int root) {
   hipStream_t s = h->streams[0];
   const ncclResult_t r = ncclBroadcast(h->t_master, h->t_master, h->host_master.size(), ncclFloat, root, h->comm, s);
   if (r != ncclSuccess) return fail(h, SCANN_ERR_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
-  launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, h->range_flag, s);
-  h->sp_dirty = true;
-  if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
-    launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
-                     h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
+  if (h->generic) {
+    HIPCHK(h, hipMemcpyAsync(h->g_weights, h->t_master, h->host_master.size() * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    launch_repack(h->t_descs, (int)h->descs.size(), h->t_master, h->d_weights, h->range_flag, s);
+    h->sp_dirty = true;
+    if (!h->cfg.use_ring && !h->cfg.feature_cgcnn)
+      launch_embed_lut(h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, h->cfg.n_atoms,
+                       h->cfg.embedding_dim, h->d_weights + h->o_lut, s);
+  }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(h->host_master.data(), h->t_master, h->host_master.size() * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));

@@ -719,3 +719,169 @@ def test_batch_uploaded_before_training_mode_trains_the_same(hip_lib):
         assert np.array_equal(grads[0][k], grads[1][k]) or np.allclose(grads[0][k], grads[1][k], rtol=1e-5, atol=1e-8), k
     late.free()
     early.free()
+
+
+# ---- widths other than 128 / 8: the plain-fp32 training kernels of csrc/scann_generic_train.hip ----
+
+OTHER_WIDTHS = {
+    "64x4": dict(local_dim=64, num_head=4, global_dim=96, dense_out=32),
+    "192x6_L3": dict(local_dim=192, num_head=6, global_dim=160, dense_out=200, n_attention=3),
+    "48x48_base_plain": dict(local_dim=48, num_head=48, global_dim=16, dense_out=8, g_update=False, use_attn_norm=False, use_ga_norm=False),
+    "32x1_ring": dict(local_dim=32, num_head=1, global_dim=300, dense_out=128, use_ring=True),
+    "128x16": dict(local_dim=128, num_head=16, global_dim=128, dense_out=128),
+    "96x8_cgcnn": dict(local_dim=96, num_head=8, global_dim=64, dense_out=64, feature="cgcnn"),
+    "40x5_e_b": dict(local_dim=40, num_head=5, global_dim=24, dense_out=72, n_attention=1),
+}
+
+
+def setup_widths(over, n=6, seed=1, target=None):
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    cfg = so.default_config("qm9")
+    cfg["model"]["n_attention"] = 2
+    cfg["model"].update(over)
+    cfg["model"]["n_atoms"] = 100
+    if target:
+        cfg["hyper"]["target"] = target
+    ring, cg = bool(cfg["model"].get("use_ring")), cfg["model"].get("feature") == "cgcnn"
+    w = so.init_weights(cfg, 3, perturb=True)
+    de, dn = so.synth_dataset(n, seed, use_ring=ring)
+    inputs, targets = so.pad_batch(de, dn, cfg["model"]["g_update"], use_ring=ring)
+    if cg:
+        table = np.random.default_rng(5).integers(0, 2, size=(101, 92)).astype("float32")
+        inputs["atomic"] = table[inputs["atomic"]]
+    pk = _hip.pack_inputs(inputs)
+    model = HipModel(cfg, w, device=0)
+    return cfg, w, pk, targets, model
+
+
+@pytest.mark.parametrize("name", list(OTHER_WIDTHS))
+def test_gradients_at_other_widths(hip_lib, name):
+    """The reference compiles and fits whatever create_model built (scann_model.py:199-241 on :330-434).  A handle whose widths are
+    not 128 / 8 trains on the plain-fp32 kernels (csrc/scann_generic_train.hip); its gradients are held to the rule of the
+    128-wide path (check_grads: the fp64 autograd of the torch graph, slack relative to the same graph in fp32), on both LocalAttention
+    branches, with the ring / cgcnn embeddings, and through mrelu (target e_b).  Two backward calls accumulate."""
+    cfg, w, pk, targets, model = setup_widths(OTHER_WIDTHS[name], target="e_b" if name.endswith("e_b") else None)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    rmse, _ = check_grads(got, cfg, w, pk, targets)
+    assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6)
+    eng.train_backward(rb, sse, pk.n_struct)
+    g2 = eng.get_grads()
+    for k in got:
+        assert np.allclose(g2[k], 2 * got[k], rtol=1e-5, atol=1e-9 + 1e-6 * np.abs(got[k]).max()), k
+    # the training forward (Dropout off) is the inference forward: same kernels up to the property head
+    y_inf = model.predict(pk)
+    assert abs(float(np.sum((np.asarray(y_inf).ravel() - np.asarray(targets).ravel()) ** 2)) - sse) <= 1e-4 * max(sse, 1e-9)
+    rb.free()
+
+
+def test_plain_fp32_training_cross_checks_the_mfma_path(hip_lib, monkeypatch):
+    """Two independent GPU implementations of the training step on the 128 / 8 QM9 config: the split-fp16 MFMA kernels and the plain-fp32
+    kernels (SCANN_GENERIC=1).  Same gradients to the fp32 floor, and three Adam steps with the Dropout layers active (the masks are a
+    function of (seed, layer, element) in both) end in the same weights."""
+    from scann.models.scann_model import HipModel
+
+    cfg, w, pk, targets, fast = setup(n=12, L=2, seed=6)
+    monkeypatch.setenv("SCANN_GENERIC", "1")
+    plain = HipModel(cfg, w, device=0)
+    monkeypatch.delenv("SCANN_GENERIC")
+    out = {}
+    for name, model in (("mfma", fast), ("plain", plain)):
+        eng = model.engine
+        eng.train_begin()
+        rb = eng.upload(pk)
+        sse = eng.train_forward(rb, targets)
+        eng.zero_grads()
+        eng.train_backward(rb, sse, pk.n_struct)
+        g = eng.get_grads()
+        check_grads(g, cfg, w, pk, targets)
+        sses = []
+        for step in range(3):
+            s_, cnt = eng.train_step(rb, targets, 1e-3, dropout=0.1, seed=40 + step)
+            assert cnt == pk.n_struct
+            sses.append(s_)
+        out[name] = (sse, g, sses, eng.get_weights())
+        rb.free()
+    (sse_a, ga, sa, wa), (sse_b, gb, sb, wb) = out["mfma"], out["plain"]
+    assert abs(sse_a - sse_b) <= 1e-4 * sse_a
+    for k in ga:
+        scale = max(float(np.abs(ga[k]).max()), 1e-12)
+        assert float(np.abs(ga[k] - gb[k]).max()) <= 2e-4 * scale, k
+    assert np.allclose(sa, sb, rtol=2e-3), (sa, sb)
+    for k in wa:  # Adam moves a weight by ~lr * sign(g): where |g| sits at the rounding floor the two paths may step apart (<= 2 lr a step)
+        diff = np.abs(wa[k] - wb[k]).ravel()
+        assert float(np.quantile(diff, 0.9)) <= 2e-4 and float(diff.max()) <= 6.5e-3, (k, float(np.quantile(diff, 0.9)), float(diff.max()))
+
+
+def test_attention_dropout_gradients_at_other_widths(hip_lib):
+    """use_drop on a generic-width handle: the mask of gen_attn_kernel (element = edge * num_head + head), rebuilt on the host, is fed to
+    the torch graph; gradients match.  And the Dropout(0.1) layers are active, seed-keyed and reproducible to the bit."""
+    cfg, w, pk, targets, model = setup_widths(OTHER_WIDTHS["64x4"], seed=2)
+    H = cfg["model"]["num_head"]
+    eng = model.engine
+    eng.train_begin()
+    eng.set_attention_dropout(0.3)
+    rb = eng.upload(pk)
+    seed = 4242
+    sse = eng.train_forward(rb, targets, dropout=0.0, seed=seed)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    idx = np.arange(pk.n_edge * H, dtype=np.uint64)
+    scales = [drop_scale_np(seed, 2000 + l, idx, 0.3).reshape(pk.n_edge, H) for l in range(2)]
+    rmse, _ = check_grads(got, cfg, w, pk, targets, attn_scale=scales)
+    assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6)
+    eng.set_attention_dropout(0.0)
+    s0 = eng.train_forward(rb, targets)
+    grads = []
+    for sd in (1, 2, 1):
+        s_ = eng.train_forward(rb, targets, dropout=0.1, seed=sd)
+        eng.zero_grads()
+        eng.train_backward(rb, s_, pk.n_struct)
+        grads.append((s_, eng.get_grads()))
+    assert grads[0][0] != s0 and grads[0][0] != grads[1][0] and grads[0][0] == grads[2][0]
+    for k in grads[0][1]:  # no atomics anywhere on this path: the same step twice gives the same BITS
+        assert np.array_equal(grads[0][1][k], grads[2][1][k]), k
+    rb.free()
+
+
+def test_fit_at_other_widths_lowers_the_loss(hip_lib):
+    """train_step on a generic-width handle: Adam (tf.keras formula, l2 regulariser) against the NumPy restatement for one step, then
+    the loss of a fixed batch goes down over 30 steps and the inference forward sees the updated weights."""
+    import torch_ref
+    from scann.models.scann_model import HipModel
+
+    cfg, w, pk, targets, model = setup_widths(OTHER_WIDTHS["64x4"], n=16, seed=9)
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    sse0 = eng.train_forward(rb, targets)
+    eng.zero_grads()
+    eng.train_backward(rb, sse0, pk.n_struct)
+    g = eng.get_grads()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-7
+    eng.adam_step(lr)
+    got = eng.get_weights()
+    for k in w:
+        gi = g[k].astype(np.float64) + (2e-4 * w[k].astype(np.float64) if k.endswith(torch_ref.REGULARIZED) else 0.0)
+        m, v = (1 - b1) * gi, (1 - b2) * gi * gi
+        ref = w[k].astype(np.float64) - lr * np.sqrt(1 - b2) / (1 - b1) * m / (np.sqrt(v) + eps)
+        assert np.allclose(got[k], ref, rtol=1e-4, atol=2e-6), k
+    t2 = np.asarray(targets) * 0.5 + 0.3
+    first = last = None
+    for step in range(30):
+        sse, cnt = eng.train_step(rb, t2, 2e-3, dropout=0.0, seed=step)
+        first = sse if first is None else first
+        last = sse
+    assert last < 0.5 * first, (first, last)
+    y_new, _ = eng.forward(pk)
+    y_fresh = HipModel(cfg, eng.get_weights(), device=0).predict(pk)
+    assert np.allclose(np.asarray(y_new).ravel(), np.asarray(y_fresh).ravel(), rtol=1e-5, atol=1e-6)
+    rb.free()
