@@ -3,7 +3,7 @@
 // reference compiles and fits whatever create_model built (scann_model.py:199-241); every shipped yaml is 128 / 8 and trains on the
 // MFMA kernels of scann_train.hip / scann_train_fused.hip, which are written for exactly those widths.
 //
-// No atomics anywhere: every sum has a fixed order (weight gradients: 32-row chunks in row order; per-atom sums: the atom's own CSR
+// No atomics anywhere: every sum has a fixed order (weight gradients: 32-row chunks in row order, row slabs in slab order; per-atom sums: the atom's own CSR
 // row, then its incoming edges in reverse-adjacency order; LayerNorm gamma / beta: row chunks, then chunk order), so a step is
 // bit-reproducible like the 128-wide one.
 //
@@ -15,7 +15,7 @@
 //   gen_attn_bwd_kernel       per atom: softmax / logits / context backward (attention.py:170-212), Dropout on the attention weights
 //   gen_pool_bwd_kernel       per structure: GlobalAttention pooling backward (attention.py:279-316)
 //   gen_edge_to_atom_kernel   d c[a] = [d c[a]] + sum over a's own edges + sum over the edges that have a as their neighbour
-//   gen_table_grad_kernel     Embedding gradient: rows of d v summed per species
+//   gen_table_part / _final   Embedding gradient: rows of d v summed per species (per 64-atom chunk, then chunk order)
 #include "scann_internal.h"
 #include "scann_mma.h"
 
@@ -36,6 +36,21 @@ __device__ __forceinline__ float gt_wave_max64(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
+}
+
+// sum of p[0], p[stride], ... p[(n - 1) * stride] in that order; eight loads in flight (the additions keep their order)
+__device__ __forceinline__ float gt_ordered_sum(const float* __restrict__ p, int n, size_t stride) {
+  float s = 0.f;
+  int c = 0;
+  for (; c + 8 <= n; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(c + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; c < n; ++c) s += p[(size_t)c * stride];
+  return s;
 }
 
 // dst[o * kn + kk] = src[(k0 + kk) * N + o]: rows [k0, k0 + kn) of a row-major [*, N] kernel, transposed
@@ -75,41 +90,54 @@ __global__ void gen_relu_kernel(float* __restrict__ y, int n) {
   if (i < n) y[i] = fmaxf(y[i], 0.f);
 }
 
-// dW[k][o] += sum_r X[r][k] dZ[r][o] for a 32 x 32 tile of dW per workgroup: the rows are walked in 32-row chunks staged in LDS (X
-// assembled from its gathered segments, or as the product of two), a chunk's partial sum is formed first and added to the running
-// sum second (two-level: the rounding error of a 40 k-row sum stays that of ~1.3 k additions).  Workgroups of the first tile row also
-// form db[o] += sum_r dZ[r][o].
+// dW[k][o] = sum_r X[r][k] dZ[r][o]: a workgroup owns a 32 x 32 tile of dW and ONE SLAB of the rows (blockIdx.z), walked in 32-row
+// chunks staged in LDS (X assembled from its gathered segments, or as the product of two; the next chunk's elements are requested
+// before the current chunk is multiplied).  A chunk's partial sum is formed first and added to the running sum second (two-level:
+// the rounding error of a long sum stays that of a few dozen additions), the slab's tile goes to part[slab][K][N] (+ [slab][N] column
+// sums of dZ behind the tiles, written by the first tile row) and gen_dw_reduce_kernel adds the slabs in order into dW / db.
 __global__ __launch_bounds__(256) void gen_dense_dw_kernel(GenDwArgs a) {
 #pragma clang fp contract(off)
   __shared__ float sXc[32][33], sZc[32][33];
   const int tid = threadIdx.x, k0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
   const int tk = tid >> 4, to = tid & 15;  // this thread's outputs: k = k0 + tk + {0, 16}, o = o0 + to + {0, 16}
+  const int rbeg = blockIdx.z * a.slab_rows, rend = min(a.rows, rbeg + a.slab_rows);
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bacc[2] = {0.f, 0.f};
-  const bool bias = a.db && blockIdx.x == 0 && tk == 0;
-  for (int r0 = 0; r0 < a.rows; r0 += 32) {
-    for (int i = tid; i < 32 * 32; i += 256) {
-      const int rr = i >> 5, kk = i & 31;
+  float xr[4], zr[4];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j, rr = i >> 5, kk = i & 31;
       const int r = r0 + rr, k = k0 + kk, o = o0 + kk;
       float xv = 0.f, zv = 0.f;
-      if (r < a.rows) {
+      if (r < rend) {
         if (k < a.K) {
           if (a.prod) {
             xv = a.seg[0].p[(size_t)(a.seg[0].idx ? a.seg[0].idx[r] : r) * a.K + k] * a.seg[1].p[(size_t)(a.seg[1].idx ? a.seg[1].idx[r] : r) * a.K + k];
           } else {
-            int kq = k, s = 0;
-            while (s < a.n_seg - 1 && kq >= a.seg[s].w) {
-              kq -= a.seg[s].w;
-              ++s;
+            int kq = k, sg = 0;
+            while (sg < a.n_seg - 1 && kq >= a.seg[sg].w) {
+              kq -= a.seg[sg].w;
+              ++sg;
             }
-            xv = a.seg[s].p[(size_t)(a.seg[s].idx ? a.seg[s].idx[r] : r) * a.seg[s].w + kq];
+            xv = a.seg[sg].p[(size_t)(a.seg[sg].idx ? a.seg[sg].idx[r] : r) * a.seg[sg].w + kq];
           }
         }
         if (o < a.N) zv = a.dZ[(size_t)r * a.N + o];
       }
-      sXc[rr][kk] = xv;
-      sZc[rr][kk] = zv;
+      xr[j] = xv;
+      zr[j] = zv;
+    }
+  };
+  if (rbeg < rend) fetch(rbeg);
+  for (int r0 = rbeg; r0 < rend; r0 += 32) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j;
+      sXc[i >> 5][i & 31] = xr[j];
+      sZc[i >> 5][i & 31] = zr[j];
     }
     __syncthreads();
+    if (r0 + 32 < rend) fetch(r0 + 32);
     float p[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, bp[2] = {0.f, 0.f};
 #pragma unroll 8
     for (int rr = 0; rr < 32; ++rr) {
@@ -125,19 +153,28 @@ __global__ __launch_bounds__(256) void gen_dense_dw_kernel(GenDwArgs a) {
     bacc[0] += bp[0]; bacc[1] += bp[1];
     __syncthreads();
   }
+  float* pt = a.part + (size_t)blockIdx.z * a.K * a.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k = k0 + tk + 16 * i, o = o0 + to + 16 * j;
-      if (k < a.K && o < a.N) a.dW[(size_t)k * a.N + o] += acc[i][j];
+      if (k < a.K && o < a.N) pt[(size_t)k * a.N + o] = acc[i][j];
     }
-  if (bias)
+  if (a.db && blockIdx.x == 0 && tk == 0) {
+    float* pb = a.part + (size_t)gridDim.z * a.K * a.N + (size_t)blockIdx.z * a.N;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int o = o0 + to + 16 * j;
-      if (o < a.N) a.db[o] += bacc[j];
+      if (o < a.N) pb[o] = bacc[j];
     }
+  }
+}
+// dW[i] += sum over the slabs, in slab order, of part[slab][i]; db likewise
+__global__ void gen_dw_reduce_kernel(const float* __restrict__ part, int n_slab, int KN, int N, float* __restrict__ dW, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < KN) dW[i] += gt_ordered_sum(part + i, n_slab, (size_t)KN);
+  else if (db && i < KN + N) db[i - KN] += gt_ordered_sum(part + (size_t)n_slab * KN + (i - KN), n_slab, (size_t)N);
 }
 
 // one wave per row.  x = X (+ res) is the LayerNorm's input; xhat = (x - mean) rstd; g = dY gamma;
@@ -185,7 +222,24 @@ __global__ void gen_ln_param_kernel(const float* __restrict__ X, const float* __
   if (k >= N) return;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float sg = 0.f, sb = 0.f;
-  for (int r = r0; r < r1; ++r) {
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {  // four rows requested together; the additions keep the row order
+    float x[4], dd[4], mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t i = (size_t)(r + j) * N + k;
+      x[j] = res ? X[i] + res[i] : X[i];
+      dd[j] = dY[i];
+      mu[j] = stats[2 * (size_t)(r + j)];
+      rs[j] = stats[2 * (size_t)(r + j) + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sg += dd[j] * ((x[j] - mu[j]) * rs[j]);
+      sb += dd[j];
+    }
+  }
+  for (; r < r1; ++r) {
     const size_t i = (size_t)r * N + k;
     const float x = res ? X[i] + res[i] : X[i];
     const float xh = (x - stats[2 * (size_t)r]) * stats[2 * (size_t)r + 1], d = dY[i];
@@ -198,13 +252,8 @@ __global__ void gen_ln_param_kernel(const float* __restrict__ X, const float* __
 __global__ void gen_ln_param_final_kernel(const float* __restrict__ part, int n_chunk, int N, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= N) return;
-  float sg = 0.f, sb = 0.f;
-  for (int c = 0; c < n_chunk; ++c) {
-    sg += part[((size_t)c * 2) * N + k];
-    sb += part[((size_t)c * 2 + 1) * N + k];
-  }
-  dgamma[k] += sg;
-  dbeta[k] += sb;
+  dgamma[k] += gt_ordered_sum(part + k, n_chunk, (size_t)2 * N);
+  dbeta[k] += gt_ordered_sum(part + N + k, n_chunk, (size_t)2 * N);
 }
 
 // one workgroup per atom (the forward: gen_attn_kernel).  P = softmax of the scaled logits per head, P' = P * Dropout scale;
@@ -387,20 +436,28 @@ __global__ void gen_edge_to_atom_kernel(const int32_t* __restrict__ edge_offset,
   out[i] = s;
 }
 
-// dTable[z][k] += sum over the atoms of species z of dV[a][k] (a thread per table element, atoms in order)
-__global__ void gen_table_grad_kernel(const int32_t* __restrict__ atomic, int n_atom, const float* __restrict__ dV, int emb, int n_species,
-                                      float* __restrict__ dTable) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_species * emb) return;
-  const int z = i / emb, k = i - z * emb;
-  float s = 0.f;
-  bool any = false;
-  for (int a = 0; a < n_atom; ++a)
-    if (atomic[a] == z) {
+// Embedding gradient, two stages.  part[chunk][z][:] = sum over the atoms of species z among the chunk's 64 atoms of dV[a][:], atoms in
+// order (a wave per (species, chunk): one ballot over the chunk's atomic numbers, lanes over the columns); then
+// dTable[z][:] += the chunks' sums in chunk order.
+__global__ __launch_bounds__(64) void gen_table_part_kernel(const int32_t* __restrict__ atomic, int n_atom, const float* __restrict__ dV, int emb, int n_species,
+                                                           float* __restrict__ part) {
+  const int z = blockIdx.x, a0 = blockIdx.y * 64, lane = threadIdx.x;
+  const unsigned long long m0 = __ballot(a0 + lane < n_atom && atomic[a0 + lane] == z);
+  float* out = part + ((size_t)blockIdx.y * n_species + z) * emb;
+  for (int k = lane; k < emb; k += 64) {
+    float s = 0.f;
+    unsigned long long m = m0;
+    while (m) {
+      const int a = a0 + __ffsll((long long)m) - 1;
+      m &= m - 1;
       s += dV[(size_t)a * emb + k];
-      any = true;
     }
-  if (any) dTable[i] += s;
+    out[k] = s;
+  }
+}
+__global__ void gen_table_final_kernel(const float* __restrict__ part, int n_chunk, int n, float* __restrict__ dTable) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dTable[i] += gt_ordered_sum(part + i, n_chunk, (size_t)n);
 }
 
 }  // namespace
@@ -424,11 +481,25 @@ void launch_gen_relu(float* y, int n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(gen_relu_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, n);
 }
-void launch_gen_dense_dw(const GenDwArgs& a, hipStream_t s) {
-  if (a.rows <= 0 || a.K <= 0 || a.N <= 0) return;
-  hipLaunchKernelGGL(gen_dense_dw_kernel, dim3((a.K + 31) / 32, (a.N + 31) / 32), dim3(256), 0, s, a);
+// slabs of a weight gradient over `rows` rows: enough workgroups to fill the chip (~1024 with the K x N tiles), at least one 32-row
+// chunk per slab, and <= 32 Mi floats of partial tiles
+int gen_dw_slabs(int rows, int K, int N) {
+  const int tiles = ((K + 31) / 32) * ((N + 31) / 32), chunks = (rows + 31) / 32;
+  int s = std::max(1, std::min(std::min(64, chunks), (1024 + tiles - 1) / tiles));
+  while (s > 1 && (size_t)s * ((size_t)K * N + N) > ((size_t)32 << 20)) --s;
+  return s;
 }
-int gen_ln_chunks(int rows) { return std::max(1, std::min(64, (rows + 255) / 256)); }
+size_t gen_dw_part_floats(int rows, int K, int N) { return (size_t)gen_dw_slabs(rows, K, N) * ((size_t)K * N + N); }
+void launch_gen_dense_dw(const GenDwArgs& a0, hipStream_t s) {
+  if (a0.rows <= 0 || a0.K <= 0 || a0.N <= 0) return;
+  GenDwArgs a = a0;
+  const int n_slab = gen_dw_slabs(a.rows, a.K, a.N);
+  a.slab_rows = (((a.rows + n_slab - 1) / n_slab) + 31) / 32 * 32;
+  hipLaunchKernelGGL(gen_dense_dw_kernel, dim3((a.K + 31) / 32, (a.N + 31) / 32, n_slab), dim3(256), 0, s, a);
+  const int n = a.K * a.N + (a.db ? a.N : 0);
+  hipLaunchKernelGGL(gen_dw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, n_slab, a.K * a.N, a.N, a.dW, a.db);
+}
+int gen_ln_chunks(int rows) { return std::max(1, std::min(512, (rows + 63) / 64)); }
 void launch_gen_layernorm_bwd(const float* X, const float* res, const float* gamma, const float* dY, int rows, int N, float* dX, float* stats,
                               float* part, float* dgamma, float* dbeta, hipStream_t s) {
   if (rows <= 0) return;
@@ -456,9 +527,11 @@ void launch_gen_edge_to_atom(const int32_t* edge_offset, const int32_t* in_off, 
   hipLaunchKernelGGL(gen_edge_to_atom_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, edge_offset, in_off, in_edge, S_out, S_in, P_a, P_b, acc,
                      n_atom, d, out);
 }
-void launch_gen_table_grad(const int32_t* atomic, int n_atom, const float* dV, int emb, int n_species, float* dTable, hipStream_t s) {
+void launch_gen_table_grad(const int32_t* atomic, int n_atom, const float* dV, int emb, int n_species, float* part, float* dTable, hipStream_t s) {
   if (n_atom <= 0) return;
-  hipLaunchKernelGGL(gen_table_grad_kernel, dim3((n_species * emb + 255) / 256), dim3(256), 0, s, atomic, n_atom, dV, emb, n_species, dTable);
+  const int n_chunk = (n_atom + 63) / 64, n = n_species * emb;  // part: n_chunk * n_species * emb floats
+  hipLaunchKernelGGL(gen_table_part_kernel, dim3(n_species, n_chunk), dim3(64), 0, s, atomic, n_atom, dV, emb, n_species, part);
+  hipLaunchKernelGGL(gen_table_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, n_chunk, n, dTable);
 }
 
 }  // namespace scann

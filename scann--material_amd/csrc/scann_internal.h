@@ -242,7 +242,11 @@ struct GenDwArgs {
   const float* dZ;  // [rows, N] gradient of the layer's pre-activation
   int32_t K, N, rows;
   float *dW, *db;   // [K, N], [N] (null: no bias): ACCUMULATED into
+  float* part;      // gen_dw_part_floats(rows, K, N) floats of per-slab partial tiles
+  int32_t slab_rows;  // (set by the launcher)
 };
+int gen_dw_slabs(int rows, int K, int N);
+size_t gen_dw_part_floats(int rows, int K, int N);
 void launch_gen_transpose(const GenTransDesc* descs, int n_desc, int max_elems, const float* W, float* WT, hipStream_t s);
 void launch_gen_act_bwd(const float* dY, const float* pre, const float* row_scale, int rows, int N, float drop_p, unsigned drop_tag,
                         unsigned long long drop_seed, float* out, hipStream_t s);
@@ -258,7 +262,8 @@ void launch_gen_pool_bwd(const int32_t* mol_offset, int n_struct, int max_atoms,
                          const float* drep, float* dgq, float* dgk, hipStream_t s);
 void launch_gen_edge_to_atom(const int32_t* edge_offset, const int32_t* in_off, const int32_t* in_edge, const float* S_out, const float* S_in,
                              const float* P_a, const float* P_b, const float* acc, int n_atom, int d, float* out, hipStream_t s);
-void launch_gen_table_grad(const int32_t* atomic, int n_atom, const float* dV, int emb, int n_species, float* dTable, hipStream_t s);
+// part: ceil(n_atom / 64) * n_species * emb floats of per-chunk sums
+void launch_gen_table_grad(const int32_t* atomic, int n_atom, const float* dV, int emb, int n_species, float* part, float* dTable, hipStream_t s);
 
 struct ReadoutArgs {
   const int32_t* mol_offset;  // [n_struct+1]

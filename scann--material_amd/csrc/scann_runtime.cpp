@@ -2533,8 +2533,13 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
   // ---- temporaries ----
   const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1), fB = (size_t)B;
   const size_t dmax = (size_t)std::max(d, std::max(dg, dout));
-  const size_t need = 4 * (fA * (8 * (size_t)d + 4 * (size_t)dg + (size_t)emb + 10) + fE * 9 * (size_t)d + fB * (2 * (size_t)dout + (size_t)dg) +
-                           2 * std::max(fA, fE) + 2 * 64 * dmax) + 256 * 48;
+  const size_t need0 = 4 * (fA * (8 * (size_t)d + 4 * (size_t)dg + (size_t)emb + 10) + fE * 9 * (size_t)d + fB * (2 * (size_t)dout + (size_t)dg) +
+                           2 * std::max(fA, fE) + 2 * 512 * dmax) + 256 * 48;
+  // per-slab partial tiles of a weight gradient (gen_dense_dw_kernel): slabs x tiles <= 1024 + tiles (gen_dw_slabs), 1024 floats a tile
+  const size_t Kmax = (size_t)std::max(std::max(3 * d, dg), std::max(std::max(dout, cin), 92));
+  const size_t wpart = (1024 + ((Kmax + 31) / 32) * ((dmax + 31) / 32)) * 1024 + 64 * dmax;
+  const size_t tpart = c.feature_cgcnn ? 0 : ((fA + 63) / 64) * (size_t)c.n_atoms * (size_t)emb;  // Embedding gradient: per-chunk sums
+  const size_t need = need0 + 4 * (wpart + tpart);
   if (kp.bbytes < need) {
     HIPCHK(h, hipStreamSynchronize(s));
     cached_free(kp.barena);
@@ -2550,7 +2555,7 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
   float *dK = take(fE * d), *dang = take(fE * d), *dGt = take(fE * d), *dT = take(fE * d), *dZ = take(fE * d), *dXi = take(fE * d), *dXj = take(fE * d);
   float *dGa = take(fE * d), *dGb = take(fE * d);
   float *dhid = take(fB * dout), *drep = take(fB * dg);
-  float *stats = take(2 * std::max(fA, fE)), *part = take(2 * 64 * dmax);
+  float *stats = take(2 * std::max(fA, fE)), *part = take(2 * 512 * dmax), *wp = take(wpart), *tp_ = take(tpart);
   if (reinterpret_cast<char*>(p) > kp.barena + kp.bbytes) return fail(h, SCANN_ERR_HIP, "backward (generic widths): workspace overrun");
   // ---- helpers ----
   launch_gen_transpose(h->d_gt_descs, (int)h->gt_descs.size(), h->gt_max, h->g_weights, h->g_WT, s);
@@ -2565,10 +2570,12 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
     a.W = wt; a.b = nullptr; a.K = n_out; a.N = n_in; a.rows = rows; a.res = res; a.Y = out;
     launch_gen_dense(a, s);
   };
+  bool part_overrun = false;
   auto dw = [&](GenSeg s0, GenSeg s1, GenSeg s2, int n_seg, int prod, const float* dZ_, int K_, int N_, int rows, const std::string& name) {
     GenDwArgs a{};
     a.seg[0] = s0; a.seg[1] = s1; a.seg[2] = s2; a.n_seg = n_seg; a.prod = prod;
-    a.dZ = dZ_; a.K = K_; a.N = N_; a.rows = rows; a.dW = G(name + "/kernel"); a.db = G(name + "/bias");
+    a.dZ = dZ_; a.K = K_; a.N = N_; a.rows = rows; a.dW = G(name + "/kernel"); a.db = G(name + "/bias"); a.part = wp;
+    if (rows > 0 && gen_dw_part_floats(rows, K_, N_) > wpart) { part_overrun = true; return; }
     launch_gen_dense_dw(a, s);
   };
   auto lnb = [&](const float* X, const float* res, const std::string& name, const float* dY, int rows, float* dX) {
@@ -2649,11 +2656,12 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
   else dw(e0, none, none, 1, 0, tA1, emb, d, A, "dense_embed");
   dx(tA1, A, d, emb, WT("dense_embed", 0), nullptr, dv);
   if (c.feature_cgcnn) dw(GenSeg{db->cgcnn, nullptr, 92}, none, none, 1, 0, dv, 92, emb, A, "embed_atom");
-  else launch_gen_table_grad(db->atomic, A, dv, emb, c.n_atoms, G("embed_atom/embeddings"), s);
+  else launch_gen_table_grad(db->atomic, A, dv, emb, c.n_atoms, tp_, G("embed_atom/embeddings"), s);
   if (c.use_ring) {
     dx(tA1, A, d, 10, WT("dense_embed", 1), nullptr, dv);
     dw(GenSeg{db->ring, nullptr, 2}, none, none, 1, 0, dv, 2, 10, A, "extra_embed");
   }
+  if (part_overrun) return fail(h, SCANN_ERR_HIP, "backward (generic widths): a weight gradient's partial tiles exceed their scratch");
   HIPCHK(h, hipGetLastError());
   return SCANN_OK;
 }

@@ -205,15 +205,19 @@ def _write_dataset(tmp_path, n=96, seed=5):
     return str(tmp_path / "data_energy.npy"), str(tmp_path / "data_nei.npy")
 
 
-def test_scann_train_evaluate_roundtrip(hip_lib, tmp_path):
+@pytest.mark.parametrize("widths", ["128x8", "64x4"])
+def test_scann_train_evaluate_roundtrip(hip_lib, tmp_path, widths):
     """SCANN.prepare_dataset -> train -> evaluate like train.py does: checkpoint, config.yaml, report.txt, hist_data.npy;
-    then infer mode from the checkpoint (predict_model.py path) reproduces the evaluation predictions."""
+    then infer mode from the checkpoint (predict_model.py path) reproduces the evaluation predictions.  Once at the shipped widths
+    (MFMA kernels) and once at local_dim 64 / 4 heads / global_dim 96 / dense_out 32 (the plain-fp32 kernels)."""
     import yaml
     from scann.models import SCANN
 
     e_path, n_path = _write_dataset(tmp_path)
     cfg = so.default_config("qm9")
     cfg["model"]["n_attention"] = 2
+    if widths == "64x4":
+        cfg["model"].update(OTHER_WIDTHS["64x4"])
     cfg["hyper"].update(batch_size=16, test_percent=0.125, scaler=True, scheduler="cosine", train_size="", test_size="",
                         data_size=96, data_nei_path=n_path, data_energy_path=e_path, lr=2e-3, min_lr=2e-4,
                         save_path=str(tmp_path / "run"), pretrained="", use_ref=False, target="homo")

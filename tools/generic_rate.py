@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Rate of the plain-fp32 forward (csrc/scann_generic.hip) on resident QM9-shaped batches, for the record: widths the MFMA kernels
-do not implement, and -- with SCANN_GENERIC=1 -- the 128 / 8 config itself beside the MFMA path.
+do not implement, and -- with SCANN_GENERIC=1 -- the 128 / 8 config itself beside the MFMA path; then the training step
+(scann_train_step on one resident 128-molecule batch, Dropout 0.1) of the same handles (csrc/scann_generic_train.hip).
   python3 tools/generic_rate.py [batches per launch = 8]"""
 import os, sys, time
 import numpy as np
@@ -35,4 +36,23 @@ for label, over, env in (("128 x 8 (MFMA kernels)", {}, None), ("128 x 8 (plain 
     eng.sync()
     dt = time.perf_counter() - t0
     print("%-40s %10.0f molecules/s  (%.2f ms per %d-molecule launch sequence)" % (label, n * pk.n_struct / dt, 1e3 * dt / n, pk.n_struct))
+    rb.free()
+    # training step on one batch of 128 (the reference's batch size), resident
+    if env:
+        os.environ["SCANN_GENERIC"] = env
+    tmodel = HipModel(cfg, device=0, seed=1234)
+    os.environ.pop("SCANN_GENERIC", None)
+    teng = tmodel.engine
+    teng.train_begin()
+    pk1 = bench.synth_packed_batch(np.random.default_rng(1), 128)
+    rb = teng.upload(pk1)
+    tgt = np.random.default_rng(2).normal(size=pk1.n_struct).astype(np.float32)
+    for i in range(3):
+        teng.train_step(rb, tgt, 1e-3, dropout=0.1, seed=i)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:
+        teng.train_step(rb, tgt, 1e-3, dropout=0.1, seed=n)
+        n += 1
+    dt = time.perf_counter() - t0
+    print("%-40s %10.2f ms per training step of %d molecules (%d atoms, %d edges)" % ("", 1e3 * dt / n, pk1.n_struct, pk1.n_atom, pk1.n_edge))
     rb.free()
