@@ -102,9 +102,10 @@ int scann_device_count(void);
 
 /* Replaces create_model(config) (scann_model.py:329).  local_dim = global_dim = dense_out = 128 with num_head = 8 (every shipped
  * reference yaml) runs on the split-fp16 MFMA kernels; any other widths the reference accepts (scann_model.py:330-434; here: each
- * <= 1024, local_dim a multiple of num_head) evaluate on the plain-fp32 kernels of csrc/scann_generic.hip -- same entry points, same
- * packed batch, inference only (scann_train_begin returns SCANN_ERR_UNSUPPORTED), about ten times slower at equal width.  Env
- * SCANN_GENERIC=1 forces that path for a 128 / 8 handle (the cross-check of tests/test_gpu_parity.py). */
+ * <= 1024, local_dim a multiple of num_head) evaluate AND train on the plain-fp32 kernels of csrc/scann_generic.hip /
+ * csrc/scann_generic_train.hip -- same entry points, same packed batch, about ten times slower at equal width (a training step
+ * about seven times).  Env SCANN_GENERIC=1 forces that path for a 128 / 8 handle (the cross-check of tests/test_gpu_parity.py and
+ * tests/test_gpu_training.py). */
 int scann_create(const scann_config_t* cfg, int device_id, scann_handle_t** out);
 void scann_destroy(scann_handle_t* h);
 const char* scann_last_error(const scann_handle_t* h); /* h may be NULL: last create error */
@@ -195,7 +196,8 @@ int scann_debug_stamps(scann_handle_t* h, scann_dbatch_t* db, uint64_t* out, int
 /* ---- training step: replaces model.compile(loss=rmse, Adam(lr, decay=1e-5)) + model.fit (scann_model.py:199-241) ----
  * Gradients are hand-written derivatives of the forward graph; parameters, gradients and Adam moments are flat fp32
  * vectors in scann_weight_name() order.  Every architecture switch of create_model is covered (g_update on/off,
- * use_attn_norm, use_ga_norm, use_ring, feature="cgcnn", target "e_b").
+ * use_attn_norm, use_ga_norm, use_ring, feature="cgcnn", target "e_b"), at the shipped widths (128 / 8: MFMA kernels) and at any
+ * other widths scann_create accepts (plain-fp32 kernels, every sum in a fixed order: a step is bit-reproducible on both).
  * Data-parallel use: every rank calls forward on its shard, the SSE / count are summed over ranks (host side or
  * scann_allreduce_sse), then backward, scann_allreduce_grads (one flat RCCL all-reduce), scann_adam_step. */
 int64_t scann_param_count(const scann_handle_t* h);
