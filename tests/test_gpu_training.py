@@ -28,7 +28,7 @@ def setup(n=6, L=2, seed=1, **model_over):
 GRAD_FLOOR, GRAD_SLACK, GRAD_CAP = 2e-5, 4.0, 2e-4
 
 
-def check_grads(got, cfg, w, pk, targets, attn_scale=None):
+def check_grads(got, cfg, w, pk, targets, attn_scale=None, cap=None):
     """Gradient parity rule.  Reference: fp64 autograd of the independent torch graph.  A single-precision step cannot be closer
     to it than the SAME graph run by torch in fp32 is, so every tensor is held to max(GRAD_FLOOR, GRAD_SLACK x that fp32
     error), and to GRAD_CAP overall.  (Measured, tests/manual/grad_floor.py: HIP errors 4e-7 ... 1.5e-5 of the tensor scale,
@@ -43,7 +43,7 @@ def check_grads(got, cfg, w, pk, targets, attn_scale=None):
             ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
             g32[k] = g32[k] - 2e-4 * w[k].astype(np.float64)
     e_gpu, e_32 = grad_errors(got, ref), grad_errors(g32, ref)
-    bad = {k: (e_gpu[k], e_32[k]) for k in ref if not e_gpu[k] <= min(GRAD_CAP, max(GRAD_FLOOR, GRAD_SLACK * e_32[k]))}
+    bad = {k: (e_gpu[k], e_32[k]) for k in ref if not e_gpu[k] <= min(cap or GRAD_CAP, max(GRAD_FLOOR, GRAD_SLACK * e_32[k]))}
     assert not bad, bad
     return rmse, e_gpu
 
@@ -888,4 +888,57 @@ def test_fit_at_other_widths_lowers_the_loss(hip_lib):
     y_new, _ = eng.forward(pk)
     y_fresh = HipModel(cfg, eng.get_weights(), device=0).predict(pk)
     assert np.allclose(np.asarray(y_new).ravel(), np.asarray(y_fresh).ravel(), rtol=1e-5, atol=1e-6)
+    rb.free()
+
+
+def test_gradients_at_other_widths_corner_batches(hip_lib):
+    """Generic-width training on the batches the 128-wide path has corner tests for: an atom with 130 neighbours and one with 70 among
+    ordinary molecules, an atom without neighbours and a one-atom structure (GlobalAttention without normalisation: the reference's
+    0 / 0 otherwise), a batch without any edge, and a model without LocalAttention layers."""
+    from scann import _hip
+    from scann.models.scann_model import HipModel
+
+    over = dict(local_dim=64, num_head=4, global_dim=96, dense_out=32, use_ga_norm=False)
+    cfg, w, _, _, model = setup_widths(over, n=2, seed=3)
+    cfg_n, w_n, _, _, model_n = setup_widths(dict(over, use_ga_norm=True), n=2, seed=3)  # the 140-atom structure: normalised scores
+    rng = np.random.default_rng(4)
+    A = 140
+    deg = {0: 70, 5: 130, 139: 65}
+    nb = []
+    for a in range(A):
+        dd = deg.get(a, int(rng.integers(1, 7)))
+        js = rng.choice(np.delete(np.arange(A), a), dd, replace=False)
+        nb.append([[6, int(j), float(rng.uniform(0.4, 3.5)), 1.0, float(rng.uniform(0.9, 4.0))] for j in js])
+    de, dn = so.synth_dataset(2, 3)
+    de3, dn3 = np.empty(3, dtype=object), np.empty(3, dtype=object)
+    de3[0], dn3[0] = de[0], dn[0]
+    de3[1], dn3[1] = [[int(z) for z in rng.choice([1, 6, 7, 8], A)], 0.3], nb
+    de3[2], dn3[2] = de[1], dn[1]
+    inputs, targets = so.pad_batch(de3, dn3, True)
+    big = _hip.pack_inputs(inputs)
+    lone = _hip.PackedBatch([6, 1, 8, 1], [0, 1, 4], [0, 0, 1, 2, 2], [2, 1], [1.1, 1.3], [0.9, 1.7])
+    bare = _hip.PackedBatch([6, 1, 8], [0, 1, 3], [0, 0, 0, 0], [], [], [])
+    model.engine.train_begin()
+    model_n.engine.train_begin()
+    for name, pk, tg in (("big", big, targets), ("lone", lone, np.array([0.3, -0.2], np.float32)), ("bare", bare, np.array([0.1, 0.4], np.float32))):
+        eng, cfg_, w_ = (model_n.engine, cfg_n, w_n) if name == "big" else (model.engine, cfg, w)
+        rb = eng.upload(pk)
+        sse = eng.train_forward(rb, tg)
+        eng.zero_grads()
+        eng.train_backward(rb, sse, pk.n_struct)
+        got = eng.get_grads()
+        # (un-normalised GlobalAttention scores, use_ga_norm=False: the query gradient is a difference of nearly equal terms -- d agg sums
+        #  to ~0 over a structure's atoms -- and the SAME graph in torch fp32 can sit above the overall cap (2.3e-4 in the L = 0 case
+        #  below); the cap is lifted for those models, the 4 x fp32 rule stands)
+        rmse, _ = check_grads(got, cfg_, w_, pk, tg, cap=None if name == "big" else 2e-3)
+        assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6), name
+        rb.free()
+    cfg0, w0, pk0, t0, model0 = setup_widths(dict(over, n_attention=0), n=5, seed=8)
+    eng0 = model0.engine
+    eng0.train_begin()
+    rb = eng0.upload(pk0)
+    sse = eng0.train_forward(rb, t0)
+    eng0.zero_grads()
+    eng0.train_backward(rb, sse, pk0.n_struct)
+    check_grads(eng0.get_grads(), cfg0, w0, pk0, t0, cap=2e-3)  # (un-normalised scores: the fp32 graph itself sits 2.3e-4 off)
     rb.free()

@@ -44,7 +44,8 @@ def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64
     reg = sum((W[k] ** 2).sum() for k in W if k.endswith(REGULARIZED)) * 1e-4
     loss = rmse + reg
     loss.backward()
-    return float(loss.detach()), float(rmse.detach()), {k: v.grad.numpy().astype(np.float64) for k, v in W.items()}, y.detach().numpy()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy().astype(np.float64) for k, v in W.items()}  # (None: a tensor the graph does not reach)
+    return float(loss.detach()), float(rmse.detach()), grads, y.detach().numpy()
 
 
 def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_scale=None):
