@@ -225,6 +225,7 @@ struct scann_dbatch {
   int32_t *in_off = nullptr, *in_edge = nullptr;  // reverse adjacency: edges sorted by their neighbour atom (backward pass)
   bool has_rev = false;          // in_off / in_edge are filled (uploads of a handle in training mode; else built on first backward)
   hipEvent_t upload_ev = nullptr;  // end of the asynchronous input copy (scann_batch_upload); null: the copy was synchronous
+  bool upload_done = false;        // ... and it has been seen complete: launches on the batch no longer wait for it (wait_upload)
   int32_t* tile_part = nullptr;  // per tile: partial slot of a chunk tile or -1 (null without big atoms)
   int32_t* big_tab = nullptr;    // per atom with > 64 neighbours: atom row, first slot, number of slots
   float* part_buf = nullptr;     // [n_slot][3][128] softmax state of the chunk tiles
@@ -247,6 +248,19 @@ struct scann_dbatch {
 static void free_train_ws(scann_dbatch* db);
 
 namespace {
+
+// The inputs' copy runs on the copy stream (scann_batch_upload returns when it is ENQUEUED): the first launches on the batch wait for
+// its event.  A resident batch is launched on again and again; once the event has been seen complete the wait -- a barrier packet
+// that costs the stream ~5 us even when it has nothing to wait for -- is left out.
+hipError_t wait_upload(scann_dbatch* db, hipStream_t s) {
+  if (!db->upload_ev || db->upload_done) return hipSuccess;
+  if (hipEventQuery(db->upload_ev) == hipSuccess) {
+    db->upload_done = true;
+    return hipSuccess;
+  }
+  (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error)
+  return hipStreamWaitEvent(s, db->upload_ev, 0);
+}
 
 int fail(scann_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -1355,7 +1369,7 @@ int run_forward(scann_handle* h, scann_dbatch* db, hipStream_t s, Timer* tm, boo
   if ((h->force_exact || h->weights_exact) && !h->debug && !h->in_train_forward) exact = true;
   db->idle = false;  // work is being enqueued on the batch (scann_batch_release)
   if (!h->loaded) return fail(h, SCANN_ERR_WEIGHTS, "forward: weights not loaded");
-  if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
+  HIPCHK(h, wait_upload(db, s));  // the inputs' copy (scann_batch_upload returned when it was enqueued)
   if (h->generic) {
     if (tm) { tm->mark(-1); }
     const int r = run_forward_generic(h, db, s, h->in_train_forward ? h->gen_keep : nullptr);
@@ -2199,7 +2213,7 @@ static int ensure_reverse(scann_handle_t* h, scann_dbatch_t* db) {
   if (db->has_rev) return SCANN_OK;
   const int A = db->n_atom, E = db->n_edge;
   hipStream_t s = h->streams[0];
-  if (db->upload_ev) HIPCHK(h, hipStreamWaitEvent(s, db->upload_ev, 0));
+  HIPCHK(h, wait_upload(db, s));
   std::vector<int32_t> col((size_t)std::max(E, 1)), in_off((size_t)A + 1, 0), in_edge((size_t)std::max(E, 1));
   if (E > 0) HIPCHK(h, hipMemcpyAsync(col.data(), db->edge_col, (size_t)E * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));

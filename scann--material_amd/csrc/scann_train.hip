@@ -462,11 +462,73 @@ __global__ __launch_bounds__(1024) void vec_reduce_kernel(WgradReduceSet set) {
   }
 }
 
+// both of the above in ONE launch (a layer's flush at batch 128: 7 matrices + <= 17 vectors): blocks [0, 16 n_mat) take the matrices
+// (1,024 elements each, wgrad_reduce_kernel's sum), the rest a vector each (vec_reduce_kernel's sum) -- the two used to be two
+// latency-bound launches one behind the other on the side stream, ~11 us each, and the step ends when the side stream does
+__global__ __launch_bounds__(1024) void wgrad_reduce_all_kernel(WgradReduceSet set, int n_mat) {
+  __shared__ float sg[8][D];
+  const int b = blockIdx.x;
+  if (b < 16 * n_mat) {
+    const WgradReduceEntry e = set.e[b >> 4];
+    const int idx = (b & 15) * 1024 + threadIdx.x;
+    if (idx >= e.numel) return;
+    const float* __restrict__ p = e.part + idx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= e.n_slab; k += 4) {
+      s0 += p[(size_t)k * e.numel];
+      s1 += p[(size_t)(k + 1) * e.numel];
+      s2 += p[(size_t)(k + 2) * e.numel];
+      s3 += p[(size_t)(k + 3) * e.numel];
+    }
+    for (; k < e.n_slab; ++k) s0 += p[(size_t)k * e.numel];
+    e.dst[idx] += (s0 + s1) + (s2 + s3);
+    return;
+  }
+  const WgradReduceEntry e = set.e[n_mat + (b - 16 * n_mat)];
+  const int col = threadIdx.x & (D - 1), grp = threadIdx.x >> 7;
+  const float* __restrict__ p = e.part + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = grp;
+  for (; k + 24 < e.n_slab; k += 32) {
+    s0 += p[(size_t)k * D];
+    s1 += p[(size_t)(k + 8) * D];
+    s2 += p[(size_t)(k + 16) * D];
+    s3 += p[(size_t)(k + 24) * D];
+  }
+  for (; k < e.n_slab; k += 8) s0 += p[(size_t)k * D];
+  sg[grp][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) t += sg[g2][col];
+    e.dst[col] += t;
+  }
+}
+
 void wgrad_flush(WgradCtx& ctx, hipStream_t s) {
   // the (destination, slots) records travel as kernel arguments: no table copy, so a flush can follow each layer's gradient
   // launch on the side stream
   std::vector<WgradReduceEntry> mats, vecs;
   for (const WgradReduceEntry& e : ctx.entries) (e.numel == D ? vecs : mats).push_back(e);
+  {
+    size_t bytes = 0;
+    bool fits = !mats.empty() && !vecs.empty() && mats.size() + vecs.size() <= (size_t)WGRAD_REDUCE_MAX;
+    for (const WgradReduceEntry& e : mats) {
+      bytes += (size_t)e.n_slab * e.numel * 4;
+      fits = fits && e.numel <= 16 * 1024;
+    }
+    if (fits && bytes < ((size_t)24 << 20)) {  // (beyond that the 16-byte-load shape of the matrix sum pays: below)
+      WgradReduceSet set{};
+      int n = 0;
+      for (const WgradReduceEntry& e : mats) set.e[n++] = e;
+      for (const WgradReduceEntry& e : vecs) set.e[n++] = e;
+      hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(16 * (unsigned)mats.size() + (unsigned)vecs.size()), dim3(1024), 0, s, set, (int)mats.size());
+      ctx.entries.clear();
+      return;
+    }
+  }
   for (size_t e0 = 0; e0 < mats.size(); e0 += WGRAD_REDUCE_MAX) {
     const int n = (int)std::min<size_t>(WGRAD_REDUCE_MAX, mats.size() - e0);
     WgradReduceSet set{};

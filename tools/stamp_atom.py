@@ -25,3 +25,8 @@ print("tiles", st.shape[0], "total cycles/tile mean", (st[:, 12] - st[:, 0]).mea
 for n, (i, j) in zip(names, zip(order[:-1], order[1:])):
     col = st[:, j] - st[:, i]
     print("%-22s mean %8.0f  median %8.0f  max %8.0f" % (n, col.mean(), np.median(col), col.max()))
+# launch-level picture: when the tiles start and end relative to the first start (all tiles of a <= 1,024-tile launch are resident at once)
+t0 = st[:, 0].min()
+start, end = st[:, 0] - t0, st[:, 12] - t0
+print("tile starts: median %d  p90 %d  max %d cycles after the first;  ends: median %d  p90 %d  max %d" %
+      (np.median(start), np.percentile(start, 90), start.max(), np.median(end), np.percentile(end, 90), end.max()))
