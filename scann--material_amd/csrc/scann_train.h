@@ -35,7 +35,7 @@ struct WgradReduceEntry {
   int32_t n_slab, numel;
 };
 constexpr int WGRAD_MAX_JOBS = 8;
-constexpr int WGRAD_REDUCE_MAX = 24;  // gradient tensors per reduce launch (one layer has <= 19)
+constexpr int WGRAD_REDUCE_MAX = 32;  // gradient tensors per reduce launch (a layer has <= 19; the last layer + the readout 29)
 struct WgradCtx {
   struct Job {
     const float *X, *dY;
