@@ -2337,10 +2337,11 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     const float* W[3];
     bool fresh = false;  // dC holds nothing yet: the terms ARE d loss / d centres (first use: dpreA.Wa^T of the readout)
   } pend;
+  hipStream_t tail_s = s;  // where the embedding chain goes (below)
   auto flush_pend = [&]() {
     if (pend.n)
       launch_linear_sum(pend.X[0], pend.W[0], pend.n > 1 ? pend.X[1] : nullptr, pend.n > 1 ? pend.W[1] : nullptr,
-                        pend.n > 2 ? pend.X[2] : nullptr, pend.n > 2 ? pend.W[2] : nullptr, dC, A, pend.fresh ? 0 : 1, s);
+                        pend.n > 2 ? pend.X[2] : nullptr, pend.n > 2 ? pend.W[2] : nullptr, dC, A, pend.fresh ? 0 : 1, tail_s);
     pend.n = 0;
     pend.fresh = false;
   };
@@ -2481,7 +2482,14 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     wgrad_add(wg, Gin, eU, fgk + (size_t)D * D, nullptr, E);  // dW2
     wgrad_add(wg, c_in, dP1, fgk, g(la + "filter_geo/bias"), A);
     wgrad_add(wg, c_in, dP3, fgk + (size_t)2 * D * D, nullptr, A);
-    if ((L - 1 - l) % fork_every == fork_every - 1 || l == 0) {
+    if (l == 0 && side && ev_sums) {
+      // The FIRST layer's gradient launch and its reductions are the longest thing left (the main stream only has the embedding chain,
+      // ~40 us): they stay on the main stream, with no hand-over in front of them, and the embedding chain goes to the side stream
+      // instead (0.830 -> 0.819 ms per step, eight alternations on one box: profiles/r05_notes.md)
+      wgrad_launch(wg, s);
+      wgrad_flush(wg, s);
+      tail_s = fork_after(ev_sums);
+    } else if ((L - 1 - l) % fork_every == fork_every - 1 || l == 0) {
       // every weight gradient of this layer (ResidualNorm 2, key, query, filter_geo 3) in ONE launch, then the fixed-order sum of its
       // partial slots (and of the layer's LayerNorm gamma / beta slots): both beside the chains of the layers below
       hipStream_t ws = ev_sums ? fork_after(ev_sums) : fork();
@@ -2501,7 +2509,7 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
   if (dG_in && !basis_done) basis_leaf(dG_in, nullptr);
   flush_pend();
   if (c.use_ring || c.feature_cgcnn) {
-    launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, s);
+    launch_dropout(dC, nA, w.seed, DROP_TAG_EMBED, w.drop_p, tail_s);
     EmbedArgs e = h->embed;
     e.n_atom = A; e.atomic = db->atomic; e.c0 = db->c0;
     e.ring = c.use_ring ? db->ring : nullptr;
@@ -2509,11 +2517,11 @@ static int backward_impl(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& 
     launch_embed_general_bwd(e, dC, c.feature_cgcnn ? nullptr : g("embed_atom/embeddings"),
                              c.feature_cgcnn ? g("embed_atom/kernel") : nullptr, c.feature_cgcnn ? g("embed_atom/bias") : nullptr,
                              c.use_ring ? g("extra_embed/kernel") : nullptr, c.use_ring ? g("extra_embed/bias") : nullptr,
-                             g("dense_embed/kernel"), g("dense_embed/bias"), s);
+                             g("dense_embed/kernel"), g("dense_embed/bias"), tail_s);
   } else {
     launch_embed_bwd(dC, db->atomic, A, h->d_weights + h->o_emb, h->d_weights + h->o_Wde, h->d_weights + h->o_bde, w.dlut,
                      c.n_atoms, c.embedding_dim, g("embed_atom/embeddings"), g("dense_embed/kernel"), g("dense_embed/bias"), w.seed,
-                     DROP_TAG_EMBED, w.drop_p, s);
+                     DROP_TAG_EMBED, w.drop_p, tail_s);
   }
   if (wg.off > w.wpart_floats)
     return fail(h, SCANN_ERR_HIP, "scann_train_backward: weight-gradient partial arena overrun");
