@@ -28,7 +28,7 @@ def setup(n=6, L=2, seed=1, **model_over):
 GRAD_FLOOR, GRAD_SLACK, GRAD_CAP = 2e-5, 4.0, 2e-4
 
 
-def check_grads(got, cfg, w, pk, targets, attn_scale=None, cap=None):
+def check_grads(got, cfg, w, pk, targets, attn_scale=None, cap=None, drop=None):
     """Gradient parity rule.  Reference: fp64 autograd of the independent torch graph.  A single-precision step cannot be closer
     to it than the SAME graph run by torch in fp32 is, so every tensor is held to max(GRAD_FLOOR, GRAD_SLACK x that fp32
     error), and to GRAD_CAP overall.  (Measured, tests/manual/grad_floor.py: HIP errors 4e-7 ... 1.5e-5 of the tensor scale,
@@ -36,8 +36,8 @@ def check_grads(got, cfg, w, pk, targets, attn_scale=None, cap=None):
     Returns (rmse of the fp64 graph, errors)."""
     import torch_ref
 
-    _, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=attn_scale)
-    _, _, g32, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=attn_scale, dtype="float32")
+    _, rmse, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=attn_scale, drop=drop)
+    _, _, g32, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, attn_scale=attn_scale, dtype="float32", drop=drop)
     for k in ref:  # the autograd loss includes the l2 term; the library adds 2*l2*W inside the optimiser step -> remove it here
         if k.endswith(torch_ref.REGULARIZED):
             ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
@@ -306,15 +306,9 @@ def test_cli_train_then_predict_model(hip_lib, tmp_path):
 
 
 def drop_scale_np(seed, tag, idx, p):
-    """NumPy twin of drop_scale() in scann_internal.h (64-bit mix, top 24 bits -> uniform)."""
-    M = np.uint64(0xFFFFFFFFFFFFFFFF)
-    with np.errstate(over="ignore"):
-        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx.astype(np.uint64) + np.uint64(1)) + (np.uint64(tag) << np.uint64(48))) & M
-        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
-        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
-        z = z ^ (z >> np.uint64(31))
-    u = (z >> np.uint64(40)).astype(np.float64) / 16777216.0
-    return np.where(u < np.float32(p), 0.0, 1.0 / (1.0 - float(np.float32(p))))
+    import torch_ref
+
+    return torch_ref.drop_scale_np(seed, tag, idx, p)
 
 
 @pytest.mark.parametrize("g_update", [True, False], ids=["scann_plus", "base"])
@@ -941,4 +935,31 @@ def test_gradients_at_other_widths_corner_batches(hip_lib):
     eng0.zero_grads()
     eng0.train_backward(rb, sse, pk0.n_struct)
     check_grads(eng0.get_grads(), cfg0, w0, pk0, t0, cap=2e-3)  # (un-normalised scores: the fp32 graph itself sits 2.3e-4 off)
+    rb.free()
+
+
+@pytest.mark.parametrize("path", ["mfma", "plain", "64x4"])
+def test_dropout_layer_gradients_match_autograd(hip_lib, monkeypatch, path):
+    """The two Dropout(0.1) layers of the training graph (scann_model.py:374 on the centres, attention.py:29 inside ResidualNorm) with the
+    library's counter-based masks rebuilt on the host and fed to the torch graph: loss and gradients of a Dropout-active step against
+    fp64 autograd, on the MFMA kernels, on the plain-fp32 kernels at the same widths, and at 64 / 4."""
+    from scann.models.scann_model import HipModel
+
+    if path == "64x4":
+        cfg, w, pk, targets, model = setup_widths(OTHER_WIDTHS["64x4"], n=8, seed=5)
+    else:
+        cfg, w, pk, targets, model = setup(n=8, L=3, seed=5)
+        if path == "plain":
+            monkeypatch.setenv("SCANN_GENERIC", "1")
+            model = HipModel(cfg, w, device=0)
+            monkeypatch.delenv("SCANN_GENERIC")
+    eng = model.engine
+    eng.train_begin()
+    rb = eng.upload(pk)
+    for seed, p in ((7, 0.1), (123456789, 0.35)):
+        sse = eng.train_forward(rb, targets, dropout=p, seed=seed)
+        eng.zero_grads()
+        eng.train_backward(rb, sse, pk.n_struct)
+        rmse, _ = check_grads(eng.get_grads(), cfg, w, pk, targets, drop=(seed, p))
+        assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6), (seed, p)
     rb.free()

@@ -30,15 +30,28 @@ def _mrelu(x):
     return MRelu.apply(x)
 
 
-def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64"):
+def drop_scale_np(seed, tag, idx, p):
+    """NumPy twin of drop_scale() in csrc/scann_internal.h (64-bit mix, top 24 bits -> uniform): 0 or 1 / (1 - p) per element index."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx.astype(np.uint64) + np.uint64(1)) + (np.uint64(tag) << np.uint64(48))) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float64) / 16777216.0
+    return np.where(u < np.float32(p), 0.0, 1.0 / (1.0 - float(np.float32(p))))
+
+
+def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64", drop=None):
     """Training loss of the reference (scann_model.py:210-214: RMSE + sum of l2(1e-4) kernel regularisers) and its
     gradient w.r.t. every tensor, by torch autograd in fp64 (``dtype="float32"``: the same graph in single precision --
-    the rounding floor any fp32 implementation of the step sits on).  Dropout layers are inactive (rate 0)."""
+    the rounding floor any fp32 implementation of the step sits on).  Dropout layers are inactive (rate 0) unless ``drop`` =
+    (seed, rate) asks for the library's counter-based masks of the two Dropout(0.1) layers (scann_model.py:374, attention.py:29)."""
     import torch
 
     dt = getattr(torch, dtype)
     W = {k: torch.tensor(np.asarray(v), dtype=dt, requires_grad=True) for k, v in weights.items()}
-    y, _ = forward_packed(config, W, pk, dtype, as_tensor=True, attn_scale=attn_scale)
+    y, _ = forward_packed(config, W, pk, dtype, as_tensor=True, attn_scale=attn_scale, drop=drop)
     t = torch.tensor(np.asarray(targets), dtype=dt).reshape(-1, 1)
     rmse = torch.sqrt(torch.mean((y - t) ** 2))  # losses.py:5-6
     reg = sum((W[k] ** 2).sum() for k in W if k.endswith(REGULARIZED)) * 1e-4
@@ -48,8 +61,10 @@ def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64
     return float(loss.detach()), float(rmse.detach()), grads, y.detach().numpy()
 
 
-def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_scale=None):
-    """attn_scale: optional list (one [E, H] array per layer) of inverted-dropout factors for the attention weights."""
+def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_scale=None, drop=None):
+    """attn_scale: optional list (one [E, H] array per layer) of inverted-dropout factors for the attention weights.
+    drop: optional (seed, rate): the library's masks on the centres after dense_embed (tag 1000) and on the ResidualNorm branch of
+    layer l (tag l), element index = atom * local_dim + column."""
     import torch
     import torch.nn.functional as F
 
@@ -84,6 +99,12 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_s
     if cfg.get("use_ring", False):  # scann_model.py:367-371
         v = torch.cat([v, lin(torch.tensor(pk.ring, dtype=dt), "extra_embed")], -1)
     c = F.silu(lin(v, "dense_embed"))
+
+    def mask(tag):
+        return torch.tensor(drop_scale_np(drop[0], tag, np.arange(A * d, dtype=np.uint64), drop[1]).reshape(A, d), dtype=dt)
+
+    if drop:
+        c = c * mask(1000)
     gd = gauss(dist, cfg["gaussian_d"])
     if cfg["g_update"]:
         geom = F.silu(lin(gd, "neighbor_d")) * F.silu(lin(gauss(wgt, math.pi * 2), "neighbor_w"))
@@ -110,7 +131,8 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_s
         ctx = ln(ctx, p + "/layer_norm")
         if cfg["use_attn_norm"]:
             r = "residual_norm_%d" % i
-            c = ln(ctx + lin(F.silu(lin(ctx, r + "/dense_1")), r + "/dense_2"), r + "/layer_norm")
+            ffn = lin(F.silu(lin(ctx, r + "/dense_1")), r + "/dense_2")
+            c = ln(ctx + (ffn * mask(i) if drop else ffn), r + "/layer_norm")
         else:
             c = ctx
     z = F.silu(lin(c, "after_Lc"))
