@@ -201,6 +201,10 @@ struct scann_handle {
   // reusable scratch of the synchronous scann_forward path (grow-only device arena + pinned host staging)
   char* sc_arena = nullptr;
   size_t sc_cap = 0;
+  // scann_forward_padded: the padded payload goes over the bus BEFORE the host reads the masks (pinned + device block, grow-only)
+  char* pp_host = nullptr;
+  char* pp_dev = nullptr;
+  size_t pp_cap = 0;
   char* sc_host = nullptr;
   size_t sc_host_cap = 0;
   struct scann_dbatch* sc_db = nullptr;
@@ -546,6 +550,8 @@ void scann_destroy(scann_handle_t* h) {
     delete h->sc_db;
   }
   if (h->sc_arena) (void)hipFree(h->sc_arena);
+  if (h->pp_dev) (void)hipFree(h->pp_dev);
+  if (h->pp_host) (void)hipHostFree(h->pp_host);
   if (h->sc_host) (void)hipHostFree(h->sc_host);
   cache_release(h->device);
   delete h;
@@ -908,6 +914,11 @@ struct PaddedSrc {
   int32_t mask_size;
   const float *weight, *dist;
   const int32_t* row_of;  // [B*M] host
+  // the payload arrays are ALREADY on their way to the device (scann_forward_padded enqueued the copy on the stream the upload uses,
+  // before it read the masks): their device addresses; null: upload_impl stages and copies them itself
+  const int32_t *d_atomic = nullptr, *d_neighbors = nullptr;
+  const void* d_mask = nullptr;
+  const float *d_weight = nullptr, *d_dist = nullptr;
 };
 
 // memcpy of a large block on up to 8 threads (the padded payload of a 2,048-structure chunk is ~10 MB, of a whole dataset ~100: one
@@ -1008,8 +1019,9 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   const size_t o_ring = take(h->cfg.use_ring ? (size_t)A * 2 * 4 : 0), o_cg = take(h->cfg.feature_cgcnn ? (size_t)A * 92 * 4 : 0);
   // device packing: the padded payload as it came (transient: read once by pack_padded_kernel), the row map and the flag word
   const size_t BM = pad ? (size_t)B * pad->M : 0, BMN = pad ? BM * pad->N : 0;
-  const size_t o_prow = take(BM * 4), o_pat = take(BM * 4), o_pnbr = take(BMN * 4), o_pmask = take(pad ? BMN * pad->mask_size : 0);
-  const size_t o_pw = take(BMN * 4), o_pd = take(BMN * 4);
+  const bool pre = pad && pad->d_atomic;  // the payload is already on the device
+  const size_t o_prow = take(BM * 4), o_pat = take(pre ? 0 : BM * 4), o_pnbr = take(pre ? 0 : BMN * 4);
+  const size_t o_pmask = take(pad && !pre ? BMN * pad->mask_size : 0), o_pw = take(pre ? 0 : BMN * 4), o_pd = take(pre ? 0 : BMN * 4);
   const size_t in_bytes = off;
   const size_t rowA = (size_t)A * D * 4, rowE = (size_t)std::max(E, 1) * D * 4;
   const size_t o_geom = take(h->cfg.g_update ? rowE + D * 4 : 0);  // + the spare row edge-less tiles store to (EdgeArgs::n_edge)
@@ -1063,8 +1075,8 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   }
   struct ImgView { char* p; char* data() const { return p; } } img{img_ptr};
   if (b->atomic && !pad) memcpy(img.data() + o_atomic, b->atomic, (size_t)A * 4);
-  if (pad) {
-    memcpy(img.data() + o_prow, pad->row_of, BM * 4);
+  if (pad) memcpy(img.data() + o_prow, pad->row_of, BM * 4);
+  if (pad && !pre) {
     memcpy(img.data() + o_pat, pad->atomic, BM * 4);
     par_memcpy(img.data() + o_pnbr, pad->neighbors, BMN * 4);
     par_memcpy(img.data() + o_pmask, pad->neighbor_mask, BMN * pad->mask_size);
@@ -1105,9 +1117,10 @@ static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t
   if (pad) {
     char* a0 = db->arena;
     pa.B = B; pa.M = pad->M; pa.N = pad->N; pa.n_species = h->cfg.n_atoms;
-    pa.row_of = (const int32_t*)(a0 + o_prow); pa.edge_offset = d_eoff; pa.atomic = (const int32_t*)(a0 + o_pat);
-    pa.neighbors = (const int32_t*)(a0 + o_pnbr); pa.neighbor_mask = a0 + o_pmask; pa.mask_size = pad->mask_size;
-    pa.weight = (const float*)(a0 + o_pw); pa.dist = (const float*)(a0 + o_pd);
+    pa.row_of = (const int32_t*)(a0 + o_prow); pa.edge_offset = d_eoff; pa.atomic = pre ? pad->d_atomic : (const int32_t*)(a0 + o_pat);
+    pa.neighbors = pre ? pad->d_neighbors : (const int32_t*)(a0 + o_pnbr); pa.neighbor_mask = pre ? pad->d_mask : a0 + o_pmask;
+    pa.mask_size = pad->mask_size;
+    pa.weight = pre ? pad->d_weight : (const float*)(a0 + o_pw); pa.dist = pre ? pad->d_dist : (const float*)(a0 + o_pd);
     pa.out_atomic = (int32_t*)(a0 + o_atomic); pa.out_col = (int32_t*)(a0 + o_col);
     pa.out_dist = (float*)(a0 + o_dist); pa.out_weight = (float*)(a0 + o_wgt);
     pa.flag = (int32_t*)(a0 + o_pflag);
@@ -1694,10 +1707,40 @@ int scann_forward_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, con
   std::vector<float>& ga_packed = ps.ga;
   int r;
   if (device_pack) {
-    if (scann_count_padded(B, M, N, atom_mask, 1, neighbor_mask, 1, mol.data(), eoff.data(), gidx.data(), &na, &ne))
+    // The payload (13/14 of the bytes) does not depend on what the masks say: it is staged and its copy ENQUEUED first, on the stream the
+    // rest of the call uses, and crosses the bus while this thread reads the masks and plans the tiles -- for one batch of 128 the copy
+    // (~25 us) and the mask pass + plan (~20 us) used to run one after the other in front of the first launch.
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t BMN = BM * (size_t)N;
+    const size_t p_at = 0, p_nbr = align_up(BM * 4), p_mask = p_nbr + align_up(BMN * 4), p_w = p_mask + align_up(BMN), p_d = p_w + align_up(BMN * 4);
+    const size_t p_bytes = p_d + align_up(BMN * 4);
+    if (p_bytes > h->pp_cap) {
+      HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+      if (h->pp_dev) (void)hipFree(h->pp_dev);
+      if (h->pp_host) (void)hipHostFree(h->pp_host);
+      h->pp_dev = h->pp_host = nullptr;
+      h->pp_cap = 0;
+      const size_t want = p_bytes + p_bytes / 2;
+      HIPCHK(h, hipMalloc((void**)&h->pp_dev, want));
+      HIPCHK(h, hipHostMalloc((void**)&h->pp_host, want, hipHostMallocDefault));
+      h->pp_cap = want;
+    }
+    memcpy(h->pp_host + p_at, atomic, BM * 4);
+    if (BMN) {
+      par_memcpy(h->pp_host + p_nbr, neighbors, BMN * 4);
+      par_memcpy(h->pp_host + p_mask, neighbor_mask, BMN);
+      par_memcpy(h->pp_host + p_w, neighbor_weight, BMN * 4);
+      par_memcpy(h->pp_host + p_d, neighbor_distance, BMN * 4);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->pp_dev, h->pp_host, p_bytes, hipMemcpyHostToDevice, h->streams[0]));
+    if (scann_count_padded(B, M, N, atom_mask, 1, neighbor_mask, 1, mol.data(), eoff.data(), gidx.data(), &na, &ne)) {
+      (void)hipStreamSynchronize(h->streams[0]);  // (the staging block is about to be reusable again)
       return fail(h, SCANN_ERR_INVALID, std::string("scann_forward_padded: ") + scann_pack_last_error());
+    }
     pb.n_struct = B; pb.n_atom = na; pb.n_edge = ne; pb.mol_offset = mol.data(); pb.edge_offset = eoff.data();
-    const PaddedSrc src{M, N, atomic, neighbors, neighbor_mask, 1, neighbor_weight, neighbor_distance, gidx.data()};
+    PaddedSrc src{M, N, atomic, neighbors, neighbor_mask, 1, neighbor_weight, neighbor_distance, gidx.data()};
+    src.d_atomic = (const int32_t*)(h->pp_dev + p_at); src.d_neighbors = (const int32_t*)(h->pp_dev + p_nbr); src.d_mask = h->pp_dev + p_mask;
+    src.d_weight = (const float*)(h->pp_dev + p_w); src.d_dist = (const float*)(h->pp_dev + p_d);
     if (ga_out) grow_f(ps.ga, (size_t)na);
     scann_dbatch_t* db = nullptr;
     r = upload_impl(h, &pb, &db, true, &src);

@@ -10,7 +10,7 @@ masks, and the same graph in fp32 as the floor.  These batches are adversarial o
 rows differ only by their Dropout masks puts the GlobalAttention gradients on differences of nearly equal numbers, and over 30 Dropout
 seeds of one such batch every implementation, the torch fp32 graph included, moves between 8e-6 and 1.5e-4 of the tensor's rms, each
 with its own outlier (the plain path 6.3e-4 = 12 x the fp32 graph on one seed, the MFMA path 4 x on another).  A tensor more than
-16 x the fp32 graph's distance from fp64 is REPORTED as ill-conditioned (profiles/r05_fuzz_grads_plain.txt: 25 tensors in 5 of 18,376
+16 x the fp32 graph's distance from fp64 is REPORTED as ill-conditioned (profiles/r05_fuzz_grads_plain.txt: 25 tensors in 4 of 18,376
 batches, the worst the GlobalAttention query kernel at 5e-3 of its rms where the fp32 graph sits at 2.5e-4; fp64 statistics in the
 pooling backward or fp64 sums in every dense layer, both tried, move these cases around without removing them); beyond 2e-2 of the
 rms, or not finite, it is a MISMATCH -- what a wrong formula or index would read."""
