@@ -621,14 +621,19 @@ def test_fused_backward_kernels_match_the_modular_ones(hip_lib, monkeypatch):
         assert float(np.max(np.abs(grads["1", "tiny"][k].astype(np.float64) * 2.0 ** 20 - ref))) / scale < 2e-5, k
 
 
-def test_two_steps_in_flight_equal_one_at_a_time(hip_lib):
+@pytest.mark.parametrize("widths", ["128x8", "64x4"])
+def test_two_steps_in_flight_equal_one_at_a_time(hip_lib, widths):
     """scann_train_step_begin may be called for step k + 1 before scann_train_step_end of step k (the device then never waits for
     the host): same weights as ending every step before the next begins, the reported {sse, count, sum |y - t|} belong to the
-    right step, a third begin is refused, and the batches are released without a device-wide synchronisation."""
+    right step, a third begin is refused, and the batches are released without a device-wide synchronisation.  On the MFMA kernels and
+    on the plain-fp32 ones (64 / 4), whose per-batch tensors and temporaries are released with the batch as well."""
     from scann import _hip
     from scann.models.scann_model import HipModel
 
-    cfg, w, pk, targets, _ = setup(n=20, L=2, seed=31)
+    if widths == "64x4":
+        cfg, w, pk, targets, _ = setup_widths(OTHER_WIDTHS["64x4"], n=20, seed=31)
+    else:
+        cfg, w, pk, targets, _ = setup(n=20, L=2, seed=31)
     de, dn = so.synth_dataset(14, 77)
     inputs2, targets2 = so.pad_batch(de, dn, cfg["model"]["g_update"])
     pk2 = _hip.pack_inputs(inputs2)
