@@ -485,7 +485,61 @@ def exact_fp32_leg(cfg, batches, batch_size, seconds=0.8, group=8):
                     "an operand leaves the split-fp16 range)"}
 
 
-LEGS = {"two_streams": two_stream_leg, "exact_fp32": exact_fp32_leg, "one_batch_per_launch": one_batch_leg, "end_to_end": end_to_end, "training_step": training_leg,
+def training_b16_leg(cfg, batches, batch_size, seconds=1.0):
+    """configs[2] as the reference would run it on 8 GPUs: GLOBAL batch 128 (model_qm9.yaml:16; the reference's optimisation trajectory,
+    SURVEY.md 7 'Training DP semantics') = 16 molecules per rank and step.  This is ONE rank's step at that shape, without the two
+    collectives (a scalar and 3.56 MB over xGMI): the device-side floor of a rank's step, the number DESIGN.md 6's <= 1.35 x prediction
+    for the 8-way split rests on."""
+    import numpy as np
+
+    rng = np.random.default_rng(1016)
+    small = [synth_packed_batch(rng, 16) for _ in range(8)]
+    out = training_leg(cfg, small, 16, seconds)
+    out["what"] = ("forward + backward + Adam on resident 16-molecule batches: one rank's share of configs[2] at the reference's global batch "
+                   "of 128 over 8 GPUs (no collective in this leg), two steps in flight")
+    return out
+
+
+def roofline_shapes(eng, batches, batch_size, A, E, groups=(12, 14, 16), forwards=48):
+    """The dominant kernel's HBM-roofline fraction at launch shapes other than the timed one, measured in this run with the same HIP
+    events (scann_edge_timing, every launch of the plain edge kernel sampled; one stream): 12 / 14 / 16 batches per launch, and the
+    least-squares line through them -- microseconds per 64-row edge tile in steady state (the slope) and per launch (the intercept:
+    ramp, drain and the last, partly filled round of workgroups).  SURVEY.md 8(d)(ii) bytes throughout."""
+    import numpy as np
+    from scann import _hip
+
+    pts = []
+    for g in groups:
+        n_g = max(1, min(len(batches) // g, 4))
+        res = [eng.upload(_hip.concat_packed([batches[(i * g + j) % len(batches)] for j in range(g)])) for i in range(n_g)]
+        for i in range(8):
+            eng.forward_resident(res[i % n_g], 0)
+        eng.sync()
+        eng.edge_timing(1)
+        for i in range(forwards):
+            eng.forward_resident(res[i % n_g], 0)
+        eng.sync()
+        us, n, edges = eng.edge_timing_read()
+        eng.edge_timing(0)
+        for rb in res:
+            rb.free()
+        if n:
+            a_l = edges * A / E
+            pts.append({"batches_per_launch": g, "avg_launch_us": us, "launches_sampled": n, "edges_per_launch": edges,
+                        "frac": edge_bytes(a_l, edges) / (us * 1e-6) / 1e12 / PEAK_HBM_TBS})
+    out = {"points": pts}
+    if len(pts) >= 2:
+        x = np.array([p["edges_per_launch"] / 64.0 for p in pts])
+        y = np.array([p["avg_launch_us"] for p in pts])
+        slope, icpt = np.polyfit(x, y, 1)
+        tile_bytes = 64 * (2 * D * 4 + 8) + 64 * (A / E) * (2 * D * 4)
+        out["per_tile"] = {"ns_per_64_edge_tile": slope * 1e3, "intercept_us": icpt, "bytes_per_tile": tile_bytes,
+                           "frac_steady_state": tile_bytes / (slope * 1e-6) / 1e12 / PEAK_HBM_TBS if slope > 0 else None,
+                           "what": "least-squares line through the points: slope = a tile's cost with the chip full, intercept = per-launch ramp / drain / partial last round"}
+    return out
+
+
+LEGS = {"two_streams": two_stream_leg, "training_step_b16": training_b16_leg, "exact_fp32": exact_fp32_leg, "one_batch_per_launch": one_batch_leg, "end_to_end": end_to_end, "training_step": training_leg,
         "padded_predict": padded_predict_leg}
 
 
@@ -711,6 +765,10 @@ def main():
                         "profiles/r05_kernel_stats_g10.csv lists all three; achieved = ALGORITHMIC bytes or FLOPs of a launch / that time",
                 "per_forward_ms": {k: float(np.mean([p[k] for p in prof])) for k in
                                    ("ms_basis", "ms_atom", "ms_edge", "ms_readout", "ms_total")} if prof else None}
+        if not args.no_extras and world == 1 and args.config == "qm9" and not args.worst:
+            # the same kernel at 12 / 14 / 16 batches per launch and its per-tile slope, beside the timed shape's figure (read "0.37 here,
+            # 0.39 there, 0.41 in steady state" off ONE record); one stream, kernel sampling as above
+            roof["shapes"] = {"timed": {"batches_per_launch": gmax, "avg_launch_us": us, "frac": frac_hbm}, **roofline_shapes(eng, batches, args.batch, A, E)}
         value = world * args.steps * args.batch / elapsed
         L_cfg, emb_cfg = model_cfg["n_attention"], model_cfg["embedding_dim"]
         out = {
@@ -747,7 +805,7 @@ def main():
         if not args.no_extras and world == 1 and args.config == "qm9" and not args.worst:
             # each in a process of its own (leg_in_subprocess); this process's engine goes first, so that the legs have the device
             eng.close()
-            for name in ("two_streams", "one_batch_per_launch", "end_to_end", "padded_predict", "training_step", "exact_fp32"):
+            for name in ("two_streams", "one_batch_per_launch", "end_to_end", "padded_predict", "training_step", "training_step_b16", "exact_fp32"):
                 out[name] = leg_in_subprocess(name, args.batch)
         if not args.no_cpu_baseline and not args.no_extras and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -40,11 +40,11 @@ typedef enum scann_status {
 typedef struct scann_config {
   int32_t n_atoms;        /* Embedding vocabulary, scann_model.py:362 */
   int32_t embedding_dim;  /* :362 */
-  int32_t local_dim;      /* :373  (kernels require 128) */
-  int32_t num_head;       /* :399  (kernels require 8) */
+  int32_t local_dim;      /* :373  (128 with num_head 8, global_dim 128, dense_out 128 = every shipped yaml: the MFMA kernels; */
+  int32_t num_head;       /* :399   any other widths: the plain-fp32 kernels of scann_generic*.hip, ~10 x slower) */
   int32_t n_attention;    /* :413 */
-  int32_t global_dim;     /* :425  (128) */
-  int32_t dense_out;      /* :438  (128) */
+  int32_t global_dim;     /* :425 */
+  int32_t dense_out;      /* :438 */
   int32_t n_gauss;        /* 20, scann_model.py:378 */
   float gaussian_d;       /* :378 */
   int32_t g_update;       /* :380  SCANN+ geometry update */
@@ -188,6 +188,10 @@ int scann_edge_timing_read(scann_handle_t* h, double* avg_us, int64_t* n_launche
  * Only valid when the forward was run with scann_set_debug(h, 1) (keeps per-layer copies). */
 int scann_set_debug(scann_handle_t* h, int on);
 int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer, float* out);
+/* Test hook, plain-fp32 (generic-width) training only: copy a tensor of the readout's backward of the last scann_train_backward on
+ * `db` to host -- name one of "gq", "gk", "z" [n_atom, global_dim] (kept by the forward), "rep" [n_struct, global_dim],
+ * "drep" [n_struct, global_dim], "dgq", "dgk", "dz" [n_atom, global_dim] (dz: gradient of after_Lc's pre-activation).  `cap` = floats `out` holds; returns the number of floats copied or a negative status. */
+int64_t scann_train_debug_read(scann_handle_t* h, scann_dbatch_t* db, const char* name, float* out, int64_t cap);
 
 /* Diagnostic builds (-DSCANN_STAMPS) only: per-tile phase clocks [n_tile, 16] of the last edge-kernel launch of
  * `db`; returns the number of tiles copied.  The shipped library returns SCANN_ERR_UNSUPPORTED. */
@@ -208,7 +212,7 @@ int scann_train_forward(scann_handle_t* h, scann_dbatch_t* db, const float* targ
 /* accumulates d(rmse)/d(params) into the gradient vector; rmse = sqrt(sse_global / count_global) (losses.py:5-6) */
 int scann_train_backward(scann_handle_t* h, scann_dbatch_t* db, double sse_global, int64_t count_global);
 /* model.use_drop (train.py --use_drop): Dropout(0.05) on the local-attention weights during training forwards
- * (attention.py:116,191); 0 disables.  g_update path only. */
+ * (attention.py:116,191); 0 disables.  Both branches (g_update on / off), MFMA and plain-fp32 kernels alike. */
 int scann_set_attention_dropout(scann_handle_t* h, float p);
 int scann_zero_grads(scann_handle_t* h);
 int scann_allreduce_grads(scann_handle_t* h);                 /* RCCL sum over the communicator; no-op without one */
@@ -277,6 +281,10 @@ int scann_slice_batch(const int64_t* ds_mol_offset, const int64_t* ds_edge_offse
 int scann_count_padded(int32_t B, int32_t M, int32_t N, const void* atom_mask, int32_t atom_mask_size, const void* neighbor_mask,
                        int32_t neighbor_mask_size, int32_t* out_mol_offset, int32_t* out_edge_offset, int32_t* out_row_of,
                        int32_t* n_atom, int32_t* n_edge);
+/* The staging copy of the padded path (host only): memcpy on up to 8 threads for blocks of >= 8 MiB (disjoint ranges, joined before the
+ * return); what scann_upload_padded / scann_forward_padded move the payload arrays into pinned memory with.  Exposed so that it can be
+ * checked without a GPU and under ThreadSanitizer (tests/test_tsan.py). */
+int scann_host_copy(void* dst, const void* src, int64_t bytes);
 /* The edge-tile plan scann_batch_upload builds for a packed batch (host only; exposed so that it can be checked without a
  * GPU): whole atoms per tile, <= tile_rows (32 | 64) edges and <= tile_atoms (<= 32) atoms; with allow_chunks an atom with
  * more than 64 neighbours becomes ceil(deg/64) single-atom chunk tiles, part_out[tile] = its softmax-merge slot (-1 for

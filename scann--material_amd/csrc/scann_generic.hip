@@ -52,6 +52,43 @@ __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
   constexpr int COLS = 256 / (GR / RPT);
   const int rb = (tid / COLS) * RPT;  // this thread's first staged row
   for (int o = tid % COLS; o < a.N; o += COLS) {
+#if defined(SCANN_DIAG_DENSE64)  // diagnostic: exact products, fp64 sums, one rounding per output
+    double acc[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) acc[rr] = 0.0;
+    const float* __restrict__ wp = a.W + o;
+    for (int k = 0; k < a.K; ++k) {
+      const double w = wp[(size_t)k * a.N];
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) acc[rr] = fma((double)sX[(rb + rr) * Ks + k], w, acc[rr]);
+    }
+    const double bias = a.b ? a.b[o] : 0.f;
+#elif defined(SCANN_DIAG_DENSE4)  // diagnostic: four interleaved fp32 partial sums (k mod 4), combined pairwise
+    float acc4[RPT][4];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) acc4[rr][0] = acc4[rr][1] = acc4[rr][2] = acc4[rr][3] = 0.f;
+    const float* __restrict__ wp = a.W + o;
+    for (int k = 0; k < K4; k += 4) {
+      const float w0 = wp[(size_t)k * a.N], w1 = wp[(size_t)(k + 1) * a.N], w2 = wp[(size_t)(k + 2) * a.N], w3 = wp[(size_t)(k + 3) * a.N];
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) {
+        const float4 x = *reinterpret_cast<const float4*>(&sX[(rb + rr) * Ks + k]);
+        acc4[rr][0] = fmaf(x.x, w0, acc4[rr][0]);
+        acc4[rr][1] = fmaf(x.y, w1, acc4[rr][1]);
+        acc4[rr][2] = fmaf(x.z, w2, acc4[rr][2]);
+        acc4[rr][3] = fmaf(x.w, w3, acc4[rr][3]);
+      }
+    }
+    for (int k = K4; k < a.K; ++k) {
+      const float w = wp[(size_t)k * a.N];
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) acc4[rr][k & 3] = fmaf(sX[(rb + rr) * Ks + k], w, acc4[rr][k & 3]);
+    }
+    float acc[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) acc[rr] = (acc4[rr][0] + acc4[rr][1]) + (acc4[rr][2] + acc4[rr][3]);
+    const float bias = a.b ? a.b[o] : 0.f;
+#else
     float acc[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) acc[rr] = 0.f;
@@ -73,11 +110,12 @@ __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
       for (int rr = 0; rr < RPT; ++rr) acc[rr] = fmaf(sX[(rb + rr) * Ks + k], w, acc[rr]);
     }
     const float bias = a.b ? a.b[o] : 0.f;
+#endif
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) {
       const int r = r0 + rb + rr;
       if (r >= a.rows) break;
-      float y = acc[rr] + bias;
+      float y = (float)(acc[rr] + bias);
       if (a.pre) a.pre[(size_t)r * a.N + o] = y;  // training forward: the pre-activation the backward differentiates swish at
       if (a.act) y = swish_exact(y);
       if (a.drop_p > 0.f) y = y * drop_scale(a.drop_seed, a.drop_tag, (size_t)r * a.N + o, a.drop_p);  // Dropout on the layer's OUTPUT

@@ -48,10 +48,16 @@ __global__ __launch_bounds__(256, RT == 2 ? (EX ? 2 : 3) : (MODE == 1 ? 3 : 4)) 
   static_assert(!(EX && KEEP), "the training forward runs the split-fp16 kernels");
   constexpr int TAR = 32 * RT;  // atom rows per tile
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TAR * PLANE_STRIDE * 2];  // hi / lo planes of the current GEMM input
-  __shared__ __attribute__((aligned(16))) float sRed[TAR * 8];  // LayerNorm partial statistics [row][wave][mean, m2]
+  __shared__ __attribute__((aligned(16))) float sRed[TAR * 8];  // LayerNorm partial statistics [wave][row][mean, m2]
+#ifdef SCANN_DIAG_SE_ROWMAJOR  // A/B build: round 5's [row][wave][2]
+#define SR_STAT(w, r) (((r) * 4 + (w)) * 2)
+#else
+#define SR_STAT(w, r) (((w) * TAR + (r)) * 2)
+#endif
   __shared__ __attribute__((aligned(16))) float sPar[7 * D];   // bf1 | bf2 | lnr_g | lnr_b | bA | bC | bD
 #define SCANN_ATOM_BIX blockIdx.x
 #include "scann_atom_body.inc"
+#undef SR_STAT
 #undef SCANN_ATOM_BIX
 }
 
@@ -134,7 +140,16 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
   // hi / lo planes of the A operand (G or the basis, then ang): 2 x 64 x 272 B; afterwards K as fp32 [64][LDS_STRIDE]
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * TEK * PLANE_STRIDE * 2];
   __shared__ __attribute__((aligned(16))) float sQ[TQ * LDS_STRIDE];  // P1 rows, then query rows of the tile's atoms, then context
-  __shared__ __attribute__((aligned(16))) float sE[TEK * NHEAD];      // LayerNorm_g partial statistics [row][wave][2], then logits
+  // LayerNorm_g partial statistics [wave][row] (mean, m2), then logits [head][row] with one float of padding per head: lanes that one LDS
+  // cycle serves hold consecutive rows, so the row is the fastest index of both (scann_edge_body.inc)
+  __shared__ __attribute__((aligned(16))) float sE[NHEAD * (TEK + 1)];
+#ifdef SCANN_DIAG_SE_ROWMAJOR  // A/B build: round 5's [row][wave][2] / [row][head] layouts
+#define SE_STAT(w, r) (((r) * 4 + (w)) * 2)
+#define SE_LOGIT(r, h) ((r) * NHEAD + (h))
+#else
+#define SE_STAT(w, r) (((w) * TEK + (r)) * 2)
+#define SE_LOGIT(r, h) ((h) * (TEK + 1) + (r))
+#endif
   __shared__ __attribute__((aligned(16))) float sPar[5 * D];          // layer_norm_g gamma/beta (base: filter bias), layer_norm gamma/beta, key bias
   __shared__ int sOff[TQ + 1];
 #ifdef SCANN_DIAG_OCC2  // diagnostic: two workgroups per CU instead of three (how much of the time is latency hidden by occupancy?)
@@ -145,6 +160,8 @@ __global__ __launch_bounds__(256, RT == 2 ? 3 : 4) void edge_kernel(EdgeArgs a) 
 #define SCANN_EDGE_TIX (a.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x)
 #include "scann_edge_body.inc"
 #undef SCANN_EDGE_TIX
+#undef SE_STAT
+#undef SE_LOGIT
 #ifdef SCANN_DIAG_TAILWAIT  // diagnostic: what the layer launch's producer side costs an edge tile (its stores acknowledged before it ends)
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();

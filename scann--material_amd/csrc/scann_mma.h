@@ -333,6 +333,52 @@ __device__ __forceinline__ void tile_store(unsigned char* tile, int row, int col
     *reinterpret_cast<f16x4*>(sL + row * PLANE_STRIDE + col) = l;
   }
 }
+// Two neighbouring pieces of one staged row -- columns col .. col + 3 (v0) and col + 8 .. col + 11 (v1), col = 32 wave + 4 (lane >> 5) + 8 j
+// with j even: the accumulator layout's pieces j and j + 1 -- as ONE 16-byte store per plane instead of two 8-byte stores per piece.
+// tile_store's ds_write_b64 is served in groups of 16 consecutive lanes = 16 consecutive rows at one column, and rows r and r + 8 of the
+// 272-byte planes share their banks ((68 r) mod 32 = 4 (r mod 8)): every one of them a two-way conflict -- 4/5 of the conflict cycles
+// of edge_kernel and atom_kernel (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 19.5 % / 18 %, profiles/r05g16_counters.txt).  A lane and its
+// partner (lane ^ 32: same row, the other four columns of each piece) trade halves through v_permlane32_swap (VALU): the lower lane
+// ends up with all eight columns of piece j, the upper lane with those of piece j + 1, and ds_write_b128 is served in groups of 8
+// consecutive lanes = rows r .. r + 7 x 4 banks each = the 32 banks once.  The bytes in LDS are the same as tile_store's.
+#ifdef SCANN_DIAG_TILE_B64  // A/B build: round 5's 8-byte stores everywhere
+constexpr bool TILE_B64_ALL = true;
+#else
+constexpr bool TILE_B64_ALL = false;
+#endif
+#ifdef SCANN_DIAG_EPI_B64  // A/B build: 8-byte stores in edge_kernel's gated-row epilogue only
+constexpr bool TILE_B64_EPI = true;
+#else
+constexpr bool TILE_B64_EPI = false;
+#endif
+template <bool EX, int TR, bool B64 = false>
+__device__ __forceinline__ void tile_store2(unsigned char* tile, int row, int col, const float4 v0, const float4 v1) {
+  if constexpr (B64 || TILE_B64_ALL) {
+    tile_store<EX, TR>(tile, row, col, v0);
+    tile_store<EX, TR>(tile, row, col + 8, v1);
+    return;
+  }
+  if constexpr (EX) {
+    float* p = reinterpret_cast<float*>(tile) + row * LDS_STRIDE + col;
+    *reinterpret_cast<float4*>(p) = v0;
+    *reinterpret_cast<float4*>(p + 8) = v1;
+  } else {
+    _Float16* sH = reinterpret_cast<_Float16*>(tile);
+    _Float16* sL = sH + TR * PLANE_STRIDE;
+    f16x4 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    const u32x2 a = __builtin_bit_cast(u32x2, h0), b = __builtin_bit_cast(u32x2, h1);
+    const u32x2 c = __builtin_bit_cast(u32x2, l0), d = __builtin_bit_cast(u32x2, l1);
+    // swap(x, y): [0] = {x's lower lanes, y's lower lanes}, [1] = {x's upper lanes, y's upper lanes}
+    const auto h01 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false), h23 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    const auto l01 = __builtin_amdgcn_permlane32_swap(c.x, d.x, false, false), l23 = __builtin_amdgcn_permlane32_swap(c.y, d.y, false, false);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int o = row * PLANE_STRIDE + col + (col & 4);  // lower lanes: piece j's first column; upper lanes: piece j + 1's
+    *reinterpret_cast<u32x4*>(sH + o) = u32x4{h01[0], h23[0], h01[1], h23[1]};
+    *reinterpret_cast<u32x4*>(sL + o) = u32x4{l01[0], l23[0], l01[1], l23[1]};
+  }
+}
 // acc = X . W for the staged tile with W in `w`; when NEXT, the halves of the following kernel are requested into the same registers
 // as soon as the products that read them have been issued (gemm_tile's schedule)
 template <bool EX, bool NEXT, int TR, int RT>

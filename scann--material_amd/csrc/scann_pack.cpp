@@ -233,6 +233,26 @@ inline bool mask_at(const void* m, int size, int64_t i) {
 }
 }  // namespace
 
+// memcpy of a large block on up to 8 threads (the padded payload of a 2,048-structure chunk is ~10 MB, of a whole dataset ~100: one
+// thread moves ~7-10 GB/s, which would make the staging copy the longest host step of the padded path).  Disjoint 64-byte-aligned
+// ranges, joined before the return.
+int scann_host_copy(void* dst, const void* src, int64_t bytes_) {
+  if (bytes_ < 0 || ((!dst || !src) && bytes_ > 0)) return pack_fail("scann_host_copy: null argument or negative size");
+  const size_t bytes = (size_t)bytes_;
+  const unsigned hw = std::thread::hardware_concurrency();
+  size_t n_thr = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), bytes >> 22);  // >= 4 MiB per thread
+  if (const char* e = getenv("SCANN_COPY_THREADS")) n_thr = (size_t)std::max(1, std::min(64, atoi(e)));  // (tests: threads on a small block)
+  if (n_thr <= 1 || bytes < 64 * n_thr) { memcpy(dst, src, bytes); return SCANN_OK; }
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < n_thr; ++t) {
+    const size_t o0 = (bytes * t / n_thr) & ~(size_t)63, o1 = t + 1 == n_thr ? bytes : (bytes * (t + 1) / n_thr) & ~(size_t)63;
+    th.emplace_back([=] { memcpy(static_cast<char*>(dst) + o0, static_cast<const char*>(src) + o0, o1 - o0); });
+  }
+  memcpy(dst, src, (bytes / n_thr) & ~(size_t)63);
+  for (std::thread& x : th) x.join();
+  return SCANN_OK;
+}
+
 int scann_count_padded(int32_t B, int32_t M, int32_t N, const void* atom_mask, int32_t atom_mask_size, const void* neighbor_mask,
                        int32_t neighbor_mask_size, int32_t* out_mol_offset, int32_t* out_edge_offset, int32_t* out_row_of, int32_t* n_atom,
                        int32_t* n_edge) {

@@ -921,20 +921,8 @@ struct PaddedSrc {
   const float *d_weight = nullptr, *d_dist = nullptr;
 };
 
-// memcpy of a large block on up to 8 threads (the padded payload of a 2,048-structure chunk is ~10 MB, of a whole dataset ~100: one
-// thread moves ~7-10 GB/s, which would make the staging copy the longest host step of the padded path)
-static void par_memcpy(void* dst, const void* src, size_t bytes) {
-  const unsigned hw = std::thread::hardware_concurrency();
-  const size_t n_thr = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), bytes >> 22);  // >= 4 MiB per thread
-  if (n_thr <= 1) { memcpy(dst, src, bytes); return; }
-  std::vector<std::thread> th;
-  for (size_t t = 1; t < n_thr; ++t) {
-    const size_t o0 = (bytes * t / n_thr) & ~(size_t)63, o1 = t + 1 == n_thr ? bytes : (bytes * (t + 1) / n_thr) & ~(size_t)63;
-    th.emplace_back([=] { memcpy(static_cast<char*>(dst) + o0, static_cast<const char*>(src) + o0, o1 - o0); });
-  }
-  memcpy(dst, src, (bytes / n_thr) & ~(size_t)63);
-  for (std::thread& x : th) x.join();
-}
+// (the threaded staging copy of the padded payload: scann_host_copy, scann_pack.cpp -- host-only code, built under ThreadSanitizer too)
+static inline void par_memcpy(void* dst, const void* src, size_t bytes) { (void)scann_host_copy(dst, src, (int64_t)bytes); }
 
 static int upload_impl(scann_handle_t* h, const scann_batch_t* b, scann_dbatch_t** out, bool scratch, const PaddedSrc* pad = nullptr) {
   if (!h || !b || !out) return fail(h, SCANN_ERR_INVALID, "scann_batch_upload: null argument");
@@ -1227,6 +1215,7 @@ struct GenKeep {
   float *cc_L = nullptr, *z_pre = nullptr, *z = nullptr, *gq = nullptr, *gk = nullptr, *rep = nullptr, *hid_pre = nullptr, *hid = nullptr;
   float drop_p = 0.f, attn_p = 0.f;
   unsigned long long seed = 0;
+  std::map<std::string, std::pair<const float*, size_t>> dbg;  // scann_train_debug_read: tensors of the last backward's readout stage
 };
 
 // create_model (scann_model.py:362-447) for a handle whose widths are not 128 / 8: one plain-fp32 kernel per formula
@@ -1786,12 +1775,26 @@ int scann_upload_padded(scann_handle_t* h, int32_t B, int32_t M, int32_t N, cons
   return SCANN_OK;
 }
 
+// A batch packed on the device (scann_upload_padded) carries what pack_padded_kernel found wrong with the input in a flag word that
+// scann_batch_download reads with the results.  The entry points that hand device-side tensors back WITHOUT a download (read_csr,
+// forward_profile, debug_read) read the word themselves -- otherwise they would return the kernel's sanitised stand-ins (col = row,
+// z = 0) as if they were the caller's data.  Call with the packing finished (upload event or stream synchronised).
+static int check_pack_flag(scann_handle_t* h, scann_dbatch_t* db, const char* who) {
+  if (!db->pack_flag) return SCANN_OK;
+  int32_t bad = 0;
+  HIPCHK(h, hipMemcpy(&bad, db->pack_flag, 4, hipMemcpyDeviceToHost));
+  if (bad & 1) return fail(h, SCANN_ERR_INVALID, std::string(who) + ": an unmasked neighbour slot points at a padded atom (or outside the structure)");
+  if (bad & 2) return fail(h, SCANN_ERR_INVALID, std::string(who) + ": atomic number outside the embedding table (n_atoms)");
+  return SCANN_OK;
+}
+
 int scann_batch_read_csr(scann_handle_t* h, scann_dbatch_t* db, int32_t* atomic, int32_t* mol_offset, int32_t* edge_offset, int32_t* edge_col,
                          float* edge_dist, float* edge_weight) {
   if (!h || !db) return fail(h, SCANN_ERR_INVALID, "scann_batch_read_csr: null argument");
   HIPCHK(h, hipSetDevice(h->device));
   if (db->upload_ev) HIPCHK(h, hipEventSynchronize(db->upload_ev));
   else HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  if (const int rp = check_pack_flag(h, db, "scann_batch_read_csr")) return rp;
   const size_t A = (size_t)db->n_atom, E = (size_t)db->n_edge;
   if (atomic) HIPCHK(h, hipMemcpy(atomic, db->atomic, A * 4, hipMemcpyDeviceToHost));
   if (mol_offset) HIPCHK(h, hipMemcpy(mol_offset, db->mol_offset, ((size_t)db->n_struct + 1) * 4, hipMemcpyDeviceToHost));
@@ -1811,6 +1814,7 @@ int scann_forward_profile(scann_handle_t* h, scann_dbatch_t* db, scann_profile_t
   const int r = run_forward(h, db, h->streams[0], &tm);
   if (r) return r;
   HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  if (const int rp = check_pack_flag(h, db, "scann_forward_profile")) return rp;
   for (size_t i = 1; i < tm.ev.size(); ++i) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]);
@@ -1877,6 +1881,7 @@ int scann_debug_read(scann_handle_t* h, scann_dbatch_t* db, int what, int layer,
   if (db->dbg_layers != L) return fail(h, SCANN_ERR_INVALID, "scann_debug_read: forward was not run with debug on");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->streams[db->last_slot]));
+  if (const int rp = check_pack_flag(h, db, "scann_debug_read")) return rp;
   const size_t rowA = (size_t)db->n_atom * D, rowE = (size_t)db->n_edge * D;
   const float* src = nullptr;
   size_t n = 0;
@@ -2595,6 +2600,15 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
   if (!kp.arena || (int)kp.layer.size() != L) return fail(h, SCANN_ERR_INVALID, "scann_train_backward: run scann_train_forward on this batch first");
   if ((size_t)std::max(std::max(dg, dout), std::max(3 * d, std::max(cin, 92))) * 4 * 4 > 60000)
     return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): a layer's rows exceed one workgroup's LDS");
+  // launch limits of two kernels, checked BEFORE anything is launched (a refused launch would otherwise surface as a bare hipGetLastError at
+  // the end, after earlier kernels have added into the gradient vector): gen_table_part_kernel's grid.y = 64-atom chunks,
+  // gen_attn_bwd_kernel's dynamic LDS = 3 x max_degree x heads floats
+  if (!c.feature_cgcnn && (A + 63) / 64 > 65535)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): more than 4,194,240 atoms in one batch (Embedding gradient: 65,535 chunks of 64 atoms)");
+  if ((size_t)3 * std::max(1, db->max_degree) * H * sizeof(float) > 65536)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): an atom's neighbours x heads exceed one workgroup's LDS (3 x max_degree x num_head floats <= 64 KiB)");
+  if (((size_t)3 * db->max_atoms + 4) * sizeof(float) > 65536)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): a structure's atoms exceed one workgroup's LDS (GlobalAttention pooling: 3 x atoms floats <= 64 KiB)");
   // ---- temporaries ----
   const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1), fB = (size_t)B;
   const size_t dmax = (size_t)std::max(d, std::max(dg, dout));
@@ -2655,6 +2669,8 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
   dx(dhid, B, dout, dg, WT("bf_property"), nullptr, drep);
   // ---- GlobalAttention pooling, its projections, after_Lc (attention.py:279-316; scann_model.py:424-434) ----
   launch_gen_pool_bwd(db->mol_offset, B, db->max_atoms, kp.gq, kp.gk, dg, c.use_ga_norm, drep, dgq, dgk, s);
+  kp.dbg = {{"gq", {kp.gq, fA * dg}}, {"gk", {kp.gk, fA * dg}}, {"z", {kp.z, fA * dg}}, {"rep", {kp.rep, fB * dg}}, {"drep", {drep, fB * dg}},
+            {"dgq", {dgq, fA * dg}}, {"dgk", {dgk, fA * dg}}, {"dz", {dz, fA * dg}}};
   dw(GenSeg{kp.z, nullptr, dg}, none, none, 1, 0, dgq, dg, dg, A, "global_attention/query");
   dw(GenSeg{kp.z, nullptr, dg}, none, none, 1, 0, dgk, dg, dg, A, "global_attention/key");
   dx(dgq, A, dg, dg, WT("global_attention/query"), nullptr, dz);
@@ -2729,6 +2745,25 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
   if (part_overrun) return fail(h, SCANN_ERR_HIP, "backward (generic widths): a weight gradient's partial tiles exceed their scratch");
   HIPCHK(h, hipGetLastError());
   return SCANN_OK;
+}
+
+int64_t scann_train_debug_read(scann_handle_t* h, scann_dbatch_t* db, const char* name, float* out, int64_t cap) {
+  if (!h || !db || !name || !out) return fail(h, SCANN_ERR_INVALID, "scann_train_debug_read: null argument");
+  if (!h->generic) return fail(h, SCANN_ERR_UNSUPPORTED, "scann_train_debug_read: plain-fp32 (generic-width) training handles only");
+  scann_train_ws* w = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_train_mu);
+    auto it = g_train_ws.find(db);
+    if (it != g_train_ws.end()) w = &it->second;
+  }
+  if (!w || w->gen.dbg.empty()) return fail(h, SCANN_ERR_INVALID, "scann_train_debug_read: run scann_train_backward on this batch first");
+  auto it = w->gen.dbg.find(name);
+  if (it == w->gen.dbg.end()) return fail(h, SCANN_ERR_INVALID, std::string("scann_train_debug_read: no tensor named ") + name);
+  if ((int64_t)it->second.second > cap) return fail(h, SCANN_ERR_INVALID, "scann_train_debug_read: output buffer too small");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->streams[0]));
+  HIPCHK(h, hipMemcpy(out, it->second.first, it->second.second * 4, hipMemcpyDeviceToHost));
+  return (int64_t)it->second.second;
 }
 
 static int adam_impl(scann_handle_t* h, float lr_t, float beta1, float beta2, float eps, float l2, int zero_g) {

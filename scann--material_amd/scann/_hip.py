@@ -19,7 +19,7 @@ STATUS = {0: "OK", -1: "INVALID", -2: "UNSUPPORTED", -3: "NO_DEVICE", -4: "HIP",
 class ScannHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libscann_hip: %s (%d): %s" % (STATUS.get(code, "?"), code, msg))
-        self.code = code
+        self.code, self.detail = code, msg
 
 
 class Config(C.Structure):
@@ -75,6 +75,7 @@ SYMBOLS = [
     ("scann_edge_timing_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("scann_set_debug", C.c_int, [_P, C.c_int]),
     ("scann_debug_read", C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    ("scann_train_debug_read", C.c_int64, [_P, _P, C.c_char_p, _P, C.c_int64]),
     ("scann_debug_stamps", C.c_int, [_P, _P, _P, C.c_int]),
     ("scann_param_count", C.c_int64, [_P]),
     ("scann_train_begin", C.c_int, [_P]),
@@ -106,6 +107,7 @@ SYMBOLS = [
     ("scann_upload_padded", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, C.c_int32, _P, _P, C.POINTER(_P),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("scann_batch_read_csr", C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    ("scann_host_copy", C.c_int, [_P, _P, C.c_int64]),
 ]
 
 _lib = None
@@ -343,14 +345,24 @@ def slice_dataset(ds_mol_offset, ds_edge_offset, ds_atomic, ds_ring, ds_edge_loc
 
 
 def _mask_arg(m):
-    """A mask of the Keras input dict as the C ABI takes it: (contiguous array, element size 1 | 4) -- bool / uint8 and float32 / int32
-    masks go through AS THEY ARE (no `!= 0` pass over a whole dataset's neighbour slots); anything else is compared once."""
+    """A mask of the Keras input dict as the C ABI takes it: (contiguous array, element size 1 | 4).  ONE truth rule on every path --
+    NumPy's `m != 0` (what the reference's bool(...) / cast-to-float32 masks mean, datagenerator.py:123-133): bool / uint8 / int8 and
+    float32 masks go through AS THEY ARE (no `!= 0` pass over a whole dataset's neighbour slots: a byte is set iff non-zero; a float32
+    word is set iff any bit but the sign is, i.e. -0.0 is unset and NaN is set, exactly `!= 0`); anything else -- int32 included, whose
+    0x80000000 the 4-byte rule would read as unset -- is compared once."""
     m = np.asarray(m)
     if m.dtype in (np.bool_, np.uint8, np.int8):
         return np.ascontiguousarray(m), 1
-    if m.dtype in (np.float32, np.int32, np.uint32):
+    if m.dtype == np.float32:
         return np.ascontiguousarray(m), 4
     return np.ascontiguousarray(m != 0), 1
+
+
+def _mask_bytes(m):
+    """The same truth rule as one byte per element (scann_forward_padded takes uint8 masks): a cast to uint8 would turn 0.5 into 0 and
+    wrap 256.0 to 0."""
+    m, size = _mask_arg(m)
+    return (m if size == 1 else np.ascontiguousarray(m != 0)).view(np.uint8)
 
 
 def count_padded(inputs):
@@ -480,10 +492,10 @@ class Engine:
         """The padded Keras dict straight through the C ABI (native CSR packing)."""
         atomic = np.ascontiguousarray(inputs["atomic"], dtype=np.int32)
         B, M = atomic.shape
-        amask = np.ascontiguousarray(np.asarray(inputs["atom_mask"]).reshape(B, M), dtype=np.uint8)
+        amask = _mask_bytes(np.asarray(inputs["atom_mask"]).reshape(B, M))
         nbr = np.ascontiguousarray(inputs["neighbors"], dtype=np.int32)
         N = nbr.shape[2]
-        nmask = np.ascontiguousarray(inputs["neighbor_mask"], dtype=np.uint8)
+        nmask = _mask_bytes(inputs["neighbor_mask"])
         wgt = np.ascontiguousarray(inputs["neighbor_weight"], dtype=np.float32)
         dst = np.ascontiguousarray(inputs["neighbor_distance"], dtype=np.float32)
         if nbr.shape != (B, M, N) or nmask.shape != nbr.shape or wgt.shape != nbr.shape or dst.shape != nbr.shape:
@@ -664,6 +676,16 @@ class Engine:
         if n < 0:
             self._check(n)
         return out[:n]
+
+    def train_debug_read(self, rb, name, width):
+        """A tensor of the plain-fp32 backward's readout stage (scann_train_debug_read): rows x `width`."""
+        rows = rb.packed.n_struct if name in ("rep", "drep") else rb.packed.n_atom
+        out = np.empty((rows, int(width)), dtype=np.float32)
+        n = self.lib.scann_train_debug_read(self._h, rb._h, name.encode(), _ptr(out), out.size)
+        if n < 0:
+            self._check(int(n))
+        assert n == out.size, (n, out.shape)
+        return out
 
     def debug_read(self, rb, what, layer):
         n = rb.packed.n_edge if what in (1, 3, 4, 5, 6) else rb.packed.n_atom

@@ -166,9 +166,13 @@ class HipModel:
         pending, ys, gas = [], [], []
 
         def fetch_oldest():
-            rb = pending.pop(0)
+            rb, first = pending.pop(0)
             try:
                 y, ga = eng.download(rb, want_ga=self.infer)
+            except _hip.ScannHipError as e:
+                rb.free()
+                # (a device-packed chunk reports bad input only here, up to `window` chunks after it was uploaded: say WHICH chunk)
+                raise _hip.ScannHipError(e.code, "%s [structures %d..%d of this call]" % (e.detail, first, min(first + C, B) - 1)) from e
             except BaseException:
                 rb.free()
                 raise
@@ -193,11 +197,11 @@ class HipModel:
                     rb.free()
                     raise
                 k += 1
-                pending.append(rb)
+                pending.append((rb, i))
             while pending:
                 fetch_oldest()
         finally:
-            for rb in pending:
+            for rb, _ in pending:
                 rb.free()
         y = np.concatenate(ys).reshape(-1, 1)
         if not self.infer:

@@ -60,7 +60,12 @@ class MultiGpuPredictor:
         cum = np.concatenate([[0.0], np.cumsum(np.asarray(costs, dtype=np.float64))])
         cuts = [0]
         for s in range(1, n):
-            c = int(np.searchsorted(cum, cum[-1] * s / n))
+            # the batch boundary NEAREST to the s-th share of the cost (the first boundary at or beyond it -- plain searchsorted -- rounds
+            # every cut up: over 64 batches and 8 devices the last run came out 20 % lighter than the heaviest)
+            target = cum[-1] * s / n
+            c = int(np.searchsorted(cum, target))
+            if c > 0 and target - cum[c - 1] < cum[min(c, len(cum) - 1)] - target:
+                c -= 1
             cuts.append(min(max(c, cuts[-1] + 1), len(costs) - (n - s)))
         cuts.append(len(costs))
         return list(zip(cuts[:-1], cuts[1:]))

@@ -62,12 +62,14 @@ class MultiProcessPredictor:
         listener = Listener(os.path.join(self._dir, "sock"), family="AF_UNIX", authkey=key)
         env = dict(os.environ, SCANN_MP_KEY=key.hex(), PYTHONPATH=pkg_dir + os.pathsep + os.environ.get("PYTHONPATH", ""))
         env.pop("WORLD_SIZE", None)  # a worker is a single-device process of its own, not a rank
+        # (before the try: the handler below sets `stop` -- a Popen that raises, ENOMEM or a bad interpreter, must reach the clean-up, not
+        # an UnboundLocalError that hides the reason and leaves the workers already started, the listener and the temp dir behind)
+        accepted, failure, stop = [], [], threading.Event()
         try:
             for d in self.devices:
                 self._procs.append(subprocess.Popen([sys.executable, "-m", "scann.parallel._mp_worker", listener.address], env=env))
             # accept() has no timeout of its own: do it on a thread and watch the children meanwhile -- a worker that dies before
             # it connects (import error, missing libscann_hip.so, bad PYTHONPATH) must not hang the parent
-            accepted, failure, stop = [], [], threading.Event()
             try:  # accept() polls (0.2 s) so that the thread ends when start-up is abandoned: closing a listener does not wake a blocked accept()
                 listener._listener._socket.settimeout(0.2)
             except Exception:

@@ -713,30 +713,33 @@ def test_bench_two_ranks_through_the_self_spawning_launcher(hip_lib):
     assert out["value"] <= 2.0 * max(out["rank_values"]) * 1.001  # the job's rate is 2 x the SLOWEST rank's
 
 
-def test_keras_h5_checkpoint_loads_and_predicts(hip_lib, tmp_path):
+def test_keras_h5_checkpoint_loads_and_predicts(hip_lib):
     """SCANN(config, pretrained=<Keras .h5>, mode="infer") -- the reference's way of loading a trained model
-    (scann_model.py:79-83) -- through the pure-Python HDF5 reader and the Keras-name map; the file is written in Keras' layout
-    by h5py (not by TensorFlow: unavailable here).  Same predictions as the same weights loaded from the native container."""
-    import json
+    (scann_model.py:79-83) -- through the pure-Python HDF5 reader and the Keras-name map, on the COMMITTED file
+    tests/golden/keras_layout_qm9_L2.h5 (Keras' ModelCheckpoint layout written by h5py, not by TensorFlow: unavailable here;
+    tests/golden/make_keras_fixture.py) -- no h5py needed on the box that runs this.  Same predictions as the same seeded weights
+    loaded from the native container, and the oracle's numbers."""
+    import importlib.util
     import os
-    import subprocess
 
     from scann.models import SCANN
+    from scann.models.scann_model import HipModel
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    py = "/opt/conda/bin/python3.9"
-    if not os.path.exists(py) or subprocess.run([py, "-c", "import h5py"], capture_output=True).returncode != 0:
-        pytest.skip("no interpreter with h5py to write the Keras-layout file")
-    cfg, w, inputs, model = make(n=10, seed=3)
-    npz, h5 = tmp_path / "model.npz", tmp_path / "model_homo.h5"
-    np.savez(npz, __config__=np.array(json.dumps(model.config)), **w)
-    subprocess.run([py, os.path.join(root, "tools", "make_keras_h5_fixture.py"), str(npz), str(h5)], check=True)
+    spec = importlib.util.spec_from_file_location("make_keras_fixture", os.path.join(root, "tests", "golden", "make_keras_fixture.py"))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    cfg, w = fx.fixture_config(), fx.fixture_weights()
+    de, dn = so.synth_dataset(10, 3)
+    inputs, _ = so.pad_batch(de, dn, g_update=cfg["model"]["g_update"])
     yaml_cfg = {"model": {k: v for k, v in cfg["model"].items() if k in ("n_atoms", "scale")}, "hyper": {"target": "homo"}}
-    scann = SCANN(yaml_cfg, pretrained=str(h5), mode="infer")
+    scann = SCANN(yaml_cfg, pretrained=os.path.join(root, "tests", "golden", fx.NAME), mode="infer")
     y1, ga1 = scann.model.predict(inputs)
-    y0, ga0 = model.predict(inputs)
+    y0, ga0 = HipModel(cfg, w, device=0, infer=True).predict(inputs)
     assert np.array_equal(y1, y0) and np.array_equal(ga1, ga0)
-    assert scann.model.config["model"]["n_attention"] == cfg["model"]["n_attention"]
+    assert scann.model.config["model"]["n_attention"] == 2
+    y_ref, ga_ref = so.forward(cfg, w, inputs, np.float32)
+    assert rel_err(y1, y_ref) <= RTOL and rel_err(ga1, ga_ref) <= RTOL
 
 
 def test_activation_outside_the_split_fp16_range_is_rerun_in_exact_fp32(hip_lib, monkeypatch):
@@ -1025,5 +1028,25 @@ def test_device_packing_reports_what_the_host_packer_refuses(hip_lib):
     bad["atomic"][0, 0] = cfg["model"]["n_atoms"] + 3
     with pytest.raises(_hip.ScannHipError, match="embedding table"):
         model.predict(bad)
+    y, _ = model.predict(inputs)
+    assert np.isfinite(y).all()
+    # the entry points that hand device-side tensors back without a download read the flag too (no sanitised stand-ins as data), and the
+    # chunked pipeline names the chunk whose input was bad although the error surfaces chunks later
+    eng = model.engine
+    bad = dict(inputs)
+    bad["neighbors"] = inputs["neighbors"].copy()
+    bad["neighbors"][b, 0, 0] = M - 1
+    rb = eng.upload_padded(bad)
+    with pytest.raises(_hip.ScannHipError, match="scann_batch_read_csr.*padded atom"):
+        eng.read_csr(rb)
+    rb.free()
+    big = {k: np.concatenate([v] * 200) for k, v in inputs.items()}  # 2,400 structures: the chunked path (>= 1,024)
+    big["atomic"] = big["atomic"].copy()
+    big["atomic"][1500, 0] = cfg["model"]["n_atoms"] + 3
+    with pytest.raises(_hip.ScannHipError, match=r"embedding table.*\[structures (\d+)\.\.(\d+) of this call\]") as ei:
+        model.predict(big)
+    import re
+    lo, hi = map(int, re.search(r"structures (\d+)\.\.(\d+)", str(ei.value)).groups())
+    assert lo <= 1500 <= hi
     y, _ = model.predict(inputs)
     assert np.isfinite(y).all()

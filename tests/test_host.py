@@ -344,6 +344,34 @@ def test_hdf5_files_go_to_the_keras_importer_and_bad_ones_fail_loudly(tmp_path):
     assert "superblock version" in str(e.value)
 
 
+def test_every_padded_entry_point_reads_masks_by_one_rule():
+    """`m != 0` on every path into the packers (pack_inputs, forward_padded's byte masks, count_padded / upload_padded's 1- and 4-byte
+    masks): fractional and large floats are set, -0.0 is unset, NaN is set, an int32 0x80000000 is set -- the same input dict packs the
+    same way whatever the batch size routes it through."""
+    from scann import _hip
+
+    de, dn = so.synth_dataset(6, 2)
+    inputs, _ = so.pad_batch(de, dn, True)
+    ref = _hip.pack_inputs(inputs)
+    am, nm = inputs["atom_mask"][..., 0].astype(bool), inputs["neighbor_mask"].astype(bool)
+    mol_ref, eoff_ref, row_ref = _hip.count_padded(inputs)
+    assert np.array_equal(mol_ref, ref.mol_offset) and np.array_equal(eoff_ref, ref.edge_offset)
+    odd_f = lambda m: np.where(m, np.float32(0.5), np.float32(-0.0)).astype(np.float32)  # noqa: E731
+    big_f = lambda m: np.where(m, np.float32(256.0), np.float32(0.0)).astype(np.float32)  # noqa: E731
+    nan_f = lambda m: np.where(m, np.float32(np.nan), np.float32(0.0)).astype(np.float32)  # noqa: E731
+    min_i = lambda m: np.where(m, np.int32(-2 ** 31), np.int32(0)).astype(np.int32)  # noqa: E731
+    f64 = lambda m: np.where(m, 0.25, 0.0)  # noqa: E731
+    for enc in (odd_f, big_f, nan_f, min_i, f64, lambda m: m.astype(np.uint8) * 2, lambda m: m.astype(np.int64) * -7):
+        x = dict(inputs, atom_mask=enc(am)[..., None], neighbor_mask=enc(nm))
+        got = _hip.pack_inputs(x)
+        for f in ("atomic", "mol_offset", "edge_offset", "edge_col", "edge_dist", "edge_weight"):
+            assert np.array_equal(getattr(got, f), getattr(ref, f)), (f, enc(am).dtype)
+        mol, eoff, row_of = _hip.count_padded(x)
+        assert np.array_equal(mol, mol_ref) and np.array_equal(eoff, eoff_ref) and np.array_equal(row_of, row_ref), enc(am).dtype
+        assert np.array_equal(_hip._mask_bytes(x["neighbor_mask"]) != 0, nm) and np.array_equal(_hip._mask_bytes(x["atom_mask"])[..., 0] != 0, am)
+    assert _hip._mask_arg(min_i(nm))[1] == 1 and _hip._mask_arg(odd_f(nm))[1] == 4 and _hip._mask_arg(nm)[1] == 1
+
+
 def test_native_packers_ring_cgcnn_masks_and_errors():
     """scann_pack_padded / scann_slice_batch (host C++, f-1): optional inputs, float masks, garbage in masked slots, errors."""
     from scann import _hip
@@ -535,6 +563,31 @@ def test_process_per_gpu_predictor_does_not_hang_on_a_dead_worker(monkeypatch):
     with pytest.raises(RuntimeError, match="0 of 1 workers connected"):
         multi_proc.MultiProcessPredictor(cfg, so.init_weights(cfg, 1), devices=[0])
     assert time.monotonic() - t0 < 30
+
+
+def test_process_per_gpu_predictor_cleans_up_when_a_worker_cannot_be_started(monkeypatch):
+    """Popen itself raising on the SECOND worker (ENOMEM, a bad interpreter): the caller sees that error -- not an UnboundLocalError
+    from the clean-up handler --, the worker already started is killed and the socket directory is gone."""
+    import glob
+    import tempfile
+
+    from scann.parallel import multi_proc
+
+    real, started = multi_proc.subprocess.Popen, []
+
+    def second_one_fails(args, **kw):
+        if started:
+            raise OSError(12, "Cannot allocate memory")
+        started.append(real([sys.executable, "-c", "import time; time.sleep(60)"], **kw))
+        return started[-1]
+
+    monkeypatch.setattr(multi_proc.subprocess, "Popen", second_one_fails)
+    before = set(glob.glob(os.path.join(tempfile.gettempdir(), "scann_mp_*")))
+    cfg = so.default_config("qm9")
+    with pytest.raises(OSError, match="Cannot allocate memory"):
+        multi_proc.MultiProcessPredictor(cfg, so.init_weights(cfg, 1), devices=[0, 1])
+    assert len(started) == 1 and started[0].poll() is not None  # killed and reaped
+    assert set(glob.glob(os.path.join(tempfile.gettempdir(), "scann_mp_*"))) == before
 
 
 def test_runtime_env_warnings(monkeypatch):
@@ -1029,7 +1082,8 @@ class Model:
     def save(self, path): save_container(path, self.config, self._weights)
 
 
-de, dn = so.synth_dataset(21 + 11, 5)
+NT, NV, BS = int(os.environ.get("DP_NTRAIN", "21")), int(os.environ.get("DP_NVAL", "11")), int(os.environ.get("DP_BATCH", "10"))
+de, dn = so.synth_dataset(NT + NV, 5)
 for i, d in enumerate(de):
     d[1] = float(i)                                   # the target identifies the structure
 out = os.environ["DP_OUT"]
@@ -1038,23 +1092,30 @@ sc = SCANN.__new__(SCANN)
 sc.config, sc.mean, sc.std = cfg, 0.0, 1.0
 eng = StubEngine()
 sc.model = Model(eng, cfg)
-kw = dict(batch_size=10, use_ring=False, feature="atomic", g_update=True, atomic_features=None)
-sc.trainIter = PackedDataset(data_energy=de[:21], data_neighbor=dn[:21], shuffle=False, **kw)   # 21 = 10 + 10 + 1: tail < world
-sc.validIter = PackedDataset(data_energy=de[21:], data_neighbor=dn[21:], shuffle=False, **kw)   # 11 = 10 + 1
+kw = dict(batch_size=BS, use_ring=False, feature="atomic", g_update=True, atomic_features=None)
+sc.trainIter = PackedDataset(data_energy=de[:NT], data_neighbor=dn[:NT], shuffle=False, **kw)   # default 21 = 10 + 10 + 1: tail < world
+sc.validIter = PackedDataset(data_energy=de[NT:], data_neighbor=dn[NT:], shuffle=False, **kw)   # default 11 = 10 + 1
 orig = trainer.Communicator.__init__
 def init(self, engine, rendezvous=None):
     orig(self, engine, rendezvous)
     engine.rdzv = self.rdzv
 trainer.Communicator.__init__ = init
 hist = trainer.fit(sc, epochs=2, verbose=False)
-assert trainer.dp_batches(sc.trainIter, world) == (2, True) and trainer.dp_batches(sc.validIter, world) == (1, True)
-assert eng.steps == 2 * 2, eng.steps                  # two steps per epoch on EVERY rank
+full_t, full_v = NT // BS, NV // BS
+assert 0 < NT - full_t * BS < world and 0 < NV - full_v * BS < world      # both end in a batch shorter than the ranks
+assert trainer.dp_batches(sc.trainIter, world) == (full_t, True) and trainer.dp_batches(sc.validIter, world) == (full_v, True)
+assert eng.steps == 2 * full_t, eng.steps             # the same number of steps per epoch on EVERY rank
+per_step = [len(eng.seen) // 2]                       # this rank's structures per epoch
 seen = eng.rdzv.allgather([eng.seen, eng.val_seen])
 if rank == 0:
     train_all = sorted(t for s, _ in seen for t in s)
-    assert train_all == sorted(list(range(21)) * 2), train_all          # every structure once per epoch, none lost to the tail
-    assert sorted(t for _, v in seen for t in v) == sorted(list(range(21, 32)) * 2)
+    assert train_all == sorted(list(range(NT)) * 2), train_all          # every structure once per epoch, none lost to the tail
+    assert sorted(t for _, v in seen for t in v) == sorted(list(range(NT, NT + NV)) * 2)
     assert all(len(s) > 0 for s, _ in seen)
+    sizes = [len(s) // 2 for s, _ in seen]            # structures per rank and epoch: equal shares (+- the folded tail)
+    assert max(sizes) - min(sizes) <= full_t, sizes
+    if BS % world == 0:                               # the reference's global batch on 8 ranks: 128 / 8 = 16 per rank and full step
+        assert min(sizes) >= full_t * (BS // world), sizes
     z = np.load(os.path.join(out + "_t", "models", "model_t.h5"))
     assert "w" in z.files and json.loads(str(z["__config__"]))["hyper"]["target"] == "t"
     assert not [f for f in os.listdir(os.path.join(out + "_t", "models")) if f.endswith(".tmp")]
@@ -1121,9 +1182,10 @@ comm = Communicator(eng, rdzv)
 region = 0.010 * (1 + rdzv.rank)                      # this rank's own time for the K steps
 per_rank = rdzv.gather([region])
 if rdzv.rank == 0:
-    line = {"n_gpus": rdzv.world, **bench.scaling_fields(rdzv.world, 20 * 128, [t[0] for t in per_rank], 0.009, eng.comm_ranks())}
-    assert line["rccl_ranks"] == 2 and line["ranks_reporting"] == 2, line
-    assert line["rank_values"] == [20 * 128 / 0.010, 20 * 128 / 0.020], line
+    W = rdzv.world
+    line = {"n_gpus": W, **bench.scaling_fields(W, 20 * 128, [t[0] for t in per_rank], 0.009, eng.comm_ranks())}
+    assert line["rccl_ranks"] == W and line["ranks_reporting"] == W, line
+    assert line["rank_values"] == [20 * 128 / (0.010 * (1 + r)) for r in range(W)], line
     assert abs(line["n1_same_layout"]["value"] - 20 * 128 / 0.009) < 1e-6, line
     json.dumps(line)
 rdzv.barrier()
@@ -1150,6 +1212,99 @@ def test_two_rank_bench_line_carries_the_scaling_fields(tmp_path):
     script.write_text(prelude + _SCALE_WORKER)
     env = dict(os.environ, OMP_NUM_THREADS="2", SCANN_NO_AFFINITY="1")
     assert spawn_ranks([str(script)], 2, env=env, timeout=300) == 0
+
+
+def test_eight_rank_layout_fit_and_bench_line(tmp_path):
+    """The target machine's layout rehearsed on CPU ranks: WORLD_SIZE = 8 through the package's launcher and the
+    torch-free rendezvous.  (a) trainer.fit at the reference's GLOBAL batch of 128 (model_qm9.yaml:16 -> 16 structures per rank and
+    step) over 261 training structures (128 + 128 + 5: a final batch shorter than the ranks, folded on every rank alike) and 131
+    validation structures: same step count on all eight ranks, every structure once per epoch, nobody with an empty shard, rank 0
+    alone writes; (b) the bench line of an 8-rank run: 8 rank_values, rccl_ranks = 8, the N = 1 figure of the same layout."""
+    pytest.importorskip("torch")  # (the scale worker's stand-in engine is the torch graph)
+    sys.path.insert(0, os.path.join(ROOT, "scann--material_amd"))
+    from scann.parallel.launch import spawn_ranks
+
+    script = tmp_path / "dp_fit_worker8.py"
+    script.write_text("ROOT = %r\n" % ROOT + _DP_FIT_WORKER)
+    env = dict(os.environ, DP_OUT=str(tmp_path / "run8"), DP_NTRAIN="261", DP_NVAL="131", DP_BATCH="128", OMP_NUM_THREADS="1", SCANN_NO_AFFINITY="1")
+    assert spawn_ranks([str(script)], 8, env=env, timeout=600) == 0
+    assert os.path.exists(str(tmp_path / "run8") + "_t/models/model_t.h5")
+    prelude = ("import os, sys\nROOT = %r\n"
+               "sys.path[:0] = [os.path.join(ROOT, 'scann--material_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')]\n" % ROOT)
+    script = tmp_path / "scale_worker8.py"
+    script.write_text(prelude + _SCALE_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="1", SCANN_NO_AFFINITY="1")
+    assert spawn_ranks([str(script)], 8, env=env, timeout=600) == 0
+
+
+_MP_STANDIN = r'''
+# sitecustomize of the workers MultiProcessPredictor starts in tests/test_host.py::test_eight_worker_predictor_on_a_stand_in_engine: the
+# model class the worker would build on a GPU is replaced by a stand-in whose "prediction" of a structure is a function of that
+# structure's own data (sum of its edge distances + its atom count), computed from the run of batches the worker was handed.
+import os
+try:
+    import scann  # (only the workers have the package on their path; helper processes of multiprocessing do not)
+except ImportError:
+    scann = None
+if os.environ.get("SCANN_TEST_STANDIN") == "1" and scann is not None:
+    import numpy as np
+    import scann.models.scann_model as sm
+    import scann.parallel.affinity as aff
+    aff.pin_to_device = lambda device: None
+
+    class _Eng:
+        def close(self): pass
+
+    class StandInModel:
+        def __init__(self, config, weights=None, device=0, infer=False, seed=None):
+            self.engine, self.device = _Eng(), device
+        def predict_dataset(self, run, group=None, want_ga=False):
+            ys, gas, ts = [], [], []
+            for i in range(len(run)):
+                pk, tgt = run[i]
+                eoff, mol = np.asarray(pk.edge_offset, np.int64), np.asarray(pk.mol_offset, np.int64)
+                cs = np.concatenate([[0.0], np.cumsum(np.asarray(pk.edge_dist, np.float64))])
+                ys.append((cs[eoff[mol[1:]]] - cs[eoff[mol[:-1]]] + np.diff(mol)).astype(np.float32))
+                gas.append(np.full(pk.n_atom, float(self.device), np.float32))
+                ts.append(np.asarray(tgt, np.float32))
+            return np.concatenate(ys), (np.concatenate(gas) if want_ga else None), np.concatenate(ts)
+
+    sm.HipModel = StandInModel
+'''
+
+
+def test_eight_worker_predictor_on_a_stand_in_engine(tmp_path, monkeypatch):
+    """MultiProcessPredictor with EIGHT worker processes (the 8-GPU node's layout), the model in each worker replaced by a stand-in
+    (no GPU here): the shared-memory dataset, the run boundaries, the order of the outputs and the edge balance of the eight runs --
+    within 10 % of each other on a QM9-shaped set, as SURVEY.md 8(e) asks of the inference shards."""
+    from scann.parallel import multi_proc
+    from scann.parallel.multi_gpu import MultiGpuPredictor
+    from scann.utils import PackedDataset
+
+    (tmp_path / "sitecustomize.py").write_text(_MP_STANDIN)
+    monkeypatch.setenv("PYTHONPATH", str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    monkeypatch.setenv("SCANN_TEST_STANDIN", "1")
+    de, dn = so.synth_dataset(1024, 9)
+    ds = PackedDataset(data_energy=de, data_neighbor=dn, batch_size=16, use_ring=False, feature="atomic", g_update=True, atomic_features=None,
+                       shuffle=False)
+    mol, eoff = ds.mol_offset, ds.edge_offset
+    cfg = so.default_config("qm9")
+    with multi_proc.MultiProcessPredictor(cfg, so.init_weights(cfg, 1), devices=list(range(8))) as mp:
+        assert len(mp._procs) == 8
+        y, ga, t = mp.predict_dataset(ds, want_ga=True)
+        cs = np.concatenate([[0.0], np.cumsum(np.asarray(ds.edge_dist, np.float64))])
+        want = (cs[eoff[mol[1:]]] - cs[eoff[mol[:-1]]] + np.diff(mol)).astype(np.float32)
+        assert y.shape == (1024,) and np.allclose(y, want, rtol=1e-6) and np.array_equal(t, np.asarray(ds.target, np.float32))
+        # which worker produced which atoms (the stand-in writes its device id): eight contiguous runs, balanced by edges
+        owner = ga.astype(int)
+        assert np.all(np.diff(owner) >= 0) and sorted(set(owner.tolist())) == list(range(8))
+        edges = np.array([int(np.diff(eoff)[owner == d].sum()) for d in range(8)])
+        assert edges.sum() == int(eoff[-1]) and edges.max() <= 1.10 * edges.min(), edges.tolist()
+        per_struct = (eoff[mol[1:]] - eoff[mol[:-1]]) + 8 * np.diff(mol)
+        runs = MultiGpuPredictor._runs(np.add.reduceat(per_struct.astype(np.float64), np.arange(0, 1024, 16)), 8)
+        assert len(runs) == 8 and runs[0][0] == 0 and runs[-1][1] == 64 and all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
+        y2, _, _ = mp.predict_dataset(ds)  # the shared segments are reused
+        assert np.array_equal(y2, y)
 
 
 def test_checkpoint_replace_is_atomic(tmp_path):

@@ -159,6 +159,46 @@ def test_keras_name_map_rejects_foreign_layers():
         map_keras_weights(layers)
 
 
+def _committed_fixture():
+    spec = importlib.util.spec_from_file_location("make_keras_fixture", os.path.join(ROOT, "tests", "golden", "make_keras_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return os.path.join(ROOT, "tests", "golden", mod.NAME), mod.fixture_config(), mod.fixture_weights()
+
+
+def test_committed_keras_layout_file_loads_without_h5py():
+    """tests/golden/keras_layout_qm9_L2.h5 (written once by h5py in Keras' ModelCheckpoint layout, tests/golden/make_keras_fixture.py;
+    scann_model.py:166-177) through the pure-Python reader and the Keras-name map: the seeded weights bit for bit, the architecture read
+    from the file, every tensor mapped exactly once -- on any box, no h5py, no TensorFlow."""
+    from scann.models.keras_import import load_keras_h5, mapping_report
+
+    path, cfg, w = _committed_fixture()
+    got_cfg, got = load_keras_h5(path, {"model": {"n_atoms": 10, "scale": 0.5}, "hyper": {"target": "homo"}})
+    assert set(got) == set(w)
+    for k in w:
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], w[k]), k
+    for key in ("n_attention", "g_update", "use_attn_norm", "use_ga_norm", "use_ring", "feature", "gaussian_d", "embedding_dim", "num_head",
+                "local_dim", "global_dim", "dense_out"):
+        assert got_cfg["model"][key] == cfg["model"][key], (key, got_cfg["model"][key], cfg["model"][key])
+    rep = mapping_report(path)
+    assert rep["tensors"] == len(w) and rep["parameters"] == sum(int(v.size) for v in w.values()) == 310497 and set(rep["names"]) == set(w)
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "keras_h5_to_container.py"), "--check", path], capture_output=True, text=True)
+    assert r.returncode == 0 and "CHECK OK" in r.stdout and "310497 parameters" in r.stdout, r.stderr[-500:]
+
+
+@pytest.mark.skipif(H5PY_PYTHON is None, reason="no interpreter with h5py to write the Keras-layout file")
+def test_committed_keras_layout_file_is_what_the_generator_writes(tmp_path):
+    """(where h5py exists) the committed file is reproducible: regenerating it gives the same datasets."""
+    from scann.models.keras_import import load_keras_h5
+
+    path, cfg, w = _committed_fixture()
+    npz, h5 = tmp_path / "m.npz", tmp_path / "m.h5"
+    np.savez(npz, __config__=np.array(json.dumps(cfg)), **w)
+    subprocess.run([H5PY_PYTHON, os.path.join(ROOT, "tools", "make_keras_h5_fixture.py"), str(npz), str(h5)], check=True)
+    a, b = load_keras_h5(path, None)[1], load_keras_h5(str(h5), None)[1]
+    assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a)
+
+
 @pytest.mark.skipif(H5PY_PYTHON is None, reason="no interpreter with h5py to write the Keras-layout file")
 @pytest.mark.parametrize("name", sorted(CASES) + ["e_b"])
 def test_container_to_keras_h5_and_back(tmp_path, name):

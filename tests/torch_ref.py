@@ -42,7 +42,7 @@ def drop_scale_np(seed, tag, idx, p):
     return np.where(u < np.float32(p), 0.0, 1.0 / (1.0 - float(np.float32(p))))
 
 
-def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64", drop=None):
+def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64", drop=None, capture=None):
     """Training loss of the reference (scann_model.py:210-214: RMSE + sum of l2(1e-4) kernel regularisers) and its
     gradient w.r.t. every tensor, by torch autograd in fp64 (``dtype="float32"``: the same graph in single precision --
     the rounding floor any fp32 implementation of the step sits on).  Dropout layers are inactive (rate 0) unless ``drop`` =
@@ -51,17 +51,23 @@ def loss_and_grads(config, weights, pk, targets, attn_scale=None, dtype="float64
 
     dt = getattr(torch, dtype)
     W = {k: torch.tensor(np.asarray(v), dtype=dt, requires_grad=True) for k, v in weights.items()}
-    y, _ = forward_packed(config, W, pk, dtype, as_tensor=True, attn_scale=attn_scale, drop=drop)
+    y, _ = forward_packed(config, W, pk, dtype, as_tensor=True, attn_scale=attn_scale, drop=drop, capture=capture)
     t = torch.tensor(np.asarray(targets), dtype=dt).reshape(-1, 1)
     rmse = torch.sqrt(torch.mean((y - t) ** 2))  # losses.py:5-6
     reg = sum((W[k] ** 2).sum() for k in W if k.endswith(REGULARIZED)) * 1e-4
     loss = rmse + reg
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy().astype(np.float64) for k, v in W.items()}  # (None: a tensor the graph does not reach)
+    if capture is not None:  # readout-stage tensors and their gradients (tools/debug_plain_grads.py): name -> (value, gradient)
+        reps = capture.pop("_reps")
+        for k in list(capture):
+            t = capture[k]
+            capture[k] = (t.detach().numpy().astype(np.float64), t.grad.numpy().astype(np.float64))
+        capture["rep"] = (np.stack([r.detach().numpy() for r in reps]).astype(np.float64), np.stack([r.grad.numpy() for r in reps]).astype(np.float64))
     return float(loss.detach()), float(rmse.detach()), grads, y.detach().numpy()
 
 
-def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_scale=None, drop=None):
+def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_scale=None, drop=None, capture=None):
     """attn_scale: optional list (one [E, H] array per layer) of inverted-dropout factors for the attention weights.
     drop: optional (seed, rate): the library's masks on the centres after dense_embed (tag 1000) and on the ResidualNorm branch of
     layer l (tag l), element index = atom * local_dim + column."""
@@ -137,6 +143,7 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_s
             c = ctx
     z = F.silu(lin(c, "after_Lc"))
     gq, gk = lin(z, "global_attention/query"), lin(z, "global_attention/key")
+    reps = []
     ys, gas = [], []
     for s in range(pk.n_struct):
         a0, a1 = pk.mol_offset[s], pk.mol_offset[s + 1]
@@ -146,11 +153,19 @@ def forward_packed(config, weights, pk, dtype="float64", as_tensor=False, attn_s
             agg = agg / torch.linalg.vector_norm(agg)
         at = F.softmax(agg, 0)
         rep = (at[:, None] * gk[a0:a1]).sum(0)
+        reps.append(rep)
         y = lin(F.silu(lin(rep, "bf_property")), "predict_property")
         if config.get("hyper", {}).get("target") == "e_b":
             y = _mrelu(y)
         ys.append(y)
         gas.append(at)
+    if capture is not None:
+        capture.update(z=z, gq=gq, gk=gk)
+        for t in capture.values():
+            t.retain_grad()
+        for r in reps:
+            r.retain_grad()
+        capture["_reps"] = reps
     if as_tensor:
         return torch.stack(ys).reshape(-1, 1), torch.cat(gas)
     return torch.stack(ys).numpy().reshape(-1, 1), torch.cat(gas).numpy()

@@ -1,7 +1,8 @@
-# Round-5 measurement pass (run on the GPU box from the repo root: bash tools/prof_r4.sh): the default and the driver-shape bench
+# Round-5 measurement pass (run on the GPU box from the repo root: bash tools/prof_r5.sh): the default and the driver-shape bench
 # lines, rocprofv3 kernel-trace summaries at both launch shapes, FETCH_SIZE / WRITE_SIZE (separate passes) at both, SQ counters at
 # 16 batches per launch.  --pmc is never combined with a tracing domain.
 set -u
+: ${GRAFT_REPO_ROOT:?}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 python3 $R/bench.py > $O/r05_bench_default.json 2> $O/r05_bench_default.err
 python3 $R/bench.py --steps 20 --warmup 5 > $O/r05_bench_steps20.json 2> $O/r05_bench_steps20.err
