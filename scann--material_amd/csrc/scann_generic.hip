@@ -22,7 +22,7 @@ namespace {
 
 // GR rows per workgroup: every weight element fetched serves GR rows (8 while the staged rows fit 48 KB of LDS, else 4).  A thread
 // owns RPT of them for one output column at a time, so that narrow layers (N <= 128, <= 64) still use all 256 threads: the workgroup
-// covers 256 / (GR / RPT) columns per pass.  A row's sum over k is the same sequence in every shape.
+// covers 256 / (GR / RPT) columns per pass.  A row's sum over k is the same sequence in every shape (four interleaved partial sums).
 template <int GR, int RPT>
 __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
 #pragma clang fp contract(off)
@@ -63,7 +63,22 @@ __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
       for (int rr = 0; rr < RPT; ++rr) acc[rr] = fma((double)sX[(rb + rr) * Ks + k], w, acc[rr]);
     }
     const double bias = a.b ? a.b[o] : 0.f;
-#elif defined(SCANN_DIAG_DENSE4)  // diagnostic: four interleaved fp32 partial sums (k mod 4), combined pairwise
+#elif defined(SCANN_DIAG_DENSE1)  // diagnostic: round 5's single fmaf chain over k
+    float acc[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) acc[rr] = 0.f;
+    const float* __restrict__ wp = a.W + o;
+    for (int k = 0; k < a.K; ++k) {
+      const float w = wp[(size_t)k * a.N];
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) acc[rr] = fmaf(sX[(rb + rr) * Ks + k], w, acc[rr]);
+    }
+    const float bias = a.b ? a.b[o] : 0.f;
+#else
+    // four interleaved partial sums (k mod 4), combined pairwise at the end: one fixed summation order for every shape, dependent chains
+    // a quarter as long as one running sum's, and a rounding error that grows with K / 4 + 2 additions instead of K (a 128-term fmaf
+    // chain sat a factor ~3 above the blocked sums of a BLAS or MFMA product -- visible where the graph is ill-conditioned:
+    // profiles/r06_notes.md, 'plain backward')
     float acc4[RPT][4];
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) acc4[rr][0] = acc4[rr][1] = acc4[rr][2] = acc4[rr][3] = 0.f;
@@ -79,36 +94,17 @@ __global__ __launch_bounds__(256) void gen_dense_kernel(GenDenseArgs a) {
         acc4[rr][3] = fmaf(x.w, w3, acc4[rr][3]);
       }
     }
-    for (int k = K4; k < a.K; ++k) {
-      const float w = wp[(size_t)k * a.N];
 #pragma unroll
-      for (int rr = 0; rr < RPT; ++rr) acc4[rr][k & 3] = fmaf(sX[(rb + rr) * Ks + k], w, acc4[rr][k & 3]);
+    for (int t = 0; t < 3; ++t) {  // K mod 4 trailing terms: term K4 + t continues partial sum t (a compile-time index: registers)
+      if (K4 + t < a.K) {
+        const float w = wp[(size_t)(K4 + t) * a.N];
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) acc4[rr][t] = fmaf(sX[(rb + rr) * Ks + K4 + t], w, acc4[rr][t]);
+      }
     }
     float acc[RPT];
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr) acc[rr] = (acc4[rr][0] + acc4[rr][1]) + (acc4[rr][2] + acc4[rr][3]);
-    const float bias = a.b ? a.b[o] : 0.f;
-#else
-    float acc[RPT];
-#pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) acc[rr] = 0.f;
-    const float* __restrict__ wp = a.W + o;
-    for (int k = 0; k < K4; k += 4) {  // (k ascending inside and across the groups of four: one fixed summation order)
-      const float w0 = wp[(size_t)k * a.N], w1 = wp[(size_t)(k + 1) * a.N], w2 = wp[(size_t)(k + 2) * a.N], w3 = wp[(size_t)(k + 3) * a.N];
-#pragma unroll
-      for (int rr = 0; rr < RPT; ++rr) {
-        const float4 x = *reinterpret_cast<const float4*>(&sX[(rb + rr) * Ks + k]);
-        acc[rr] = fmaf(x.x, w0, acc[rr]);
-        acc[rr] = fmaf(x.y, w1, acc[rr]);
-        acc[rr] = fmaf(x.z, w2, acc[rr]);
-        acc[rr] = fmaf(x.w, w3, acc[rr]);
-      }
-    }
-    for (int k = K4; k < a.K; ++k) {
-      const float w = wp[(size_t)k * a.N];
-#pragma unroll
-      for (int rr = 0; rr < RPT; ++rr) acc[rr] = fmaf(sX[(rb + rr) * Ks + k], w, acc[rr]);
-    }
     const float bias = a.b ? a.b[o] : 0.f;
 #endif
 #pragma unroll
@@ -227,19 +223,11 @@ __global__ __launch_bounds__(256) void gen_readout_kernel(const int32_t* __restr
   float* sRep = sA + n;
   float* sHid = sRep + dg;
   float* sRed = sHid + dout;
-  // agg_i = sum over j != i of k_i . q_j  (the literal form: no S - q_i cancellation)
-  for (int i = tid; i < n; i += 256) {
-    const float* ki = gk + (size_t)(a0 + i) * dg;
-    float agg = 0.f;
-    for (int j = 0; j < n; ++j) {
-      if (j == i) continue;
-      const float* qj = gq + (size_t)(a0 + j) * dg;
-      float e = 0.f;
-      for (int k = 0; k < dg; ++k) e = fmaf(ki[k], qj[k], e);
-      agg += e;
-    }
-    sA[i] = agg;
-  }
+  // agg_i = sum over j != i of k_i . q_j  (the literal form: no S - q_i cancellation) -- products and sums in fp64, rounded once.  The
+  // score of a small structure can be a thousandth of its terms (a two-atom molecule with nearly orthogonal key and query rows:
+  // |k_0 . q_1| = 0.03 against sum |terms| = 22, tools/debug_plain_grads.py), the normalisation divides by it, and gen_pool_bwd_kernel
+  // forms the same scores again: in fp32 the two evaluations differ by 6e-5 of the score and the pooling gradient by ten times that.
+  for (int i = tid; i < n; i += 256) sA[i] = (float)gen_pool_score(gq, gk, a0, n, i, dg);
   __syncthreads();
   auto block_sum = [&](float v) {
     v = gen_wave_sum64(v);

@@ -32,11 +32,6 @@ __device__ __forceinline__ float gt_wave_sum64(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-__device__ __forceinline__ float gt_wave_max64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
 
 // sum of p[0], p[stride], ... p[(n - 1) * stride] in that order; eight loads in flight (the additions keep their order)
 __device__ __forceinline__ float gt_ordered_sum(const float* __restrict__ p, int n, size_t stride) {
@@ -328,74 +323,84 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void gen_pool_bwd_kernel(const int32_t* __restrict__ mol_offset, const float* __restrict__ gq, const float* __restrict__ gk, int dg,
                                                            int use_ga_norm, const float* __restrict__ drep, float* __restrict__ dgq, float* __restrict__ dgk) {
 #pragma clang fp contract(off)
-  extern __shared__ float sm[];  // [n] u, [n] at, [n] d at -> d agg, [4] reductions
+  // The per-structure scalars -- scores, normalisation, softmax and their derivatives -- in fp64 (n values per structure: no cost), on the
+  // scores of gen_pool_score, the forward's own: d agg = (du - u (u . du)) / |agg| cancels ten-fold for a two-atom structure and is divided
+  // by a norm that can be a thousandth of the score's terms, so every fp32 rounding in this chain is a 1e-4 error of the structure's
+  // whole gradient (and through it of every tensor upstream of the readout).  With the chain exact, what is left is what the fp32
+  // STORAGE of gq / gk / d rep carries in -- the floor of any fp32 graph (tools/debug_plain_grads.py, profiles/r06_notes.md).
+  extern __shared__ double smd[];  // [n] u, [n] at, [n] d at -> d agg, [4] reductions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a0 = mol_offset[blockIdx.x], n = mol_offset[blockIdx.x + 1] - a0;
-  float* sU = sm;
-  float* sA = sU + n;
-  float* sD = sA + n;
-  float* sRed = sD + n;
+  double* sU = smd;
+  double* sA = sU + n;
+  double* sD = sA + n;
+  double* sRed = sD + n;
   const float* dr = drep + (size_t)blockIdx.x * dg;
   for (int i = tid; i < n; i += 256) {
     const float* ki = gk + (size_t)(a0 + i) * dg;
-    float agg = 0.f;
-    for (int j = 0; j < n; ++j) {
-      if (j == i) continue;
-      const float* qj = gq + (size_t)(a0 + j) * dg;
-      float e = 0.f;
-      for (int k = 0; k < dg; ++k) e = fmaf(ki[k], qj[k], e);
-      agg += e;
+    sU[i] = gen_pool_score(gq, gk, a0, n, i, dg);
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= dg; k += 4) {
+      d0 = fma((double)dr[k], (double)ki[k], d0);
+      d1 = fma((double)dr[k + 1], (double)ki[k + 1], d1);
+      d2 = fma((double)dr[k + 2], (double)ki[k + 2], d2);
+      d3 = fma((double)dr[k + 3], (double)ki[k + 3], d3);
     }
-    sU[i] = agg;
-    float da = 0.f;
-    for (int k = 0; k < dg; ++k) da = fmaf(dr[k], ki[k], da);
-    sD[i] = da;
+    for (; k < dg; ++k) d0 = fma((double)dr[k], (double)ki[k], d0);
+    sD[i] = (d0 + d1) + (d2 + d3);
   }
   __syncthreads();
-  auto block_sum = [&](float v) {
-    v = gt_wave_sum64(v);
+  auto wave_sum = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  auto block_sum = [&](double v) {
+    v = wave_sum(v);
     if (lane == 0) sRed[wave] = v;
     __syncthreads();
-    const float t = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    const double t = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
     __syncthreads();
     return t;
   };
-  auto block_max = [&](float v) {
-    v = gt_wave_max64(v);
+  auto block_max = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     if (lane == 0) sRed[wave] = v;
     __syncthreads();
-    const float t = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
+    const double t = fmax(fmax(sRed[0], sRed[1]), fmax(sRed[2], sRed[3]));
     __syncthreads();
     return t;
   };
-  float nrm = 1.0f;
+  double nrm = 1.0;
   if (use_ga_norm) {
-    float ss = 0.f;
+    double ss = 0.0;
     for (int i = tid; i < n; i += 256) ss += sU[i] * sU[i];
-    nrm = sqrtf(block_sum(ss));
+    nrm = sqrt(block_sum(ss));
     for (int i = tid; i < n; i += 256) sU[i] = sU[i] / nrm;
     __syncthreads();
   }
-  float m = -INFINITY;
-  for (int i = tid; i < n; i += 256) m = fmaxf(m, sU[i]);
+  double m = -INFINITY;
+  for (int i = tid; i < n; i += 256) m = fmax(m, sU[i]);
   m = block_max(m);
-  float ss = 0.f;
+  double ss = 0.0;
   for (int i = tid; i < n; i += 256) {
-    const float e = expf(sU[i] - m);
+    const double e = exp(sU[i] - m);
     sA[i] = e;
     ss += e;
   }
   ss = block_sum(ss);
-  float dot = 0.f;
+  double dot = 0.0;
   for (int i = tid; i < n; i += 256) {
-    const float at = sA[i] / ss;
+    const double at = sA[i] / ss;
     sA[i] = at;
     dot += at * sD[i];
   }
   dot = block_sum(dot);
-  float dotu = 0.f;
+  double dotu = 0.0;
   for (int i = tid; i < n; i += 256) {
-    const float du = sA[i] * (sD[i] - dot);
+    const double du = sA[i] * (sD[i] - dot);
     sD[i] = du;
     dotu += sU[i] * du;
   }
@@ -405,14 +410,14 @@ __global__ __launch_bounds__(256) void gen_pool_bwd_kernel(const int32_t* __rest
   __syncthreads();
   for (int t = tid; t < n * dg; t += 256) {
     const int i = t / dg, k = t - i * dg;
-    float sq = 0.f, sk = 0.f;
+    double sq = 0.0, sk = 0.0;
     for (int j = 0; j < n; ++j) {
       if (j == i) continue;
-      sq += gq[(size_t)(a0 + j) * dg + k];
-      sk = fmaf(sD[j], gk[(size_t)(a0 + j) * dg + k], sk);
+      sq += (double)gq[(size_t)(a0 + j) * dg + k];
+      sk = fma(sD[j], (double)gk[(size_t)(a0 + j) * dg + k], sk);
     }
-    dgk[(size_t)(a0 + i) * dg + k] = sA[i] * dr[k] + sD[i] * sq;
-    dgq[(size_t)(a0 + i) * dg + k] = sk;
+    dgk[(size_t)(a0 + i) * dg + k] = (float)(sA[i] * (double)dr[k] + sD[i] * sq);
+    dgq[(size_t)(a0 + i) * dg + k] = (float)sk;
   }
 }
 
@@ -517,7 +522,7 @@ void launch_gen_attn_bwd(const float* q, const float* K, const int32_t* edge_off
 void launch_gen_pool_bwd(const int32_t* mol_offset, int n_struct, int max_atoms, const float* gq, const float* gk, int dg, int use_ga_norm,
                          const float* drep, float* dgq, float* dgk, hipStream_t s) {
   if (n_struct <= 0) return;
-  const size_t lds = ((size_t)3 * max_atoms + 4) * sizeof(float);
+  const size_t lds = ((size_t)3 * max_atoms + 4) * sizeof(double);
   hipLaunchKernelGGL(gen_pool_bwd_kernel, dim3(n_struct), dim3(256), lds, s, mol_offset, gq, gk, dg, use_ga_norm, drep, dgq, dgk);
 }
 void launch_gen_edge_to_atom(const int32_t* edge_offset, const int32_t* in_off, const int32_t* in_edge, const float* S_out, const float* S_in,

@@ -31,6 +31,30 @@ __host__ __device__ inline float drop_scale(unsigned long long seed, unsigned ta
   const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
   return u < p ? 0.f : 1.0f / (1.0f - p);
 }
+#ifdef __HIPCC__
+// GlobalAttention score of atom i of a structure (attention.py:279-292): sum over j != i of gk_i . gq_j, exact products, fp64 sums, four
+// interleaved partial sums per dot product (shared by the forward and by the pooling backward, which must see the SAME scores)
+__device__ __forceinline__ double gen_pool_score(const float* __restrict__ gq, const float* __restrict__ gk, int a0, int n, int i, int dg) {
+  const float* ki = gk + (size_t)(a0 + i) * dg;
+  double agg = 0.0;
+  for (int j = 0; j < n; ++j) {
+    if (j == i) continue;
+    const float* qj = gq + (size_t)(a0 + j) * dg;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= dg; k += 4) {
+      e0 = fma((double)ki[k], (double)qj[k], e0);
+      e1 = fma((double)ki[k + 1], (double)qj[k + 1], e1);
+      e2 = fma((double)ki[k + 2], (double)qj[k + 2], e2);
+      e3 = fma((double)ki[k + 3], (double)qj[k + 3], e3);
+    }
+    for (; k < dg; ++k) e0 = fma((double)ki[k], (double)qj[k], e0);
+    agg += (e0 + e1) + (e2 + e3);
+  }
+  return agg;
+}
+#endif
+
 // Range guard of the split-fp16 projections (|activation| and |weight| * 2^8 must stay below 65504, the largest fp16): an operand
 // that overflows becomes inf in its hi part, the product NaN, and the NaN reaches the statistics of the next LayerNorm.  The
 // kernels therefore test every LayerNorm variance (and the one activation that no LayerNorm follows) for finiteness and, on

@@ -2607,8 +2607,8 @@ static int gen_backward(scann_handle_t* h, scann_dbatch_t* db, scann_train_ws& w
     return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): more than 4,194,240 atoms in one batch (Embedding gradient: 65,535 chunks of 64 atoms)");
   if ((size_t)3 * std::max(1, db->max_degree) * H * sizeof(float) > 65536)
     return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): an atom's neighbours x heads exceed one workgroup's LDS (3 x max_degree x num_head floats <= 64 KiB)");
-  if (((size_t)3 * db->max_atoms + 4) * sizeof(float) > 65536)
-    return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): a structure's atoms exceed one workgroup's LDS (GlobalAttention pooling: 3 x atoms floats <= 64 KiB)");
+  if (((size_t)3 * db->max_atoms + 4) * sizeof(double) > 65536)
+    return fail(h, SCANN_ERR_UNSUPPORTED, "backward (generic widths): a structure's atoms exceed one workgroup's LDS (GlobalAttention pooling: 3 x atoms doubles <= 64 KiB)");
   // ---- temporaries ----
   const size_t fA = (size_t)A, fE = (size_t)std::max(E, 1), fB = (size_t)B;
   const size_t dmax = (size_t)std::max(d, std::max(dg, dout));

@@ -968,3 +968,55 @@ def test_dropout_layer_gradients_match_autograd(hip_lib, monkeypatch, path):
         rmse, _ = check_grads(eng.get_grads(), cfg, w, pk, targets, drop=(seed, p))
         assert abs(np.sqrt(sse / pk.n_struct) - rmse) <= 2e-5 * max(rmse, 1e-6), (seed, p)
     rb.free()
+
+
+def test_plain_backward_on_the_ill_conditioned_two_atom_batch(hip_lib, monkeypatch):
+    """Batch 7797 of tests/manual/fuzz_grads.py (committed: tests/golden/fuzz_batch_7797.npz; six structures, one of them a C-O pair whose
+    GlobalAttention score k_0 . q_1 = 0.034 is 1.5e-3 of the sum of its terms' magnitudes).  Round 5's plain-fp32 backward sat 17 x further
+    from fp64 autograd than the fp32 graph on it, the same factor in every tensor upstream of the readout: gen_pool_bwd_kernel formed the
+    scores a second time in fp32 (6e-5 of the score apart from the forward's), the normalisation backward (du - u (u . du)) / |agg|
+    cancels ten-fold, and the structure's whole gradient inherits the error.  Now the scores (forward and backward: one function) and the
+    per-structure scalar chain are fp64: (a) the kernel's d gq / d gk equal the fp64 formula on the kernel's OWN fp32 inputs to 1e-5
+    (1.8e-3 before); (b) what is left is carried in by the fp32 activations -- every tensor within 8 x the fp32 graph's own distance from
+    fp64 (tools/debug_plain_grads.py prints the stages; profiles/r06_notes.md has the before / after and a census over random batches)."""
+    import importlib.util
+
+    import torch_ref
+    from scann import _hip
+    from scann.models.scann_model import HipModel, normalize_config
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("debug_plain_grads", os.path.join(root, "tools", "debug_plain_grads.py"))
+    dbg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dbg)
+    z = np.load(os.path.join(root, "tests", "golden", "fuzz_batch_7797.npz"))
+    targets = z["targets"]
+    pk = _hip.pack_inputs({k: z[k] for k in z.files if k != "targets"})
+    assert np.diff(pk.mol_offset).tolist() == [4, 7, 8, 2, 3, 26] and pk.n_edge == 148
+    cfg = normalize_config(so.default_config("qm9"))
+    cfg["model"].update(n_attention=3)
+    w = so.init_weights(cfg, 77, perturb=True)
+    monkeypatch.setenv("SCANN_GENERIC", "1")
+    eng = HipModel(cfg, w, device=0).engine
+    monkeypatch.delenv("SCANN_GENERIC")
+    eng.train_begin()
+    rb = eng.upload(pk)
+    drop, seed = 0.1, 100 + 7797
+    sse = eng.train_forward(rb, targets, dropout=drop, seed=seed)
+    eng.zero_grads()
+    eng.train_backward(rb, sse, pk.n_struct)
+    got = eng.get_grads()
+    dg = cfg["model"]["global_dim"]
+    t = {k: eng.train_debug_read(rb, k, dg).astype(np.float64) for k in ("gq", "gk", "drep", "dgq", "dgk")}
+    rb.free()
+    own_q, own_k = dbg.pool_bwd64(pk, t["gq"], t["gk"], t["drep"], cfg["model"]["use_ga_norm"])
+    assert max(dbg.per_struct(pk, t["dgq"], own_q)) <= 1e-5 and max(dbg.per_struct(pk, t["dgk"], own_k)) <= 1e-5
+    _, _, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, drop=(seed, drop))
+    _, _, g32, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, dtype="float32", drop=(seed, drop))
+    for k in ref:
+        if k.endswith(torch_ref.REGULARIZED):
+            ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
+            g32[k] = g32[k] - 2e-4 * w[k].astype(np.float64)
+    e_gpu, e_32 = grad_errors(got, ref), grad_errors(g32, ref)
+    bad = {k: (e_gpu[k], e_32[k]) for k in ref if not e_gpu[k] <= max(GRAD_FLOOR, 8.0 * e_32[k])}
+    assert not bad, bad
