@@ -500,11 +500,11 @@ def training_b16_leg(cfg, batches, batch_size, seconds=1.0):
     return out
 
 
-def roofline_shapes(eng, batches, batch_size, A, E, groups=(12, 14, 16), forwards=48):
+def roofline_shapes(eng, batches, batch_size, A, E, groups=(10, 12, 14, 16), forwards=96):
     """The dominant kernel's HBM-roofline fraction at launch shapes other than the timed one, measured in this run with the same HIP
-    events (scann_edge_timing, every launch of the plain edge kernel sampled; one stream): 12 / 14 / 16 batches per launch, and the
-    least-squares line through them -- microseconds per 64-row edge tile in steady state (the slope) and per launch (the intercept:
-    ramp, drain and the last, partly filled round of workgroups).  SURVEY.md 8(d)(ii) bytes throughout."""
+    events (scann_edge_timing on every third forward, like the timed region's sparse sample; one stream): 10 / 12 / 14 / 16 batches per
+    launch, and the least-squares line through them -- microseconds per 64-row edge tile in steady state (the slope) and per launch (the
+    intercept: ramp, drain and the last, partly filled round of workgroups).  SURVEY.md 8(d)(ii) bytes throughout."""
     import numpy as np
     from scann import _hip
 
@@ -512,10 +512,10 @@ def roofline_shapes(eng, batches, batch_size, A, E, groups=(12, 14, 16), forward
     for g in groups:
         n_g = max(1, min(len(batches) // g, 4))
         res = [eng.upload(_hip.concat_packed([batches[(i * g + j) % len(batches)] for j in range(g)])) for i in range(n_g)]
-        for i in range(8):
+        for i in range(32):
             eng.forward_resident(res[i % n_g], 0)
         eng.sync()
-        eng.edge_timing(1)
+        eng.edge_timing(3)
         for i in range(forwards):
             eng.forward_resident(res[i % n_g], 0)
         eng.sync()
@@ -766,7 +766,7 @@ def main():
                 "per_forward_ms": {k: float(np.mean([p[k] for p in prof])) for k in
                                    ("ms_basis", "ms_atom", "ms_edge", "ms_readout", "ms_total")} if prof else None}
         if not args.no_extras and world == 1 and args.config == "qm9" and not args.worst:
-            # the same kernel at 12 / 14 / 16 batches per launch and its per-tile slope, beside the timed shape's figure (read "0.37 here,
+            # the same kernel at 10 / 12 / 14 / 16 batches per launch and its per-tile slope, beside the timed shape's figure (read "0.37 here,
             # 0.39 there, 0.41 in steady state" off ONE record); one stream, kernel sampling as above
             roof["shapes"] = {"timed": {"batches_per_launch": gmax, "avg_launch_us": us, "frac": frac_hbm}, **roofline_shapes(eng, batches, args.batch, A, E)}
         value = world * args.steps * args.batch / elapsed

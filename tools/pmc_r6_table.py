@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The vector-memory path of the dominant kernels as ONE table (profiles/r06_memory_path.txt), from the per-launch counter averages that
-tools/pmc_report.py wrote for the passes of tools/pmc_r6.py:  python3 tools/pmc_r6_table.py r06g10 r06g16 [> profiles/r06_memory_path.txt]
+tools/pmc_report.py wrote for the passes of tools/pmc_r6.py:  python3 tools/pmc_r6_table.py r06fg10 r06fg16 [> profiles/r06_memory_path.txt]
 
 Units (checked against this kernel's known byte counts, profiles/r05_notes.md): TCC_EA0_RDREQ are 128-B requests on gfx950 (RDREQ_32B
 = 0; 1.727 M x 128 B = 221 MB = the fetch the FETCH_SIZE passes give after the guide's x 2), TCC_EA0_WRREQ are 64-B requests (2.506 M x
@@ -32,7 +32,7 @@ def load(tag):
 
 
 def main():
-    for tag in sys.argv[1:] or ["r06g10", "r06g16"]:
+    for tag in sys.argv[1:] or ["r06fg10", "r06fg16"]:
         ks = load(tag)
         print("==== %s (rocprofv3 --pmc passes of tools/pmc_r6.py; per-launch averages; 256 CUs, 8 XCDs, 128 L2 channels)" % tag)
         for pat, label in KERNELS:
