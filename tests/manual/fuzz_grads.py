@@ -6,13 +6,15 @@ the switch is read at scann_train_begin, so two engines are created under differ
 batches on the plain-fp32 training kernels written for other widths (SCANN_GENERIC=1, csrc/scann_generic_train.hip), an implementation
 that shares no kernel with the other two: quick bound 4e-4 of a tensor's rms + 4 x the difference of the two FORWARDS relative to the
 rmse (the seed of the backward); a tensor beyond it goes to arbitration -- fp64 autograd of the torch graph with the library's Dropout
-masks, and the same graph in fp32 as the floor.  These batches are adversarial on purpose: a homonuclear two-atom molecule whose two
-rows differ only by their Dropout masks puts the GlobalAttention gradients on differences of nearly equal numbers, and over 30 Dropout
-seeds of one such batch every implementation, the torch fp32 graph included, moves between 8e-6 and 1.5e-4 of the tensor's rms, each
-with its own outlier (the plain path 6.3e-4 = 12 x the fp32 graph on one seed, the MFMA path 4 x on another).  A tensor more than
-16 x the fp32 graph's distance from fp64 is REPORTED as ill-conditioned (profiles/r05_fuzz_grads_plain.txt: 25 tensors in 4 of 18,376
-batches, the worst the GlobalAttention query kernel at 5e-3 of its rms where the fp32 graph sits at 2.5e-4; fp64 statistics in the
-pooling backward or fp64 sums in every dense layer, both tried, move these cases around without removing them); beyond 2e-2 of the
+masks, and the same graph in fp32 as the floor.  These batches are adversarial on purpose: a two-atom molecule whose GlobalAttention
+score k_0 . q_1 nearly cancels (1.5e-3 of the sum of its terms' magnitudes in batch 7797) is divided by that score's norm, and ONE fp32
+rounding of gq / gk moves its whole gradient -- and every tensor upstream of the readout with it -- by 2e-4 of the tensor's rms
+(tools/debug_plain_grads.py prints the stages; profiles/r06_notes.md section 3).  A tensor more than 16 x the fp32 graph's distance
+from fp64 is REPORTED as ill-conditioned.  Round 5: 25 tensors in 4 of 18,376 batches, same factor in every tensor of a batch -- a third
+of it the plain pooling backward forming the scores a second time in fp32, the rest the luck of the roundings (the fp32 graph is the lucky
+one on batches SELECTED by this ratio).  Round 6 (fp64 scores shared by forward and backward, dense outputs as four partial sums): 0 in a
+3,017-batch sweep, and `census=K` answers the symmetric question -- every K-th batch arbitrated whatever the quick bound says, all three
+implementations tallied against the fp32 graph (profiles/r06_fuzz_census.txt: plain 0, MFMA 3 of 24,192 tensors beyond 4 x).  Beyond 2e-2 of the
 rms, or not finite, it is a MISMATCH -- what a wrong formula or index would read."""
 import os, sys, time
 import numpy as np
