@@ -1226,6 +1226,7 @@ int run_forward_generic(scann_handle* h, scann_dbatch* db, hipStream_t s, GenKee
   const int L = c.n_attention, A = db->n_atom, E = db->n_edge, B = db->n_struct;
   const int d = c.local_dim, dg = c.global_dim, dout = c.dense_out, H = c.num_head, emb = c.embedding_dim;
   const int cin = emb + (c.use_ring ? 10 : 0);
+  if (kp) kp->dbg.clear();  // (scann_train_debug_read: the tensors it names belong to the backward of THIS forward's arena)
   if ((size_t)std::max(1, db->max_degree) * H * 4 * (kp ? 3 : 1) > 60000 || ((size_t)db->max_atoms * (kp ? 3 : 1) + dg + dout + 4) * 4 > 60000 ||
       (size_t)4 * 3 * d * 4 > 60000)
     return fail(h, SCANN_ERR_UNSUPPORTED, "forward (generic widths): an atom's neighbours x heads, or a structure's atoms, exceed one workgroup's LDS");
