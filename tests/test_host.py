@@ -946,6 +946,57 @@ def test_bench_group_sizes_cover_exactly_the_steps():
     assert bench.group_sizes(7, 1) == [1] * 7
 
 
+def test_bench_roofline_shapes_fits_the_per_tile_line():
+    """`roofline.shapes` of the bench line: the dominant kernel's fraction at 10 / 12 / 14 / 16 batches per launch and
+    the least-squares per-tile slope, computed from the engine's launch samples.  A stand-in engine whose launches take 5 us + 20 ns per
+    64 edges must come back as exactly that line, and every point's fraction as SURVEY 8(d)(ii) bytes / time / 8 TB/s."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from scann import _hip
+
+    class RB:
+        def __init__(self, pk):
+            self.packed = pk
+
+        def free(self):
+            pass
+
+    class Eng:
+        def __init__(self):
+            self.every, self.n_fwd, self.samples = 0, 0, []
+
+        def upload(self, pk):
+            return RB(pk)
+
+        def forward_resident(self, rb, slot=0):
+            if self.every and self.n_fwd % self.every == 0:
+                self.samples += [rb.packed.n_edge] * 5  # the five middle-layer launches of a 7-layer forward
+            self.n_fwd += 1
+
+        def sync(self):
+            pass
+
+        def edge_timing(self, every):
+            self.every, self.n_fwd, self.samples = every, 0, []
+
+        def edge_timing_read(self):
+            e = np.asarray(self.samples, np.float64)
+            return float(np.mean(5.0 + 0.020 * e / 64.0)), len(e), float(e.mean())
+
+    rng = np.random.default_rng(0)
+    batches = [bench.synth_packed_batch(rng, 16) for _ in range(32)]
+    A = float(np.mean([b.n_atom for b in batches]))
+    E = float(np.mean([b.n_edge for b in batches]))
+    out = bench.roofline_shapes(Eng(), batches, 16, A, E, groups=(10, 12, 14, 16), forwards=12)
+    assert [p["batches_per_launch"] for p in out["points"]] == [10, 12, 14, 16] and all(p["launches_sampled"] == 20 for p in out["points"])
+    for p in out["points"]:
+        want = bench.edge_bytes(p["edges_per_launch"] * A / E, p["edges_per_launch"]) / (p["avg_launch_us"] * 1e-6) / 1e12 / bench.PEAK_HBM_TBS
+        assert abs(p["frac"] - want) < 1e-12
+    t = out["per_tile"]
+    assert abs(t["ns_per_64_edge_tile"] - 20.0) < 1e-6 and abs(t["intercept_us"] - 5.0) < 1e-6
+    assert abs(t["frac_steady_state"] - t["bytes_per_tile"] / 20e-9 / 1e12 / bench.PEAK_HBM_TBS) < 1e-9
+
+
 def test_slice_packed_carries_ring_and_cgcnn():
     from scann import _hip
     from scann.parallel import rank_slice, slice_packed
