@@ -976,9 +976,12 @@ def test_plain_backward_on_the_ill_conditioned_two_atom_batch(hip_lib, monkeypat
     from fp64 autograd than the fp32 graph on it, the same factor in every tensor upstream of the readout: gen_pool_bwd_kernel formed the
     scores a second time in fp32 (6e-5 of the score apart from the forward's), the normalisation backward (du - u (u . du)) / |agg|
     cancels ten-fold, and the structure's whole gradient inherits the error.  Now the scores (forward and backward: one function) and the
-    per-structure scalar chain are fp64: (a) the kernel's d gq / d gk equal the fp64 formula on the kernel's OWN fp32 inputs to 1e-5
-    (1.8e-3 before); (b) what is left is carried in by the fp32 activations -- every tensor within 8 x the fp32 graph's own distance from
-    fp64 (tools/debug_plain_grads.py prints the stages; profiles/r06_notes.md has the before / after and a census over random batches)."""
+    per-structure scalar chain are fp64:
+    (a) the kernel's d gq / d gk equal the fp64 formula on the kernel's OWN fp32 inputs to 1e-5 of the batch rms (1.8e-3 before);
+    (b) what is left is carried in by the fp32 activations: the pair's d gq sits within 12 x what ONE fp32 rounding of gq / gk / d rep does
+        to it (8 x measured; 26 x before), every other structure's within 1e-4 of the batch rms;
+    (c) every parameter gradient within 16 x the fp32 graph's own distance from fp64 (6 x measured; 17-20 x before).
+    tools/debug_plain_grads.py prints the stages; profiles/r06_notes.md section 3 has the before / after and a census over random batches."""
     import importlib.util
 
     import torch_ref
@@ -992,7 +995,8 @@ def test_plain_backward_on_the_ill_conditioned_two_atom_batch(hip_lib, monkeypat
     z = np.load(os.path.join(root, "tests", "golden", "fuzz_batch_7797.npz"))
     targets = z["targets"]
     pk = _hip.pack_inputs({k: z[k] for k in z.files if k != "targets"})
-    assert np.diff(pk.mol_offset).tolist() == [4, 7, 8, 2, 3, 26] and pk.n_edge == 148
+    sizes = np.diff(pk.mol_offset).tolist()
+    assert sizes == [4, 7, 8, 2, 3, 26] and pk.n_edge == 148
     cfg = normalize_config(so.default_config("qm9"))
     cfg["model"].update(n_attention=3)
     w = so.init_weights(cfg, 77, perturb=True)
@@ -1006,17 +1010,31 @@ def test_plain_backward_on_the_ill_conditioned_two_atom_batch(hip_lib, monkeypat
     eng.zero_grads()
     eng.train_backward(rb, sse, pk.n_struct)
     got = eng.get_grads()
-    dg = cfg["model"]["global_dim"]
+    dg, norm = cfg["model"]["global_dim"], cfg["model"]["use_ga_norm"]
     t = {k: eng.train_debug_read(rb, k, dg).astype(np.float64) for k in ("gq", "gk", "drep", "dgq", "dgk")}
     rb.free()
-    own_q, own_k = dbg.pool_bwd64(pk, t["gq"], t["gk"], t["drep"], cfg["model"]["use_ga_norm"])
+    # (a) the kernel against the fp64 formula on its own inputs
+    own_q, own_k = dbg.pool_bwd64(pk, t["gq"], t["gk"], t["drep"], norm)
     assert max(dbg.per_struct(pk, t["dgq"], own_q)) <= 1e-5 and max(dbg.per_struct(pk, t["dgk"], own_k)) <= 1e-5
-    _, _, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, drop=(seed, drop))
+    # (b) against fp64 autograd, per structure, in units of what one fp32 rounding of the inputs does
+    cap = {}
+    _, _, ref, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, drop=(seed, drop), capture=cap)
+    ref_q, _ = dbg.pool_bwd64(pk, cap["gq"][0], cap["gk"][0], cap["rep"][1], norm)
+    rng = np.random.default_rng(0)
+    pert = lambda x: x * (1.0 + rng.uniform(-6e-8, 6e-8, x.shape))  # noqa: E731
+    one_q, _ = dbg.pool_bwd64(pk, pert(cap["gq"][0]), pert(cap["gk"][0]), pert(cap["rep"][1]), norm)
+    pair = sizes.index(2)
+    sens = dbg.per_struct(pk, one_q, ref_q)[pair]
+    err = dbg.per_struct(pk, t["dgq"], cap["gq"][1])
+    assert 5e-5 < sens < 1e-3, sens                      # (the batch IS ill-conditioned there: 2.3e-4 of the batch rms per rounding)
+    assert err[pair] <= 12.0 * sens, (err[pair], sens)
+    assert max(e for i, e in enumerate(err) if i != pair) <= 1e-4, err
+    # (c) parameter gradients against the fp32 graph's own distance
     _, _, g32, _ = torch_ref.loss_and_grads(cfg, w, pk, targets, dtype="float32", drop=(seed, drop))
     for k in ref:
         if k.endswith(torch_ref.REGULARIZED):
             ref[k] = ref[k] - 2e-4 * w[k].astype(np.float64)
             g32[k] = g32[k] - 2e-4 * w[k].astype(np.float64)
     e_gpu, e_32 = grad_errors(got, ref), grad_errors(g32, ref)
-    bad = {k: (e_gpu[k], e_32[k]) for k in ref if not e_gpu[k] <= max(GRAD_FLOOR, 8.0 * e_32[k])}
+    bad = {k: (e_gpu[k], e_32[k]) for k in ref if not e_gpu[k] <= max(GRAD_FLOOR, 16.0 * e_32[k])}
     assert not bad, bad
