@@ -48,7 +48,7 @@ os.environ.pop("SCANN_GENERIC")
 m.engine.train_begin()
 engines["plain"] = m
 rng = np.random.default_rng(5)
-t_end, n, worst, bad, worst_p, n_arb, n_ill = time.time() + budget, 0, {}, 0, {}, 0, 0
+t_end, n, worst, bad, worst_p, n_arb, n_ill, n_4x = time.time() + budget, 0, {}, 0, {}, 0, 0, 0
 census = {"plain": [], "modular": [], "fused": []}  # per arbitrated tensor: distance from fp64 / max(the fp32 graph's distance, 2e-5)
 
 
@@ -104,6 +104,10 @@ while time.time() < t_end:
             gross = not (e_plain <= 2e-2) or not np.isfinite(grads["plain"][k]).all()  # (a wrong formula or index reads 1e-1 .. 1)
             if gross:
                 bad += 1
+            if not gross and not (e_plain <= max(2e-5, 4 * e_t32)):
+                n_4x += 1  # (the review's ruler: beyond 4 x the fp32 graph's distance)
+                print("beyond 4 x (plain fp32) batch %d (structures %d, atoms %d, edges %d, dropout %.1f): %s  plain %.3e  modular %.3e  the torch graph in fp32 %.3e"
+                      % (n, pk.n_struct, pk.n_atom, pk.n_edge, drop, k, e_plain, e_mod, e_t32))
             if gross or not (e_plain <= max(2e-5, 16 * e_t32)):
                 n_ill += 0 if gross else 1
                 print(("MISMATCH" if gross else "ill-conditioned") + " (plain fp32) batch %d (structures %d, atoms %d, edges %d, dropout %.1f): %s differs from the modular path by %.3e; "
@@ -132,6 +136,6 @@ if CENSUS:
 top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
 print("%d batches; largest fused-vs-modular differences (of the tensor's rms): %s" % (n, ", ".join("%s %.2e" % kv for kv in top)))
 top = sorted(worst_p.items(), key=lambda kv: -kv[1])[:5]
-print("largest plain-fp32-vs-modular differences: %s; %d batches went to the fp64 arbitration, %d tensors sat more than 16 x the fp32 graph's distance from fp64 (none beyond 2e-3 of the rms unless reported as MISMATCH)"
-      % (", ".join("%s %.2e" % kv for kv in top), n_arb, n_ill))
+print("largest plain-fp32-vs-modular differences: %s; %d batches went to the fp64 arbitration, %d tensors sat more than 16 x and %d more than 4 x the fp32 graph's distance from fp64 (none beyond 2e-2 of the rms unless reported as MISMATCH)"
+      % (", ".join("%s %.2e" % kv for kv in top), n_arb, n_ill, n_4x))
 sys.exit(1 if bad else 0)
